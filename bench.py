@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on MI355X (driver contract, see README).
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): tied-state
+triphone-sized GMM, S=3000 states x M=16 mixtures x D=39, outprob kernel only.
+One "step" = one pass of the GMM outprob path over one batch of
+`--utts` synthetic utterances x 1000 frames (seeded synthetic MFCC) already
+resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
+
+  value   = frame*states scored per second, whole job (all ranks)
+  rtf_inv = audio-seconds per wall-second (100 frames = 1 s)
+  roofline = algorithmic bytes of the frame-synchronous formulation
+             (S*M*(2D+2)*4 + D*4 + S*4 per frame) / HIP-event
+             kernel time, against the 8 TB/s HBM peak; `valu` is the fp32 VALU
+             issue roofline that actually binds the frame-tiled kernel
+             (DESIGN.md "K1 roofline").
+  cpu_baseline = the compiled reference (oracle/_ref, kind "reference") scoring
+             a bounded sample of the same workload on ONE host core, or the
+             oracle port when _ref is absent.
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL used only for the
+barrier and the max-over-ranks clock); utterances are sharded, no data-path
+collective ("weak" scaling: per-GPU batch fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+S, M, D = 3000, 16, 39
+FRAMES_PER_UTT = 1000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one fp32 op/lane/clk (no FMA allowed)
+
+
+def cpu_baseline(model, frames, seconds_budget=12.0):
+    """Reference CPU path on a bounded sample (rank 0, N=1 only)."""
+    from oracle import pyoracle
+    try:
+        ref = pyoracle.Ref()
+        am = ref.am_from_flat(model)
+        am.outprob(frames[:20], want_out=False)          # warm + calibrate
+        per = max(am.last_seconds / 20, 1e-5)
+        n = int(min(len(frames), max(50, seconds_budget / per)))
+        am.outprob(frames[:n], want_out=False)
+        sec = am.last_seconds
+        kind = "reference"
+        what = "compiled reference libsent (outprob_state batch loop -> calc_mix -> gprune_none -> addlog_array)"
+    except (FileNotFoundError, OSError):
+        orc = pyoracle.Oracle()
+        t = time.perf_counter(); orc.gmm_outprob(model, frames[:10]); per = (time.perf_counter() - t) / 10
+        n = int(min(len(frames), max(20, seconds_budget / per)))
+        t = time.perf_counter(); orc.gmm_outprob(model, frames[:n]); sec = time.perf_counter() - t
+        kind = "port"
+        what = "oracle/jamd_oracle_am.c restatement"
+    return {
+        "value": n * S / sec, "unit": "frame*states/s", "cores": 1, "kind": kind,
+        "sample": f"{n} frames x {S} states eager scoring, {what}, {sec:.2f} s on 1 of {os.cpu_count()} host cores",
+        "rtf_inv": n / 100.0 / sec,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--utts", type=int, default=16, help="utterances (x1000 frames) per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from julius_amd import lib, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    # same model on every rank (replicated); each rank its own utterances
+    model = synth.make_gmm(S=S, M=M, D=D, seed=0)
+    T = args.utts * FRAMES_PER_UTT
+    frames = np.concatenate([synth.make_frames(model, T=FRAMES_PER_UTT, seed=1000 + rank * args.utts + u)
+                             for u in range(args.utts)])
+    eng = lib.Engine(local_rank)
+    gmm = lib.Gmm(eng, model)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_out = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        gmm.outprob_dev(d_frames.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # spot parity inside the bench: a few (t, s) entries of the last output vs the oracle
+    if rank == 0:
+        from oracle import pyoracle
+        rng = np.random.default_rng(0)
+        ss = np.sort(rng.choice(S, 8, replace=False))
+        tt = np.sort(rng.choice(T, 8, replace=False))
+        sub = dict(model)
+        sub["st_off"] = (np.arange(len(ss) + 1) * M).astype(np.int32)
+        idx = np.concatenate([np.arange(model["st_off"][s], model["st_off"][s + 1]) for s in ss])
+        sub["ent_dens"], sub["ent_logw"] = model["ent_dens"][idx], model["ent_logw"][idx]
+        want = pyoracle.Oracle().gmm_outprob(sub, frames[tt])
+        got = d_out[torch.from_numpy(tt).cuda()][:, torch.from_numpy(ss).cuda()].cpu().numpy()
+        parity = bool(np.array_equal(got, want))
+    else:
+        parity = None
+
+    if rank == 0:
+        total_frames = T * world * args.steps
+        value = total_frames * S / elapsed
+        E = int(model["st_off"][-1])
+        bytes_per_frame = E * (2 * D + 2) * 4 + D * 4 + S * 4
+        alg_bytes = bytes_per_frame * T                  # per launch (one launch per step per rank)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9    # GB/s
+        valu_ops = T * E * D * 4.0                       # sub, mul, mul, add per (frame, Gaussian, dim)
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic_gmm_tile.json"
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                if tj.get("frames_per_launch") == T:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "frames_x_states_scored_per_sec", "value": value, "unit": "frame*states/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf_inv": total_frames / 100.0 / elapsed,
+            "config": {"workload": "C2 (BASELINE.json configs[1]): tied-state triphone GMM outprob only, "
+                                   f"S={S} x M={M} x D={D}, {args.utts} utterances x {FRAMES_PER_UTT} frames per GPU per step, "
+                                   "gprune none", "frames_per_step_per_gpu": T, "parallelism": f"utterance-sharded x{world}",
+                       "kernel": gmm.last_kernel()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "frame-tiled kernel: the model is streamed once per 512-frame block, so algorithmic "
+                                 "(per-frame) bytes exceed real HBM traffic and frac may exceed 1; see valu",
+                         "valu": {"achieved": valu_ops / (kern_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
+                                  "unit": "Tops/s (fp32, unfused)", "frac": valu_ops / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}},
+            "parity_spot_check": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, frames)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * julius_amd.h -- C ABI of the MI355X (gfx950) engine for Julius' frame-
+ * synchronous first pass: acoustic scoring (GMM / tied-mixture / DNN) and
+ * first-pass token passing.  Plain pointers and sizes only; no torch, no
+ * reference types.  The reference-side binding (a C shim compiled inside the
+ * Julius tree that flattens HTK_HMM_INFO / DNNData / WCHMM_INFO and exports the
+ * reference's own symbols) is julius_amd/shim/ and is described in
+ * INTEGRATION.md.  All paths cited below are relative to the reference root.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success and a negative JAMD_E* code on
+ *     failure; jamd_last_error() returns a message for the calling thread.
+ *     (The reference's boolean/LOG_ZERO error returns are produced by the shim
+ *     from these codes.)
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device
+ *     memory on the engine's device; `stream` is a hipStream_t passed as void*
+ *     (NULL = the engine's own stream).
+ *   - scores are fp32 log10 likelihoods exactly as LOGPROB in
+ *     libsent/include/sent/stddefs.h:194; LOG_ZERO = -1000000 (:171).
+ *   - an engine object is not re-entrant (neither is HMMWork,
+ *     libsent/include/sent/hmm_calc.h:90-111); use one per thread/stream.
+ */
+#ifndef JULIUS_AMD_H
+#define JULIUS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAMD_ABI_VERSION 1
+
+#define JAMD_OK        0
+#define JAMD_EINVAL   -1   /* bad argument / unsupported model feature        */
+#define JAMD_ENODEV   -2   /* no usable gfx950 device / HIP runtime failure   */
+#define JAMD_ENOMEM   -3
+#define JAMD_ELAUNCH  -4   /* kernel launch or execution failed               */
+#define JAMD_ESTATE   -5   /* call sequence violation                         */
+
+#define JAMD_LOG_ZERO (-1000000.0f)
+
+/* Gaussian pruning selector; values of GPRUNE_SEL_* that the engine implements
+ * on the device (libsent/include/sent/hmm_calc.h:38-45).  heu/beam are
+ * frame-order-dependent approximations and stay on the reference's CPU code. */
+#define JAMD_GPRUNE_NONE 0  /* gprune_none()  libsent/src/phmm/gprune_none.c:133 */
+#define JAMD_GPRUNE_SAFE 1  /* gprune_safe()  libsent/src/phmm/gprune_safe.c:160 */
+
+/* pseudo-phone set reduction (hmminfo->cdset_method, htk_hmm.h:388) */
+#define JAMD_IWCD_MAX   0   /* outprob_cd_max   libsent/src/phmm/outprob.c:332 */
+#define JAMD_IWCD_AVG   1   /* outprob_cd_avg   outprob.c:356 */
+#define JAMD_IWCD_NBEST 2   /* outprob_cd_nbest outprob.c:287 */
+
+typedef struct jamd_engine jamd_engine;
+typedef struct jamd_gmm    jamd_gmm;
+typedef struct jamd_cdset  jamd_cdset;
+typedef struct jamd_dnn    jamd_dnn;
+
+/* ------------------------------------------------------------------ engine */
+int         jamd_abi_version(void);
+const char *jamd_last_error(void);
+int         jamd_device_count(void);
+
+/* Create an engine on HIP device `device`.  Builds the addlog table of
+ * make_log_tbl() (libsent/src/phmm/addlog.c:42) and the logistic table of
+ * logistic_table_build() (libsent/src/phmm/calc_dnn.c:349) on the host with the
+ * same libm expressions and uploads them.  Replaces the table part of
+ * outprob_init() (libsent/src/phmm/outprob_init.c:161). */
+int  jamd_engine_create(int device, jamd_engine **out);
+void jamd_engine_destroy(jamd_engine *e);
+int  jamd_engine_device(const jamd_engine *e);
+int  jamd_engine_sync(jamd_engine *e);
+/* Device allocation helpers for callers without their own HIP runtime. */
+int  jamd_malloc(jamd_engine *e, size_t bytes, void **dev);
+int  jamd_free(jamd_engine *e, void *dev);
+int  jamd_memcpy_h2d(jamd_engine *e, void *dev, const void *host, size_t bytes);
+int  jamd_memcpy_d2h(jamd_engine *e, void *host, const void *dev, size_t bytes);
+
+/* --------------------------------------------------------------- GMM model */
+/* Flattened HTK_HMM_INFO (libsent/include/sent/htk_hmm.h:330-420) after
+ * outprob_init() has inverted the variances (outprob_init.c:74-79):
+ *   densities   mean[ndens][veclen], ivar[ndens][veclen], gconst[ndens]
+ *               (HTK_HMM_Dens, htk_hmm.h:120-131; gconst as computed by
+ *               libsent/src/hmminfo/rdhmmdef_dens.c:39-48)
+ *   states      st_off[nstate+1] into the entry arrays, in HTK_HMM_State.id order
+ *   entries     ent_dens[nentry] (density index, -1 for a NULL density),
+ *               ent_logw[nentry] (bweight = ln w, rdhmmdef_mpdf.c:189)
+ *   st_book     [nstate] codebook id of a tied-mixture state (its entries list
+ *               the GCODEBOOK's densities in codebook order, htk_hmm.h:196-201),
+ *               -1 for a plain state; may be NULL when nbook == 0.
+ * Single-stream models only (nstream must be 1; multi-stream -> JAMD_EINVAL). */
+typedef struct {
+  int nstate, veclen, ndens, nentry, nbook, nstream;
+  const float *mean, *ivar, *gconst;
+  const int   *st_off;
+  const int   *ent_dens;
+  const float *ent_logw;
+  const int   *st_book;
+} jamd_gmm_desc;
+
+/* Replaces outprob_init()'s selection of compute_gaussset/calc_outprob
+ * (outprob_init.c:99-147): gprune = JAMD_GPRUNE_*, gprune_num = -tmix /
+ * OP_gprune_num (ignored for NONE).  Uploads the model in the engine's device
+ * layout (DESIGN.md "HBM layout"). */
+int  jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gprune_num,
+                     jamd_gmm **out);
+void jamd_gmm_destroy(jamd_gmm *g);
+int  jamd_gmm_nstate(const jamd_gmm *g);
+int  jamd_gmm_veclen(const jamd_gmm *g);
+
+/* Score every state for frames 0..T-1: out[t][s] = log10 b_s(o_t), the values
+ * outprob_state() (libsent/src/phmm/outprob.c:184) would cache in
+ * outprob_cache[t][s] via calc_mix() (calc_mix.c:41) / calc_tied_mix()
+ * (calc_tied_mix.c:162) with the batch loop outprob.c:230-242.
+ * frames is [T][veclen] row-major, out is [T][nstate] row-major (the
+ * outprob_cache layout, outprob.c:127-129). */
+int  jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out,
+                          void *stream);
+/* Same with host buffers (packs HTK_Param rows, uploads, scores, downloads). */
+int  jamd_gmm_outprob_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
+/* Tied-mixture codebook cache of calc_tied_mix.c:189-227 for inspection: top-N
+ * (score,id) per (frame, codebook), descending, as MIXCACHE (hmm_calc.h:57-60).
+ * dev_score/dev_id are [T][nbook][gprune_num]; dev_num [T][nbook]. */
+int  jamd_gmm_tmix_cache_dev(jamd_gmm *g, const float *dev_frames, int T,
+                             float *dev_score, int *dev_id, int *dev_num, void *stream);
+/* Name of the kernel variant the last outprob call used ("tile<39,2>", ...). */
+const char *jamd_gmm_last_kernel(const jamd_gmm *g);
+
+/* ------------------------------------------------- pseudo-phone state sets */
+/* CD_State_Set table (htk_hmm.h:249-253): set i = states[set_off[i]..set_off[i+1]).
+ * Replaces outprob_cd() (outprob.c:383): cd[t][i] from one [T][nstate] score
+ * matrix. nbest = hmminfo->cdmax_num. */
+int  jamd_cdset_create(jamd_engine *e, int nset, const int *set_off, const int *states,
+                       int method, int nbest, jamd_cdset **out);
+void jamd_cdset_destroy(jamd_cdset *c);
+int  jamd_cdset_outprob_dev(jamd_cdset *c, const float *dev_scores, int T, int nstate,
+                            float *dev_cd, void *stream);
+
+/* --------------------------------------------------------------------- DNN */
+/* Flattened DNNData (libsent/include/sent/dnn.h:41-74): nlayer = hnum + 1
+ * affine layers, dims[0..nlayer] = inputnodenum, hidden..., outputnodenum;
+ * w[l] is [dims[l+1]][dims[l]] row-major exactly as dnn_layer_load() reads the
+ * .npy (calc_dnn.c:225-335), b[l] is [dims[l+1]]; state_prior[dims[nlayer]] as
+ * stored after dnn_setup() (log10 already applied when state_prior_log10nize,
+ * calc_dnn.c:699-703). */
+typedef struct {
+  int nlayer;
+  const int *dims;
+  const float *const *w;
+  const float *const *b;
+  const float *state_prior;
+} jamd_dnn_desc;
+
+int  jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out);
+void jamd_dnn_destroy(jamd_dnn *n);
+/* Replaces dnn_calc_outprob() (calc_dnn.c:774) for a batch of frames:
+ * out[t][i] = INV_LOG_TEN*(x_i - addlog_array(x)) - state_prior[i]
+ * (calc_dnn.c:858-866).  frames [T][dims[0]] already spliced
+ * (libjulius/src/wav2mfcc.c:163-169 does the splicing upstream). */
+int  jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev_out,
+                          void *stream);
+int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JULIUS_AMD_H */

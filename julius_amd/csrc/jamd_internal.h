@@ -1,0 +1,69 @@
+// jamd_internal.h -- shared internals of the gfx950 engine (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "julius_amd.h"
+
+// addlog.c:28-30
+#define JAMD_TBLSIZE 500000
+#define JAMD_TMAG 33333.3333
+// stddefs.h:176 / :111 (double constants in the reference)
+#define JAMD_LOG_ADDMIN (-13.815510558)
+#define JAMD_INV_LOG_TEN (.434294482)
+// calc_dnn.c:344-347
+#define JAMD_LOGISTIC_FACTOR 20000
+#define JAMD_LOGISTIC_MAX (16 * JAMD_LOGISTIC_FACTOR)
+
+void jamd_set_error(const char *fmt, ...);
+
+#define JAMD_HIP(call)                                                            \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      jamd_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                     __FILE__, __LINE__);                                         \
+      return (e_ == hipErrorOutOfMemory) ? JAMD_ENOMEM : JAMD_ENODEV;             \
+    }                                                                             \
+  } while (0)
+
+struct jamd_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;   // engine-owned stream
+  float *d_addlog = nullptr;      // [JAMD_TBLSIZE]
+  float *d_logistic = nullptr;    // [JAMD_LOGISTIC_MAX + 1]
+  float addmin_f = 0.f;           // smallest float >= LOG_ADDMIN (exact float form of the double compare)
+  int num_cu = 256;
+};
+
+struct jamd_gmm {
+  jamd_engine *eng = nullptr;
+  int S = 0, D = 0, E = 0, nbook = 0;
+  int gprune = 0, gprune_num = 0;
+  int rec = 0;                    // floats per entry record
+  int maxmix = 0;
+  bool uniform_mix = false;       // every state has the same entry count
+  // device model
+  float *d_rec = nullptr;         // [E][rec]: mean[D], ivar[D], gconst, logw
+  int *d_st_off = nullptr;        // [S+1]
+  // tied-mixture
+  int *d_st_book = nullptr;       // [S]
+  int *d_book_off = nullptr;      // [nbook+1] into book records
+  float *d_book_rec = nullptr;    // [sum book sizes][rec] (logw unused)
+  float *d_ent_logw = nullptr;    // [E] entry weights (tied states index by codebook position)
+  int maxbook = 0;
+  std::vector<int> h_book_off;
+  // scratch
+  float *d_frames = nullptr; size_t frames_cap = 0;
+  float *d_out = nullptr; size_t out_cap = 0;
+  float *d_tm_score = nullptr; int *d_tm_id = nullptr; int *d_tm_num = nullptr; size_t tm_cap = 0;
+  char last_kernel[64] = {0};
+};
+
+static inline hipStream_t jamd_stream(jamd_engine *e, void *s) {
+  return s ? (hipStream_t)s : e->stream;
+}

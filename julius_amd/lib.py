@@ -1,0 +1,188 @@
+"""ctypes binding of the C ABI in include/julius_amd.h (libjulius_amd.so).
+
+This module is plumbing for tests and bench.py; the product is the shared
+library.  There is NO fallback: if the HIP library is missing, or no gfx950
+device is present when an engine is created, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libjulius_amd.so"
+
+LOG_ZERO = -1000000.0
+GPRUNE_NONE, GPRUNE_SAFE = 0, 1
+IWCD_MAX, IWCD_AVG, IWCD_NBEST = 0, 1, 2
+
+
+class JamdError(RuntimeError):
+    pass
+
+
+class GmmDesc(C.Structure):
+    _fields_ = [
+        ("nstate", C.c_int), ("veclen", C.c_int), ("ndens", C.c_int),
+        ("nentry", C.c_int), ("nbook", C.c_int), ("nstream", C.c_int),
+        ("mean", C.c_void_p), ("ivar", C.c_void_p), ("gconst", C.c_void_p),
+        ("st_off", C.c_void_p), ("ent_dens", C.c_void_p), ("ent_logw", C.c_void_p),
+        ("st_book", C.c_void_p),
+    ]
+
+
+class DnnDesc(C.Structure):
+    _fields_ = [
+        ("nlayer", C.c_int), ("dims", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p),
+        ("state_prior", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libjulius_amd.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise JamdError(
+            f"{LIB_PATH} not found: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C julius_amd/csrc)")
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    P = C.POINTER
+    sig = {
+        "jamd_abi_version": (ci, []),
+        "jamd_last_error": (C.c_char_p, []),
+        "jamd_device_count": (ci, []),
+        "jamd_engine_create": (ci, [ci, P(vp)]),
+        "jamd_engine_destroy": (None, [vp]),
+        "jamd_engine_device": (ci, [vp]),
+        "jamd_engine_sync": (ci, [vp]),
+        "jamd_malloc": (ci, [vp, C.c_size_t, P(vp)]),
+        "jamd_free": (ci, [vp, vp]),
+        "jamd_memcpy_h2d": (ci, [vp, vp, vp, C.c_size_t]),
+        "jamd_memcpy_d2h": (ci, [vp, vp, vp, C.c_size_t]),
+        "jamd_gmm_create": (ci, [vp, P(GmmDesc), ci, ci, P(vp)]),
+        "jamd_gmm_destroy": (None, [vp]),
+        "jamd_gmm_nstate": (ci, [vp]),
+        "jamd_gmm_veclen": (ci, [vp]),
+        "jamd_gmm_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
+        "jamd_gmm_outprob_host": (ci, [vp, vp, ci, vp]),
+        "jamd_gmm_tmix_cache_dev": (ci, [vp, vp, ci, vp, vp, vp, vp]),
+        "jamd_gmm_last_kernel": (C.c_char_p, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    """Every `jamd_*` function declared in include/julius_amd.h."""
+    import re
+    hdr = (_PKG.parent / "include" / "julius_amd.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(jamd_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise JamdError(f"{what} failed ({rc}): {load().jamd_last_error().decode()}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        _check(lib.jamd_engine_create(device, C.byref(h)), "jamd_engine_create")
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        _check(load().jamd_engine_sync(self.h), "jamd_engine_sync")
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Gmm:
+    """Device-resident flattened GMM acoustic model (jamd_gmm)."""
+
+    def __init__(self, eng: Engine, model: dict, gprune: int = GPRUNE_NONE, gprune_num: int = 0):
+        lib = load()
+        self.eng = eng
+        self._keep = {
+            "mean": _f32(model["mean"]), "ivar": _f32(model["ivar"]), "gconst": _f32(model["gconst"]),
+            "st_off": _i32(model["st_off"]), "ent_dens": _i32(model["ent_dens"]),
+            "ent_logw": _f32(model["ent_logw"]),
+        }
+        st_book = model.get("st_book")
+        nbook = int(model.get("nbook", 0))
+        if st_book is not None:
+            self._keep["st_book"] = _i32(st_book)
+        d = GmmDesc()
+        d.nstate = len(self._keep["st_off"]) - 1
+        d.veclen = self._keep["mean"].shape[1]
+        d.ndens = self._keep["mean"].shape[0]
+        d.nentry = len(self._keep["ent_dens"])
+        d.nbook = nbook
+        d.nstream = int(model.get("nstream", 1))
+        for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+            setattr(d, k, self._keep[k].ctypes.data)
+        d.st_book = self._keep["st_book"].ctypes.data if "st_book" in self._keep else None
+        h = C.c_void_p()
+        _check(lib.jamd_gmm_create(eng.h, C.byref(d), gprune, gprune_num, C.byref(h)), "jamd_gmm_create")
+        self.h = h
+        self.S, self.D = d.nstate, d.veclen
+        self.nbook, self.gprune_num = nbook, gprune_num
+
+    def outprob_host(self, frames: np.ndarray) -> np.ndarray:
+        fr = _f32(frames)
+        T = fr.shape[0]
+        assert fr.ndim == 2 and fr.shape[1] == self.D
+        out = np.empty((T, self.S), dtype=np.float32)
+        _check(load().jamd_gmm_outprob_host(self.h, fr.ctypes.data, T, out.ctypes.data),
+               "jamd_gmm_outprob_host")
+        return out
+
+    def outprob_dev(self, dev_frames: int, T: int, dev_out: int, stream: int = 0):
+        _check(load().jamd_gmm_outprob_dev(self.h, dev_frames, T, dev_out, stream or None),
+               "jamd_gmm_outprob_dev")
+
+    def last_kernel(self) -> str:
+        return load().jamd_gmm_last_kernel(self.h).decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,126 @@
+/*
+ * jamd_flatten.c -- HTK_HMM_INFO -> jamd_gmm_desc (see jamd_flatten.h).
+ *
+ * Structures walked (all reference headers, nothing redefined here):
+ *   HTK_HMM_INFO.ststart / totalstatenum      libsent/include/sent/htk_hmm.h:337,398
+ *   HTK_HMM_State {nstream, pdf[], id, next}  htk_hmm.h:163-170
+ *   HTK_HMM_PDF {tmix, mix_num, b, bweight}   htk_hmm.h:151-159
+ *   GCODEBOOK {num, d[], id}                  htk_hmm.h:196-201
+ *   HTK_HMM_Dens {mean, var->vec, gconst}     htk_hmm.h:120-131
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "jamd_flatten.h"
+
+/* open-addressing pointer -> index map for density de-duplication */
+typedef struct { const void **key; int *val; size_t cap; } pmap;
+
+static size_t phash(const void *p, size_t cap) {
+  size_t x = (size_t)p;
+  x ^= x >> 17; x *= (size_t)0x9E3779B97F4A7C15ull; x ^= x >> 29;
+  return x & (cap - 1);
+}
+static int pmap_get(pmap *m, const void *k, int newval) {
+  size_t i = phash(k, m->cap);
+  while (m->key[i] != NULL && m->key[i] != k) i = (i + 1) & (m->cap - 1);
+  if (m->key[i] == NULL) { m->key[i] = k; m->val[i] = newval; return -1; }
+  return m->val[i];
+}
+
+int jamd_flatten_hmminfo(HTK_HMM_INFO *hmminfo, jamd_flat_gmm *out)
+{
+  HTK_HMM_State *st;
+  int S = hmminfo->totalstatenum;
+  int D = hmminfo->opt.vec_size;
+  int E = 0, G = 0, s, i;
+  pmap m;
+
+  memset(out, 0, sizeof(*out));
+  if (hmminfo->opt.stream_info.num != 1) return JAMD_EINVAL;
+  if (!hmminfo->variance_inversed) return JAMD_EINVAL;
+
+  /* pass 1: count entries and distinct densities */
+  for (st = hmminfo->ststart; st; st = st->next) {
+    HTK_HMM_PDF *p = st->pdf[0];
+    E += p->tmix ? ((GCODEBOOK *)p->b)->num : p->mix_num;
+  }
+  m.cap = 64; while (m.cap < (size_t)(2 * E + 16)) m.cap <<= 1;
+  m.key = (const void **)calloc(m.cap, sizeof(void *));
+  m.val = (int *)malloc(m.cap * sizeof(int));
+  out->st_off = (int *)malloc(sizeof(int) * (S + 1));
+  out->ent_dens = (int *)malloc(sizeof(int) * (E ? E : 1));
+  out->ent_logw = (float *)malloc(sizeof(float) * (E ? E : 1));
+  out->st_book = (int *)malloc(sizeof(int) * S);
+  out->mean = (float *)malloc(sizeof(float) * (size_t)(E ? E : 1) * D);
+  out->ivar = (float *)malloc(sizeof(float) * (size_t)(E ? E : 1) * D);
+  out->gconst = (float *)malloc(sizeof(float) * (E ? E : 1));
+  for (s = 0; s <= S; s++) out->st_off[s] = -1;
+
+  /* pass 2: states are visited in list order but placed by id; entry ranges
+   * are assigned in id order afterwards, so first record sizes */
+  {
+    int *cnt = (int *)calloc(S, sizeof(int));
+    for (st = hmminfo->ststart; st; st = st->next) {
+      HTK_HMM_PDF *p = st->pdf[0];
+      if (st->id < 0 || st->id >= S) { free(cnt); free(m.key); free(m.val); return JAMD_EINVAL; }
+      cnt[st->id] = p->tmix ? ((GCODEBOOK *)p->b)->num : p->mix_num;
+    }
+    out->st_off[0] = 0;
+    for (s = 0; s < S; s++) out->st_off[s + 1] = out->st_off[s] + cnt[s];
+    free(cnt);
+  }
+  for (st = hmminfo->ststart; st; st = st->next) {
+    HTK_HMM_PDF *p = st->pdf[0];
+    HTK_HMM_Dens **dl;
+    int n, e0 = out->st_off[st->id];
+    if (p->tmix) {
+      GCODEBOOK *bk = (GCODEBOOK *)p->b;
+      dl = bk->d; n = bk->num;
+      out->st_book[st->id] = bk->id;
+      if (n > out->book_size_max) out->book_size_max = n;
+    } else {
+      dl = p->b; n = p->mix_num;
+      out->st_book[st->id] = -1;
+    }
+    for (i = 0; i < n; i++) {
+      HTK_HMM_Dens *d = dl[i];
+      int gi = -1;
+      if (d != NULL) {
+        if (d->meanlen != D || d->var->len != D) { free(m.key); free(m.val); return JAMD_EINVAL; }
+        gi = pmap_get(&m, d, G);
+        if (gi < 0) {
+          gi = G++;
+          memcpy(out->mean + (size_t)gi * D, d->mean, sizeof(float) * D);
+          memcpy(out->ivar + (size_t)gi * D, d->var->vec, sizeof(float) * D);
+          out->gconst[gi] = d->gconst;
+        }
+      }
+      out->ent_dens[e0 + i] = gi;
+      out->ent_logw[e0 + i] = p->bweight[i];
+    }
+  }
+  free(m.key); free(m.val);
+
+  out->desc.nstate = S; out->desc.veclen = D; out->desc.ndens = G; out->desc.nentry = E;
+  out->desc.nbook = hmminfo->is_tied_mixture ? hmminfo->codebooknum : 0;
+  out->desc.nstream = 1;
+  out->desc.mean = out->mean; out->desc.ivar = out->ivar; out->desc.gconst = out->gconst;
+  out->desc.st_off = out->st_off; out->desc.ent_dens = out->ent_dens;
+  out->desc.ent_logw = out->ent_logw; out->desc.st_book = out->st_book;
+  return JAMD_OK;
+}
+
+void jamd_flat_gmm_free(jamd_flat_gmm *f)
+{
+  free(f->mean); free(f->ivar); free(f->gconst); free(f->st_off);
+  free(f->ent_dens); free(f->ent_logw); free(f->st_book);
+  memset(f, 0, sizeof(*f));
+}
+
+float *jamd_pack_param(const HTK_Param *param, int t0, int t1)
+{
+  int D = param->veclen, t;
+  float *buf = (float *)malloc(sizeof(float) * (size_t)(t1 - t0 > 0 ? t1 - t0 : 1) * D);
+  for (t = t0; t < t1; t++) memcpy(buf + (size_t)(t - t0) * D, param->parvec[t], sizeof(float) * D);
+  return buf;
+}

@@ -1,0 +1,47 @@
+/*
+ * jamd_flatten.h -- reference-side half of the drop-in boundary.
+ *
+ * These functions are compiled INSIDE the Julius tree (against the reference's
+ * own <sent/...> / <julius/...> headers) and turn the pointer-linked model
+ * structures the unmodified loaders build into the flat arrays that the C ABI
+ * of include/julius_amd.h takes.  See INTEGRATION.md.
+ */
+#ifndef JAMD_FLATTEN_H
+#define JAMD_FLATTEN_H
+
+#include <sent/stddefs.h>
+#include <sent/htk_hmm.h>
+#include <sent/htk_param.h>
+#include <sent/hmm.h>
+#include <sent/hmm_calc.h>
+#include "julius_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Owned flat copy of an HTK_HMM_INFO's state pool (all arrays malloc'ed). */
+typedef struct {
+  jamd_gmm_desc desc;       /* points into the arrays below */
+  float *mean, *ivar, *gconst;
+  int *st_off, *ent_dens;
+  float *ent_logw;
+  int *st_book;
+  int book_size_max;
+} jamd_flat_gmm;
+
+/* Walk hmminfo->ststart (HTK_HMM_State.id order), de-duplicate HTK_HMM_Dens by
+ * pointer, and fill `out`.  Variances must already be inverted
+ * (hmminfo->variance_inversed, outprob_init.c:74-79).  Returns 0 or JAMD_EINVAL
+ * (multi-stream model, inconsistent vector lengths). */
+int  jamd_flatten_hmminfo(HTK_HMM_INFO *hmminfo, jamd_flat_gmm *out);
+void jamd_flat_gmm_free(jamd_flat_gmm *f);
+
+/* Pack HTK_Param rows (each parvec[t] is a separate allocation,
+ * libsent/src/anlz/param_malloc.c:52-77) into one [T][veclen] block. */
+float *jamd_pack_param(const HTK_Param *param, int t0, int t1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""Seeded synthetic models and inputs for tests and bench.py.
+
+Everything here is *data preparation*: numpy restatements of what the
+reference's model loader leaves in memory (inverse variances, gconst, ln
+weights), plus writers for the HTK text/binary formats so that the very same
+model can be loaded by the compiled reference (oracle/_ref) for parity pinning.
+
+Reference formulas followed:
+  ivar   = 1.0/var in double, stored float   libsent/src/hmminfo/rdhmmdef.c:162-173
+  gconst = (float)(D*LOGTPI) then += (float)log(var_d) in float, d ascending
+                                              libsent/src/hmminfo/rdhmmdef_dens.c:39-48
+  ln w   = (float)log(w)                      libsent/src/hmminfo/rdhmmdef_mpdf.c:189
+"""
+from __future__ import annotations
+
+import struct
+from pathlib import Path
+
+import numpy as np
+
+LOGTPI = 1.83787706640935  # libsent/include/sent/stddefs.h:105
+MFCC_E_D_A = 6 | 0x40 | 0x100 | 0x200  # htk_defs: MFCC + _E + _D + _A
+PARM_USER = 9
+
+
+def gconst_of(var: np.ndarray) -> np.ndarray:
+    """update_gconst(): sequential float32 accumulation over dimensions."""
+    var = np.asarray(var, dtype=np.float32)
+    D = var.shape[-1]
+    g = np.full(var.shape[:-1], np.float32(D * LOGTPI), dtype=np.float32)
+    for d in range(D):
+        g = (g + np.log(var[..., d].astype(np.float64)).astype(np.float32)).astype(np.float32)
+    return g
+
+
+def make_gmm(S=3000, M=16, D=39, seed=0, ragged=False, null_frac=0.0):
+    """Plain (non tied-mixture) GMM state pool: S states x M diagonal Gaussians.
+
+    ragged=True gives every state its own mixture count in [1, M];
+    null_frac>0 replaces that fraction of entries by NULL densities.
+    Returns the flat layout of include/julius_amd.h::jamd_gmm_desc plus the raw
+    `var` and `weight` arrays used by the HTK writer.
+    """
+    rng = np.random.default_rng(seed)
+    if ragged:
+        nmix = rng.integers(1, M + 1, size=S)
+    else:
+        nmix = np.full(S, M, dtype=np.int64)
+    st_off = np.zeros(S + 1, dtype=np.int32)
+    st_off[1:] = np.cumsum(nmix)
+    E = int(st_off[-1])
+    # state centres spread out so different states win on different frames
+    centre = rng.normal(0.0, 1.0, size=(S, D)).astype(np.float32)
+    owner = np.repeat(np.arange(S), nmix)
+    mean = (centre[owner] + rng.normal(0.0, 0.5, size=(E, D))).astype(np.float32)
+    var = rng.uniform(0.5, 2.0, size=(E, D)).astype(np.float32)
+    weight = np.empty(E, dtype=np.float64)
+    for s in range(S):
+        n = int(nmix[s])
+        w = rng.dirichlet(np.full(n, 2.0)) if n > 1 else np.ones(1)
+        # weights as they would be parsed back from a 6-significant-digit text file
+        weight[st_off[s]:st_off[s + 1]] = np.array([float(f"{x:.6e}") for x in np.maximum(w, 1e-5)])
+    ent_dens = np.arange(E, dtype=np.int32)
+    if null_frac > 0:
+        kill = rng.random(E) < null_frac
+        kill[st_off[:-1]] = False  # keep the first mixture of every state
+        ent_dens[kill] = -1
+    model = dict(
+        mean=mean,
+        var=var,
+        ivar=(1.0 / var.astype(np.float64)).astype(np.float32),
+        gconst=gconst_of(var),
+        weight=weight,
+        st_off=st_off,
+        ent_dens=ent_dens,
+        ent_logw=np.log(weight).astype(np.float32),
+        st_book=None,
+        nbook=0,
+        nstream=1,
+        centre=centre,
+    )
+    # a <Mixture> that is absent from the file leaves b[i]=NULL, bweight=LOG_ZERO
+    # (libsent/src/hmminfo/rdhmmdef_mpdf.c:170-174)
+    model["ent_logw"][ent_dens < 0] = np.float32(-1000000.0)
+    return model
+
+
+def make_tied_gmm(S=120, nbook=3, K=64, D=39, seed=0):
+    """Tied-mixture model: nbook codebooks of K Gaussians, every state is a
+    weight vector over one codebook (HTK <TMix>)."""
+    rng = np.random.default_rng(seed)
+    G = nbook * K
+    mean = rng.normal(0.0, 1.5, size=(G, D)).astype(np.float32)
+    var = rng.uniform(0.5, 2.0, size=(G, D)).astype(np.float32)
+    st_book = rng.integers(0, nbook, size=S).astype(np.int32)
+    st_book[:nbook] = np.arange(nbook)  # every codebook used
+    st_off = (np.arange(S + 1) * K).astype(np.int32)
+    ent_dens = np.concatenate([np.arange(b * K, (b + 1) * K) for b in st_book]).astype(np.int32)
+    weight = np.empty(S * K, dtype=np.float64)
+    for s in range(S):
+        w = rng.dirichlet(np.full(K, 0.3))
+        weight[s * K:(s + 1) * K] = np.array([float(f"{x:.6e}") for x in np.maximum(w, 1e-7)])
+    return dict(
+        mean=mean, var=var, ivar=(1.0 / var.astype(np.float64)).astype(np.float32),
+        gconst=gconst_of(var), weight=weight, st_off=st_off, ent_dens=ent_dens,
+        ent_logw=np.log(weight).astype(np.float32), st_book=st_book, nbook=nbook, nstream=1,
+        book_size=K,
+    )
+
+
+def make_frames(model, T=1000, seed=1, noise=1.0):
+    """Synthetic 'MFCC' frames: a random walk over state centres plus noise, so
+    likelihood rankings vary over time (non-degenerate best paths)."""
+    rng = np.random.default_rng(seed)
+    D = model["mean"].shape[1]
+    if "centre" in model and model["centre"] is not None:
+        S = model["centre"].shape[0]
+        seg = rng.integers(0, S, size=(T + 9) // 10)
+        base = model["centre"][np.repeat(seg, 10)[:T]]
+    else:
+        base = np.zeros((T, D), dtype=np.float32)
+    return (base + rng.normal(0.0, noise, size=(T, D))).astype(np.float32)
+
+
+# --------------------------------------------------------------------- HTK I/O
+def write_htk_param(path, frames: np.ndarray, parmkind=MFCC_E_D_A, samp_period=100000):
+    """HTK parameter file: 12-byte big-endian header + big-endian float32 rows
+    (reader: libsent/src/anlz/rdparam.c:110-170)."""
+    frames = np.ascontiguousarray(frames, dtype=np.float32)
+    T, D = frames.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack(">iihh", T, samp_period, D * 4, parmkind))
+        f.write(frames.astype(">f4").tobytes())
+
+
+def read_htk_param(path):
+    raw = Path(path).read_bytes()
+    T, period, size, kind = struct.unpack(">iihh", raw[:12])
+    D = size // 4
+    return np.frombuffer(raw[12:12 + T * size], dtype=">f4").reshape(T, D).astype(np.float32), kind
+
+
+def _vec(v):
+    return " ".join(f"{float(x):.9e}" for x in v)
+
+
+def write_hmmdefs(path, model, phones=None, trans=None, kind="MFCC_E_D_A", state_names=None):
+    """HTK ascii hmmdefs holding the model's states as ~s macros (state id =
+    order of appearance) and 3-state left-to-right ~h models.
+
+    phones: list of (name, (s1, s2, s3)) physical HMMs; default = monophones
+    "p0".."pN" covering the state pool in order (S must be a multiple of 3).
+    """
+    S = len(model["st_off"]) - 1
+    D = model["mean"].shape[1]
+    tied = model.get("st_book") is not None and model.get("nbook", 0) > 0
+    if phones is None:
+        assert S % 3 == 0, "default topology needs S % 3 == 0"
+        phones = [(f"p{i}", (3 * i, 3 * i + 1, 3 * i + 2)) for i in range(S // 3)]
+    if trans is None:
+        trans = np.array([[0, 1, 0, 0, 0], [0, .6, .4, 0, 0], [0, 0, .6, .4, 0],
+                          [0, 0, 0, .7, .3], [0, 0, 0, 0, 0]], dtype=np.float64)
+    L = []
+    L.append(f"~o <STREAMINFO> 1 {D} <VECSIZE> {D} <NULLD> <{kind}> <DIAGC>")
+    if tied:
+        K = model["book_size"]
+        for b in range(model["nbook"]):
+            for k in range(K):
+                g = b * K + k
+                L.append(f'~m "book{b}_{k + 1}"')
+                L.append(f"<MEAN> {D}\n {_vec(model['mean'][g])}")
+                L.append(f"<VARIANCE> {D}\n {_vec(model['var'][g])}")
+    for s in range(S):
+        e0, e1 = int(model["st_off"][s]), int(model["st_off"][s + 1])
+        name = state_names[s] if state_names else f"s{s}"
+        L.append(f'~s "{name}"')
+        if tied:
+            b = int(model["st_book"][s])
+            L.append(f"<NUMMIXES> {e1 - e0}")
+            L.append(f"<TMIX> book{b}_ " + " ".join(f"{w:.6e}" for w in model["weight"][e0:e1]))
+        else:
+            L.append(f"<NUMMIXES> {e1 - e0}")
+            for m, e in enumerate(range(e0, e1)):
+                if model["ent_dens"][e] < 0:
+                    continue  # a missing <MIXTURE> leaves a NULL density in the reference
+                L.append(f"<MIXTURE> {m + 1} {model['weight'][e]:.6e}")
+                L.append(f"<MEAN> {D}\n {_vec(model['mean'][model['ent_dens'][e]])}")
+                L.append(f"<VARIANCE> {D}\n {_vec(model['var'][model['ent_dens'][e]])}")
+    L.append('~t "t0"\n<TRANSP> 5')
+    for row in trans:
+        L.append(" " + " ".join(f"{x:.6e}" for x in row))
+    for name, (a, b, c) in phones:
+        sn = (lambda i: state_names[i]) if state_names else (lambda i: f"s{i}")
+        L.append(f'~h "{name}"\n<BEGINHMM>\n<NUMSTATES> 5')
+        L.append(f'<STATE> 2\n~s "{sn(a)}"\n<STATE> 3\n~s "{sn(b)}"\n<STATE> 4\n~s "{sn(c)}"')
+        L.append('~t "t0"\n<ENDHMM>')
+    Path(path).write_text("\n".join(L) + "\n")
+    return phones
+
+
+# ------------------------------------------------------------------------ DNN
+def make_dnn(dims=(528, 2048, 2048, 2048, 2048, 2048, 2048, 4000), seed=0):
+    """Random-init DNN of the ENVR-v5.4 shape (BASELINE.json configs[3]):
+    W[l] ~ N(0, 1/sqrt(in)) stored [out][in], b ~ N(0, 0.1), Dirichlet prior
+    stored as log10 (state_prior_log10nize, calc_dnn.c:699-703)."""
+    rng = np.random.default_rng(seed)
+    w, b = [], []
+    for l in range(len(dims) - 1):
+        w.append((rng.standard_normal((dims[l + 1], dims[l])) / np.sqrt(dims[l])).astype(np.float32))
+        b.append((0.1 * rng.standard_normal(dims[l + 1])).astype(np.float32))
+    p = rng.dirichlet(np.full(dims[-1], 5.0)).astype(np.float32)
+    prior = np.log10(p.astype(np.float64)).astype(np.float32)
+    return dict(dims=np.asarray(dims, dtype=np.int32), w=w, b=b, prior=prior, prior_lin=p)
+
+
+def write_npy(path, a):
+    """NPY v1 '<f4' C-order, the only form load_npy() accepts (calc_dnn.c:225-335)."""
+    np.save(path, np.ascontiguousarray(a, dtype="<f4"))

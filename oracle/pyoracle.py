@@ -1,0 +1,264 @@
+"""ctypes access to the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Two libraries live under oracle/:
+  liboracle.so        our CPU restatement (jamd_oracle_*.c)           -> class Oracle
+  _ref/libjref.so     the compiled, unmodified reference + taps       -> class Ref
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module, and only as the checker / reported baseline.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ORACLE_SO = HERE / "liboracle.so"
+REF_SO = HERE / "_ref" / "libjref.so"
+
+GPRUNE_NONE, GPRUNE_SAFE = 0, 1
+# reference enum (libsent/include/sent/hmm_calc.h:45)
+REF_GPRUNE = {"none": 1, "safe": 2, "heu": 3, "beam": 4}
+IWCD_MAX, IWCD_AVG, IWCD_NBEST = 0, 1, 2
+# reference enum iwcd_type (libsent/include/sent/htk_hmm.h:85-90)
+REF_IWCD = {"max": 1, "avg": 2, "nbest": 3}
+DNN_SCALAR, DNN_FMA, DNN_AVX, DNN_SSE = 0, 1, 2, 3
+
+
+def build(ref: bool = True):
+    """(Re)build liboracle.so and, when /root/reference exists, _ref/libjref.so."""
+    subprocess.run(["make", "-s", "-C", str(HERE), "oracle"], check=True)
+    if ref:
+        subprocess.run(["make", "-s", "-j8", "-C", str(HERE), "ref"], check=True)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self):
+        if not ORACLE_SO.exists():
+            build(ref=False)
+        self.lib = lib = C.CDLL(str(ORACLE_SO))
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        lib.jo_log_tbl.restype = vp
+        lib.jo_log_tbl_size.restype = ci
+        lib.jo_logistic_tbl.restype = vp
+        lib.jo_logistic_tbl_size.restype = ci
+        lib.jo_addlog_array.restype = cf
+        lib.jo_addlog_array.argtypes = [vp, ci]
+        lib.jo_addlog.restype = cf
+        lib.jo_addlog.argtypes = [cf, cf]
+        lib.jo_logistic.restype = cf
+        lib.jo_logistic.argtypes = [cf]
+        lib.jo_gmm_outprob.restype = ci
+        lib.jo_gmm_outprob.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp]
+        lib.jo_tmix_topn.restype = ci
+        lib.jo_tmix_topn.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, vp, ci, vp, vp, vp]
+        lib.jo_outprob_cd.restype = cf
+        lib.jo_outprob_cd.argtypes = [vp, vp, ci, ci, ci]
+        lib.jo_dnn_outprob.restype = ci
+        lib.jo_dnn_outprob.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp]
+
+    def log_tbl(self):
+        n = self.lib.jo_log_tbl_size()
+        return np.ctypeslib.as_array(C.cast(self.lib.jo_log_tbl(), C.POINTER(C.c_float)), (n,)).copy()
+
+    def logistic_tbl(self):
+        n = self.lib.jo_logistic_tbl_size()
+        return np.ctypeslib.as_array(C.cast(self.lib.jo_logistic_tbl(), C.POINTER(C.c_float)), (n,)).copy()
+
+    def addlog_array(self, a):
+        a = _f32(a)
+        return float(self.lib.jo_addlog_array(_p(a), len(a)))
+
+    def gmm_outprob(self, model, frames, gprune=GPRUNE_NONE, gprune_num=0):
+        mean, ivar, gconst = _f32(model["mean"]), _f32(model["ivar"]), _f32(model["gconst"])
+        st_off, ent_dens, ent_logw = _i32(model["st_off"]), _i32(model["ent_dens"]), _f32(model["ent_logw"])
+        nbook = int(model.get("nbook", 0) or 0)
+        st_book = _i32(model["st_book"]) if model.get("st_book") is not None else None
+        fr = _f32(frames)
+        T, D = fr.shape
+        S = len(st_off) - 1
+        out = np.empty((T, S), dtype=np.float32)
+        rc = self.lib.jo_gmm_outprob(S, D, _p(mean), _p(ivar), _p(gconst), _p(st_off), _p(ent_dens),
+                                     _p(ent_logw), _p(st_book) if st_book is not None else None,
+                                     nbook, gprune, gprune_num, _p(fr), T, _p(out))
+        assert rc == 0
+        return out
+
+    def tmix_topn(self, model, book, frames, gprune, gprune_num):
+        mean, ivar, gconst = _f32(model["mean"]), _f32(model["ivar"]), _f32(model["gconst"])
+        # a codebook's densities, in codebook order, are the entries of any state tied to it
+        s0 = int(np.nonzero(np.asarray(model["st_book"]) == book)[0][0])
+        dens = _i32(model["ent_dens"][model["st_off"][s0]:model["st_off"][s0 + 1]])
+        K = len(dens)
+        fr = _f32(frames)
+        T, D = fr.shape
+        cap = K if gprune == GPRUNE_NONE else gprune_num
+        sc = np.zeros((T, cap), dtype=np.float32)
+        ids = np.zeros((T, cap), dtype=np.int32)
+        num = np.zeros(T, dtype=np.int32)
+        self.lib.jo_tmix_topn(D, _p(mean), _p(ivar), _p(gconst), _p(dens), K, gprune, gprune_num,
+                              _p(fr), T, _p(sc), _p(ids), _p(num))
+        return sc, ids, num
+
+    def outprob_cd(self, scores, set_off, states, method, nbest):
+        scores = _f32(scores)
+        set_off, states = _i32(set_off), _i32(states)
+        T = scores.shape[0]
+        nset = len(set_off) - 1
+        out = np.empty((T, nset), dtype=np.float32)
+        for t in range(T):
+            row = scores[t]
+            for i in range(nset):
+                sub = states[set_off[i]:set_off[i + 1]]
+                out[t, i] = self.lib.jo_outprob_cd(_p(row), _p(sub), len(sub), method, nbest)
+        return out
+
+    def dnn_outprob(self, dnn, frames, simd=DNN_FMA):
+        dims = _i32(dnn["dims"])
+        nl = len(dims) - 1
+        ws = [_f32(w) for w in dnn["w"]]
+        bs = [_f32(b) for b in dnn["b"]]
+        wp = (C.c_void_p * nl)(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * nl)(*[b.ctypes.data for b in bs])
+        prior = _f32(dnn["prior"])
+        fr = _f32(frames)
+        T = fr.shape[0]
+        out = np.empty((T, int(dims[-1])), dtype=np.float32)
+        rc = self.lib.jo_dnn_outprob(nl, _p(dims), wp, bp, _p(prior), simd, _p(fr), T, _p(out))
+        assert rc == 0
+        return out
+
+
+class Ref:
+    """The compiled reference (oracle/_ref/libjref.so)."""
+
+    def __init__(self, quiet=True):
+        if not REF_SO.exists():
+            raise FileNotFoundError(
+                f"{REF_SO} missing: run `make -C oracle ref` where /root/reference is available")
+        self.lib = lib = C.CDLL(str(REF_SO))
+        vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+        lib.jref_quiet.argtypes = [ci]
+        lib.jref_am_load.restype = vp
+        lib.jref_am_load.argtypes = [C.c_char_p, C.c_char_p, ci, ci, ci, ci]
+        lib.jref_am_free.argtypes = [vp]
+        lib.jref_am_dims.argtypes = [vp, vp]
+        lib.jref_am_export.argtypes = [vp] * 8
+        lib.jref_am_outprob.restype = cd
+        lib.jref_am_outprob.argtypes = [vp, vp, ci, vp]
+        lib.jref_am_outprob_list.restype = cd
+        lib.jref_am_outprob_list.argtypes = [vp, vp, ci, vp, vp, ci, vp]
+        lib.jref_am_tmix_cache.restype = ci
+        lib.jref_am_tmix_cache.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+        lib.jref_am_outprob_cd.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+        lib.jref_am_from_flat.restype = vp
+        lib.jref_am_from_flat.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci]
+        lib.jref_quiet(1 if quiet else 0)
+
+    def am_load(self, hmmdefs, hmmlist=None, gprune="none", gprune_num=2, cdset="max", cdmax=3):
+        h = self.lib.jref_am_load(str(hmmdefs).encode(), str(hmmlist).encode() if hmmlist else None,
+                                  REF_GPRUNE[gprune], gprune_num, REF_IWCD[cdset], cdmax)
+        if not h:
+            raise RuntimeError(f"reference failed to load {hmmdefs}")
+        return RefAM(self, h)
+
+    def am_from_flat(self, model, gprune="none", gprune_num=0):
+        """Reference scoring code over in-memory structures built from flat arrays
+        (plain states only); the arrays are kept alive by the returned object."""
+        keep = dict(mean=_f32(model["mean"]), ivar=_f32(model["ivar"]), gconst=_f32(model["gconst"]),
+                    st_off=_i32(model["st_off"]), ent_dens=_i32(model["ent_dens"]),
+                    ent_logw=_f32(model["ent_logw"]))
+        S = len(keep["st_off"]) - 1
+        G, D = keep["mean"].shape
+        h = self.lib.jref_am_from_flat(S, D, G, *[_p(keep[k]) for k in
+                                                  ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw")],
+                                       REF_GPRUNE[gprune], gprune_num)
+        if not h:
+            raise RuntimeError("jref_am_from_flat failed")
+        return RefAM(self, h, flat=keep)
+
+
+class RefAM:
+    def __init__(self, ref: Ref, h, flat=None):
+        self.ref, self.h = ref, h
+        if flat is not None:  # built by jref_am_from_flat: dims come from the arrays
+            self._keep = flat
+            self.S = len(flat["st_off"]) - 1
+            self.G, self.D = flat["mean"].shape
+            self.E, self.nbook, self.is_tied = len(flat["ent_dens"]), 0, 0
+            self.from_flat = True
+            return
+        self.from_flat = False
+        dims = np.zeros(8, dtype=np.int32)
+        assert ref.lib.jref_am_dims(h, _p(dims)) == 0, "flatten failed"
+        (self.S, self.D, self.G, self.E, self.nbook, self.book_size_max, self.is_tied,
+         self.maxmix) = [int(x) for x in dims]
+
+    def export(self):
+        m = dict(
+            mean=np.empty((self.G, self.D), np.float32), ivar=np.empty((self.G, self.D), np.float32),
+            gconst=np.empty(self.G, np.float32), st_off=np.empty(self.S + 1, np.int32),
+            ent_dens=np.empty(self.E, np.int32), ent_logw=np.empty(self.E, np.float32),
+            st_book=np.empty(self.S, np.int32))
+        rc = self.ref.lib.jref_am_export(self.h, *[_p(m[k]) for k in
+                                                   ("mean", "ivar", "gconst", "st_off", "ent_dens",
+                                                    "ent_logw", "st_book")])
+        assert rc == 0
+        m["nbook"] = self.nbook
+        m["nstream"] = 1
+        if self.nbook:
+            m["book_size"] = self.book_size_max
+        else:
+            m["st_book"] = None
+        return m
+
+    def outprob(self, frames, want_out=True):
+        fr = _f32(frames)
+        T = fr.shape[0]
+        out = np.empty((T, self.S), np.float32) if want_out else None
+        sec = self.ref.lib.jref_am_outprob(self.h, _p(fr), T, _p(out) if want_out else None)
+        self.last_seconds = float(sec)
+        return out
+
+    def outprob_list(self, frames, tt, ss):
+        fr, tt, ss = _f32(frames), _i32(tt), _i32(ss)
+        out = np.empty(len(tt), np.float32)
+        self.last_seconds = float(
+            self.ref.lib.jref_am_outprob_list(self.h, _p(fr), fr.shape[0], _p(tt), _p(ss), len(tt), _p(out)))
+        return out
+
+    def tmix_cache(self, frames, book, cap):
+        fr = _f32(frames)
+        T = fr.shape[0]
+        sc = np.zeros((T, cap), np.float32)
+        ids = np.zeros((T, cap), np.int32)
+        num = np.zeros(T, np.int32)
+        got = self.ref.lib.jref_am_tmix_cache(self.h, _p(fr), T, book, _p(sc), _p(ids), _p(num))
+        assert got == cap, (got, cap)
+        return sc, ids, num
+
+    def outprob_cd(self, frames, set_off, states):
+        fr, set_off, states = _f32(frames), _i32(set_off), _i32(states)
+        nset = len(set_off) - 1
+        out = np.empty((fr.shape[0], nset), np.float32)
+        self.ref.lib.jref_am_outprob_cd(self.h, _p(fr), fr.shape[0], nset, _p(set_off), _p(states), _p(out))
+        return out
+
+    def close(self):
+        if self.h and not self.from_flat:
+            self.ref.lib.jref_am_free(self.h)
+        self.h = None

@@ -1,0 +1,252 @@
+/*
+ * ref_driver.c -- our own tap driver over the UNMODIFIED reference library.
+ * TEST INFRASTRUCTURE ONLY.  Linked with the reference objects into
+ * oracle/_ref/libjref.so (oracle/Makefile) and loaded from Python with ctypes.
+ * It only *calls* reference functions (through their public headers) and
+ * copies values out of the reference's own data structures; no reference code
+ * is reproduced here.
+ *
+ * Taps (all prefixed jref_):
+ *   AM   load an HTK hmmdefs with the reference loader, run outprob_init(),
+ *        export the flattened model (via julius_amd/shim/jamd_flatten.c, the
+ *        product-side flattening, so that code is exercised against the real
+ *        structures), score [T][S] through outprob_state()/outprob_cd().
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <sent/stddefs.h>
+#include <sent/htk_hmm.h>
+#include <sent/htk_param.h>
+#include <sent/hmm.h>
+#include <sent/hmm_calc.h>
+#include <sent/util.h>
+
+#include "../julius_amd/shim/jamd_flatten.h"
+
+typedef struct {
+  HTK_HMM_INFO *hmminfo;
+  HMMWork wrk;
+  jamd_flat_gmm flat;
+  int have_flat;
+  HTK_HMM_State **by_id;   /* state pointer by id */
+} jref_am;
+
+static double now_sec(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+void jref_quiet(int quiet) { jlog_set_output(quiet ? NULL : stderr); }
+
+/* gprune: GPRUNE_SEL_* (1 none, 2 safe, 3 heuristic, 4 beam; hmm_calc.h:45) */
+void *jref_am_load(const char *hmmdefs, const char *hmmlist, int gprune, int gprune_num,
+                   int cdset_method, int cdmax_num)
+{
+  jref_am *a = (jref_am *)calloc(1, sizeof(jref_am));
+  HTK_HMM_State *st;
+  a->hmminfo = hmminfo_new();
+  if (!init_hmminfo(a->hmminfo, (char *)hmmdefs, (char *)hmmlist, NULL)) { free(a); return NULL; }
+  a->hmminfo->cdset_method = cdset_method;
+  a->hmminfo->cdmax_num = cdmax_num;
+  memset(&a->wrk, 0, sizeof(a->wrk));
+  if (!outprob_init(&a->wrk, a->hmminfo, NULL, 0, gprune, gprune_num, NULL)) { free(a); return NULL; }
+  a->by_id = (HTK_HMM_State **)calloc(a->hmminfo->totalstatenum, sizeof(HTK_HMM_State *));
+  for (st = a->hmminfo->ststart; st; st = st->next) a->by_id[st->id] = st;
+  return a;
+}
+
+void jref_am_free(void *h)
+{
+  jref_am *a = (jref_am *)h;
+  if (!a) return;
+  if (a->have_flat) jamd_flat_gmm_free(&a->flat);
+  outprob_free(&a->wrk);
+  hmminfo_free(a->hmminfo);
+  free(a->by_id);
+  free(a);
+}
+
+static int ensure_flat(jref_am *a)
+{
+  if (a->have_flat) return 0;
+  if (jamd_flatten_hmminfo(a->hmminfo, &a->flat) != 0) return -1;
+  a->have_flat = 1;
+  return 0;
+}
+
+/* dims: S, D, G, E, nbook, book_size_max, is_tied_mixture, maxmixturenum */
+int jref_am_dims(void *h, int *dims)
+{
+  jref_am *a = (jref_am *)h;
+  if (ensure_flat(a)) return -1;
+  dims[0] = a->flat.desc.nstate; dims[1] = a->flat.desc.veclen; dims[2] = a->flat.desc.ndens;
+  dims[3] = a->flat.desc.nentry; dims[4] = a->flat.desc.nbook; dims[5] = a->flat.book_size_max;
+  dims[6] = a->hmminfo->is_tied_mixture; dims[7] = a->hmminfo->maxmixturenum;
+  return 0;
+}
+
+int jref_am_export(void *h, float *mean, float *ivar, float *gconst, int *st_off, int *ent_dens,
+                   float *ent_logw, int *st_book)
+{
+  jref_am *a = (jref_am *)h;
+  const jamd_gmm_desc *d;
+  if (ensure_flat(a)) return -1;
+  d = &a->flat.desc;
+  memcpy(mean, d->mean, sizeof(float) * (size_t)d->ndens * d->veclen);
+  memcpy(ivar, d->ivar, sizeof(float) * (size_t)d->ndens * d->veclen);
+  memcpy(gconst, d->gconst, sizeof(float) * d->ndens);
+  memcpy(st_off, d->st_off, sizeof(int) * (d->nstate + 1));
+  memcpy(ent_dens, d->ent_dens, sizeof(int) * d->nentry);
+  memcpy(ent_logw, d->ent_logw, sizeof(float) * d->nentry);
+  memcpy(st_book, d->st_book, sizeof(int) * d->nstate);
+  return 0;
+}
+
+static HTK_Param *make_param(const float *frames, int T, int D)
+{
+  HTK_Param *p = new_param();
+  int t;
+  param_alloc(p, T, D);
+  p->samplenum = T; p->veclen = D;
+  p->header.samplenum = T; p->header.sampsize = D * sizeof(float);
+  for (t = 0; t < T; t++) memcpy(p->parvec[t], frames + (size_t)t * D, sizeof(float) * D);
+  return p;
+}
+
+/* Eager scoring: outprob_prepare() then, frame by frame, every state through
+ * outprob_state() with batch_computation on (the -outprobout path).  Returns
+ * elapsed seconds of the scoring loop (model load and param packing excluded). */
+double jref_am_outprob(void *h, const float *frames, int T, float *out)
+{
+  jref_am *a = (jref_am *)h;
+  int S = a->hmminfo->totalstatenum, D = a->hmminfo->opt.vec_size, t, s;
+  HTK_Param *p = make_param(frames, T, D);
+  double t0;
+  outprob_set_batch_computation(&a->wrk, TRUE);
+  t0 = now_sec();
+  outprob_prepare(&a->wrk, T);
+  for (t = 0; t < T; t++) {
+    /* one call triggers the all-state batch loop (outprob.c:230-242) */
+    (void)outprob_state(&a->wrk, t, a->by_id[0], p);
+    if (out) memcpy(out + (size_t)t * S, a->wrk.outprob_cache[t], sizeof(float) * S);
+  }
+  t0 = now_sec() - t0;
+  (void)s;
+  free_param(p);
+  return t0;
+}
+
+/* Lazy scoring of an explicit (t, state) list, the way the beam touches it. */
+double jref_am_outprob_list(void *h, const float *frames, int T, const int *tt, const int *ss,
+                            int n, float *out)
+{
+  jref_am *a = (jref_am *)h;
+  int D = a->hmminfo->opt.vec_size, i;
+  HTK_Param *p = make_param(frames, T, D);
+  double t0;
+  outprob_set_batch_computation(&a->wrk, FALSE);
+  t0 = now_sec();
+  outprob_prepare(&a->wrk, T);
+  for (i = 0; i < n; i++) out[i] = outprob_state(&a->wrk, tt[i], a->by_id[ss[i]], p);
+  t0 = now_sec() - t0;
+  free_param(p);
+  return t0;
+}
+
+/* Tied-mixture codebook cache after scoring frame t with state `sid`'s
+ * codebook: copies mixture_cache[t][book] (calc_tied_mix.c:189-227). */
+int jref_am_tmix_cache(void *h, const float *frames, int T, int book, float *score, int *id, int *num)
+{
+  jref_am *a = (jref_am *)h;
+  int S = a->hmminfo->totalstatenum, D = a->hmminfo->opt.vec_size, t, s, i;
+  int cap = a->wrk.OP_gprune_num;
+  HTK_Param *p = make_param(frames, T, D);
+  outprob_set_batch_computation(&a->wrk, TRUE);
+  outprob_prepare(&a->wrk, T);
+  for (t = 0; t < T; t++) {
+    (void)outprob_state(&a->wrk, t, a->by_id[0], p);
+    num[t] = a->wrk.mixture_cache_num[t][book];
+    for (i = 0; i < num[t]; i++) {
+      score[(size_t)t * cap + i] = a->wrk.mixture_cache[t][book][i].score;
+      id[(size_t)t * cap + i] = a->wrk.mixture_cache[t][book][i].id;
+    }
+  }
+  (void)S; (void)s;
+  free_param(p);
+  return cap;
+}
+
+/* outprob_cd() (outprob.c:383) for explicit state sets on every frame:
+ * sets given as CSR (set_off, states); out is [T][nset]. */
+int jref_am_outprob_cd(void *h, const float *frames, int T, int nset, const int *set_off,
+                       const int *states, float *out)
+{
+  jref_am *a = (jref_am *)h;
+  int D = a->hmminfo->opt.vec_size, t, i, k;
+  HTK_Param *p = make_param(frames, T, D);
+  outprob_set_batch_computation(&a->wrk, FALSE);
+  outprob_prepare(&a->wrk, T);
+  for (t = 0; t < T; t++) {
+    for (i = 0; i < nset; i++) {
+      CD_State_Set set;
+      int n = set_off[i + 1] - set_off[i];
+      set.s = (HTK_HMM_State **)malloc(sizeof(HTK_HMM_State *) * (n ? n : 1));
+      set.num = n; set.maxnum = n;
+      for (k = 0; k < n; k++) set.s[k] = a->by_id[states[set_off[i] + k]];
+      out[(size_t)t * nset + i] = outprob_cd(&a->wrk, t, &set, p);
+      free(set.s);
+    }
+  }
+  free_param(p);
+  return 0;
+}
+
+/* Build the reference's own in-memory model structures from flat arrays
+ * (plain states only) and run outprob_init() on them -- used to time and check
+ * the reference's scoring code at sizes where writing/parsing a 50 MB ascii
+ * hmmdefs would dominate.  Only struct fields the scoring path reads are set
+ * (hmm_calc.h / htk_hmm.h); the model cannot be used for anything else. */
+void *jref_am_from_flat(int S, int D, int G, const float *mean, const float *ivar,
+                        const float *gconst, const int *st_off, const int *ent_dens,
+                        const float *ent_logw, int gprune, int gprune_num)
+{
+  jref_am *a = (jref_am *)calloc(1, sizeof(jref_am));
+  HTK_HMM_INFO *h = hmminfo_new();
+  HTK_HMM_Dens *dens = (HTK_HMM_Dens *)calloc(G, sizeof(HTK_HMM_Dens));
+  HTK_HMM_Var *var = (HTK_HMM_Var *)calloc(G, sizeof(HTK_HMM_Var));
+  HTK_HMM_State *st = (HTK_HMM_State *)calloc(S, sizeof(HTK_HMM_State));
+  HTK_HMM_PDF *pdf = (HTK_HMM_PDF *)calloc(S, sizeof(HTK_HMM_PDF));
+  int s, g, i, maxmix = 0;
+  for (g = 0; g < G; g++) {
+    var[g].vec = (VECT *)(ivar + (size_t)g * D); var[g].len = D;
+    dens[g].mean = (VECT *)(mean + (size_t)g * D); dens[g].meanlen = D;
+    dens[g].var = &var[g]; dens[g].gconst = gconst[g];
+  }
+  for (s = 0; s < S; s++) {
+    int n = st_off[s + 1] - st_off[s];
+    if (n > maxmix) maxmix = n;
+    pdf[s].tmix = FALSE; pdf[s].stream_id = 0; pdf[s].mix_num = n;
+    pdf[s].b = (HTK_HMM_Dens **)calloc(n ? n : 1, sizeof(HTK_HMM_Dens *));
+    pdf[s].bweight = (PROB *)(ent_logw + st_off[s]);
+    for (i = 0; i < n; i++) pdf[s].b[i] = ent_dens[st_off[s] + i] >= 0 ? &dens[ent_dens[st_off[s] + i]] : NULL;
+    st[s].nstream = 1; st[s].w = NULL; st[s].id = s;
+    st[s].pdf = (HTK_HMM_PDF **)calloc(1, sizeof(HTK_HMM_PDF *));
+    st[s].pdf[0] = &pdf[s];
+    st[s].next = (s + 1 < S) ? &st[s + 1] : NULL;
+    pdf[s].next = (s + 1 < S) ? &pdf[s + 1] : NULL;
+  }
+  h->ststart = st; h->pdfstart = pdf;
+  h->opt.stream_info.num = 1; h->opt.stream_info.vsize[0] = D; h->opt.vec_size = D;
+  h->totalstatenum = S; h->maxmixturenum = maxmix; h->totalmixnum = G;
+  h->is_tied_mixture = FALSE; h->variance_inversed = TRUE; h->cdset_method = IWCD_MAX;
+  a->hmminfo = h;
+  memset(&a->wrk, 0, sizeof(a->wrk));
+  if (!outprob_init(&a->wrk, h, NULL, 0, gprune, gprune_num, NULL)) { free(a); return NULL; }
+  a->by_id = (HTK_HMM_State **)calloc(S, sizeof(HTK_HMM_State *));
+  for (s = 0; s < S; s++) a->by_id[s] = &st[s];
+  return a;   /* intentionally never freed piecewise: test/bench lifetime */
+}

@@ -1,0 +1,44 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares;
+no compute calls (there is no GPU here).  Also: no fallback -- engine creation
+must FAIL loudly without a device."""
+import subprocess
+import sys
+
+import pytest
+
+from julius_amd import lib
+
+
+def test_library_loads_and_exports_declared_symbols():
+    l = lib.load()
+    missing = [s for s in lib.declared_symbols() if not hasattr(l, s)]
+    assert not missing, f"declared in include/julius_amd.h but not exported: {missing}"
+    assert l.jamd_abi_version() == 1
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "julius_amd.h"\nint main(void){return JAMD_ABI_VERSION-1;}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(lib._PKG.parent / "include"),
+                    str(src), "-o", str(tmp_path / "t")], check=True)
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.JamdError):
+        lib.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under julius_amd/ or include/ may reference oracle/."""
+    import re
+    from pathlib import Path
+    root = lib._PKG
+    bad = []
+    for p in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.h")) + list(root.rglob("*.c")):
+        txt = p.read_text()
+        if re.search(r"(from|import)\s+oracle|liboracle|libjref|jamd_oracle", txt):
+            bad.append(str(p))
+    assert not bad, bad

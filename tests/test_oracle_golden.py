@@ -1,0 +1,67 @@
+"""CPU: the oracle restatement (oracle/jamd_oracle_am.c) against the committed
+golden fixtures, which were produced by the COMPILED REFERENCE
+(tools/make_golden.py -> oracle/_ref/libjref.so).  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import pyoracle as po
+
+
+def load(name):
+    z = np.load(GOLDEN / name)
+    m = {k: z[k] for k in z.files}
+    m["nbook"] = int(m.get("nbook", 0))
+    if "book_size" in m:
+        m["book_size"] = int(m["book_size"])
+    m.setdefault("st_book", None)
+    return m
+
+
+def test_tables(oracle):
+    g = load("tables.npz")
+    assert np.array_equal(oracle.log_tbl()[g["addlog_idx"]], g["addlog_val"])
+    assert np.array_equal(oracle.logistic_tbl()[g["logistic_idx"]], g["logistic_val"])
+
+
+def test_gmm_plain_none(oracle):
+    g = load("gmm_plain_none.npz")
+    assert np.array_equal(oracle.gmm_outprob(g, g["frames"], po.GPRUNE_NONE), g["out"])
+
+
+def test_gmm_ragged_null_densities(oracle):
+    g = load("gmm_ragged.npz")
+    assert (g["ent_dens"] < 0).any(), "fixture must contain NULL densities"
+    assert np.array_equal(oracle.gmm_outprob(g, g["frames"], po.GPRUNE_NONE), g["out"])
+    assert np.array_equal(oracle.gmm_outprob(g, g["frames"], po.GPRUNE_SAFE, 3), g["out_safe3"])
+
+
+@pytest.mark.parametrize("key,gp,n", [("out_none", po.GPRUNE_NONE, 32), ("out_safe2", po.GPRUNE_SAFE, 2),
+                                      ("out_safe4", po.GPRUNE_SAFE, 4)])
+def test_gmm_tied(oracle, key, gp, n):
+    g = load("gmm_tied.npz")
+    assert np.array_equal(oracle.gmm_outprob(g, g["frames"], gp, n), g[key])
+
+
+def test_tied_codebook_cache(oracle):
+    g = load("gmm_tied.npz")
+    sc, ids, num = oracle.tmix_topn(g, 1, g["frames"], po.GPRUNE_SAFE, 2)
+    assert np.array_equal(num, g["cache2_num"])
+    assert np.array_equal(ids, g["cache2_id"])
+    assert np.array_equal(sc, g["cache2_score"])
+
+
+@pytest.mark.parametrize("meth,code", [("max", po.IWCD_MAX), ("avg", po.IWCD_AVG), ("nbest", po.IWCD_NBEST)])
+def test_outprob_cd(oracle, meth, code):
+    g = load("cdset.npz")
+    got = oracle.outprob_cd(g["scores"], g["set_off"], g["states"], code, 3)
+    assert np.array_equal(got, g["cd_" + meth])
+
+
+def test_addlog_edge_cases(oracle):
+    # empty list -> LOG_ZERO; single element; equal elements; far-apart elements
+    assert oracle.addlog_array(np.zeros(0, np.float32)) == -1000000.0
+    assert oracle.addlog_array(np.array([-3.5], np.float32)) == np.float32(-3.5)
+    v = oracle.addlog_array(np.array([-2.0, -2.0], np.float32))
+    assert abs(v - (-2.0 + np.log(2.0))) < 2e-5
+    assert oracle.addlog_array(np.array([-100.0, 0.0], np.float32)) == 0.0

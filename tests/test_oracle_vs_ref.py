@@ -1,0 +1,57 @@
+"""CPU: oracle restatement vs the compiled reference on fresh seeded inputs
+(more shapes than the committed fixtures).  Needs oracle/_ref/libjref.so, which
+the dev container builds from /root/reference (oracle/Makefile)."""
+import numpy as np
+import pytest
+
+from julius_amd import synth
+from oracle import pyoracle as po
+
+
+@pytest.mark.parametrize("S,M,D,ragged,nullf", [(30, 16, 39, False, 0.0), (27, 5, 26, True, 0.0),
+                                                (12, 9, 13, True, 0.15), (9, 1, 39, False, 0.0)])
+@pytest.mark.parametrize("gprune,n", [("none", 0), ("safe", 2), ("safe", 64)])
+def test_plain_gmm(ref, oracle, tmp_path, S, M, D, ragged, nullf, gprune, n):
+    m = synth.make_gmm(S=S, M=M, D=D, seed=S * 7 + M, ragged=ragged, null_frac=nullf)
+    kind = "MFCC_E_D_A" if D == 39 else "USER"
+    synth.write_hmmdefs(tmp_path / "h", m, kind=kind)
+    am = ref.am_load(tmp_path / "h", gprune=gprune, gprune_num=n)
+    ex = am.export()
+    # the product-side flattening reproduces the loader's arrays
+    for k in ("mean", "ivar", "gconst"):
+        ok = ex["ent_dens"] >= 0
+        assert np.array_equal(ex[k][ex["ent_dens"][ok]], m[k][m["ent_dens"][m["ent_dens"] >= 0]])
+    assert np.array_equal(ex["st_off"], m["st_off"])
+    assert np.array_equal(ex["ent_logw"], m["ent_logw"])
+    fr = synth.make_frames(m, T=37, seed=3)
+    want = am.outprob(fr)
+    got = oracle.gmm_outprob(ex, fr, po.GPRUNE_NONE if gprune == "none" else po.GPRUNE_SAFE, n)
+    assert np.array_equal(got, want)
+    am.close()
+
+
+@pytest.mark.parametrize("gprune,n", [("none", 64), ("safe", 1), ("safe", 2), ("safe", 8)])
+def test_tied_gmm(ref, oracle, tmp_path, gprune, n):
+    m = synth.make_tied_gmm(S=21, nbook=4, K=64, D=39, seed=5)
+    synth.write_hmmdefs(tmp_path / "h", m)
+    am = ref.am_load(tmp_path / "h", gprune=gprune, gprune_num=n)
+    assert am.is_tied and am.nbook == 4
+    ex = am.export()
+    fr = synth.make_frames(m, T=45, seed=9, noise=2.0)
+    got = oracle.gmm_outprob(ex, fr, po.GPRUNE_NONE if gprune == "none" else po.GPRUNE_SAFE, n)
+    assert np.array_equal(got, am.outprob(fr))
+    am.close()
+
+
+def test_lazy_equals_eager(ref, tmp_path):
+    """outprob.c:245-247 (lazy cache fill) and :230-242 (batch) give the same values."""
+    m = synth.make_gmm(S=15, M=4, D=39, seed=2)
+    synth.write_hmmdefs(tmp_path / "h", m)
+    am = ref.am_load(tmp_path / "h")
+    fr = synth.make_frames(m, T=20, seed=4)
+    full = am.outprob(fr)
+    rng = np.random.default_rng(0)
+    tt = np.sort(rng.integers(0, 20, 100)).astype(np.int32)
+    ss = rng.integers(0, 15, 100).astype(np.int32)
+    assert np.array_equal(am.outprob_list(fr, tt, ss), full[tt, ss])
+    am.close()

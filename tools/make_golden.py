@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libjref.so).
+
+Run in the dev container (where /root/reference exists):
+    python tools/make_golden.py
+Each fixture holds a seeded synthetic model *as the reference's own loader left
+it in memory* (exported through the product-side flattening code), the input
+frames, and the reference's outputs.  The fixtures are small (<200 kB each) and
+are what pins oracle/ and the HIP engine on machines without the reference.
+"""
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from julius_amd import synth  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+
+def save(name, **kw):
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / name, **{k: v for k, v in kw.items() if v is not None})
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in kw.items() if v is not None})
+
+
+def model_arrays(m):
+    keys = ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw", "st_book")
+    d = {k: m[k] for k in keys if m.get(k) is not None}
+    d["nbook"] = np.int32(m.get("nbook", 0))
+    if m.get("book_size"):
+        d["book_size"] = np.int32(m["book_size"])
+    return d
+
+
+def main():
+    ref = pyoracle.Ref()
+    tmp = Path(tempfile.mkdtemp())
+
+    # G1: plain GMM, uniform mixtures, gprune none (calc_mix + gprune_none)
+    m = synth.make_gmm(S=24, M=8, D=39, seed=11)
+    synth.write_hmmdefs(tmp / "g1", m)
+    am = ref.am_load(tmp / "g1", gprune="none")
+    fr = synth.make_frames(m, T=40, seed=12)
+    save("gmm_plain_none.npz", frames=fr, out=am.outprob(fr), **model_arrays(am.export()))
+
+    # G2: ragged mixture counts + NULL densities, D=25, gprune none and safe(3)
+    m = synth.make_gmm(S=21, M=6, D=25, seed=21, ragged=True, null_frac=0.1)
+    synth.write_hmmdefs(tmp / "g2", m, kind="MFCC_E_D_N_Z")
+    am = ref.am_load(tmp / "g2", gprune="none")
+    fr = synth.make_frames(m, T=33, seed=22)
+    ex = am.export()
+    out_none = am.outprob(fr)
+    am2 = ref.am_load(tmp / "g2", gprune="safe", gprune_num=3)
+    save("gmm_ragged.npz", frames=fr, out=out_none, out_safe3=am2.outprob(fr), **model_arrays(ex))
+
+    # G3: tied-mixture, 3 codebooks x 32, safe top-2 / top-4 and none
+    m = synth.make_tied_gmm(S=18, nbook=3, K=32, D=39, seed=31)
+    synth.write_hmmdefs(tmp / "g3", m)
+    fr = synth.make_frames(m, T=30, seed=32, noise=2.0)
+    am = ref.am_load(tmp / "g3", gprune="none", gprune_num=32)
+    ex = am.export()
+    o_none = am.outprob(fr)
+    am2 = ref.am_load(tmp / "g3", gprune="safe", gprune_num=2)
+    o_s2 = am2.outprob(fr)
+    c2 = am2.tmix_cache(fr, 1, 2)
+    am4 = ref.am_load(tmp / "g3", gprune="safe", gprune_num=4)
+    o_s4 = am4.outprob(fr)
+    save("gmm_tied.npz", frames=fr, out_none=o_none, out_safe2=o_s2, out_safe4=o_s4,
+         cache2_score=c2[0], cache2_id=c2[1], cache2_num=c2[2], **model_arrays(ex))
+
+    # G4: pseudo-phone state sets (outprob_cd max / avg / nbest)
+    m = synth.make_gmm(S=30, M=4, D=39, seed=41)
+    synth.write_hmmdefs(tmp / "g4", m)
+    fr = synth.make_frames(m, T=25, seed=42)
+    rng = np.random.default_rng(43)
+    sizes = rng.integers(1, 9, size=12)
+    set_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    states = np.concatenate([rng.choice(30, size=n, replace=False) for n in sizes]).astype(np.int32)
+    cds = {}
+    for meth in ("max", "avg", "nbest"):
+        am = ref.am_load(tmp / "g4", gprune="none", cdset=meth, cdmax=3)
+        cds["cd_" + meth] = am.outprob_cd(fr, set_off, states)
+    scores = am.outprob(fr)
+    save("cdset.npz", scores=scores, set_off=set_off, states=states, **cds)
+
+    # tables
+    o = pyoracle.Oracle()
+    tbl = o.log_tbl()
+    save("tables.npz", addlog_idx=np.arange(0, 500000, 997, dtype=np.int32),
+         addlog_val=tbl[::997], logistic_idx=np.arange(0, 320001, 641, dtype=np.int32),
+         logistic_val=o.logistic_tbl()[::641])
+
+
+if __name__ == "__main__":
+    main()
