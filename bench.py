@@ -103,7 +103,10 @@ def main():
     gmm = lib.Gmm(eng, model)
     d_frames = torch.from_numpy(frames).cuda()
     d_out = torch.empty((T, S), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream()
+    # a non-default stream: its handle is what the C ABI launches on, and the
+    # HIP events below are recorded on that same stream
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
 
     def step():
         gmm.outprob_dev(d_frames.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)

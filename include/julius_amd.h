@@ -121,9 +121,14 @@ int  jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *de
 int  jamd_gmm_outprob_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
 /* Tied-mixture codebook cache of calc_tied_mix.c:189-227 for inspection: top-N
  * (score,id) per (frame, codebook), descending, as MIXCACHE (hmm_calc.h:57-60).
- * dev_score/dev_id are [T][nbook][gprune_num]; dev_num [T][nbook]. */
+ * dev_score/dev_id are [T][nbook][jamd_gmm_tmix_cap()]; dev_num [T][nbook]. */
 int  jamd_gmm_tmix_cache_dev(jamd_gmm *g, const float *dev_frames, int T,
                              float *dev_score, int *dev_id, int *dev_num, void *stream);
+/* Slots per (frame, codebook) of that cache (gprune_num for safe, the largest
+ * codebook for none; 0 when the model has no tied-mixture state) and the
+ * codebook count. */
+int  jamd_gmm_tmix_cap(const jamd_gmm *g);
+int  jamd_gmm_nbook(const jamd_gmm *g);
 /* Name of the kernel variant the last outprob call used ("tile<39,2>", ...). */
 const char *jamd_gmm_last_kernel(const jamd_gmm *g);
 
@@ -134,6 +139,7 @@ const char *jamd_gmm_last_kernel(const jamd_gmm *g);
 int  jamd_cdset_create(jamd_engine *e, int nset, const int *set_off, const int *states,
                        int method, int nbest, jamd_cdset **out);
 void jamd_cdset_destroy(jamd_cdset *c);
+int  jamd_cdset_nset(const jamd_cdset *c);
 int  jamd_cdset_outprob_dev(jamd_cdset *c, const float *dev_scores, int T, int nstate,
                             float *dev_cd, void *stream);
 

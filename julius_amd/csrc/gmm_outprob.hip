@@ -26,30 +26,10 @@
 // no divergence except the (predicated) table gather.  Results are staged
 // through a wave-private LDS tile so the [T][S] matrix is written in coalesced
 // row segments.  See DESIGN.md "K1".
-#include "jamd_internal.h"
+#include "jamd_device.h"
 
 namespace {
-
-__device__ __forceinline__ float addlog_step(float y, float sc, const float *__restrict__ tbl,
-                                             float addmin_f) {
-  // addlog.c:108-121 with y the running value: larger stays in y.
-  const bool gt = sc > y;
-  const float hi = gt ? sc : y;
-  const float lo = gt ? y : sc;
-  const float d = lo - hi;
-  float r = hi;
-  if (!(d < addmin_f)) {
-    const unsigned idx = (unsigned)((double)(-d) * JAMD_TMAG + 0.5);
-    r = hi + tbl[idx];
-  }
-  return r;
-}
-
-__device__ __forceinline__ float finish_state(float lse) {
-  // calc_mix.c:73-80, one stream, stream weight 1
-  if (lse <= JAMD_LOG_ZERO || lse == 0.0f) return JAMD_LOG_ZERO;
-  return (float)((double)lse * JAMD_INV_LOG_TEN);
-}
+using namespace jamd;
 
 constexpr int kWaves = 4;  // waves per workgroup
 
@@ -64,14 +44,25 @@ __device__ __forceinline__ bool decode_block(int nfb, int nstb, int &fb, int &sb
   return sb < nstb;
 }
 
-template <int D, int FPL, int NS>
+// FPL (frames per lane) is even: frames are held as packed pairs so that the
+// D-loop compiles to v_pk_add_f32 / v_pk_mul_f32 with the Gaussian's scalar
+// broadcast through op_sel from an SGPR pair.  Measured on MI355X
+// (tools/ubench_valu.hip): a plain VOP2 with an SGPR operand issues at ~0.6x
+// the VGPR-only rate, the packed forms do not pay that penalty.
+// ABL selects the mixture log-sum form: 0 = software-pipelined table gather
+// (the gather for entry e is issued after its D-loop and consumed after the
+// D-loop of entry e-1, so its latency hides behind ~160 packed VALU ops),
+// 1 = gather and wait in place, 2/3 = timing-only ablations (wrong results).
+template <int D, int FPL, int NS, int ABL>
 __global__ void __launch_bounds__(64 * kWaves)
 gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
                 const float *__restrict__ frames, const float *__restrict__ tbl,
                 float *__restrict__ out, int T, int S, int nsb, int nfb, int nstb,
                 float addmin_f) {
+  static_assert(FPL % 2 == 0, "frames are processed as packed pairs");
   constexpr int REC = ((2 * D + 2) + 3) & ~3;
   constexpr int FPW = 64 * FPL;
+  constexpr int NP = FPL / 2;
   __shared__ float tile[kWaves][FPW][NS + 1];
 
   int fb, sb;
@@ -81,14 +72,15 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
   const int t0 = (fb * kWaves + wave) * FPW;
   if (t0 >= T) return;  // whole wave out of range (no block-level barriers below)
 
-  float v[FPL][D];
+  f2 v[NP][D];
 #pragma unroll
-  for (int k = 0; k < FPL; k++) {
-    int t = t0 + k * 64 + lane;
-    if (t > T - 1) t = T - 1;
-    const float *fr = frames + (size_t)t * D;
+  for (int p = 0; p < NP; p++) {
+    int ta = t0 + (2 * p) * 64 + lane, tb = ta + 64;
+    if (ta > T - 1) ta = T - 1;
+    if (tb > T - 1) tb = T - 1;
+    const float *fa = frames + (size_t)ta * D, *fb_ = frames + (size_t)tb * D;
 #pragma unroll
-    for (int d = 0; d < D; d++) v[k][d] = fr[d];
+    for (int d = 0; d < D; d++) { v[p][d].x = fa[d]; v[p][d].y = fb_[d]; }
   }
 
   const int s_begin = sb * nsb;
@@ -97,43 +89,221 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
     const int ns = min(NS, s_end - sg);
     for (int si = 0; si < ns; si++) {
       const int e0 = st_off[sg + si], e1 = st_off[sg + si + 1];
-      float y[FPL];
+      float y[FPL], tv[FPL];
+      bool need[FPL];
 #pragma unroll
-      for (int k = 0; k < FPL; k++) y[k] = JAMD_LOG_ZERO;
+      for (int k = 0; k < FPL; k++) { y[k] = JAMD_LOG_ZERO; tv[k] = 0.0f; need[k] = false; }
       for (int e = e1 - 1; e >= e0; e--) {
         const float *__restrict__ r = rec + (size_t)e * REC;
         const float gc = r[2 * D], lw = r[2 * D + 1];
-        float acc[FPL];
+        f2 acc[NP];
 #pragma unroll
-        for (int k = 0; k < FPL; k++) acc[k] = gc;
+        for (int p = 0; p < NP; p++) acc[p] = f2{gc, gc};
 #pragma unroll
         for (int d = 0; d < D; d++) {
           const float mu = r[d], iv = r[D + d];
+          const f2 mu2 = {mu, mu}, iv2 = {iv, iv};
 #pragma unroll
-          for (int k = 0; k < FPL; k++) {
-            float x = v[k][d] - mu;
+          for (int p = 0; p < NP; p++) {
+            f2 x = v[p][d] - mu2;
             x = x * x;
-            x = x * iv;
-            acc[k] = acc[k] + x;
+            x = x * iv2;
+            acc[p] = acc[p] + x;
           }
         }
         const bool nulld = (gc != gc);  // NULL density marker (gprune_none.c:67)
 #pragma unroll
-        for (int k = 0; k < FPL; k++) {
-          float sc = acc[k] * -0.5f;
-          if (nulld) sc = JAMD_LOG_ZERO;
-          sc = sc + lw;
-          y[k] = addlog_step(y[k], sc, tbl, addmin_f);
+        for (int p = 0; p < NP; p++) {
+          float s0 = acc[p].x * -0.5f, s1 = acc[p].y * -0.5f;
+          if (nulld) { s0 = JAMD_LOG_ZERO; s1 = JAMD_LOG_ZERO; }
+          s0 = s0 + lw; s1 = s1 + lw;
+          const float sc2[2] = {s0, s1};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int k = 2 * p + h;
+            if (ABL == 0) {
+              // finish the previous step (addlog.c:119: y += tbl[idx]) with the value
+              // whose gather was issued one entry ago
+              const float yy = y[k] + (need[k] ? tv[k] : 0.0f);
+              const bool gt = sc2[h] > yy;
+              const float hi = gt ? sc2[h] : yy, lo = gt ? yy : sc2[h];
+              const float dd = lo - hi;
+              need[k] = !(dd < addmin_f);
+              const unsigned idx = need[k] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
+              tv[k] = tbl[idx];
+              y[k] = hi;
+            } else if (ABL == 1) {
+              y[k] = addlog_step(y[k], sc2[h], tbl, addmin_f);
+            } else if (ABL == 2) {  // timing only: index math but no gather
+              const bool gt = sc2[h] > y[k];
+              const float hi = gt ? sc2[h] : y[k], lo = gt ? y[k] : sc2[h];
+              const float dd = lo - hi;
+              float rr = hi;
+              if (!(dd < addmin_f)) rr = hi + (float)(unsigned)((double)(-dd) * JAMD_TMAG + 0.5);
+              y[k] = rr;
+            } else {                // timing only: running max
+              y[k] = sc2[h] > y[k] ? sc2[h] : y[k];
+            }
+          }
         }
       }
 #pragma unroll
-      for (int k = 0; k < FPL; k++) tile[wave][k * 64 + lane][si] = finish_state(y[k]);
+      for (int k = 0; k < FPL; k++) {
+        if (ABL == 0) y[k] = y[k] + (need[k] ? tv[k] : 0.0f);
+        tile[wave][k * 64 + lane][si] = finish_state(y[k]);
+      }
     }
     // wave-private tile: make the LDS writes visible to the other lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int RPI = 64 / NS;  // rows per store instruction
+    const int col = lane % NS, rsub = lane / NS;
+#pragma unroll 4
+    for (int it = 0; it < FPW / RPI; it++) {
+      const int rr = it * RPI + rsub;
+      const int t = t0 + rr;
+      if (t < T && col < ns) out[(size_t)t * S + sg + col] = tile[wave][rr][col];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Persistent form of the tile kernel: the grid is sized to the chip (waves are
+// independent, there is no block-level barrier) and every WAVE pulls
+// (16-state x 128-frame) tiles from a global ticket counter, state-group major,
+// so that (a) there is no tail quantisation of a fixed 2-3 round grid and (b)
+// waves running at the same time mostly stream the same Gaussian records
+// through the scalar cache.  SPLIT=1 additionally software-pipelines the
+// scalar loads: the record is consumed in two halves and the next half is
+// requested before the current half's ~80 packed VALU ops.
+template <int D, int NS, int SPLIT>
+__global__ void __launch_bounds__(64 * kWaves)
+gmm_ptile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
+                 const float *__restrict__ frames, const float *__restrict__ tbl,
+                 float *__restrict__ out, int T, int S, int nfg, int ntile,
+                 unsigned *__restrict__ ticket, float addmin_f) {
+  constexpr int REC = ((2 * D + 2) + 3) & ~3;
+  constexpr int FPW = 128;
+  constexpr int DA = (D + 1) / 2, DB = D - DA;   // dims in first / second half
+  __shared__ float tile[kWaves][FPW][NS + 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  for (;;) {
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(ticket, 1u);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk >= (unsigned)ntile) break;
+    const int sgi = tk / nfg, fg = tk - sgi * nfg;
+    const int sg = sgi * NS;
+    const int t0 = fg * FPW;
+    const int ns = min(NS, S - sg);
+
+    f2 v[D];
+    {
+      int ta = t0 + lane, tb = ta + 64;
+      if (ta > T - 1) ta = T - 1;
+      if (tb > T - 1) tb = T - 1;
+      const float *fa = frames + (size_t)ta * D, *fb_ = frames + (size_t)tb * D;
+#pragma unroll
+      for (int d = 0; d < D; d++) { v[d].x = fa[d]; v[d].y = fb_[d]; }
+    }
+
+    for (int si = 0; si < ns; si++) {
+      const int e0 = st_off[sg + si], e1 = st_off[sg + si + 1];
+      float y[2] = {JAMD_LOG_ZERO, JAMD_LOG_ZERO}, tv[2] = {0.0f, 0.0f};
+      bool need[2] = {false, false};
+      if (SPLIT == 0) {
+        for (int e = e1 - 1; e >= e0; e--) {
+          const float *__restrict__ r = rec + (size_t)e * REC;
+          const float gc = r[2 * D], lw = r[2 * D + 1];
+          f2 acc = {gc, gc};
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            const float mu = r[d], iv = r[D + d];
+            f2 x = v[d] - f2{mu, mu};
+            x = x * x;
+            x = x * f2{iv, iv};
+            acc = acc + x;
+          }
+          const bool nulld = (gc != gc);
+          float sc2[2] = {acc.x * -0.5f, acc.y * -0.5f};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            float sc = nulld ? JAMD_LOG_ZERO : sc2[h];
+            sc = sc + lw;
+            const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
+            const bool gt = sc > yy;
+            const float hi = gt ? sc : yy, lo = gt ? yy : sc;
+            const float dd = lo - hi;
+            need[h] = !(dd < addmin_f);
+            const unsigned idx = need[h] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
+            tv[h] = tbl[idx];
+            y[h] = hi;
+          }
+        }
+      } else {
+        // record layout for SPLIT: [muA(DA) ivA(DA) | muB(DB) ivB(DB) gc lw]
+        float a_mu[DA], a_iv[DA];
+        if (e1 > e0) {
+          const float *__restrict__ r = rec + (size_t)(e1 - 1) * REC;
+#pragma unroll
+          for (int d = 0; d < DA; d++) { a_mu[d] = r[d]; a_iv[d] = r[DA + d]; }
+        }
+        for (int e = e1 - 1; e >= e0; e--) {
+          const float *__restrict__ r = rec + (size_t)e * REC;
+          float b_mu[DB], b_iv[DB];
+#pragma unroll
+          for (int d = 0; d < DB; d++) { b_mu[d] = r[2 * DA + d]; b_iv[d] = r[2 * DA + DB + d]; }
+          const float gc = r[2 * D], lw = r[2 * D + 1];
+          f2 acc = {gc, gc};
+#pragma unroll
+          for (int d = 0; d < DA; d++) {
+            f2 x = v[d] - f2{a_mu[d], a_mu[d]};
+            x = x * x;
+            x = x * f2{a_iv[d], a_iv[d]};
+            acc = acc + x;
+          }
+          // request the next entry's first half while the second half computes
+          const float *__restrict__ rn = rec + (size_t)(e > e0 ? e - 1 : e) * REC;
+#pragma unroll
+          for (int d = 0; d < DA; d++) { a_mu[d] = rn[d]; a_iv[d] = rn[DA + d]; }
+#pragma unroll
+          for (int d = 0; d < DB; d++) {
+            f2 x = v[DA + d] - f2{b_mu[d], b_mu[d]};
+            x = x * x;
+            x = x * f2{b_iv[d], b_iv[d]};
+            acc = acc + x;
+          }
+          const bool nulld = (gc != gc);
+          float sc2[2] = {acc.x * -0.5f, acc.y * -0.5f};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            float sc = nulld ? JAMD_LOG_ZERO : sc2[h];
+            sc = sc + lw;
+            const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
+            const bool gt = sc > yy;
+            const float hi = gt ? sc : yy, lo = gt ? yy : sc;
+            const float dd = lo - hi;
+            need[h] = !(dd < addmin_f);
+            const unsigned idx = need[h] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
+            tv[h] = tbl[idx];
+            y[h] = hi;
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
+        tile[wave][h * 64 + lane][si] = finish_state(yy);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int RPI = 64 / NS;
     const int col = lane % NS, rsub = lane / NS;
 #pragma unroll 4
     for (int it = 0; it < FPW / RPI; it++) {
@@ -227,7 +397,7 @@ gmm_tile_generic_kernel(const float *__restrict__ rec, const int *__restrict__ s
   }
 }
 
-template <int D, int FPL, int NS>
+template <int D, int FPL, int NS, int ABL = 0>
 int launch_tile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
   constexpr int FPB = kWaves * 64 * FPL;
   const int nfb = (T + FPB - 1) / FPB;
@@ -237,11 +407,29 @@ int launch_tile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t
   while (nsb < 16 * NS && (long)nfb * ((g->S + 2 * nsb - 1) / (2 * nsb)) >= want) nsb *= 2;
   const int nstb = (g->S + nsb - 1) / nsb;
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
-  hipLaunchKernelGGL((gmm_tile_kernel<D, FPL, NS>), dim3(grid), dim3(64 * kWaves), 0, st,
-                     g->d_rec, g->d_st_off, frames, g->eng->d_addlog, out, T, g->S, nsb, nfb,
+  hipLaunchKernelGGL((gmm_tile_kernel<D, FPL, NS, ABL>), dim3(grid), dim3(64 * kWaves), 0, st,
+                     g->d_rec, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, nsb, nfb,
                      nstb, g->eng->addmin_f);
-  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_tile<D=%d,FPL=%d,NS=%d> grid=%d nsb=%d",
-           D, FPL, NS, grid, nsb);
+  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_tile<D=%d,FPL=%d,NS=%d,ABL=%d> grid=%d nsb=%d",
+           D, FPL, NS, ABL, grid, nsb);
+  return JAMD_OK;
+}
+
+template <int D, int NS, int SPLIT>
+int launch_ptile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st, int bpc) {
+  const int nfg = (T + 127) / 128;
+  const int nsg = (g->S + NS - 1) / NS;
+  const int ntile = nfg * nsg;
+  int grid = g->eng->num_cu * bpc;
+  const int need = (ntile + kWaves - 1) / kWaves;
+  if (grid > need) grid = need;
+  JAMD_HIP(hipMemsetAsync(g->d_ticket, 0, sizeof(unsigned), st));
+  const float *recp = SPLIT ? g->d_rec_split : g->d_rec;
+  hipLaunchKernelGGL((gmm_ptile_kernel<D, NS, SPLIT>), dim3(grid), dim3(64 * kWaves), 0, st,
+                     recp, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, nfg, ntile,
+                     g->d_ticket, g->eng->addmin_f);
+  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_ptile<D=%d,NS=%d,SPLIT=%d> grid=%d tiles=%d",
+           D, NS, SPLIT, grid, ntile);
   return JAMD_OK;
 }
 
@@ -256,7 +444,7 @@ int launch_tile_generic(jamd_gmm *g, const float *frames, int T, float *out, hip
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
   const size_t dyn = sizeof(float) * kWaves * g->D * 64 * FPL;
   hipLaunchKernelGGL((gmm_tile_generic_kernel<FPL, NS>), dim3(grid), dim3(64 * kWaves), dyn, st,
-                     g->d_rec, g->d_st_off, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec,
+                     g->d_rec, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec,
                      nsb, nfb, nstb, g->eng->addmin_f);
   snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_tile_generic<FPL=%d,NS=%d> D=%d grid=%d",
            FPL, NS, g->D, grid);
@@ -302,51 +490,122 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
     jamd_set_error("jamd_gmm_create: st_off must run from 0 to nentry");
     return JAMD_EINVAL;
   }
-  bool any_tied = false;
-  if (d->nbook > 0 && d->st_book)
-    for (int s = 0; s < d->nstate; s++) any_tied |= (d->st_book[s] >= 0);
-  if (any_tied) {
-    jamd_set_error("jamd_gmm_create: tied-mixture states are not implemented yet");
-    return JAMD_EINVAL;
-  }
-  if (gprune == JAMD_GPRUNE_SAFE) {
-    jamd_set_error("jamd_gmm_create: gprune safe for plain states is not implemented yet");
-    return JAMD_EINVAL;
-  }
   JAMD_HIP(hipSetDevice(e->device));
   jamd_gmm *g = new jamd_gmm();
-  g->eng = e; g->S = d->nstate; g->D = d->veclen; g->E = d->nentry; g->nbook = d->nbook;
+  g->eng = e; g->S = d->nstate; g->D = d->veclen; g->E = d->nentry;
   g->gprune = gprune; g->gprune_num = gprune_num;
   const int D = g->D;
   g->rec = ((2 * D + 2) + 3) & ~3;
-  g->uniform_mix = true;
+  const bool have_books = d->nbook > 0 && d->st_book;
+  std::vector<int> st_off_plain(g->S + 1, 0), tied;
+  std::vector<int> book_first(d->nbook > 0 ? d->nbook : 0, -1);
   for (int s = 0; s < g->S; s++) {
     const int n = d->st_off[s + 1] - d->st_off[s];
     if (n < 0) { delete g; jamd_set_error("jamd_gmm_create: st_off not monotone at %d", s); return JAMD_EINVAL; }
-    if (n > g->maxmix) g->maxmix = n;
-    if (n != d->st_off[1] - d->st_off[0]) g->uniform_mix = false;
+    const int b = have_books ? d->st_book[s] : -1;
+    if (b >= d->nbook) { delete g; jamd_set_error("jamd_gmm_create: codebook id %d out of range", b); return JAMD_EINVAL; }
+    if (b >= 0) {
+      tied.push_back(s);
+      if (book_first[b] < 0) book_first[b] = s;
+      else if (n != d->st_off[book_first[b] + 1] - d->st_off[book_first[b]]) {
+        delete g; jamd_set_error("jamd_gmm_create: states of codebook %d disagree on its size", b); return JAMD_EINVAL;
+      }
+      st_off_plain[s + 1] = st_off_plain[s];
+    } else {
+      if (n > g->maxmix) g->maxmix = n;
+      st_off_plain[s + 1] = st_off_plain[s] + n;
+    }
   }
-  // entry records: the state's densities laid out contiguously in state order so
-  // the scalar stream of a state range is one linear read (shared ~m/~v macros
-  // are duplicated -- 288 GB of HBM makes that free).
-  std::vector<float> rec((size_t)g->E * g->rec, 0.0f);
-  for (int en = 0; en < g->E; en++) {
-    float *r = rec.data() + (size_t)en * g->rec;
-    const int dn = d->ent_dens[en];
-    if (dn >= d->ndens) { delete g; jamd_set_error("jamd_gmm_create: density index %d out of range", dn); return JAMD_EINVAL; }
+  g->E_plain = st_off_plain[g->S];
+  g->ntied = (int)tied.size();
+  g->nbook = g->ntied ? d->nbook : 0;
+  if (gprune == JAMD_GPRUNE_SAFE && gprune_num < 1) {
+    delete g; jamd_set_error("jamd_gmm_create: gprune safe needs gprune_num >= 1"); return JAMD_EINVAL;
+  }
+  if (gprune == JAMD_GPRUNE_SAFE && gprune_num > 64) {
+    delete g; jamd_set_error("jamd_gmm_create: gprune_num %d > 64 is not supported on the device", gprune_num);
+    return JAMD_EINVAL;
+  }
+  auto fill_rec = [&](float *r, int dn, float lw) -> bool {
+    if (dn >= d->ndens) return false;
     if (dn >= 0) {
       memcpy(r, d->mean + (size_t)dn * D, sizeof(float) * D);
       memcpy(r + D, d->ivar + (size_t)dn * D, sizeof(float) * D);
       r[2 * D] = d->gconst[dn];
     } else {
-      r[2 * D] = __builtin_nanf("");
+      r[2 * D] = __builtin_nanf("");   // NULL density (gprune_none.c:67)
     }
-    r[2 * D + 1] = d->ent_logw[en];
+    r[2 * D + 1] = lw;
+    return true;
+  };
+  // entry records of the plain states, contiguous in state order so the scalar
+  // stream of a state range is one linear read (shared ~m/~v macros are
+  // duplicated -- 288 GB of HBM makes that free).
+  std::vector<float> rec((size_t)g->E_plain * g->rec, 0.0f);
+  for (int s = 0; s < g->S; s++) {
+    if (have_books && d->st_book[s] >= 0) continue;
+    for (int k = 0; k < d->st_off[s + 1] - d->st_off[s]; k++) {
+      const int en = d->st_off[s] + k;
+      if (!fill_rec(rec.data() + (size_t)(st_off_plain[s] + k) * g->rec, d->ent_dens[en], d->ent_logw[en])) {
+        delete g; jamd_set_error("jamd_gmm_create: density index %d out of range", d->ent_dens[en]); return JAMD_EINVAL;
+      }
+    }
   }
   JAMD_HIP(hipMalloc(&g->d_rec, sizeof(float) * (rec.size() ? rec.size() : 4)));
   JAMD_HIP(hipMemcpy(g->d_rec, rec.data(), sizeof(float) * rec.size(), hipMemcpyHostToDevice));
+  {
+    // same records re-ordered for the split-prefetch kernel:
+    // [muA ivA | muB ivB gc lw], A = first ceil(D/2) dims
+    const int DA = (D + 1) / 2, DB = D - DA;
+    std::vector<float> rs(rec.size(), 0.0f);
+    for (int en = 0; en < g->E_plain; en++) {
+      const float *r = rec.data() + (size_t)en * g->rec;
+      float *q = rs.data() + (size_t)en * g->rec;
+      memcpy(q, r, sizeof(float) * DA);
+      memcpy(q + DA, r + D, sizeof(float) * DA);
+      memcpy(q + 2 * DA, r + DA, sizeof(float) * DB);
+      memcpy(q + 2 * DA + DB, r + D + DA, sizeof(float) * DB);
+      q[2 * D] = r[2 * D]; q[2 * D + 1] = r[2 * D + 1];
+    }
+    JAMD_HIP(hipMalloc(&g->d_rec_split, sizeof(float) * (rs.size() ? rs.size() : 4)));
+    JAMD_HIP(hipMemcpy(g->d_rec_split, rs.data(), sizeof(float) * rs.size(), hipMemcpyHostToDevice));
+  }
+  JAMD_HIP(hipMalloc(&g->d_ticket, sizeof(unsigned)));
   JAMD_HIP(hipMalloc(&g->d_st_off, sizeof(int) * (g->S + 1)));
   JAMD_HIP(hipMemcpy(g->d_st_off, d->st_off, sizeof(int) * (g->S + 1), hipMemcpyHostToDevice));
+  JAMD_HIP(hipMalloc(&g->d_st_off_plain, sizeof(int) * (g->S + 1)));
+  JAMD_HIP(hipMemcpy(g->d_st_off_plain, st_off_plain.data(), sizeof(int) * (g->S + 1), hipMemcpyHostToDevice));
+  if (g->ntied) {
+    // codebooks: the densities of book b in codebook order are the entries of any
+    // state tied to it (GCODEBOOK.d[], htk_hmm.h:196-201)
+    std::vector<int> book_off(g->nbook + 1, 0);
+    for (int b = 0; b < g->nbook; b++) {
+      const int n = book_first[b] >= 0 ? d->st_off[book_first[b] + 1] - d->st_off[book_first[b]] : 0;
+      book_off[b + 1] = book_off[b] + n;
+      if (n > g->maxbook) g->maxbook = n;
+    }
+    std::vector<float> brec((size_t)book_off[g->nbook] * g->rec, 0.0f);
+    for (int b = 0; b < g->nbook; b++) {
+      if (book_first[b] < 0) continue;
+      for (int k = 0; k < book_off[b + 1] - book_off[b]; k++) {
+        if (!fill_rec(brec.data() + (size_t)(book_off[b] + k) * g->rec,
+                      d->ent_dens[d->st_off[book_first[b]] + k], 0.0f)) {
+          delete g; jamd_set_error("jamd_gmm_create: codebook density index out of range"); return JAMD_EINVAL;
+        }
+      }
+    }
+    g->tm_cap = (gprune == JAMD_GPRUNE_NONE) ? g->maxbook : (gprune_num < g->maxbook ? gprune_num : g->maxbook);
+    JAMD_HIP(hipMalloc(&g->d_book_rec, sizeof(float) * (brec.size() ? brec.size() : 4)));
+    JAMD_HIP(hipMemcpy(g->d_book_rec, brec.data(), sizeof(float) * brec.size(), hipMemcpyHostToDevice));
+    JAMD_HIP(hipMalloc(&g->d_book_off, sizeof(int) * (g->nbook + 1)));
+    JAMD_HIP(hipMemcpy(g->d_book_off, book_off.data(), sizeof(int) * (g->nbook + 1), hipMemcpyHostToDevice));
+    JAMD_HIP(hipMalloc(&g->d_st_book, sizeof(int) * g->S));
+    JAMD_HIP(hipMemcpy(g->d_st_book, d->st_book, sizeof(int) * g->S, hipMemcpyHostToDevice));
+    JAMD_HIP(hipMalloc(&g->d_ent_logw, sizeof(float) * (g->E ? g->E : 1)));
+    JAMD_HIP(hipMemcpy(g->d_ent_logw, d->ent_logw, sizeof(float) * g->E, hipMemcpyHostToDevice));
+    JAMD_HIP(hipMalloc(&g->d_tied_states, sizeof(int) * g->ntied));
+    JAMD_HIP(hipMemcpy(g->d_tied_states, tied.data(), sizeof(int) * g->ntied, hipMemcpyHostToDevice));
+  }
   *out = g;
   return JAMD_OK;
 }
@@ -354,7 +613,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
 void jamd_gmm_destroy(jamd_gmm *g) {
   if (!g) return;
   (void)hipSetDevice(g->eng->device);
-  void *ptrs[] = { g->d_rec, g->d_st_off, g->d_st_book, g->d_book_off, g->d_book_rec,
+  void *ptrs[] = { g->d_rec, g->d_rec_split, g->d_ticket, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
                    g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete g;
@@ -372,15 +631,49 @@ int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev
   if (T == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(g->eng->device));
   hipStream_t st = jamd_stream(g->eng, stream);
-  int rc;
+  int rc = JAMD_OK;
+  // JAMD_GMM_VARIANT: experiment switch for the D=39 kernel (bench/profiling only)
+  static const int var = getenv("JAMD_GMM_VARIANT") ? atoi(getenv("JAMD_GMM_VARIANT")) : 0;
+  if (g->E_plain == 0 && g->ntied == g->S) {
+    // all states tied-mixture: nothing for the plain-state kernels to do
+  } else if (g->gprune == JAMD_GPRUNE_SAFE && g->gprune_num < g->maxmix) {
+    rc = jamd_gmm_launch_safe(g, dev_frames, T, dev_out, st);
+  } else
+  // gprune safe with N >= the largest mixture keeps every Gaussian but in
+  // descending-score order (gprune_common.c:88); that order changes the
+  // table log-sum, so it also goes through the sorted kernel
+  if (g->gprune == JAMD_GPRUNE_SAFE) {
+    rc = jamd_gmm_launch_safe(g, dev_frames, T, dev_out, st);
+  } else
   switch (g->D) {
-    case 39: rc = launch_tile<39, 2, 16>(g, dev_frames, T, dev_out, st); break;
+    case 39:
+      switch (var) {
+        default: rc = launch_tile<39, 2, 16, 0>(g, dev_frames, T, dev_out, st); break;
+        case 1: rc = launch_tile<39, 2, 16, 1>(g, dev_frames, T, dev_out, st); break;
+        case 2: rc = launch_tile<39, 2, 16, 2>(g, dev_frames, T, dev_out, st); break;
+        case 3: rc = launch_tile<39, 2, 16, 3>(g, dev_frames, T, dev_out, st); break;
+        case 4: rc = launch_tile<39, 4, 16, 0>(g, dev_frames, T, dev_out, st); break;
+        case 5: rc = launch_tile<39, 4, 16, 3>(g, dev_frames, T, dev_out, st); break;
+        case 6: rc = launch_ptile<39, 16, 0>(g, dev_frames, T, dev_out, st, 4); break;
+        case 7: rc = launch_ptile<39, 16, 1>(g, dev_frames, T, dev_out, st, 4); break;
+        case 8: rc = launch_ptile<39, 16, 0>(g, dev_frames, T, dev_out, st, 5); break;
+        case 9: rc = launch_ptile<39, 16, 1>(g, dev_frames, T, dev_out, st, 5); break;
+      }
+      break;
     case 38: rc = launch_tile<38, 2, 16>(g, dev_frames, T, dev_out, st); break;
     case 26: rc = launch_tile<26, 2, 16>(g, dev_frames, T, dev_out, st); break;
     case 25: rc = launch_tile<25, 2, 16>(g, dev_frames, T, dev_out, st); break;
     default: rc = launch_tile_generic<2, 16>(g, dev_frames, T, dev_out, st); break;
   }
   if (rc != JAMD_OK) return rc;
+  if (g->ntied) {
+    // calc_tied_mix(): codebook top-N cache per (frame, book), then the states
+    const size_t n = (size_t)T * g->nbook * g->tm_cap;
+    if ((rc = ensure(&g->d_tm_score, &g->tm_cap_bytes, sizeof(float) * n)) != JAMD_OK) return rc;
+    if ((rc = ensure((float **)&g->d_tm_id, &g->tm_id_bytes, sizeof(int) * n)) != JAMD_OK) return rc;
+    if ((rc = ensure((float **)&g->d_tm_num, &g->tm_num_bytes, sizeof(int) * (size_t)T * g->nbook)) != JAMD_OK) return rc;
+    if ((rc = jamd_gmm_launch_tmix(g, dev_frames, T, dev_out, g->d_tm_score, g->d_tm_id, g->d_tm_num, st)) != JAMD_OK) return rc;
+  }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) {
     jamd_set_error("jamd_gmm_outprob_dev: launch failed: %s", hipGetErrorString(le));
@@ -413,9 +706,27 @@ int jamd_gmm_outprob_host(jamd_gmm *g, const float *host_frames, int T, float *h
   return JAMD_OK;
 }
 
-int jamd_gmm_tmix_cache_dev(jamd_gmm *, const float *, int, float *, int *, int *, void *) {
-  jamd_set_error("jamd_gmm_tmix_cache_dev: tied-mixture path not implemented yet");
-  return JAMD_EINVAL;
+int jamd_gmm_tmix_cap(const jamd_gmm *g) { return g ? g->tm_cap : -1; }
+int jamd_gmm_nbook(const jamd_gmm *g) { return g ? g->nbook : -1; }
+
+int jamd_gmm_tmix_cache_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_score,
+                            int *dev_id, int *dev_num, void *stream) {
+  if (!g || !dev_frames || !dev_score || !dev_id || !dev_num || T < 0) {
+    jamd_set_error("jamd_gmm_tmix_cache_dev: bad argument");
+    return JAMD_EINVAL;
+  }
+  if (!g->ntied) { jamd_set_error("jamd_gmm_tmix_cache_dev: model has no tied-mixture states"); return JAMD_ESTATE; }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(g->eng->device));
+  int rc = jamd_gmm_launch_tmix(g, dev_frames, T, nullptr, dev_score, dev_id, dev_num,
+                                jamd_stream(g->eng, stream));
+  if (rc != JAMD_OK) return rc;
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    jamd_set_error("jamd_gmm_tmix_cache_dev: launch failed: %s", hipGetErrorString(le));
+    return JAMD_ELAUNCH;
+  }
+  return JAMD_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,233 @@
+// gmm_pruned.hip -- the Gaussian-pruning and tied-mixture forms of GMM scoring.
+//
+//   gprune_safe() on plain states       libsent/src/phmm/gprune_safe.c:160-202
+//                                       + calc_mix.c:63-80
+//   tied-mixture codebook cache         libsent/src/phmm/calc_tied_mix.c:189-227
+//   per-state re-weighting + log-sum    calc_tied_mix.c:192-198,229-236
+//   cache_push() ordering               libsent/src/phmm/gprune_common.c:88-126
+//
+// gprune_safe is an EXACT top-N: compute_g_safe() abandons a Gaussian only when
+// its partial sum already exceeds the running N-th best, so the surviving list
+// is the N highest compute_g_base() scores in descending order.  The device
+// therefore evaluates every Gaussian fully (same 4-op chain as K1) and keeps a
+// register-resident sorted top-N per frame with cache_push()'s insertion rule.
+// (With exactly tied scores the reference's survivor depends on its visiting
+// order, which for tied-mixture frames t>0 starts from frame t-1's winners;
+// the device visits in index order.  See DESIGN.md "ties".)
+//
+// Same lane = frame-pair mapping as the tile kernel: Gaussian records come
+// through scalar loads, the D-loop is packed VALU.
+#include "jamd_device.h"
+
+namespace {
+using namespace jamd;
+
+constexpr int kWaves = 4;
+
+// Load the wave's 128 frames: registers (DT>0) or LDS transposed (DT==0).
+template <int DT>
+__device__ __forceinline__ void load_frames(f2 *v, float *vt, const float *__restrict__ frames,
+                                            int t0, int T, int D, int lane) {
+  int ta = t0 + lane, tb = ta + 64;
+  if (ta > T - 1) ta = T - 1;
+  if (tb > T - 1) tb = T - 1;
+  const float *fa = frames + (size_t)ta * D, *fb = frames + (size_t)tb * D;
+  if constexpr (DT > 0) {
+#pragma unroll
+    for (int d = 0; d < DT; d++) { v[d].x = fa[d]; v[d].y = fb[d]; }
+  } else {
+    for (int d = 0; d < D; d++) { vt[d * 128 + lane] = fa[d]; vt[d * 128 + 64 + lane] = fb[d]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---- plain states, gprune safe (top-`cap` by raw Gaussian score) ------------
+template <int DT, int NMAX>
+__global__ void __launch_bounds__(64 * kWaves)
+gmm_safe_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
+                const float *__restrict__ frames, const float *__restrict__ tbl,
+                float *__restrict__ out, int T, int S, int D, int REC, int cap, int nsb,
+                float addmin_f) {
+  extern __shared__ __align__(16) float dyn[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * kWaves + wave) * 128;
+  if (t0 >= T) return;
+  f2 v[DT > 0 ? DT : 1];
+  float *vt = dyn + (size_t)wave * D * 128;
+  load_frames<DT>(v, vt, frames, t0, T, D, lane);
+  const int s_begin = blockIdx.y * nsb, s_end = min(S, s_begin + nsb);
+  const int ta = t0 + lane, tb = ta + 64;
+  for (int s = s_begin; s < s_end; s++) {
+    const int e0 = st_off[s], e1 = st_off[s + 1];
+    float sc0[NMAX], sc1[NMAX];
+    int id0[NMAX], id1[NMAX];
+    int len0 = 0, len1 = 0;
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) { sc0[i] = sc1[i] = JAMD_LOG_ZERO; id0[i] = id1[i] = 0; }
+    for (int e = e0; e < e1; e++) {
+      const f2 g = gauss_pair<DT>(v, vt, lane, D, rec + (size_t)e * REC);
+      topn_push<NMAX>(sc0, id0, len0, cap, g.x, e - e0);
+      topn_push<NMAX>(sc1, id1, len1, cap, g.y, e - e0);
+    }
+    // calc_mix.c:66-72: add ln w of the survivors, log-sum from the last slot down
+    float y0 = JAMD_LOG_ZERO, y1 = JAMD_LOG_ZERO;
+#pragma unroll
+    for (int i = NMAX - 1; i >= 0; i--) {
+      if (i < len0) y0 = addlog_step(y0, sc0[i] + rec[(size_t)(e0 + id0[i]) * REC + 2 * D + 1], tbl, addmin_f);
+      if (i < len1) y1 = addlog_step(y1, sc1[i] + rec[(size_t)(e0 + id1[i]) * REC + 2 * D + 1], tbl, addmin_f);
+    }
+    if (ta < T) out[(size_t)ta * S + s] = finish_state(y0);
+    if (tb < T) out[(size_t)tb * S + s] = finish_state(y1);
+  }
+}
+
+// ---- tied-mixture codebooks: per (frame, book) top-N cache ------------------
+// NMAX == 0: gprune none -- every Gaussian of the book in index order.
+template <int DT, int NMAX>
+__global__ void __launch_bounds__(64 * kWaves)
+tmix_book_kernel(const float *__restrict__ brec, const int *__restrict__ book_off,
+                 const float *__restrict__ frames, float *__restrict__ c_score,
+                 int *__restrict__ c_id, int *__restrict__ c_num, int T, int nbook, int D, int REC,
+                 int cap) {
+  extern __shared__ __align__(16) float dyn[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * kWaves + wave) * 128;
+  if (t0 >= T) return;
+  f2 v[DT > 0 ? DT : 1];
+  float *vt = dyn + (size_t)wave * D * 128;
+  load_frames<DT>(v, vt, frames, t0, T, D, lane);
+  const int b = blockIdx.y;
+  const int k0 = book_off[b], k1 = book_off[b + 1];
+  const int ta = t0 + lane, tb = ta + 64;
+  const size_t oa = ((size_t)ta * nbook + b) * cap, ob = ((size_t)tb * nbook + b) * cap;
+  if constexpr (NMAX == 0) {
+    for (int k = k0; k < k1; k++) {
+      const f2 g = gauss_pair<DT>(v, vt, lane, D, brec + (size_t)k * REC);
+      if (ta < T) { c_score[oa + (k - k0)] = g.x; c_id[oa + (k - k0)] = k - k0; }
+      if (tb < T) { c_score[ob + (k - k0)] = g.y; c_id[ob + (k - k0)] = k - k0; }
+    }
+    if (ta < T) c_num[(size_t)ta * nbook + b] = k1 - k0;
+    if (tb < T) c_num[(size_t)tb * nbook + b] = k1 - k0;
+  } else {
+    constexpr int N = NMAX > 0 ? NMAX : 1;
+    float sc0[N], sc1[N];
+    int id0[N], id1[N];
+    int len0 = 0, len1 = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { sc0[i] = sc1[i] = JAMD_LOG_ZERO; id0[i] = id1[i] = 0; }
+    for (int k = k0; k < k1; k++) {
+      const f2 g = gauss_pair<DT>(v, vt, lane, D, brec + (size_t)k * REC);
+      topn_push<N>(sc0, id0, len0, cap, g.x, k - k0);
+      topn_push<N>(sc1, id1, len1, cap, g.y, k - k0);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (i < cap) {
+        if (ta < T) { c_score[oa + i] = sc0[i]; c_id[oa + i] = id0[i]; }
+        if (tb < T) { c_score[ob + i] = sc1[i]; c_id[ob + i] = id1[i]; }
+      }
+    }
+    if (ta < T) c_num[(size_t)ta * nbook + b] = len0;
+    if (tb < T) c_num[(size_t)tb * nbook + b] = len1;
+  }
+}
+
+// ---- tied-mixture states: weights of the cached winners + log-sum -----------
+__global__ void __launch_bounds__(256)
+tmix_state_kernel(const int *__restrict__ tied_states, int ntied, const int *__restrict__ st_off,
+                  const int *__restrict__ st_book, const float *__restrict__ ent_logw,
+                  const float *__restrict__ c_score, const int *__restrict__ c_id,
+                  const int *__restrict__ c_num, const float *__restrict__ tbl,
+                  float *__restrict__ out, int T, int S, int nbook, int cap, float addmin_f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (i >= ntied) return;
+  const int s = tied_states[i];
+  const int b = st_book[s];
+  const int e0 = st_off[s];
+  const size_t o = ((size_t)t * nbook + b) * cap;
+  const int n = c_num[(size_t)t * nbook + b];
+  float y = JAMD_LOG_ZERO;
+  for (int k = n - 1; k >= 0; k--) {
+    const float x = c_score[o + k] + ent_logw[e0 + c_id[o + k]];  // calc_tied_mix.c:194-196
+    y = addlog_step(y, x, tbl, addmin_f);
+  }
+  out[(size_t)t * S + s] = finish_state(y);
+}
+
+template <int DT>
+int launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
+  const int nfb = (T + 128 * kWaves - 1) / (128 * kWaves);
+  int nsb = 8;
+  while (nsb < 256 && (long)nfb * ((g->S + 2 * nsb - 1) / (2 * nsb)) >= g->eng->num_cu * 8) nsb *= 2;
+  const dim3 grid(nfb, (g->S + nsb - 1) / nsb);
+  const size_t dyn = DT > 0 ? 0 : sizeof(float) * kWaves * g->D * 128;
+  const int cap = g->gprune_num < g->maxmix ? g->gprune_num : g->maxmix;
+#define JAMD_SAFE(N)                                                                         \
+  hipLaunchKernelGGL((gmm_safe_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_rec,   \
+                     g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec, \
+                     cap, nsb, g->eng->addmin_f)
+  if (cap <= 2) JAMD_SAFE(2);
+  else if (cap <= 4) JAMD_SAFE(4);
+  else if (cap <= 8) JAMD_SAFE(8);
+  else if (cap <= 16) JAMD_SAFE(16);
+  else if (cap <= 32) JAMD_SAFE(32);
+  else JAMD_SAFE(64);
+#undef JAMD_SAFE
+  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_safe<DT=%d> cap=%d", DT, cap);
+  return JAMD_OK;
+}
+
+template <int DT>
+int launch_book(jamd_gmm *g, const float *frames, int T, float *c_score, int *c_id, int *c_num,
+                hipStream_t st) {
+  const int nfb = (T + 128 * kWaves - 1) / (128 * kWaves);
+  const dim3 grid(nfb, g->nbook);
+  const size_t dyn = DT > 0 ? 0 : sizeof(float) * kWaves * g->D * 128;
+  const int cap = g->tm_cap;
+#define JAMD_BOOK(N)                                                                          \
+  hipLaunchKernelGGL((tmix_book_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_book_rec, \
+                     g->d_book_off, frames, c_score, c_id, c_num, T, g->nbook, g->D, g->rec, cap)
+  if (g->gprune == JAMD_GPRUNE_NONE) JAMD_BOOK(0);
+  else if (cap <= 2) JAMD_BOOK(2);
+  else if (cap <= 4) JAMD_BOOK(4);
+  else if (cap <= 8) JAMD_BOOK(8);
+  else if (cap <= 16) JAMD_BOOK(16);
+  else if (cap <= 32) JAMD_BOOK(32);
+  else JAMD_BOOK(64);
+#undef JAMD_BOOK
+  return JAMD_OK;
+}
+
+}  // namespace
+
+// entry points used by gmm_outprob.hip
+int jamd_gmm_launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
+  switch (g->D) {
+    case 39: return launch_safe<39>(g, frames, T, out, st);
+    case 38: return launch_safe<38>(g, frames, T, out, st);
+    case 26: return launch_safe<26>(g, frames, T, out, st);
+    case 25: return launch_safe<25>(g, frames, T, out, st);
+    default: return launch_safe<0>(g, frames, T, out, st);
+  }
+}
+
+int jamd_gmm_launch_tmix(jamd_gmm *g, const float *frames, int T, float *out, float *c_score,
+                         int *c_id, int *c_num, hipStream_t st) {
+  int rc;
+  switch (g->D) {
+    case 39: rc = launch_book<39>(g, frames, T, c_score, c_id, c_num, st); break;
+    case 38: rc = launch_book<38>(g, frames, T, c_score, c_id, c_num, st); break;
+    case 26: rc = launch_book<26>(g, frames, T, c_score, c_id, c_num, st); break;
+    case 25: rc = launch_book<25>(g, frames, T, c_score, c_id, c_num, st); break;
+    default: rc = launch_book<0>(g, frames, T, c_score, c_id, c_num, st); break;
+  }
+  if (rc != JAMD_OK || !out) return rc;
+  const dim3 grid((g->ntied + 255) / 256, T);
+  hipLaunchKernelGGL(tmix_state_kernel, grid, dim3(256), 0, st, g->d_tied_states, g->ntied,
+                     g->d_st_off, g->d_st_book, g->d_ent_logw, c_score, c_id, c_num,
+                     g->eng->d_addlog, out, T, g->S, g->nbook, g->tm_cap, g->eng->addmin_f);
+  return JAMD_OK;
+}

@@ -1,0 +1,95 @@
+// jamd_device.h -- device-side helpers shared by the scoring kernels.
+#pragma once
+#include "jamd_internal.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+namespace jamd {
+
+// One step of addlog_array() (libsent/src/phmm/addlog.c:108-121): y is the
+// running log-sum, sc the next term; the larger stays, the table adds
+// log(1+e^d).  Index arithmetic in double exactly as the reference.
+__device__ __forceinline__ float addlog_step(float y, float sc, const float *__restrict__ tbl,
+                                             float addmin_f) {
+  const bool gt = sc > y;
+  const float hi = gt ? sc : y;
+  const float lo = gt ? y : sc;
+  const float d = lo - hi;
+  float r = hi;
+  if (!(d < addmin_f)) {
+    const unsigned idx = (unsigned)((double)(-d) * JAMD_TMAG + 0.5);
+    r = hi + tbl[idx];
+  }
+  return r;
+}
+
+// calc_mix.c:73-80 / calc_tied_mix.c:229-236, one stream, stream weight 1.
+__device__ __forceinline__ float finish_state(float lse) {
+  if (lse <= JAMD_LOG_ZERO || lse == 0.0f) return JAMD_LOG_ZERO;
+  return (float)((double)lse * JAMD_INV_LOG_TEN);
+}
+
+// compute_g_base() (gprune_none.c:59-82) for a packed pair of frames held in
+// registers (DT > 0, compile-time dimension) or in LDS, transposed
+// [d][128 frames of the wave] (DT == 0, run-time dimension D).
+// r -> record [mean(D) ivar(D) gconst ...]; returns the two tmp*-0.5 scores,
+// LOG_ZERO for a NULL density (gconst stored as NaN).
+template <int DT>
+__device__ __forceinline__ f2 gauss_pair(const f2 *v, const float *vt, int lane, int D,
+                                         const float *__restrict__ r) {
+  const float gc = r[2 * D];
+  f2 acc = {gc, gc};
+  if constexpr (DT > 0) {
+#pragma unroll
+    for (int d = 0; d < DT; d++) {
+      const float mu = r[d], iv = r[DT + d];
+      f2 x = v[d] - f2{mu, mu};
+      x = x * x;
+      x = x * f2{iv, iv};
+      acc = acc + x;
+    }
+  } else {
+    for (int d = 0; d < D; d++) {
+      const float mu = r[d], iv = r[D + d];
+      f2 x = f2{vt[d * 128 + lane], vt[d * 128 + 64 + lane]} - f2{mu, mu};
+      x = x * x;
+      x = x * f2{iv, iv};
+      acc = acc + x;
+    }
+  }
+  f2 sc = {acc.x * -0.5f, acc.y * -0.5f};
+  if (gc != gc) sc = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO};
+  return sc;
+}
+
+// cache_push() (gprune_common.c:88-126): keep the best `cap` (score,id) pairs
+// in descending order in a register-resident list of NMAX slots.
+//   bottom case (sc[len-1] >= score): append if there is room, else drop;
+//   otherwise insert before the first element that is not greater.
+template <int NMAX>
+__device__ __forceinline__ void topn_push(float (&sc)[NMAX], int (&id)[NMAX], int &len, int cap,
+                                          float score, int gid) {
+  int p;
+  float last = score;             // value of sc[len-1] (register array: no dynamic indexing)
+#pragma unroll
+  for (int i = 0; i < NMAX; i++) if (i == len - 1) last = sc[i];
+  if (len > 0 && last >= score) {
+    p = len;                      // bottom
+  } else {
+    p = 0;
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) p += (i < len && sc[i] > score) ? 1 : 0;
+  }
+  if (p >= cap) return;
+#pragma unroll
+  for (int i = NMAX - 1; i >= 1; i--) {
+    if (i > p && i < cap) { sc[i] = sc[i - 1]; id[i] = id[i - 1]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NMAX; i++) {
+    if (i == p) { sc[i] = score; id[i] = gid; }
+  }
+  if (len < cap) len++;
+}
+
+}  // namespace jamd

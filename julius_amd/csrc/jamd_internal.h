@@ -49,20 +49,31 @@ struct jamd_gmm {
   bool uniform_mix = false;       // every state has the same entry count
   // device model
   float *d_rec = nullptr;         // [E][rec]: mean[D], ivar[D], gconst, logw
-  int *d_st_off = nullptr;        // [S+1]
+  float *d_rec_split = nullptr;   // [E][rec]: muA ivA | muB ivB gconst logw (split-prefetch kernel)
+  unsigned *d_ticket = nullptr;   // tile ticket counter of the persistent kernel
+  int *d_st_off = nullptr;        // [S+1] original entry offsets (index d_ent_logw)
+  int *d_st_off_plain = nullptr;  // [S+1] offsets into d_rec; a tied-mixture state has an empty range
+  int E_plain = 0;
   // tied-mixture
   int *d_st_book = nullptr;       // [S]
   int *d_book_off = nullptr;      // [nbook+1] into book records
   float *d_book_rec = nullptr;    // [sum book sizes][rec] (logw unused)
   float *d_ent_logw = nullptr;    // [E] entry weights (tied states index by codebook position)
-  int maxbook = 0;
-  std::vector<int> h_book_off;
+  int *d_tied_states = nullptr;   // [ntied] ids of tied-mixture states
+  int ntied = 0;
+  int maxbook = 0;                // largest codebook
+  int tm_cap = 0;                 // slots per (frame, book) in the codebook cache
   // scratch
   float *d_frames = nullptr; size_t frames_cap = 0;
   float *d_out = nullptr; size_t out_cap = 0;
-  float *d_tm_score = nullptr; int *d_tm_id = nullptr; int *d_tm_num = nullptr; size_t tm_cap = 0;
+  float *d_tm_score = nullptr; int *d_tm_id = nullptr; int *d_tm_num = nullptr;
+  size_t tm_cap_bytes = 0, tm_id_bytes = 0, tm_num_bytes = 0;
   char last_kernel[64] = {0};
 };
+
+int jamd_gmm_launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st);
+int jamd_gmm_launch_tmix(jamd_gmm *g, const float *frames, int T, float *out, float *c_score,
+                         int *c_id, int *c_num, hipStream_t st);
 
 static inline hipStream_t jamd_stream(jamd_engine *e, void *s) {
   return s ? (hipStream_t)s : e->stream;

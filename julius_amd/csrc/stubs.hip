@@ -8,9 +8,6 @@
   return JAMD_EINVAL
 
 extern "C" {
-int jamd_cdset_create(jamd_engine *, int, const int *, const int *, int, int, jamd_cdset **) { JAMD_NOT_YET("jamd_cdset_create"); }
-void jamd_cdset_destroy(jamd_cdset *) {}
-int jamd_cdset_outprob_dev(jamd_cdset *, const float *, int, int, float *, void *) { JAMD_NOT_YET("jamd_cdset_outprob_dev"); }
 int jamd_dnn_create(jamd_engine *, const jamd_dnn_desc *, jamd_dnn **) { JAMD_NOT_YET("jamd_dnn_create"); }
 void jamd_dnn_destroy(jamd_dnn *) {}
 int jamd_dnn_outprob_dev(jamd_dnn *, const float *, int, float *, void *) { JAMD_NOT_YET("jamd_dnn_outprob_dev"); }

@@ -76,6 +76,16 @@ def load():
         "jamd_gmm_outprob_host": (ci, [vp, vp, ci, vp]),
         "jamd_gmm_tmix_cache_dev": (ci, [vp, vp, ci, vp, vp, vp, vp]),
         "jamd_gmm_last_kernel": (C.c_char_p, [vp]),
+        "jamd_gmm_tmix_cap": (ci, [vp]),
+        "jamd_gmm_nbook": (ci, [vp]),
+        "jamd_cdset_create": (ci, [vp, ci, vp, vp, ci, ci, P(vp)]),
+        "jamd_cdset_destroy": (None, [vp]),
+        "jamd_cdset_nset": (ci, [vp]),
+        "jamd_cdset_outprob_dev": (ci, [vp, vp, ci, ci, vp, vp]),
+        "jamd_dnn_create": (ci, [vp, P(DnnDesc), P(vp)]),
+        "jamd_dnn_destroy": (None, [vp]),
+        "jamd_dnn_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
+        "jamd_dnn_outprob_host": (ci, [vp, vp, ci, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -129,6 +139,39 @@ class Engine:
             pass
 
 
+class DevBuf:
+    """A raw device allocation through the C ABI (jamd_malloc / jamd_free)."""
+
+    def __init__(self, eng: "Engine", nbytes: int):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = C.c_void_p()
+        _check(load().jamd_malloc(eng.h, self.nbytes, C.byref(p)), "jamd_malloc")
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        _check(load().jamd_memcpy_h2d(self.eng.h, self.ptr, a.ctypes.data, a.nbytes), "jamd_memcpy_h2d")
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(load().jamd_memcpy_d2h(self.eng.h, out.ctypes.data, self.ptr, out.nbytes), "jamd_memcpy_d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().jamd_free(self.eng.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Gmm:
     """Device-resident flattened GMM acoustic model (jamd_gmm)."""
 
@@ -176,9 +219,62 @@ class Gmm:
     def last_kernel(self) -> str:
         return load().jamd_gmm_last_kernel(self.h).decode()
 
+    def tmix_cache_host(self, frames: np.ndarray):
+        """Codebook top-N cache (MIXCACHE) for every (frame, book): score, id, num."""
+        lib = load()
+        fr = _f32(frames)
+        T = fr.shape[0]
+        cap, nbook = lib.jamd_gmm_tmix_cap(self.h), lib.jamd_gmm_nbook(self.h)
+        d_fr = DevBuf(self.eng, fr.nbytes).upload(fr)
+        d_sc = DevBuf(self.eng, 4 * T * nbook * cap)
+        d_id = DevBuf(self.eng, 4 * T * nbook * cap)
+        d_n = DevBuf(self.eng, 4 * T * nbook)
+        _check(lib.jamd_gmm_tmix_cache_dev(self.h, d_fr.ptr, T, d_sc.ptr, d_id.ptr, d_n.ptr, None),
+               "jamd_gmm_tmix_cache_dev")
+        self.eng.sync()
+        return (d_sc.download((T, nbook, cap), np.float32), d_id.download((T, nbook, cap), np.int32),
+                d_n.download((T, nbook), np.int32))
+
     def close(self):
         if getattr(self, "h", None):
             load().jamd_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CdSet:
+    """Pseudo-phone state sets (jamd_cdset): outprob_cd() over a score matrix."""
+
+    def __init__(self, eng: Engine, set_off, states, method=IWCD_MAX, nbest=3):
+        self.eng = eng
+        self.set_off, self.states = _i32(set_off), _i32(states)
+        self.nset = len(self.set_off) - 1
+        h = C.c_void_p()
+        _check(load().jamd_cdset_create(eng.h, self.nset, self.set_off.ctypes.data, self.states.ctypes.data,
+                                        method, nbest, C.byref(h)), "jamd_cdset_create")
+        self.h = h
+
+    def outprob_dev(self, dev_scores: int, T: int, nstate: int, dev_cd: int, stream: int = 0):
+        _check(load().jamd_cdset_outprob_dev(self.h, dev_scores, T, nstate, dev_cd, stream or None),
+               "jamd_cdset_outprob_dev")
+
+    def outprob_host(self, scores: np.ndarray) -> np.ndarray:
+        sc = _f32(scores)
+        T, S = sc.shape
+        d_sc = DevBuf(self.eng, sc.nbytes).upload(sc)
+        d_cd = DevBuf(self.eng, 4 * T * max(self.nset, 1))
+        self.outprob_dev(d_sc.ptr, T, S, d_cd.ptr)
+        self.eng.sync()
+        return d_cd.download((T, self.nset), np.float32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_cdset_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -114,3 +114,86 @@ def test_bad_arguments_fail_loudly(engine):
         lib.Gmm(engine, m2)
     with pytest.raises(lib.JamdError):
         lib.Gmm(engine, m, gprune=3)
+
+
+# ----------------------------------------------------------- pruned / tied / cd
+def test_golden_safe_plain(engine):
+    g = load("gmm_ragged.npz")
+    gm = lib.Gmm(engine, g, gprune=lib.GPRUNE_SAFE, gprune_num=3)
+    assert np.array_equal(gm.outprob_host(g["frames"]), g["out_safe3"])
+
+
+@pytest.mark.parametrize("key,gp,n", [("out_none", lib.GPRUNE_NONE, 32), ("out_safe2", lib.GPRUNE_SAFE, 2),
+                                      ("out_safe4", lib.GPRUNE_SAFE, 4)])
+def test_golden_tied(engine, key, gp, n):
+    g = load("gmm_tied.npz")
+    gm = lib.Gmm(engine, g, gprune=gp, gprune_num=n)
+    assert np.array_equal(gm.outprob_host(g["frames"]), g[key])
+
+
+def test_golden_tied_codebook_cache(engine):
+    g = load("gmm_tied.npz")
+    gm = lib.Gmm(engine, g, gprune=lib.GPRUNE_SAFE, gprune_num=2)
+    sc, ids, num = gm.tmix_cache_host(g["frames"])
+    assert np.array_equal(num[:, 1], g["cache2_num"])
+    assert np.array_equal(ids[:, 1, :], g["cache2_id"])
+    assert np.array_equal(sc[:, 1, :], g["cache2_score"])
+
+
+@pytest.mark.parametrize("S,M,D,T,n", [(40, 16, 39, 300, 1), (40, 16, 39, 300, 5), (25, 9, 26, 130, 9),
+                                       (12, 20, 13, 200, 12), (12, 20, 13, 200, 40)])
+def test_safe_vs_oracle(engine, oracle, S, M, D, T, n):
+    m = synth.make_gmm(S=S, M=M, D=D, seed=S + n, ragged=True, null_frac=0.05)
+    fr = synth.make_frames(m, T=T, seed=n)
+    gm = lib.Gmm(engine, m, gprune=lib.GPRUNE_SAFE, gprune_num=n)
+    assert np.array_equal(gm.outprob_host(fr), oracle.gmm_outprob(m, fr, po.GPRUNE_SAFE, n))
+
+
+@pytest.mark.parametrize("nbook,K,D,T,gp,n", [(3, 64, 39, 260, "safe", 2), (1, 256, 39, 100, "safe", 4),
+                                              (5, 33, 25, 140, "safe", 8), (2, 40, 13, 70, "safe", 3),
+                                              (3, 64, 39, 130, "none", 64)])
+def test_tied_vs_oracle(engine, oracle, nbook, K, D, T, gp, n):
+    m = synth.make_tied_gmm(S=30, nbook=nbook, K=K, D=D, seed=K)
+    fr = synth.make_frames(m, T=T, seed=T, noise=2.0)
+    code = lib.GPRUNE_NONE if gp == "none" else lib.GPRUNE_SAFE
+    gm = lib.Gmm(engine, m, gprune=code, gprune_num=n)
+    assert np.array_equal(gm.outprob_host(fr), oracle.gmm_outprob(m, fr, code, n))
+
+
+def test_compound_model(engine, oracle):
+    """Mixed tied / plain states (calc_compound_mix, calc_tied_mix.c:258)."""
+    m = synth.make_tied_gmm(S=18, nbook=2, K=32, D=39, seed=9)
+    p = synth.make_gmm(S=12, M=4, D=39, seed=10)
+    G0 = m["mean"].shape[0]
+    mix = dict(
+        mean=np.concatenate([m["mean"], p["mean"]]), ivar=np.concatenate([m["ivar"], p["ivar"]]),
+        gconst=np.concatenate([m["gconst"], p["gconst"]]),
+        st_off=np.concatenate([m["st_off"], m["st_off"][-1] + p["st_off"][1:]]).astype(np.int32),
+        ent_dens=np.concatenate([m["ent_dens"], p["ent_dens"] + G0]).astype(np.int32),
+        ent_logw=np.concatenate([m["ent_logw"], p["ent_logw"]]),
+        st_book=np.concatenate([m["st_book"], -np.ones(12, np.int32)]).astype(np.int32), nbook=2, nstream=1)
+    fr = synth.make_frames(m, T=150, seed=3, noise=2.0)
+    for code, n in ((lib.GPRUNE_SAFE, 2), (lib.GPRUNE_NONE, 32)):
+        gm = lib.Gmm(engine, mix, gprune=code, gprune_num=n)
+        assert np.array_equal(gm.outprob_host(fr), oracle.gmm_outprob(mix, fr, code, n))
+
+
+@pytest.mark.parametrize("meth,code", [("max", lib.IWCD_MAX), ("avg", lib.IWCD_AVG), ("nbest", lib.IWCD_NBEST)])
+def test_golden_cdset(engine, meth, code):
+    g = load("cdset.npz")
+    cd = lib.CdSet(engine, g["set_off"], g["states"], code, 3)
+    assert np.array_equal(cd.outprob_host(g["scores"]), g["cd_" + meth])
+
+
+def test_cdset_vs_oracle_with_log_zero_members(engine, oracle):
+    rng = np.random.default_rng(5)
+    S, T = 200, 77
+    scores = rng.normal(-40, 10, size=(T, S)).astype(np.float32)
+    scores[rng.random((T, S)) < 0.2] = -1000000.0
+    sizes = rng.integers(1, 40, size=50)
+    set_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    states = np.concatenate([rng.choice(S, size=n, replace=False) for n in sizes]).astype(np.int32)
+    for code, nb in ((lib.IWCD_MAX, 3), (lib.IWCD_AVG, 3), (lib.IWCD_NBEST, 1), (lib.IWCD_NBEST, 3), (lib.IWCD_NBEST, 16)):
+        got = lib.CdSet(engine, set_off, states, code, nb).outprob_host(scores)
+        want = oracle.outprob_cd(scores, set_off, states, code, nb)
+        assert np.array_equal(got, want, equal_nan=True), (code, nb)
