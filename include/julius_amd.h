@@ -160,6 +160,8 @@ typedef struct {
 
 int  jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out);
 void jamd_dnn_destroy(jamd_dnn *n);
+int  jamd_dnn_nstate(const jamd_dnn *n);   /* dims[nlayer] */
+int  jamd_dnn_veclen(const jamd_dnn *n);   /* dims[0]      */
 /* Replaces dnn_calc_outprob() (calc_dnn.c:774) for a batch of frames:
  * out[t][i] = INV_LOG_TEN*(x_i - addlog_array(x)) - state_prior[i]
  * (calc_dnn.c:858-866).  frames [T][dims[0]] already spliced

@@ -1,0 +1,315 @@
+// dnn.hip -- DNN-HMM state scores on gfx950 (K3/K4): the only place MFMA is used.
+//
+// Replaces dnn_calc_outprob() (libsent/src/phmm/calc_dnn.c:774-868) for a BATCH
+// of frames (the reference is strictly frame-at-a-time, 00readme-DNN.txt:29-34):
+//   per layer   dst = W src + b         calc_dnn_fma.c:19-80 (the SIMD path the
+//                                        reference selects on an FMA host)
+//   hidden      table logistic          calc_dnn.c:342-369, :813-818
+//   output      x_i -> INV_LOG_TEN*(x_i - addlog_array(x)) - state_prior[i]
+//                                        calc_dnn.c:858-866, addlog.c:103-123
+//
+// Numerical contract: bit-exact with the reference's FMA kernel.  That kernel
+// keeps EIGHT partial sums per output (AVX lanes l = k mod 8), each a fused
+// multiply-add chain over k = l, l+8, l+16, ..., and finally adds lanes 0..7
+// left to right and then the bias (calc_dnn_fma.c:53-60).
+// v_mfma_f32_32x32x2_f32 is, per output element, exactly a k-ordered fmaf chain
+// (cdna_hip_programming.md section 3), so each 32x32 output tile keeps EIGHT
+// MFMA accumulators, accumulator l being fed only k == l (mod 8) in ascending
+// order (lanes 0-31 supply k, lanes 32-63 supply k+8), and the epilogue adds the
+// eight accumulators left to right, then the bias.  Same MFMA count as a single
+// accumulator; the price is 128 accumulator registers per wave tile.
+//
+// GEMM shape: C[t][o] = sum_k X[t][k] * W[o][k]  (both operands K-contiguous).
+// Block = 4 waves = 64 frames x 64 outputs, K slab 32 staged through LDS with
+// register prefetch of the next slab; LDS rows are pitched 36 floats so the
+// ds_read_b128 fragment reads (one 16-byte quad of k per lane) are conflict
+// free for the instruction's 16-lane groups (MI355X_MICROARCH.md, LDS).
+#include "jamd_device.h"
+
+struct jamd_dnn {
+  jamd_engine *eng = nullptr;
+  int nlayer = 0;
+  std::vector<int> dims;
+  std::vector<float *> d_w, d_b;   // W[l]: [dims[l+1]][dims[l]] as given
+  float *d_prior = nullptr;
+  int maxdim = 0;
+  float *d_act[2] = {nullptr, nullptr}; size_t act_cap = 0;
+  float *d_lse = nullptr; size_t lse_cap = 0;
+  float *d_frames = nullptr; size_t frames_cap = 0;
+  float *d_out = nullptr; size_t out_cap = 0;
+};
+
+namespace {
+using namespace jamd;
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, KS = 32, PITCH = KS + 4;
+
+// ACT: 1 = table logistic (hidden layer), 0 = raw (output layer).
+template <int ACT>
+__global__ void __launch_bounds__(256, 2)
+dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                 const float *__restrict__ bias, const float *__restrict__ sig,
+                 float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb) {
+  __shared__ __align__(16) float Xs[BM][PITCH];
+  __shared__ __align__(16) float Ws[BN][PITCH];
+  // XCD-aware order: the dispatcher puts block b on XCD b % 8; consecutive
+  // blocks of one XCD walk the N tiles of the same 64-frame strip so the strip
+  // of X stays in that XCD's L2 while W streams.
+  const int nnb = (N + BN - 1) / BN;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int mb = xcd + 8 * (q / nnb), nb = q % nnb;
+  if (mb >= nmb) return;
+  const int t0 = mb * BM, o0 = nb * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+  // staging: thread loads 2 float4 of X and 2 of W per slab: row = tid/8 (+32), quad = tid%8
+  const int lr = tid >> 3, lq = (tid & 7) * 4;
+  const float *xrow[2], *wrow[2];
+  bool wvalid[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int tr = t0 + lr + 32 * h; if (tr > T - 1) tr = T - 1;
+    xrow[h] = X + (size_t)tr * ldx;
+    int orow = o0 + lr + 32 * h; wvalid[h] = orow < N; if (orow > N - 1) orow = N - 1;
+    wrow[h] = W + (size_t)orow * K;
+  }
+  auto gload = [&](int k0, f4v (&xa)[2], f4v (&wa)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = k0 + lq;
+      if (k + 3 < K) {
+        xa[h] = *(const f4v *)(xrow[h] + k);
+        wa[h] = *(const f4v *)(wrow[h] + k);
+      } else {   // K tail: zero padding keeps every chain exact (fma(0,0,acc) == acc)
+        f4v xv = {0, 0, 0, 0}, wv = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (k + c < K) { xv[c] = xrow[h][k + c]; wv[c] = wrow[h][k + c]; }
+        xa[h] = xv; wa[h] = wv;
+      }
+      if (!wvalid[h]) wa[h] = f4v{0, 0, 0, 0};
+    }
+  };
+
+  f16v acc[8];
+#pragma unroll
+  for (int l = 0; l < 8; l++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[l][r] = 0.0f;
+
+  f4v xa[2], wa[2];
+  gload(0, xa, wa);
+  const int arow = wm + (lane & 31), brow = wn + (lane & 31), half = lane >> 5;
+  for (int k0 = 0; k0 < K; k0 += KS) {
+    __syncthreads();   // previous slab fully consumed
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      *(f4v *)&Xs[lr + 32 * h][lq] = xa[h];
+      *(f4v *)&Ws[lr + 32 * h][lq] = wa[h];
+    }
+    __syncthreads();
+    if (k0 + KS < K) gload(k0 + KS, xa, wa);   // prefetch next slab into registers
+#pragma unroll
+    for (int g = 0; g < KS; g += 16) {
+      // lanes 0-31 take k = g+0..7, lanes 32-63 k = g+8..15: accumulator l sees
+      // k = g+l then g+8+l -- ascending within its residue class mod 8
+      const f4v a0 = *(const f4v *)&Xs[arow][g + 8 * half];
+      const f4v a1 = *(const f4v *)&Xs[arow][g + 8 * half + 4];
+      const f4v b0 = *(const f4v *)&Ws[brow][g + 8 * half];
+      const f4v b1 = *(const f4v *)&Ws[brow][g + 8 * half + 4];
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[l], b0[l], acc[l], 0, 0, 0);
+        acc[l + 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[l], b1[l], acc[l + 4], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: lanes add 0..7 left to right, then the bias (calc_dnn_fma.c:53-60)
+  const int j = o0 + wn + (lane & 31);
+  const float bj = (j < N) ? bias[j] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int t = t0 + wm + i;
+    float s = acc[0][r] + acc[1][r];
+#pragma unroll
+    for (int l = 2; l < 8; l++) s = s + acc[l][r];
+    s = s + bj;
+    if (ACT) {
+      // calc_dnn.c:813-818: clamp at +-8, else table[(int)((x + 8.0f) * 20000 + 0.5)]
+      float y;
+      if (s <= -8.0f) y = (float)0.000334;
+      else if (s >= 8.0f) y = (float)0.999666;
+      else y = sig[(int)((double)((s + 8.0f) * (float)JAMD_LOGISTIC_FACTOR) + 0.5)];
+      s = y;
+    }
+    if (t < T && j < N) Y[(size_t)t * ldy + j] = s;
+  }
+}
+
+// Output layer, step 1: logprob = addlog_array(x, S) (calc_dnn.c:862), the
+// right-to-left table scan; inherently serial per frame, one lane per frame.
+__global__ void __launch_bounds__(64)
+dnn_lse_kernel(const float *__restrict__ x, const float *__restrict__ tbl, float *__restrict__ lse,
+               int T, int S, float addmin_f) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  const float *row = x + (size_t)t * S;
+  float y = JAMD_LOG_ZERO;
+  for (int n = S - 1; n >= 0; n--) y = addlog_step(y, row[n], tbl, addmin_f);
+  lse[t] = y;
+}
+
+// step 2: last_cache[i] = INV_LOG_TEN * (x_i - logprob) - state_prior[i]
+// (double expression rounded once on store, calc_dnn.c:864)
+__global__ void __launch_bounds__(256)
+dnn_norm_kernel(float *__restrict__ x, const float *__restrict__ lse, const float *__restrict__ prior,
+                int T, int S) {
+  const size_t n = (size_t)T * S;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / S), s = (int)(i - (size_t)t * S);
+    x[i] = (float)(JAMD_INV_LOG_TEN * (double)(x[i] - lse[t]) - (double)prior[s]);
+  }
+}
+
+int ensure(float **p, size_t *cap, size_t need) {
+  if (*cap >= need) return JAMD_OK;
+  if (*p) JAMD_HIP(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  JAMD_HIP(hipMalloc(p, need));
+  *cap = need;
+  return JAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out) {
+  if (!e || !d || !out || d->nlayer < 1 || !d->dims || !d->w || !d->b || !d->state_prior) {
+    jamd_set_error("jamd_dnn_create: bad argument");
+    return JAMD_EINVAL;
+  }
+  *out = nullptr;
+  for (int l = 0; l <= d->nlayer; l++) {
+    if (d->dims[l] <= 0) { jamd_set_error("jamd_dnn_create: dims[%d]=%d", l, d->dims[l]); return JAMD_EINVAL; }
+    // dnn_layer_load() insists on 8-element aligned inputs on AVX/FMA hosts
+    // (calc_dnn.c:395) and calc_dnn_fma() would silently drop a tail
+    if (l < d->nlayer && d->dims[l] % 8 != 0) {
+      jamd_set_error("jamd_dnn_create: layer %d input length %d is not a multiple of 8 "
+                     "(same restriction as the reference's SIMD path)", l, d->dims[l]);
+      return JAMD_EINVAL;
+    }
+  }
+  JAMD_HIP(hipSetDevice(e->device));
+  jamd_dnn *n = new jamd_dnn();
+  n->eng = e; n->nlayer = d->nlayer;
+  n->dims.assign(d->dims, d->dims + d->nlayer + 1);
+  for (int v : n->dims) if (v > n->maxdim) n->maxdim = v;
+  for (int l = 0; l < d->nlayer; l++) {
+    float *w = nullptr, *b = nullptr;
+    const size_t nw = (size_t)n->dims[l + 1] * n->dims[l];
+    JAMD_HIP(hipMalloc(&w, sizeof(float) * nw));
+    JAMD_HIP(hipMemcpy(w, d->w[l], sizeof(float) * nw, hipMemcpyHostToDevice));
+    JAMD_HIP(hipMalloc(&b, sizeof(float) * n->dims[l + 1]));
+    JAMD_HIP(hipMemcpy(b, d->b[l], sizeof(float) * n->dims[l + 1], hipMemcpyHostToDevice));
+    n->d_w.push_back(w); n->d_b.push_back(b);
+  }
+  const int S = n->dims[d->nlayer];
+  JAMD_HIP(hipMalloc(&n->d_prior, sizeof(float) * S));
+  JAMD_HIP(hipMemcpy(n->d_prior, d->state_prior, sizeof(float) * S, hipMemcpyHostToDevice));
+  *out = n;
+  return JAMD_OK;
+}
+
+void jamd_dnn_destroy(jamd_dnn *n) {
+  if (!n) return;
+  (void)hipSetDevice(n->eng->device);
+  for (float *p : n->d_w) (void)hipFree(p);
+  for (float *p : n->d_b) (void)hipFree(p);
+  float *ptrs[] = { n->d_prior, n->d_act[0], n->d_act[1], n->d_lse, n->d_frames, n->d_out };
+  for (float *p : ptrs) if (p) (void)hipFree(p);
+  delete n;
+}
+
+int jamd_dnn_nstate(const jamd_dnn *n) { return n ? n->dims[n->nlayer] : -1; }
+int jamd_dnn_veclen(const jamd_dnn *n) { return n ? n->dims[0] : -1; }
+
+int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev_out, void *stream) {
+  if (!n || !dev_frames || !dev_out || T < 0) {
+    jamd_set_error("jamd_dnn_outprob_dev: bad argument");
+    return JAMD_EINVAL;
+  }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(n->eng->device));
+  hipStream_t st = jamd_stream(n->eng, stream);
+  int rc;
+  // hidden activations ping-pong between two [T][maxhidden] buffers
+  int maxh = 1;
+  for (int l = 1; l < n->nlayer; l++) if (n->dims[l] > maxh) maxh = n->dims[l];
+  const size_t need = sizeof(float) * (size_t)T * maxh;
+  if (n->act_cap < need) {
+    for (int k = 0; k < 2; k++) { if (n->d_act[k]) JAMD_HIP(hipFree(n->d_act[k])); n->d_act[k] = nullptr; }
+    n->act_cap = 0;
+    JAMD_HIP(hipMalloc(&n->d_act[0], need));
+    JAMD_HIP(hipMalloc(&n->d_act[1], need));
+    n->act_cap = need;
+  }
+  if ((rc = ensure(&n->d_lse, &n->lse_cap, sizeof(float) * (size_t)T)) != JAMD_OK) return rc;
+  const int nmb = (T + BM - 1) / BM;
+  const float *src = dev_frames;
+  for (int l = 0; l < n->nlayer; l++) {
+    const int K = n->dims[l], N = n->dims[l + 1];
+    const bool last = (l == n->nlayer - 1);
+    float *dst = last ? dev_out : n->d_act[l & 1];
+    const int nnb = (N + BN - 1) / BN;
+    const int grid = 8 * ((nmb + 7) / 8) * nnb;
+    if (last)
+      hipLaunchKernelGGL((dnn_layer_kernel<0>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
+                         n->eng->d_logistic, dst, T, K, N, K, N, nmb);
+    else
+      hipLaunchKernelGGL((dnn_layer_kernel<1>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
+                         n->eng->d_logistic, dst, T, K, N, K, N, nmb);
+    src = dst;
+  }
+  const int S = n->dims[n->nlayer];
+  hipLaunchKernelGGL(dnn_lse_kernel, dim3((T + 63) / 64), dim3(64), 0, st, dev_out, n->eng->d_addlog,
+                     n->d_lse, T, S, n->eng->addmin_f);
+  hipLaunchKernelGGL(dnn_norm_kernel, dim3(2048), dim3(256), 0, st, dev_out, n->d_lse, n->d_prior, T, S);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    jamd_set_error("jamd_dnn_outprob_dev: launch failed: %s", hipGetErrorString(le));
+    return JAMD_ELAUNCH;
+  }
+  return JAMD_OK;
+}
+
+int jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *host_out) {
+  if (!n || !host_frames || !host_out || T < 0) {
+    jamd_set_error("jamd_dnn_outprob_host: bad argument");
+    return JAMD_EINVAL;
+  }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(n->eng->device));
+  const int D = n->dims[0], S = n->dims[n->nlayer];
+  int rc;
+  if ((rc = ensure(&n->d_frames, &n->frames_cap, sizeof(float) * (size_t)T * D)) != JAMD_OK) return rc;
+  if ((rc = ensure(&n->d_out, &n->out_cap, sizeof(float) * (size_t)T * S)) != JAMD_OK) return rc;
+  hipStream_t st = n->eng->stream;
+  JAMD_HIP(hipMemcpyAsync(n->d_frames, host_frames, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, st));
+  if ((rc = jamd_dnn_outprob_dev(n, n->d_frames, T, n->d_out, st)) != JAMD_OK) return rc;
+  JAMD_HIP(hipMemcpyAsync(host_out, n->d_out, sizeof(float) * (size_t)T * S, hipMemcpyDeviceToHost, st));
+  hipError_t se = hipStreamSynchronize(st);
+  if (se != hipSuccess) {
+    jamd_set_error("jamd_dnn_outprob_host: execution failed: %s", hipGetErrorString(se));
+    return JAMD_ELAUNCH;
+  }
+  return JAMD_OK;
+}
+
+}  // extern "C"

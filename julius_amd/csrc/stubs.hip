@@ -1,15 +1,3 @@
-// stubs.hip -- entry points declared in include/julius_amd.h whose device
-// implementation has not landed yet.  They fail loudly (never fall back to a
-// CPU path); each is deleted from this file when its kernel is added.
+// stubs.hip -- (empty) every entry point of include/julius_amd.h now has a device
+// implementation; kept so the Makefile's wildcard has a stable file list.
 #include "jamd_internal.h"
-
-#define JAMD_NOT_YET(name)                                            \
-  jamd_set_error(name ": not implemented in this build of the engine"); \
-  return JAMD_EINVAL
-
-extern "C" {
-int jamd_dnn_create(jamd_engine *, const jamd_dnn_desc *, jamd_dnn **) { JAMD_NOT_YET("jamd_dnn_create"); }
-void jamd_dnn_destroy(jamd_dnn *) {}
-int jamd_dnn_outprob_dev(jamd_dnn *, const float *, int, float *, void *) { JAMD_NOT_YET("jamd_dnn_outprob_dev"); }
-int jamd_dnn_outprob_host(jamd_dnn *, const float *, int, float *) { JAMD_NOT_YET("jamd_dnn_outprob_host"); }
-}

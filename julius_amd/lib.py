@@ -84,6 +84,8 @@ def load():
         "jamd_cdset_outprob_dev": (ci, [vp, vp, ci, ci, vp, vp]),
         "jamd_dnn_create": (ci, [vp, P(DnnDesc), P(vp)]),
         "jamd_dnn_destroy": (None, [vp]),
+        "jamd_dnn_nstate": (ci, [vp]),
+        "jamd_dnn_veclen": (ci, [vp]),
         "jamd_dnn_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
         "jamd_dnn_outprob_host": (ci, [vp, vp, ci, vp]),
     }
@@ -275,6 +277,55 @@ class CdSet:
     def close(self):
         if getattr(self, "h", None):
             load().jamd_cdset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dnn:
+    """Device-resident DNN acoustic model (jamd_dnn)."""
+
+    def __init__(self, eng: Engine, dnn: dict):
+        self.eng = eng
+        self.dims = _i32(dnn["dims"])
+        nl = len(self.dims) - 1
+        self._w = [_f32(w) for w in dnn["w"]]
+        self._b = [_f32(b) for b in dnn["b"]]
+        for l in range(nl):
+            assert self._w[l].shape == (self.dims[l + 1], self.dims[l]), "W[l] must be [out][in]"
+        self._wp = (C.c_void_p * nl)(*[w.ctypes.data for w in self._w])
+        self._bp = (C.c_void_p * nl)(*[b.ctypes.data for b in self._b])
+        self._prior = _f32(dnn["prior"])
+        d = DnnDesc()
+        d.nlayer = nl
+        d.dims = self.dims.ctypes.data
+        d.w = C.cast(self._wp, C.c_void_p)
+        d.b = C.cast(self._bp, C.c_void_p)
+        d.state_prior = self._prior.ctypes.data
+        h = C.c_void_p()
+        _check(load().jamd_dnn_create(eng.h, C.byref(d), C.byref(h)), "jamd_dnn_create")
+        self.h = h
+        self.S, self.D = int(self.dims[-1]), int(self.dims[0])
+
+    def outprob_host(self, frames: np.ndarray) -> np.ndarray:
+        fr = _f32(frames)
+        T = fr.shape[0]
+        assert fr.shape[1] == self.D
+        out = np.empty((T, self.S), dtype=np.float32)
+        _check(load().jamd_dnn_outprob_host(self.h, fr.ctypes.data, T, out.ctypes.data), "jamd_dnn_outprob_host")
+        return out
+
+    def outprob_dev(self, dev_frames: int, T: int, dev_out: int, stream: int = 0):
+        _check(load().jamd_dnn_outprob_dev(self.h, dev_frames, T, dev_out, stream or None),
+               "jamd_dnn_outprob_dev")
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_dnn_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -167,6 +167,13 @@ class Ref:
         lib.jref_am_outprob_cd.argtypes = [vp, vp, ci, ci, vp, vp, vp]
         lib.jref_am_from_flat.restype = vp
         lib.jref_am_from_flat.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci]
+        lib.jref_dnn_load.restype = vp
+        lib.jref_dnn_load.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
+                                      C.c_float, ci, ci]
+        lib.jref_dnn_outprob.restype = cd
+        lib.jref_dnn_outprob.argtypes = [vp, vp, ci, vp]
+        lib.jref_simd_string.restype = C.c_char_p
+        lib.jref_simd_avail.restype = ci
         lib.jref_quiet(1 if quiet else 0)
 
     def am_load(self, hmmdefs, hmmlist=None, gprune="none", gprune_num=2, cdset="max", cdmax=3):
@@ -175,6 +182,31 @@ class Ref:
         if not h:
             raise RuntimeError(f"reference failed to load {hmmdefs}")
         return RefAM(self, h)
+
+    def dnn_load(self, dnn, workdir, num_threads=1):
+        """Write the network as .npy / prior files and load it with the reference's
+        dnn_setup().  All hidden layers must share one width (reference limitation)."""
+        from julius_amd import synth
+        from pathlib import Path
+        workdir = Path(workdir)
+        dims = [int(x) for x in dnn["dims"]]
+        nl = len(dims) - 1
+        assert len(set(dims[1:-1])) == 1, "reference needs equal hidden widths"
+        wf, bf = [], []
+        for l in range(nl):
+            synth.write_npy(workdir / f"W{l}.npy", dnn["w"][l])
+            synth.write_npy(workdir / f"b{l}.npy", np.asarray(dnn["b"][l]).reshape(-1, 1))
+            wf.append(str(workdir / f"W{l}.npy").encode()); bf.append(str(workdir / f"b{l}.npy").encode())
+        with open(workdir / "prior", "w") as f:
+            for i, v in enumerate(dnn["prior_lin"]):
+                f.write(f"{i} {float(v):.9e}\n")
+        nh = nl - 1
+        wa = (C.c_char_p * nh)(*wf[:nh]); ba = (C.c_char_p * nh)(*bf[:nh])
+        h = self.lib.jref_dnn_load(dims[0], 1, dims[0], dims[-1], dims[1], nh, wa, ba, wf[-1], bf[-1],
+                                   str(workdir / "prior").encode(), 1.0, 1, num_threads)
+        if not h:
+            raise RuntimeError("reference dnn_setup failed")
+        return RefDNN(self, h, dims)
 
     def am_from_flat(self, model, gprune="none", gprune_num=0):
         """Reference scoring code over in-memory structures built from flat arrays
@@ -262,3 +294,15 @@ class RefAM:
         if self.h and not self.from_flat:
             self.ref.lib.jref_am_free(self.h)
         self.h = None
+
+
+class RefDNN:
+    def __init__(self, ref: Ref, h, dims):
+        self.ref, self.h, self.dims = ref, h, dims
+
+    def outprob(self, frames, want_out=True):
+        fr = _f32(frames)
+        T = fr.shape[0]
+        out = np.empty((T, self.dims[-1]), np.float32) if want_out else None
+        self.last_seconds = float(self.ref.lib.jref_dnn_outprob(self.h, _p(fr), T, _p(out) if want_out else None))
+        return out

@@ -250,3 +250,48 @@ void *jref_am_from_flat(int S, int D, int G, const float *mean, const float *iva
   for (s = 0; s < S; s++) a->by_id[s] = &st[s];
   return a;   /* intentionally never freed piecewise: test/bench lifetime */
 }
+
+/* ------------------------------------------------------------------ DNN tap */
+#include <sent/dnn.h>
+
+typedef struct { DNNData *dnn; HMMWork wrk; } jref_dnn;
+
+/* dnn_new() + dnn_setup() (calc_dnn.c:457/528) from .npy / prior files. */
+void *jref_dnn_load(int veclen, int contextlen, int in, int out, int hid, int nhid,
+                    const char **wfiles, const char **bfiles, const char *ow, const char *ob,
+                    const char *prior, float prior_factor, int log10nize, int num_threads)
+{
+  jref_dnn *d = (jref_dnn *)calloc(1, sizeof(jref_dnn));
+  d->dnn = dnn_new();
+  if (!dnn_setup(d->dnn, veclen, contextlen, in, out, hid, nhid, (char **)wfiles, (char **)bfiles,
+                 (char *)ow, (char *)ob, (char *)prior, prior_factor, log10nize ? TRUE : FALSE, 1,
+                 num_threads, "disable")) { free(d); return NULL; }
+  make_log_tbl();
+  memset(&d->wrk, 0, sizeof(d->wrk));
+  d->wrk.OP_dnn = d->dnn;
+  d->wrk.statenum = out;
+  return d;
+}
+
+/* dnn_calc_outprob() (calc_dnn.c:774) frame by frame; returns seconds. */
+double jref_dnn_outprob(void *h, const float *frames, int T, float *out)
+{
+  jref_dnn *d = (jref_dnn *)h;
+  int D = d->dnn->inputnodenum, S = d->dnn->outputnodenum, t;
+  HTK_Param *p = make_param(frames, T, D);
+  float *row = (float *)malloc(sizeof(float) * S);
+  double t0 = now_sec();
+  d->wrk.OP_param = p;
+  for (t = 0; t < T; t++) {
+    d->wrk.OP_time = t;
+    d->wrk.last_cache = out ? out + (size_t)t * S : row;
+    dnn_calc_outprob(&d->wrk);
+  }
+  t0 = now_sec() - t0;
+  free(row);
+  free_param(p);
+  return t0;
+}
+
+const char *jref_simd_string(void) { static char buf[256]; get_builtin_simd_string(buf); return buf; }
+int jref_simd_avail(void) { return check_avail_simd(); }

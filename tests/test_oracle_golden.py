@@ -65,3 +65,20 @@ def test_addlog_edge_cases(oracle):
     v = oracle.addlog_array(np.array([-2.0, -2.0], np.float32))
     assert abs(v - (-2.0 + np.log(2.0))) < 2e-5
     assert oracle.addlog_array(np.array([-100.0, 0.0], np.float32)) == 0.0
+
+
+def load_dnn(name):
+    z = np.load(GOLDEN / name)
+    nl = len(z["dims"]) - 1
+    return dict(dims=z["dims"], w=[z[f"w{l}"] for l in range(nl)], b=[z[f"b{l}"] for l in range(nl)],
+                prior=z["prior"]), z["frames"], z["out"]
+
+
+def test_dnn_fma_path(oracle):
+    """calc_dnn.c:774 + calc_dnn_fma.c:19 (8 fused partial sums) -- bit-exact."""
+    dnn, fr, want = load_dnn("dnn_small.npz")
+    assert np.array_equal(oracle.dnn_outprob(dnn, fr, po.DNN_FMA), want)
+    # the other reference kernels differ only by rounding: mixed tolerance of SURVEY.md 7.7
+    for mode in (po.DNN_AVX, po.DNN_SSE, po.DNN_SCALAR):
+        got = oracle.dnn_outprob(dnn, fr, mode)
+        assert np.all(np.abs(got - want) <= 1e-4 * np.maximum(1.0, np.abs(want)))

@@ -55,3 +55,13 @@ def test_lazy_equals_eager(ref, tmp_path):
     ss = rng.integers(0, 15, 100).astype(np.int32)
     assert np.array_equal(am.outprob_list(fr, tt, ss), full[tt, ss])
     am.close()
+
+
+@pytest.mark.parametrize("dims", [(48, 64, 64, 40), (40, 128, 128, 128, 128, 61), (528, 256, 256, 100)])
+def test_dnn(ref, oracle, tmp_path, dims):
+    if "FMA" not in ref.lib.jref_simd_string().decode():
+        pytest.skip("host without FMA: the reference picks another SIMD kernel")
+    dnn = synth.make_dnn(dims=dims, seed=dims[0])
+    r = ref.dnn_load(dnn, tmp_path)
+    fr = np.random.default_rng(1).normal(0, 1.5, (15, dims[0])).astype(np.float32)
+    assert np.array_equal(oracle.dnn_outprob(dnn, fr, po.DNN_FMA), r.outprob(fr))

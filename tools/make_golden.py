@@ -88,6 +88,15 @@ def main():
     scores = am.outprob(fr)
     save("cdset.npz", scores=scores, set_off=set_off, states=states, **cds)
 
+    # D1: DNN (reference FMA path, calc_dnn_fma.c) -- 48 -> 3 x 64 sigmoid -> 40
+    dnn = synth.make_dnn(dims=(48, 64, 64, 64, 40), seed=51)
+    r = ref.dnn_load(dnn, tmp)
+    fr = np.random.default_rng(52).normal(0, 1.5, (24, 48)).astype(np.float32)
+    simd = ref.lib.jref_simd_string().decode()
+    assert "FMA" in simd, "golden DNN vectors must come from the FMA path"
+    save("dnn_small.npz", frames=fr, out=r.outprob(fr), dims=dnn["dims"], prior=dnn["prior"],
+         **{f"w{l}": dnn["w"][l] for l in range(4)}, **{f"b{l}": dnn["b"][l] for l in range(4)})
+
     # tables
     o = pyoracle.Oracle()
     tbl = o.log_tbl()
