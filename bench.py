@@ -76,7 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=16, help="utterances (x1000 frames) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn"],
+                    help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half")
     args = ap.parse_args()
+    if args.workload == "dnn":
+        return main_dnn(args)
 
     import torch
     from julius_amd import lib, synth
@@ -192,6 +196,52 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_dnn(args):
+    """configs[3] scoring half: 528 -> 6 x 2048 table-sigmoid -> 4000 senones, batched frames.
+    Reported against the fp32 MFMA roofline (157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+    import torch
+    from julius_amd import lib, synth
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dnn = synth.make_dnn(seed=0)
+    T = args.utts * FRAMES_PER_UTT
+    frames = np.random.default_rng(100 + rank).normal(0, 1, (T, 528)).astype(np.float32)
+    eng = lib.Engine(local_rank)
+    net = lib.Dnn(eng, dnn)
+    d_fr = torch.from_numpy(frames).cuda()
+    d_out = torch.empty((T, net.S), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
+        b.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    dims = [int(x) for x in dnn["dims"]]
+    flops = 2.0 * T * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    from oracle import pyoracle
+    tt = np.array([0, T // 2, T - 1])
+    want = pyoracle.Oracle().dnn_outprob(dnn, frames[tt], pyoracle.DNN_FMA)
+    got = d_out[torch.from_numpy(tt).cuda()].cpu().numpy()
+    line = {"metric": "frames_x_states_scored_per_sec", "value": T * args.steps * net.S / elapsed,
+            "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": T * args.steps / 100.0 / elapsed,
+            "config": {"workload": f"C4 scoring half (BASELINE.json configs[3]): DNN {dims}, {T} frames per step"},
+            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel_ms": ms},
+            "parity_spot_check": bool(np.array_equal(got, want))}
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

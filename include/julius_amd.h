@@ -170,6 +170,89 @@ int  jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *de
                           void *stream);
 int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *host_out);
 
+
+/* ------------------------------------------------- first-pass beam (pass 1) */
+/* Flattened read side of the first pass: the tree lexicon WCHMM_INFO
+ * (libjulius/include/julius/wchmm.h:211-278), the cross-word context tables
+ * that outprob_style() (libjulius/src/outprob_style.c:354) resolves by name
+ * lookups, the LM factoring tables (libjulius/src/factoring_sub.c:345-468) and
+ * the forward 2-gram the beam reads through ngram->bigram_prob
+ * (libsent/src/ngram/ngram_access.c:288-403).  N-gram LM, non-multipath models,
+ * 1-gram factoring (the reference's default "fast" setup).  All indices are
+ * 32-bit; WORD_INVALID is -1 here.  Built by jamd_flatten_lexicon()
+ * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess. */
+#define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
+#define JAMD_AS_LSET  1   /* AS_LSET   wchmm.h:106: out_id = state-set id                */
+#define JAMD_AS_RSET  2   /* AS_RSET   wchmm.h:107: out_id = row of lc_tab               */
+#define JAMD_AS_LRSET 3   /* AS_LRSET  wchmm.h:108: out_id = row of lc_tab               */
+
+#define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */
+#define JAMD_NG_ADDITIONAL_OLD 1  /* bi_prob_additional_oldbin() ngram_access.c:320 */
+#define JAMD_NG_ADDITIONAL     2  /* bi_prob_additional()        ngram_access.c:351 */
+#define JAMD_NG_COMPUTE        3  /* bi_prob_compute()           ngram_access.c:383 */
+
+typedef struct {
+  /* tree lexicon */
+  int nnode, nword, startnum, isolatenum;
+  const float *self_a, *next_a;        /* [nnode] wchmm->self_a / next_a (next goes to node+1)   */
+  const int   *ac_off;                 /* [nnode+1] extra arcs (A_CELL2 chains, wchmm.h:162) in   */
+  const int   *ac_to;                  /*           the order beam_intra_word() walks them        */
+  const float *ac_a;                   /*           (libjulius/src/beam.c:2173-2177)              */
+  const int   *stend;                  /* [nnode] word ending here or -1 (wchmm->stend)           */
+  const int   *scid;                   /* [nnode] wchmm->state[n].scid                            */
+  const unsigned char *out_kind;       /* [nnode] JAMD_AS_*  (wchmm->outstyle)                    */
+  const int   *out_id;                 /* [nnode] see JAMD_AS_*                                   */
+  /* cross-word left context: column = base phone of the previous word's last
+   * phone (center_name(), libsent/src/hmminfo/cdhmm.c:144); column nlc = no
+   * previous word.  Entry >= 0: state id; < 0: ~(state-set id). */
+  int nlc, nlcrow;
+  const int   *lc_tab;                 /* [nlcrow][nlc+1]                                         */
+  const int   *word_lc;                /* [nword] column a word selects as LEFT context           */
+  /* pseudo-phone state sets (CD_State_Set) used by AS_LSET nodes and lc_tab */
+  int nset;
+  const int   *set_off, *set_states;   /* CSR                                                     */
+  int cdset_method, cdmax_num;         /* JAMD_IWCD_*, hmminfo->cdmax_num                         */
+  /* tree roots */
+  const int   *startnode;              /* [startnum] wchmm->startnode                             */
+  const int   *start2isolate;          /* [startnum] wchmm->start2isolate (-1 = shared root)      */
+  /* words */
+  const float *wordend_a;              /* [nword] wchmm->wordend_a                                */
+  const int   *wton;                   /* [nword] winfo->wton (N-gram entry id)                   */
+  const float *cprob;                  /* [nword] winfo->cprob                                    */
+  const unsigned char *is_transparent; /* [nword]                                                 */
+  const int   *word_head;              /* [nword] wchmm->offset[w][0]                             */
+  int head_silwid, tail_silwid;
+  /* LM factoring */
+  int nfscore, nscword;
+  const float *fscore;                 /* [nfscore] wchmm->fscore (index -scid)                   */
+  const int   *scword;                 /* [nscword] wchmm->scword (index scid)                    */
+  /* forward 2-gram as ngram->bigram_prob reads it */
+  int ng_mode;                         /* JAMD_NG_*                                               */
+  int ng_nword, ng_nbigram, ng_unk_id;
+  float ng_unk_num_log;
+  const float *ng_uni_prob;            /* d[0].prob                                               */
+  const float *ng_uni_bo;              /* d[0].bo_wt, or bo_wt_1 for the ADDITIONAL modes         */
+  const int   *ng_bi_bgn;              /* d[1].bgn  (-1 = NNID_INVALID)                           */
+  const int   *ng_bi_num;              /* d[1].num                                                */
+  const int   *ng_bi_wid;              /* d[1].nnid2wid                                           */
+  const float *ng_bi_prob;             /* d[1].prob, or p_2 for the ADDITIONAL modes              */
+  /* FSBeam local copies (libjulius/include/julius/recog.h:147-150) */
+  float lm_weight, lm_penalty, lm_penalty_trans;
+} jamd_lexicon_desc;
+
+/* One emitted word-trellis record (TRELLIS_ATOM, libjulius/include/julius/
+ * trellis.h:28-41) as save_trellis() fills it (beam.c:2209-2247).  last_tre is
+ * the index of the predecessor atom in the same output array, -1 for the
+ * sentence-start sentinel (FSBeam.bos). */
+typedef struct {
+  int   wid;
+  int   last_tre;
+  float backscore;
+  float lscore;
+  short begintime;
+  short endtime;
+} jamd_trellis_atom;
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,259 @@
+/*
+ * jamd_flatten_lex.c -- RecogProcess (WCHMM_INFO + WORD_INFO + NGRAM_INFO +
+ * HTK_HMM_INFO context tables) -> jamd_lexicon_desc.  Compiled inside the
+ * Julius tree against its own headers; see jamd_flatten.h / INTEGRATION.md.
+ *
+ * What is walked (reference structures, nothing redefined):
+ *   WCHMM_INFO   libjulius/include/julius/wchmm.h:211-278
+ *   A_CELL2      wchmm.h:162-172   (extra arcs; list order kept)
+ *   RC_INFO / LRC_INFO / ACOUSTIC_SPEC   wchmm.h:55-98
+ *   WORD_INFO    libsent/include/sent/vocabulary.h:53-86
+ *   NGRAM_INFO / NGRAM_TUPLE_INFO        libsent/include/sent/ngram2.h:137-188
+ * The cross-word context table reproduces, for every (word-head node, left
+ * context phone) pair, exactly the choice outprob_style() makes at run time
+ * (libjulius/src/outprob_style.c:385-486) by calling the same lookup helpers
+ * (get_left_context_HMM, lcdset_lookup_by_hmmname).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <julius/julius.h>
+#include "jamd_flatten.h"
+
+#define NEW(T, n) ((T *)calloc((size_t)((n) > 0 ? (n) : 1), sizeof(T)))
+
+/* ---- small pointer -> id map ------------------------------------------- */
+typedef struct { const void **key; int *val; size_t cap; int n; } pmap;
+static void pmap_init(pmap *m, size_t want) {
+  m->cap = 64; while (m->cap < 2 * want + 16) m->cap <<= 1;
+  m->key = (const void **)calloc(m->cap, sizeof(void *));
+  m->val = (int *)malloc(m->cap * sizeof(int));
+  m->n = 0;
+}
+static void pmap_grow(pmap *m) {
+  pmap o = *m; size_t i;
+  m->cap = o.cap << 1;
+  m->key = (const void **)calloc(m->cap, sizeof(void *));
+  m->val = (int *)malloc(m->cap * sizeof(int));
+  for (i = 0; i < o.cap; i++) if (o.key[i]) {
+    size_t x = (size_t)o.key[i]; x ^= x >> 17; x *= (size_t)0x9E3779B97F4A7C15ull; x ^= x >> 29;
+    x &= m->cap - 1;
+    while (m->key[x]) x = (x + 1) & (m->cap - 1);
+    m->key[x] = o.key[i]; m->val[x] = o.val[i];
+  }
+  free(o.key); free(o.val);
+}
+/* returns existing id, or assigns the next id (and sets *isnew) */
+static int pmap_id(pmap *m, const void *k, int *isnew) {
+  size_t x;
+  if ((size_t)m->n * 2 + 2 > m->cap) pmap_grow(m);
+  x = (size_t)k; x ^= x >> 17; x *= (size_t)0x9E3779B97F4A7C15ull; x ^= x >> 29; x &= m->cap - 1;
+  while (m->key[x] != NULL && m->key[x] != k) x = (x + 1) & (m->cap - 1);
+  if (m->key[x] == NULL) { m->key[x] = k; m->val[x] = m->n++; if (isnew) *isnew = 1; return m->val[x]; }
+  if (isnew) *isnew = 0;
+  return m->val[x];
+}
+static void pmap_free(pmap *m) { free(m->key); free(m->val); }
+
+/* ---- growing int array -------------------------------------------------- */
+typedef struct { int *v; int n, cap; } ivec;
+static void ivec_push(ivec *a, int x) {
+  if (a->n == a->cap) { a->cap = a->cap ? a->cap * 2 : 256; a->v = (int *)realloc(a->v, sizeof(int) * a->cap); }
+  a->v[a->n++] = x;
+}
+
+typedef struct {
+  pmap sets;         /* CD_State_Set* -> set id */
+  ivec set_off, set_states;
+} setreg;
+
+static int set_id(setreg *sr, CD_State_Set *cs)
+{
+  int isnew, id = pmap_id(&sr->sets, cs, &isnew), k;
+  if (isnew) {
+    for (k = 0; k < cs->num; k++) ivec_push(&sr->set_states, cs->s[k]->id);
+    ivec_push(&sr->set_off, sr->set_states.n);
+  }
+  return id;
+}
+
+int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
+{
+  WCHMM_INFO *wchmm = r->wchmm;
+  WORD_INFO *winfo = wchmm->winfo;
+  HTK_HMM_INFO *hmminfo = wchmm->hmminfo;
+  NGRAM_INFO *ng = wchmm->ngram;
+  jamd_lexicon_desc *d = &out->desc;
+  int n = wchmm->n, W = winfo->num, i, k, w;
+  setreg sr;
+  char **lcname = NULL; int nlc = 0;
+  int *word_lc;
+  pmap rows; ivec rowkey_kind; ivec lc_tab;
+  typedef struct { HMM_Logical *hmm; short loc; unsigned char kind; } rowkey;
+  rowkey *rk = NULL; int nrk = 0, caprk = 0;
+  char rbuf[MAX_HMMNAME_LEN], cbuf[MAX_HMMNAME_LEN];
+
+  memset(out, 0, sizeof(*out));
+  if (r->lmtype != LM_PROB || ng == NULL) return JAMD_EINVAL;      /* N-gram only (for now) */
+  if (hmminfo->multipath) return JAMD_EINVAL;
+  if (wchmm->category_tree) return JAMD_EINVAL;
+  if (r->lmvar == LM_NGRAM_USER) return JAMD_EINVAL;
+
+  memset(&sr, 0, sizeof(sr)); pmap_init(&sr.sets, 1024); ivec_push(&sr.set_off, 0);
+  memset(&rowkey_kind, 0, sizeof(rowkey_kind)); memset(&lc_tab, 0, sizeof(lc_tab));
+  pmap_init(&rows, 1024);
+
+  /* ---- left-context classes: base phone of each word's last phone -------- */
+  word_lc = NEW(int, W);
+  for (w = 0; w < W; w++) {
+    center_name(winfo->wseq[w][winfo->wlen[w] - 1]->name, cbuf);
+    for (k = 0; k < nlc; k++) if (strcmp(lcname[k], cbuf) == 0) break;
+    if (k == nlc) { lcname = (char **)realloc(lcname, sizeof(char *) * (nlc + 1)); lcname[nlc++] = strdup(cbuf); }
+    word_lc[w] = k;
+  }
+
+  /* ---- nodes ---------------------------------------------------------------- */
+  out->self_a = NEW(float, n); out->next_a = NEW(float, n); out->ac_off = NEW(int, n + 1);
+  out->stend = NEW(int, n); out->scid = NEW(int, n); out->out_kind = NEW(unsigned char, n); out->out_id = NEW(int, n);
+  {
+    ivec ato; memset(&ato, 0, sizeof(ato));
+    float *aa = NULL; int acap = 0, an = 0;
+    for (i = 0; i < n; i++) {
+      A_CELL2 *ac;
+      out->self_a[i] = wchmm->self_a[i];
+      out->next_a[i] = wchmm->next_a[i];
+      out->ac_off[i] = an;
+      for (ac = wchmm->ac[i]; ac; ac = ac->next) {
+        for (k = 0; k < ac->n; k++) {
+          if (an == acap) { acap = acap ? acap * 2 : 1024; aa = (float *)realloc(aa, sizeof(float) * acap); }
+          ivec_push(&ato, ac->arc[k]); aa[an++] = ac->a[k];
+        }
+      }
+      out->stend[i] = (wchmm->stend[i] == WORD_INVALID) ? -1 : (int)wchmm->stend[i];
+      out->scid[i] = wchmm->state[i].scid;
+    }
+    out->ac_off[n] = an;
+    out->ac_to = ato.v ? ato.v : NEW(int, 1);
+    out->ac_a = aa ? aa : NEW(float, 1);
+  }
+
+  /* ---- acoustic spec of every node (outprob_style.c:376-486) ---------------- */
+  for (i = 0; i < n; i++) {
+    unsigned char kind = wchmm->ccd_flag ? wchmm->outstyle[i] : AS_STATE;
+    if (wchmm->state[i].out.state == NULL) { free(word_lc); return JAMD_EINVAL; }   /* non-emitting: multipath only */
+    switch (kind) {
+    case AS_STATE:
+      out->out_kind[i] = JAMD_AS_STATE; out->out_id[i] = wchmm->state[i].out.state->id; break;
+    case AS_LSET:
+      out->out_kind[i] = JAMD_AS_LSET; out->out_id[i] = set_id(&sr, wchmm->state[i].out.lset); break;
+    case AS_RSET: case AS_LRSET: {
+      HMM_Logical *base = (kind == AS_RSET) ? wchmm->state[i].out.rset->hmm : wchmm->state[i].out.lrset->hmm;
+      short loc = (kind == AS_RSET) ? wchmm->state[i].out.rset->state_loc : wchmm->state[i].out.lrset->state_loc;
+      int row = -1;
+      for (k = 0; k < nrk; k++) if (rk[k].hmm == base && rk[k].loc == loc && rk[k].kind == kind) { row = k; break; }
+      if (row < 0) {
+        int c;
+        if (nrk == caprk) { caprk = caprk ? caprk * 2 : 256; rk = (rowkey *)realloc(rk, sizeof(rowkey) * caprk); }
+        rk[nrk].hmm = base; rk[nrk].loc = loc; rk[nrk].kind = kind; row = nrk++;
+        for (c = 0; c <= nlc; c++) {          /* column nlc: last_wid == WORD_INVALID */
+          HMM_Logical *rhmm = base, *ohmm;
+          int ent;
+          if (kind == AS_RSET) {                                   /* outprob_style.c:390-428 */
+            if (c < nlc && (ohmm = get_left_context_HMM(base, lcname[c], hmminfo)) != NULL) rhmm = ohmm;
+            if (rhmm->is_pseudo) ent = ~set_id(&sr, &(rhmm->body.pseudo->stateset[loc]));
+            else ent = rhmm->body.defined->s[loc]->id;
+          } else {                                                 /* outprob_style.c:440-478 */
+            CD_Set *lcd;
+            strcpy(rbuf, base->name);
+            if (c < nlc) add_left_context(rbuf, lcname[c]);
+            lcd = lcdset_lookup_by_hmmname(hmminfo, rbuf);
+            if (lcd != NULL) ent = ~set_id(&sr, &(lcd->stateset[loc]));
+            else if (base->is_pseudo) ent = ~set_id(&sr, &(base->body.pseudo->stateset[loc]));
+            else ent = base->body.defined->s[loc]->id;
+          }
+          ivec_push(&lc_tab, ent);
+        }
+      }
+      out->out_kind[i] = (kind == AS_RSET) ? JAMD_AS_RSET : JAMD_AS_LRSET;
+      out->out_id[i] = row;
+      break; }
+    default:
+      free(word_lc); return JAMD_EINVAL;
+    }
+  }
+  free(rk); pmap_free(&rows);
+
+  /* ---- roots, words ------------------------------------------------------------ */
+  out->startnode = NEW(int, wchmm->startnum); out->start2isolate = NEW(int, wchmm->startnum);
+  for (i = 0; i < wchmm->startnum; i++) { out->startnode[i] = wchmm->startnode[i]; out->start2isolate[i] = wchmm->start2isolate[i]; }
+  out->wordend_a = NEW(float, W); out->wton = NEW(int, W); out->cprob = NEW(float, W);
+  out->is_transparent = NEW(unsigned char, W); out->word_head = NEW(int, W);
+  for (w = 0; w < W; w++) {
+    out->wordend_a[w] = wchmm->wordend_a[w]; out->wton[w] = winfo->wton[w]; out->cprob[w] = winfo->cprob[w];
+    out->is_transparent[w] = winfo->is_transparent[w] ? 1 : 0; out->word_head[w] = wchmm->offset[w][0];
+  }
+  out->word_lc = word_lc;
+
+  /* ---- factoring ------------------------------------------------------------------ */
+  out->fscore = NEW(float, wchmm->fsnum); for (i = 0; i < wchmm->fsnum; i++) out->fscore[i] = wchmm->fscore[i];
+  out->scword = NEW(int, wchmm->scnum);
+  for (i = 1; i < wchmm->scnum; i++) out->scword[i] = wchmm->scword[i];
+
+  /* ---- forward 2-gram (bi_prob_func_set(), ngram_access.c:449-466) --------------------- */
+  {
+    int V = ng->max_word_num;
+    NGRAM_TUPLE_INFO *t2 = &(ng->d[1]);
+    const float *bo, *bp;
+    if (t2->is24bit || t2->bgn == NULL) { free(word_lc); return JAMD_EINVAL; }
+    if (ng->bigram_index_reversed) { d->ng_mode = JAMD_NG_ADDITIONAL_OLD; bo = ng->bo_wt_1; bp = ng->p_2; }
+    else if (ng->dir == DIR_LR) { d->ng_mode = JAMD_NG_NORMAL; bo = ng->d[0].bo_wt; bp = t2->prob; }
+    else if (ng->bo_wt_1 != NULL) { d->ng_mode = JAMD_NG_ADDITIONAL; bo = ng->bo_wt_1; bp = ng->p_2; }
+    else { d->ng_mode = JAMD_NG_COMPUTE; bo = ng->d[0].bo_wt; bp = t2->prob; }
+    out->ng_uni_prob = NEW(float, V); out->ng_uni_bo = NEW(float, V);
+    out->ng_bi_bgn = NEW(int, V); out->ng_bi_num = NEW(int, V);
+    for (i = 0; i < V; i++) {
+      out->ng_uni_prob[i] = ng->d[0].prob[i]; out->ng_uni_bo[i] = bo[i];
+      out->ng_bi_bgn[i] = (t2->bgn[i] == NNID_INVALID) ? -1 : (int)t2->bgn[i];
+      out->ng_bi_num[i] = t2->num[i];
+    }
+    out->ng_bi_wid = NEW(int, t2->totalnum); out->ng_bi_prob = NEW(float, t2->totalnum);
+    for (i = 0; i < (int)t2->totalnum; i++) { out->ng_bi_wid[i] = t2->nnid2wid[i]; out->ng_bi_prob[i] = bp[i]; }
+    d->ng_nword = V; d->ng_nbigram = t2->totalnum;
+    d->ng_unk_id = (int)ng->unk_id; d->ng_unk_num_log = ng->unk_num_log;
+  }
+
+  /* ---- descriptor ------------------------------------------------------------------------- */
+  out->lc_tab = lc_tab.v ? lc_tab.v : NEW(int, 1);
+  out->set_off = sr.set_off.v; out->set_states = sr.set_states.v ? sr.set_states.v : NEW(int, 1);
+  d->nnode = n; d->nword = W; d->startnum = wchmm->startnum; d->isolatenum = wchmm->isolatenum;
+  d->self_a = out->self_a; d->next_a = out->next_a; d->ac_off = out->ac_off; d->ac_to = out->ac_to; d->ac_a = out->ac_a;
+  d->stend = out->stend; d->scid = out->scid; d->out_kind = out->out_kind; d->out_id = out->out_id;
+  d->nlc = nlc; d->nlcrow = nrk; d->lc_tab = out->lc_tab; d->word_lc = out->word_lc;
+  d->nset = sr.sets.n; d->set_off = out->set_off; d->set_states = out->set_states;
+  d->cdset_method = (hmminfo->cdset_method == IWCD_MAX) ? JAMD_IWCD_MAX :
+                    (hmminfo->cdset_method == IWCD_AVG) ? JAMD_IWCD_AVG : JAMD_IWCD_NBEST;
+  d->cdmax_num = hmminfo->cdmax_num;
+  d->startnode = out->startnode; d->start2isolate = out->start2isolate;
+  d->wordend_a = out->wordend_a; d->wton = out->wton; d->cprob = out->cprob;
+  d->is_transparent = out->is_transparent; d->word_head = out->word_head;
+  d->head_silwid = (winfo->head_silwid == WORD_INVALID) ? -1 : (int)winfo->head_silwid;
+  d->tail_silwid = (winfo->tail_silwid == WORD_INVALID) ? -1 : (int)winfo->tail_silwid;
+  d->nfscore = wchmm->fsnum; d->nscword = wchmm->scnum; d->fscore = out->fscore; d->scword = out->scword;
+  d->ng_uni_prob = out->ng_uni_prob; d->ng_uni_bo = out->ng_uni_bo; d->ng_bi_bgn = out->ng_bi_bgn;
+  d->ng_bi_num = out->ng_bi_num; d->ng_bi_wid = out->ng_bi_wid; d->ng_bi_prob = out->ng_bi_prob;
+  d->lm_weight = r->config->lmp.lm_weight; d->lm_penalty = r->config->lmp.lm_penalty;
+  d->lm_penalty_trans = r->config->lmp.lm_penalty_trans;
+  for (k = 0; k < nlc; k++) free(lcname[k]);
+  free(lcname); pmap_free(&sr.sets);
+  return JAMD_OK;
+}
+
+void jamd_flat_lexicon_free(jamd_flat_lexicon *f)
+{
+  free(f->self_a); free(f->next_a); free(f->ac_off); free(f->ac_to); free(f->ac_a); free(f->stend);
+  free(f->scid); free(f->out_kind); free(f->out_id); free(f->lc_tab); free(f->word_lc); free(f->set_off);
+  free(f->set_states); free(f->startnode); free(f->start2isolate); free(f->wordend_a); free(f->wton);
+  free(f->cprob); free(f->is_transparent); free(f->word_head); free(f->fscore); free(f->scword);
+  free(f->ng_uni_prob); free(f->ng_uni_bo); free(f->ng_bi_bgn); free(f->ng_bi_num); free(f->ng_bi_wid);
+  free(f->ng_bi_prob);
+  memset(f, 0, sizeof(*f));
+}

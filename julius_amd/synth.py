@@ -216,3 +216,109 @@ def make_dnn(dims=(528, 2048, 2048, 2048, 2048, 2048, 2048, 4000), seed=0):
 def write_npy(path, a):
     """NPY v1 '<f4' C-order, the only form load_npy() accepts (calc_dnn.c:225-335)."""
     np.save(path, np.ascontiguousarray(a, dtype="<f4"))
+
+
+# ---------------------------------------------------- triphone task (beam tests)
+def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False):
+    """Write a complete synthetic recognition task the reference can load:
+    tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
+    forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
+    the GMM model.  Some logical triphones are deliberately left out of the
+    HMMList so word-boundary nodes fall back to pseudo-phone state sets
+    (libsent/src/hmminfo/cdset.c) and exercise outprob_cd()."""
+    workdir = Path(workdir)
+    workdir.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    phones = [f"p{i}" for i in range(nphone)]
+    sil = ["silB", "silE"]
+    model = make_gmm(S=S, M=M, D=D, seed=seed + 1)
+    # state pool partition: each centre phone owns a slice of the pool
+    per = (S - 6) // nphone
+    assert per >= 3
+    phys = []          # (name, (s1,s2,s3))
+    for ci, c in enumerate(phones):
+        base = ci * per
+        for v in range(nvar):
+            st = tuple(int(base + rng.integers(0, per)) for _ in range(3))
+            phys.append((f"{c}_v{v}", st))
+    phys.append(("silB", (S - 6, S - 5, S - 4)))
+    phys.append(("silE", (S - 3, S - 2, S - 1)))
+    write_hmmdefs(workdir / "hmmdefs", model, phones=phys)
+    # logical triphones -> physical variants; contexts include silB/silE
+    ctx = phones + sil
+    lines = ["silB silB", "silE silE"]
+    for c in phones:
+        for l in ctx:
+            for r in ctx:
+                if rng.random() > defined_frac:
+                    continue          # undefined -> pseudo phone fallback at word edges
+                v = int(rng.integers(0, nvar))
+                lines.append(f"{l}-{c}+{r} {c}_v{v}")
+        # word-internal triphones must exist for every (l, r) in phones: guarantee them
+    have = {ln.split()[0] for ln in lines}
+    for c in phones:
+        for l in phones:
+            for r in phones:
+                name = f"{l}-{c}+{r}"
+                if name not in have:
+                    lines.append(f"{name} {c}_v{int(rng.integers(0, nvar))}")
+    (workdir / "hmmlist").write_text("\n".join(lines) + "\n")
+    # dictionary
+    words = []
+    seen = set()
+    while len(words) < nword:
+        n = int(rng.integers(1, maxlen + 1))
+        ph = tuple(rng.choice(phones, size=n))
+        if ph in seen:
+            continue
+        seen.add(ph)
+        words.append((f"W{len(words):04d}", ph))
+    dl = ["<s> [] silB", "</s> [] silE"] + [f"{w} [{w}] " + " ".join(ph) for w, ph in words]
+    (workdir / "dict").write_text("\n".join(dl) + "\n")
+    # forward 2-gram ARPA (log10), entries in 1-gram order
+    vocab = ["<s>", "</s>"] + [w for w, _ in words]
+    V = len(vocab)
+    uni = rng.dirichlet(np.full(V, 1.0))
+    uni = np.log10(uni)
+    bo = -rng.uniform(0.1, 1.0, size=V)
+    big = []
+    for i in range(V):
+        if vocab[i] == "</s>":
+            continue
+        js = np.sort(rng.choice(np.arange(1, V), size=min(nbigram_per_word, V - 1), replace=False))
+        ps = np.log10(rng.dirichlet(np.full(len(js), 1.0)) * 0.8)
+        for j, p in zip(js, ps):
+            big.append((i, int(j), float(p)))
+    with open(workdir / "lm.arpa", "w") as f:
+        f.write(f"\\data\\\nngram 1={V}\nngram 2={len(big)}\n\n\\1-grams:\n")
+        for i in range(V):
+            f.write(f"{uni[i]:.6f}\t{vocab[i]}\t{bo[i]:.6f}\n")
+        f.write("\n\\2-grams:\n")
+        for i, j, p in big:
+            f.write(f"{p:.6f}\t{vocab[i]} {vocab[j]}\n")
+        f.write("\n\\end\\\n")
+    return dict(dir=workdir, hmmdefs=workdir / "hmmdefs", hmmlist=workdir / "hmmlist", dict=workdir / "dict",
+                arpa=workdir / "lm.arpa", model=model, words=words, vocab=vocab, phones=phones)
+
+
+def make_utterance(task, nwords=6, seed=0, frames_per_state=3, noise=0.7):
+    """Frames that roughly follow a random word sequence through the task's
+    models (so the best path is a real sentence, not noise)."""
+    rng = np.random.default_rng(seed)
+    model = task["model"]
+    ws = [task["words"][int(i)] for i in rng.integers(0, len(task["words"]), size=nwords)]
+    # walk: silB, words' phones (ignoring exact triphone identity: centre-phone states), silE
+    S = len(model["st_off"]) - 1
+    nphone = len(task["phones"])
+    per = (S - 6) // nphone
+    seq = [S - 6, S - 5, S - 4]
+    for _, ph in ws:
+        for p in ph:
+            ci = task["phones"].index(p)
+            base = ci * per
+            seq += [int(base + rng.integers(0, per)) for _ in range(3)]
+    seq += [S - 3, S - 2, S - 1]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
+    return fr.astype(np.float32), [w for w, _ in ws]

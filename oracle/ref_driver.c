@@ -295,3 +295,81 @@ double jref_dnn_outprob(void *h, const float *frames, int T, float *out)
 
 const char *jref_simd_string(void) { static char buf[256]; get_builtin_simd_string(buf); return buf; }
 int jref_simd_avail(void) { return check_avail_simd(); }
+
+/* ------------------------------------------------- full-engine (pass 1) taps */
+#include <julius/juliuslib.h>
+
+typedef struct { Jconf *jconf; Recog *recog; } jref_eng;
+
+/* j_config_load_args_new() + j_create_instance_from_jconf() (the julius-simple
+ * start-up sequence, julius-simple/julius-simple.c:250-270) */
+void *jref_engine_create(int argc, char **argv)
+{
+  jref_eng *e = (jref_eng *)calloc(1, sizeof(jref_eng));
+  e->jconf = j_config_load_args_new(argc, argv);
+  if (e->jconf == NULL) { free(e); return NULL; }
+  e->recog = j_create_instance_from_jconf(e->jconf);
+  if (e->recog == NULL) { free(e); return NULL; }
+  if (j_adin_init(e->recog) == FALSE) { free(e); return NULL; }
+  return e;
+}
+
+/* Recognise one HTK parameter file (-input htkparam).  Returns the number of
+ * trellis atoms, or -1.  With -1pass the word trellis is left exactly as
+ * finalize_1st_pass() built it. */
+int jref_engine_recognize(void *h, const char *mfcfile)
+{
+  jref_eng *e = (jref_eng *)h;
+  RecogProcess *r = e->recog->process_list;
+  int t, n = 0;
+  if (j_open_stream(e->recog, (char *)mfcfile) != 0) return -1;
+  if (j_recognize_stream(e->recog) == -1) return -1;
+  if (r->backtrellis->num == NULL) return 0;
+  for (t = 0; t < r->backtrellis->framelen; t++) n += r->backtrellis->num[t];
+  return n;
+}
+
+/* Copy the sorted word trellis (bt->rw[t][i]) out: per atom wid, begintime,
+ * endtime, backscore, lscore and the (wid, endtime) of its predecessor
+ * (-1,-1 for the sentence start). */
+int jref_engine_trellis(void *h, int *wid, int *bt, int *et, float *backscore, float *lscore,
+                        int *pwid, int *pet)
+{
+  jref_eng *e = (jref_eng *)h;
+  BACKTRELLIS *b = e->recog->process_list->backtrellis;
+  int t, i, n = 0;
+  if (b->num == NULL) return 0;
+  for (t = 0; t < b->framelen; t++) {
+    for (i = 0; i < b->num[t]; i++) {
+      TRELLIS_ATOM *a = b->rw[t][i];
+      wid[n] = a->wid; bt[n] = a->begintime; et[n] = a->endtime;
+      backscore[n] = a->backscore; lscore[n] = a->lscore;
+      if (a->last_tre == NULL || a->last_tre->wid == WORD_INVALID) { pwid[n] = -1; pet[n] = -1; }
+      else { pwid[n] = a->last_tre->wid; pet[n] = a->last_tre->endtime; }
+      n++;
+    }
+  }
+  return n;
+}
+
+/* pass1 best word sequence and score (r->pass1_wseq / pass1_score) */
+int jref_engine_pass1(void *h, int *wseq, float *score)
+{
+  jref_eng *e = (jref_eng *)h;
+  RecogProcess *r = e->recog->process_list;
+  int i;
+  for (i = 0; i < r->pass1_wnum; i++) wseq[i] = r->pass1_wseq[i];
+  *score = r->pass1_score;
+  return r->pass1_wnum;
+}
+
+int jref_engine_info(void *h, int *info)
+{
+  jref_eng *e = (jref_eng *)h;
+  RecogProcess *r = e->recog->process_list;
+  info[0] = r->wchmm->n; info[1] = r->wchmm->winfo->num; info[2] = r->wchmm->startnum;
+  info[3] = r->wchmm->isolatenum; info[4] = r->trellis_beam_width; info[5] = r->wchmm->hmminfo->totalstatenum;
+  info[6] = r->lmtype; info[7] = r->wchmm->hmminfo->multipath; info[8] = r->ccd_flag;
+  info[9] = r->backtrellis->framelen;
+  return 0;
+}
