@@ -41,6 +41,34 @@ void jamd_flat_gmm_free(jamd_flat_gmm *f);
  * libsent/src/anlz/param_malloc.c:52-77) into one [T][veclen] block. */
 float *jamd_pack_param(const HTK_Param *param, int t0, int t1);
 
+
+/* ---- first pass: tree lexicon + LM tables (jamd_flatten_lex.c) ------------- */
+#ifdef JAMD_WITH_LIBJULIUS   /* needs <julius/julius.h>; the GMM part above only needs libsent */
+#include <julius/julius.h>
+
+/* Owned flat copy of everything get_back_trellis_*() reads: all arrays malloc'ed,
+ * `desc` points into them. */
+typedef struct {
+  jamd_lexicon_desc desc;
+  float *self_a, *next_a; int *ac_off, *ac_to; float *ac_a;
+  int *stend, *scid; unsigned char *out_kind; int *out_id;
+  int *lc_tab, *word_lc, *set_off, *set_states;
+  int *startnode, *start2isolate;
+  float *wordend_a; int *wton; float *cprob; unsigned char *is_transparent; int *word_head;
+  float *fscore; int *scword;
+  float *ng_uni_prob, *ng_uni_bo; int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; float *ng_bi_prob;
+} jamd_flat_lexicon;
+
+/* Walk r->wchmm (after j_final_fusion()) and fill `out`.  JAMD_EINVAL for the
+ * configurations the device beam does not cover (grammar LM, multipath models,
+ * user LM plugin, 24-bit compacted 2-gram index). */
+int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
+void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
+/* Write the descriptor as a self-describing blob of named arrays (the format
+ * julius_amd/lexblob.py and jamd_lexicon_load() read). */
+int  jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
-#include <julius/julius.h>
+#include <stdio.h>
+#define JAMD_WITH_LIBJULIUS 1
 #include "jamd_flatten.h"
 
 #define NEW(T, n) ((T *)calloc((size_t)((n) > 0 ? (n) : 1), sizeof(T)))
@@ -256,4 +257,56 @@ void jamd_flat_lexicon_free(jamd_flat_lexicon *f)
   free(f->ng_uni_prob); free(f->ng_uni_bo); free(f->ng_bi_bgn); free(f->ng_bi_num); free(f->ng_bi_wid);
   free(f->ng_bi_prob);
   memset(f, 0, sizeof(*f));
+}
+
+/* ---- blob writer -------------------------------------------------------------------
+ * "JAMDLEX1", int32 nrec, then per record: char name[24], int32 dtype (0 = int32,
+ * 1 = float32, 2 = uint8), int32 count, payload padded to a multiple of 4 bytes.
+ * Scalars travel as the records "ints" and "floats" (order below).  Host byte order. */
+static int put_rec(FILE *f, const char *name, int dtype, int count, const void *data)
+{
+  char nm[24]; static const char zero[4] = {0, 0, 0, 0};
+  size_t bytes = (size_t)count * (dtype == 2 ? 1 : 4), pad = (4 - (bytes & 3)) & 3;
+  memset(nm, 0, sizeof(nm)); strncpy(nm, name, sizeof(nm) - 1);
+  if (fwrite(nm, 1, 24, f) != 24) return -1;
+  if (fwrite(&dtype, 4, 1, f) != 1 || fwrite(&count, 4, 1, f) != 1) return -1;
+  if (bytes && fwrite(data, 1, bytes, f) != bytes) return -1;
+  if (pad && fwrite(zero, 1, pad, f) != pad) return -1;
+  return 0;
+}
+
+int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
+{
+  FILE *f = fopen(path, "wb");
+  int nrec = 30, rc = 0;
+  int ints[18]; float floats[4];
+  if (f == NULL) return JAMD_EINVAL;
+  ints[0] = d->nnode; ints[1] = d->nword; ints[2] = d->startnum; ints[3] = d->isolatenum;
+  ints[4] = d->nlc; ints[5] = d->nlcrow; ints[6] = d->nset; ints[7] = d->cdset_method; ints[8] = d->cdmax_num;
+  ints[9] = d->head_silwid; ints[10] = d->tail_silwid; ints[11] = d->nfscore; ints[12] = d->nscword;
+  ints[13] = d->ng_mode; ints[14] = d->ng_nword; ints[15] = d->ng_nbigram; ints[16] = d->ng_unk_id; ints[17] = 0;
+  floats[0] = d->ng_unk_num_log; floats[1] = d->lm_weight; floats[2] = d->lm_penalty; floats[3] = d->lm_penalty_trans;
+  fwrite("JAMDLEX1", 1, 8, f); fwrite(&nrec, 4, 1, f);
+#define I32(nm, p, n) rc |= put_rec(f, nm, 0, (n), (p))
+#define F32(nm, p, n) rc |= put_rec(f, nm, 1, (n), (p))
+#define U8(nm, p, n)  rc |= put_rec(f, nm, 2, (n), (p))
+  I32("ints", ints, 18); F32("floats", floats, 4);
+  F32("self_a", d->self_a, d->nnode); F32("next_a", d->next_a, d->nnode);
+  I32("ac_off", d->ac_off, d->nnode + 1); I32("ac_to", d->ac_to, d->ac_off[d->nnode]); F32("ac_a", d->ac_a, d->ac_off[d->nnode]);
+  I32("stend", d->stend, d->nnode); I32("scid", d->scid, d->nnode);
+  U8("out_kind", d->out_kind, d->nnode); I32("out_id", d->out_id, d->nnode);
+  I32("lc_tab", d->lc_tab, d->nlcrow * (d->nlc + 1)); I32("word_lc", d->word_lc, d->nword);
+  I32("set_off", d->set_off, d->nset + 1); I32("set_states", d->set_states, d->set_off[d->nset]);
+  I32("startnode", d->startnode, d->startnum); I32("start2isolate", d->start2isolate, d->startnum);
+  F32("wordend_a", d->wordend_a, d->nword); I32("wton", d->wton, d->nword); F32("cprob", d->cprob, d->nword);
+  U8("is_transparent", d->is_transparent, d->nword); I32("word_head", d->word_head, d->nword);
+  F32("fscore", d->fscore, d->nfscore); I32("scword", d->scword, d->nscword);
+  F32("ng_uni_prob", d->ng_uni_prob, d->ng_nword); F32("ng_uni_bo", d->ng_uni_bo, d->ng_nword);
+  I32("ng_bi_bgn", d->ng_bi_bgn, d->ng_nword); I32("ng_bi_num", d->ng_bi_num, d->ng_nword);
+  I32("ng_bi_wid", d->ng_bi_wid, d->ng_nbigram); F32("ng_bi_prob", d->ng_bi_prob, d->ng_nbigram);
+#undef I32
+#undef F32
+#undef U8
+  if (fclose(f) != 0) rc = -1;
+  return rc ? JAMD_EINVAL : JAMD_OK;
 }

@@ -1,0 +1,416 @@
+/*
+ * jamd_oracle_beam.c -- CPU restatement of Julius' first pass (frame-synchronous
+ * token passing over the tree lexicon).
+ *
+ * *** TEST INFRASTRUCTURE ONLY (see jamd_oracle.h). ***
+ *
+ * Written from scratch over the FLAT tables of include/julius_amd.h
+ * (jamd_lexicon_desc), following the reference's sequential algorithm step by
+ * step -- including the partial heap sort that decides the iteration order of
+ * the surviving tokens -- so that its word trellis is the reference's word
+ * trellis even where Viterbi ties are broken by visiting order.  Scope: N-gram
+ * LM, non-multipath models, the reference's default "fast" configuration
+ * (UNIGRAM_FACTORING, PASS1_IWCD, SCORE_PRUNING; no WPAIR / WORD_GRAPH /
+ * spsegment).  Paths below are relative to the reference root.
+ *
+ * Parity status: PINNED against the compiled reference (oracle/_ref) by
+ * tests/test_beam_oracle_vs_ref.py and the fixtures under tests/golden/.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "jamd_oracle.h"
+#include "../include/julius_amd.h"
+
+typedef struct {          /* TOKEN2, libjulius/include/julius/beam.h:35-45 */
+  int   last_tre;         /* index into atoms[], -1 = FSBeam.bos */
+  int   last_cword;
+  float last_lscore;
+  float score;
+  int   node;
+} tok;
+
+typedef struct {
+  const jamd_lexicon_desc *lx;
+  const float *sc; int S;
+  tok *tlist[2]; int *tindex[2]; int tnum[2]; int maxtnum, expand_step;
+  int *token;               /* node -> token id in tlist[tn], -1 = none */
+  int tn, tl, n_start, n_end;
+  float score_pruning_threshold, score_pruning_max;
+  float wordend_best_score; int wordend_best_node, wordend_best_tre, wordend_best_last_cword;
+  jamd_trellis_atom *atoms; int natom, atom_cap, overflow;
+} beam;
+
+/* ---- LM ------------------------------------------------------------------- */
+/* search_bigram(), libsent/src/ngram/ngram_access.c:225-247 */
+static int search_bigram(const jamd_lexicon_desc *lx, int w_context, int w)
+{
+  int left = lx->ng_bi_bgn[w_context], right, mid;
+  if (left < 0) return -1;
+  right = left + lx->ng_bi_num[w_context] - 1;
+  while (left < right) {
+    mid = (left + right) / 2;
+    if (lx->ng_bi_wid[mid] < w) left = mid + 1; else right = mid;
+  }
+  return (lx->ng_bi_wid[left] == w) ? left : -1;
+}
+
+/* ngram->bigram_prob as selected by bi_prob_func_set(), ngram_access.c:288-466 */
+float jo_bigram_prob(const jamd_lexicon_desc *lx, int w1, int w2)
+{
+  int n2; float prob;
+  switch (lx->ng_mode) {
+  case JAMD_NG_NORMAL: case JAMD_NG_ADDITIONAL_OLD:          /* :288 / :320 (LR index) */
+    if ((n2 = search_bigram(lx, w1, w2)) >= 0) prob = lx->ng_bi_prob[n2];
+    else prob = lx->ng_uni_bo[w1] + lx->ng_uni_prob[w2];
+    break;
+  case JAMD_NG_ADDITIONAL:                                   /* :351 (RL index) */
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx->ng_bi_prob[n2];
+    else prob = lx->ng_uni_bo[w1] + lx->ng_uni_prob[w2];
+    break;
+  default:                                                   /* :383 bi_prob_compute */
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx->ng_bi_prob[n2];
+    else prob = lx->ng_uni_bo[w2] + lx->ng_uni_prob[w1];
+    prob = prob + lx->ng_uni_prob[w2] - lx->ng_uni_prob[w1];
+    break;
+  }
+  if (w2 != lx->ng_unk_id) return prob;
+  return prob - lx->ng_unk_num_log;
+}
+
+/* max_successor_prob(), libjulius/src/factoring_sub.c:942-1008 (UNIGRAM_FACTORING;
+ * the per-scid cache there is a pure memo) */
+static float max_successor_prob(const jamd_lexicon_desc *lx, int lastword, int node)
+{
+  int scid, w;
+  if (lastword < 0) return 0.0f;
+  scid = lx->scid[node];
+  if (scid < 0) return lx->fscore[-scid];
+  w = lx->scword[scid];
+  return jo_bigram_prob(lx, lx->wton[lastword], lx->wton[w]) + lx->cprob[w];
+}
+
+/* one entry of max_successor_prob_iw()'s array, factoring_sub.c:1119-1143 */
+static float iw_prob(const jamd_lexicon_desc *lx, int lastword, int stid)
+{
+  int w = lx->scword[lx->scid[lx->startnode[stid]]];
+  return jo_bigram_prob(lx, lx->wton[lastword], lx->wton[w]) + lx->cprob[w];
+}
+
+/* ---- acoustic score of a node: outprob_style(), libjulius/src/outprob_style.c:354 */
+static float outprob_style(const beam *b, int node, int last_wid, int t)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  const float *row = b->sc + (size_t)t * b->S;
+  int id = lx->out_id[node], ent;
+  switch (lx->out_kind[node]) {
+  case JAMD_AS_STATE: return row[id];
+  case JAMD_AS_LSET: ent = ~id; break;
+  default:
+    ent = lx->lc_tab[(size_t)id * (lx->nlc + 1) + (last_wid < 0 ? lx->nlc : lx->word_lc[last_wid])];
+    break;
+  }
+  if (ent >= 0) return row[ent];
+  ent = ~ent;
+  return jo_outprob_cd(row, lx->set_states + lx->set_off[ent], lx->set_off[ent + 1] - lx->set_off[ent],
+                       lx->cdset_method, lx->cdmax_num);
+}
+
+/* ---- token space: beam.c:997-1200 ---------------------------------------------- */
+static void expand_tlist(beam *b)                       /* :1025 */
+{
+  int i;
+  b->maxtnum += b->expand_step;
+  for (i = 0; i < 2; i++) {
+    b->tlist[i] = (tok *)realloc(b->tlist[i], sizeof(tok) * b->maxtnum);
+    b->tindex[i] = (int *)realloc(b->tindex[i], sizeof(int) * b->maxtnum);
+  }
+}
+static int create_token(beam *b)                        /* :1148 */
+{
+  int tn = b->tn, newid = b->tnum[tn];
+  b->tnum[tn]++;
+  while (b->tnum[tn] >= b->maxtnum) expand_tlist(b);
+  b->tindex[tn][newid] = newid;
+  return newid;
+}
+
+/* sort_token_upward / _downward / _no_order, beam.c:1342-1516 (1-based heap over tindex) */
+#define SD(A) ti[(A) - 1]
+#define SVAL(A) (tl[ti[(A) - 1]].score)
+static void sort_token_upward(beam *b, int neednum, int totalnum)
+{
+  tok *tl = b->tlist[b->tn]; int *ti = b->tindex[b->tn];
+  int n, root, child, parent, s;
+  for (root = totalnum / 2; root >= 1; root--) {
+    s = SD(root); parent = root;
+    while ((child = parent * 2) <= totalnum) {
+      if (child < totalnum && SVAL(child) < SVAL(child + 1)) child++;
+      if (tl[s].score >= SVAL(child)) break;
+      SD(parent) = SD(child); parent = child;
+    }
+    SD(parent) = s;
+  }
+  n = totalnum;
+  while (n > totalnum - neednum) {
+    s = SD(n); SD(n) = SD(1); n--; parent = 1;
+    while ((child = parent * 2) <= n) {
+      if (child < n && SVAL(child) < SVAL(child + 1)) child++;
+      if (tl[s].score >= SVAL(child)) break;
+      SD(parent) = SD(child); parent = child;
+    }
+    SD(parent) = s;
+  }
+}
+static void sort_token_downward(beam *b, int neednum, int totalnum)
+{
+  tok *tl = b->tlist[b->tn]; int *ti = b->tindex[b->tn];
+  int n, root, child, parent, s;
+  for (root = totalnum / 2; root >= 1; root--) {
+    s = SD(root); parent = root;
+    while ((child = parent * 2) <= totalnum) {
+      if (child < totalnum && SVAL(child) > SVAL(child + 1)) child++;
+      if (tl[s].score <= SVAL(child)) break;
+      SD(parent) = SD(child); parent = child;
+    }
+    SD(parent) = s;
+  }
+  n = totalnum;
+  while (n > totalnum - neednum) {
+    s = SD(n); SD(n) = SD(1); n--; parent = 1;
+    while ((child = parent * 2) <= n) {
+      if (child < n && SVAL(child) > SVAL(child + 1)) child++;
+      if (tl[s].score <= SVAL(child)) break;
+      SD(parent) = SD(child); parent = child;
+    }
+    SD(parent) = s;
+  }
+}
+static void sort_token_no_order(beam *b, int neednum)   /* :1492 */
+{
+  int totalnum = b->tnum[b->tn], restnum = totalnum - neednum;
+  if (neednum >= totalnum) { b->n_start = 0; b->n_end = totalnum - 1; }
+  else if (neednum < restnum) { sort_token_upward(b, neednum, totalnum); b->n_start = totalnum - neednum; b->n_end = totalnum - 1; }
+  else { sort_token_downward(b, restnum, totalnum); b->n_start = 0; b->n_end = neednum - 1; }
+}
+
+/* propagate_token(), beam.c:1945-1980 */
+static void propagate_token(beam *b, int next_node, float next_score, int last_tre, int last_cword,
+                            float last_lscore)
+{
+  tok *tk; int id;
+  if (next_score <= JO_LOG_ZERO) return;
+  if ((id = b->token[next_node]) >= 0) {
+    tk = &b->tlist[b->tn][id];
+    if (tk->score < next_score) {
+      tk->last_tre = last_tre; tk->last_cword = last_cword; tk->last_lscore = last_lscore; tk->score = next_score;
+    }
+  } else {
+    id = create_token(b);
+    tk = &b->tlist[b->tn][id];
+    tk->last_tre = last_tre; tk->last_cword = last_cword; tk->last_lscore = last_lscore; tk->score = next_score;
+    b->token[next_node] = id; tk->node = next_node;      /* node_assign_token :1194 */
+  }
+}
+
+/* beam_intra_word_core(), beam.c:2004-2135 (LM_PROB branch) */
+static void intra_word_core(beam *b, int j, int next_node, float next_a)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];       /* copy: the list may be realloc'ed */
+  float tmpsum = tk.score + next_a, ngram_score_cache = JO_LOG_ZERO;
+  if (next_node != tk.node && lx->scid[next_node] != 0) {
+    ngram_score_cache = max_successor_prob(lx, tk.last_cword, next_node) * lx->lm_weight + lx->lm_penalty;
+    tmpsum -= tk.last_lscore;
+    tmpsum += ngram_score_cache;
+  }
+  if (ngram_score_cache == JO_LOG_ZERO) ngram_score_cache = tk.last_lscore;
+  propagate_token(b, next_node, tmpsum, tk.last_tre, tk.last_cword, ngram_score_cache);
+}
+
+/* beam_intra_word(), beam.c:2154-2180 */
+static void intra_word(beam *b, int j)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  int node = b->tlist[b->tl][b->tindex[b->tl][j]].node, k;
+  if (lx->self_a[node] != JO_LOG_ZERO) intra_word_core(b, j, node, lx->self_a[node]);
+  if (lx->next_a[node] != JO_LOG_ZERO) intra_word_core(b, j, node + 1, lx->next_a[node]);
+  for (k = lx->ac_off[node]; k < lx->ac_off[node + 1]; k++) intra_word_core(b, j, lx->ac_to[k], lx->ac_a[k]);
+}
+
+/* save_trellis(), beam.c:2209-2247 */
+static int save_trellis(beam *b, const tok *tk, int t)
+{
+  jamd_trellis_atom *a;
+  if (b->natom >= b->atom_cap) { b->overflow = 1; return b->natom - 1; }
+  a = &b->atoms[b->natom];
+  a->wid = b->lx->stend[tk->node];
+  a->backscore = tk->score;
+  a->begintime = (short)((tk->last_tre < 0 ? -1 : b->atoms[tk->last_tre].endtime) + 1);
+  a->endtime = (short)(t - 1);
+  a->last_tre = tk->last_tre;
+  a->lscore = tk->last_lscore;
+  return b->natom++;
+}
+
+/* beam_inter_word(), beam.c:2271-2520 (LM_PROB, UNIGRAM_FACTORING, non-multipath) */
+static void inter_word(beam *b, int j, int tre)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+  int node = tk.node, sword = lx->stend[node], stid, isoid;
+  int last_word = lx->is_transparent[sword] ? tk.last_cword : sword;
+  float tmpprob, tmpsum, ngram_score_cache;
+  if (sword == lx->tail_silwid) return;
+  tmpprob = tk.score + lx->wordend_a[sword];
+  if (b->wordend_best_score < tmpprob) {
+    b->wordend_best_score = tmpprob; b->wordend_best_node = node;
+    b->wordend_best_tre = tre; b->wordend_best_last_cword = tk.last_cword;
+  }
+  for (stid = lx->startnum - 1; stid >= 0; stid--) {
+    isoid = lx->start2isolate[stid];
+    if (isoid == -1) continue;
+    tmpprob = iw_prob(lx, last_word, stid);      /* iwparray[isoid], keyed by the same word :2323-2327 */
+    tmpsum = tk.score;
+    tmpsum += lx->wordend_a[sword];
+    ngram_score_cache = tmpprob * lx->lm_weight + lx->lm_penalty;
+    tmpsum += ngram_score_cache;
+    if (lx->is_transparent[sword] && tk.last_cword >= 0 && lx->is_transparent[tk.last_cword])
+      tmpsum += lx->lm_penalty_trans;
+    propagate_token(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
+  }
+}
+
+/* beam_inter_word_factoring(), beam.c:2549-2637 */
+static void inter_word_factoring(beam *b)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  int node = b->wordend_best_node, sword = lx->stend[node], stid, next_node;
+  int last_word = lx->is_transparent[sword] ? b->wordend_best_last_cword : sword;
+  float tmpsum, ngram_score_cache;
+  for (stid = lx->startnum - 1; stid >= 0; stid--) {
+    next_node = lx->startnode[stid];
+    if (lx->start2isolate[stid] != -1) continue;
+    ngram_score_cache = lx->fscore[-lx->scid[next_node]] * lx->lm_weight + lx->lm_penalty;
+    tmpsum = b->wordend_best_score;
+    tmpsum += ngram_score_cache;
+    if (lx->is_transparent[sword] && b->wordend_best_last_cword >= 0 &&
+        lx->is_transparent[b->wordend_best_last_cword]) tmpsum += lx->lm_penalty_trans;
+    if (tmpsum < b->score_pruning_threshold) continue;
+    propagate_token(b, next_node, tmpsum, b->wordend_best_tre, last_word, ngram_score_cache);
+  }
+}
+
+/*
+ * The whole first pass for one utterance:
+ *   get_back_trellis_init()    beam.c:1825 (+ init_nodescore :1552, N-gram branch)
+ *   get_back_trellis_proceed() beam.c:2663 for t = 1..T-1 (non-multipath branch)
+ *   get_back_trellis_end()     beam.c:3052
+ *   find_1pass_result()        beam.c:372 (+ trace_backptr :294)
+ * sc is the [T][S] state score matrix (what outprob_state() would return).
+ * atoms come out in creation order; last_tre indexes the same array (-1 = bos).
+ * Returns 0 = ok, 1 = no sentence-end word survived (search failed), 2 = beam
+ * died at frame *died_at (the reference would segment the input there), -1 =
+ * atom buffer too small.
+ */
+int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
+                  int beam_width, float score_pruning_width,
+                  jamd_trellis_atom *atoms, int atom_cap, int *natom,
+                  int *wseq, int wseq_cap, int *wnum, float *pass1_score, int *died_at)
+{
+  beam B, *b = &B;
+  int t, j, i, node, rc = 0;
+  memset(b, 0, sizeof(*b));
+  b->lx = lx; b->sc = sc; b->S = S; b->atoms = atoms; b->atom_cap = atom_cap;
+  *natom = 0; *wnum = 0; *pass1_score = JO_LOG_ZERO; *died_at = -1;
+  if (T <= 0) return 1;
+
+  /* get_back_trellis_init */
+  b->tn = 0; b->tl = 1;
+  b->maxtnum = beam_width * 2 + lx->startnum;             /* malloc_nodes :1871 */
+  if (b->maxtnum < 2) b->maxtnum = 2;
+  b->expand_step = beam_width > 0 ? beam_width : 1;       /* prepare_nodes :1873 */
+  for (i = 0; i < 2; i++) {
+    b->tlist[i] = (tok *)malloc(sizeof(tok) * b->maxtnum);
+    b->tindex[i] = (int *)malloc(sizeof(int) * b->maxtnum);
+  }
+  b->token = (int *)malloc(sizeof(int) * lx->nnode);
+  for (i = 0; i < lx->nnode; i++) b->token[i] = -1;
+  {                                                        /* init_nodescore :1622-1665 */
+    int id = create_token(b);
+    tok *nw = &b->tlist[b->tn][id];
+    node = lx->word_head[lx->head_silwid];
+    nw->last_lscore = (lx->scid[node] != 0) ? max_successor_prob(lx, -1, node) : 0.0f;
+    nw->last_lscore = nw->last_lscore * lx->lm_weight + lx->lm_penalty;
+    nw->last_tre = -1; nw->last_cword = -1;
+    nw->score = outprob_style(b, node, -1, 0) + nw->last_lscore;
+    b->token[node] = id; nw->node = node;
+  }
+  sort_token_no_order(b, beam_width);
+  b->score_pruning_threshold = JO_LOG_ZERO;
+
+  /* get_back_trellis_proceed */
+  for (t = 1; t < T; t++) {
+    int tl, tn;
+    b->tl = b->tn; b->tn = b->tn ? 0 : 1;
+    tl = b->tl; tn = b->tn;
+    b->wordend_best_score = JO_LOG_ZERO;
+    for (j = 0; j < b->tnum[tl]; j++) b->token[b->tlist[tl][j].node] = -1;   /* clear_tokens :1122 */
+    for (j = b->n_start; j <= b->n_end; j++) {
+      tok tk = b->tlist[tl][b->tindex[tl][j]];
+      if (tk.score <= JO_LOG_ZERO) continue;
+      if (tk.score < b->score_pruning_threshold) continue;
+      intra_word(b, j);
+      if (lx->stend[tk.node] >= 0) {
+        int tre = save_trellis(b, &tk, t);
+        inter_word(b, j, tre);
+      }
+    }
+    if (b->wordend_best_score > JO_LOG_ZERO) inter_word_factoring(b);
+    b->score_pruning_max = JO_LOG_ZERO;
+    for (j = 0; j < b->tnum[tn]; j++) {                                       /* :2944-2951 */
+      tok *tk = &b->tlist[tn][b->tindex[tn][j]];
+      int lw = tk->last_tre < 0 ? -1 : atoms[tk->last_tre].wid;
+      tk->score += outprob_style(b, tk->node, lw, t);
+      if (b->score_pruning_max < tk->score) b->score_pruning_max = tk->score;
+    }
+    if (score_pruning_width >= 0.0f) b->score_pruning_threshold = b->score_pruning_max - score_pruning_width;
+    else b->score_pruning_threshold = JO_LOG_ZERO;
+    b->tnum[tl] = 0;                                                           /* clear_tlist */
+    sort_token_no_order(b, beam_width);
+    if (b->tnum[tn] == 0) { *died_at = t; rc = 2; break; }
+  }
+
+  if (rc == 0) {
+    /* get_back_trellis_end (non-multipath) :3076-3086 */
+    b->tl = b->tn; b->tn = b->tn ? 0 : 1;
+    for (j = b->n_start; j <= b->n_end; j++) {
+      tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+      if (lx->stend[tk.node] >= 0) save_trellis(b, &tk, T);
+    }
+    /* find_1pass_result :399-431: the tail-silence word ending latest */
+    {
+      int best = -1, last_time;
+      for (last_time = T - 1; last_time >= 0 && best < 0; last_time--) {
+        for (i = 0; i < b->natom; i++)
+          if (atoms[i].endtime == last_time && atoms[i].wid == lx->tail_silwid && atoms[i].backscore > JO_LOG_ZERO) {
+            best = i; break;
+          }
+      }
+      if (best < 0) rc = 1;
+      else {                                               /* trace_backptr :294-340 */
+        int n = 0, k, a = best;
+        int *rev = (int *)malloc(sizeof(int) * (b->natom + 1));
+        rev[n++] = atoms[a].wid;
+        while (atoms[a].begintime > 0) { a = atoms[a].last_tre; rev[n++] = atoms[a].wid; }
+        for (k = 0; k < n && k < wseq_cap; k++) wseq[k] = rev[n - 1 - k];
+        *wnum = n; *pass1_score = atoms[best].backscore;
+        free(rev);
+      }
+    }
+  }
+  *natom = b->natom;
+  if (b->overflow) rc = -1;
+  for (i = 0; i < 2; i++) { free(b->tlist[i]); free(b->tindex[i]); }
+  free(b->token);
+  return rc;
+}

@@ -127,6 +127,27 @@ class Oracle:
                 out[t, i] = self.lib.jo_outprob_cd(_p(row), _p(sub), len(sub), method, nbest)
         return out
 
+    def beam_pass1(self, lex, scores, beam_width, score_pruning_width=-1.0, atom_cap=None):
+        """First pass over a [T][S] state score matrix.  Returns (atoms structured
+        array in emission order, pass-1 word sequence, pass-1 score, rc, died_at)."""
+        from julius_amd import lexblob
+        lib = self.lib
+        lib.jo_beam_pass1.restype = C.c_int
+        lib.jo_beam_pass1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        d, keep = lexblob.make_desc(lex)
+        sc = _f32(scores)
+        T, S = sc.shape
+        cap = atom_cap or (T * max(beam_width, 16) + 16)
+        atoms = np.zeros(cap, dtype=lexblob.ATOM_DTYPE)
+        natom, wnum, died = C.c_int(), C.c_int(), C.c_int()
+        score = C.c_float()
+        wseq = np.zeros(4096, np.int32)
+        rc = lib.jo_beam_pass1(C.byref(d), _p(sc), T, S, beam_width, score_pruning_width, _p(atoms), cap,
+                               C.byref(natom), _p(wseq), len(wseq), C.byref(wnum), C.byref(score), C.byref(died))
+        return atoms[:natom.value].copy(), wseq[:wnum.value].copy(), float(score.value), rc, died.value
+
     def dnn_outprob(self, dnn, frames, simd=DNN_FMA):
         dims = _i32(dnn["dims"])
         nl = len(dims) - 1
@@ -306,3 +327,53 @@ class RefDNN:
         out = np.empty((T, self.dims[-1]), np.float32) if want_out else None
         self.last_seconds = float(self.ref.lib.jref_dnn_outprob(self.h, _p(fr), T, _p(out) if want_out else None))
         return out
+
+
+class RefEngine:
+    """A complete reference recogniser (j_create_instance_from_jconf) driven
+    through the jref_engine_* taps of ref_driver.c: first-pass word trellis,
+    pass-1 best sequence, and the flattened lexicon blob."""
+
+    def __init__(self, ref: Ref, args):
+        self.ref = ref
+        lib = ref.lib
+        vp, ci = C.c_void_p, C.c_int
+        lib.jref_engine_create.restype = vp
+        lib.jref_engine_create.argtypes = [ci, vp]
+        lib.jref_engine_recognize.argtypes = [vp, C.c_char_p]
+        lib.jref_engine_trellis.argtypes = [vp] * 8
+        lib.jref_engine_pass1.argtypes = [vp, vp, vp]
+        lib.jref_engine_info.argtypes = [vp, vp]
+        lib.jref_engine_save_lexicon.argtypes = [vp, C.c_char_p]
+        args = ["julius"] + [str(a) for a in args]
+        self._argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        self.h = lib.jref_engine_create(len(args), self._argv)
+        if not self.h:
+            raise RuntimeError("reference engine failed to start: " + " ".join(args))
+        info = np.zeros(16, np.int32)
+        lib.jref_engine_info(self.h, _p(info))
+        (self.nnode, self.nword, self.startnum, self.isolatenum, self.beam_width, self.nstate,
+         self.lmtype, self.multipath, self.ccd) = [int(x) for x in info[:9]]
+
+    def save_lexicon(self, path):
+        rc = self.ref.lib.jref_engine_save_lexicon(self.h, str(path).encode())
+        if rc != 0:
+            raise RuntimeError(f"jamd_flatten_lexicon/jamd_lexicon_save failed ({rc})")
+
+    def recognize(self, mfcfile):
+        """Run the recogniser on one HTK parameter file.  Returns the word trellis
+        in bt->rw[t][i] order as a dict of arrays, and (pass1 words, score)."""
+        lib = self.ref.lib
+        n = lib.jref_engine_recognize(self.h, str(mfcfile).encode())
+        if n < 0:
+            raise RuntimeError("reference recognition failed")
+        a = {k: np.zeros(n, np.int32) for k in ("wid", "begintime", "endtime", "pwid", "pendtime")}
+        a["backscore"] = np.zeros(n, np.float32)
+        a["lscore"] = np.zeros(n, np.float32)
+        got = lib.jref_engine_trellis(self.h, _p(a["wid"]), _p(a["begintime"]), _p(a["endtime"]),
+                                      _p(a["backscore"]), _p(a["lscore"]), _p(a["pwid"]), _p(a["pendtime"]))
+        assert got == n
+        wseq = np.zeros(256, np.int32)
+        sc = C.c_float()
+        k = lib.jref_engine_pass1(self.h, _p(wseq), C.byref(sc))
+        return a, (wseq[:k].copy(), float(sc.value))

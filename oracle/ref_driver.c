@@ -24,6 +24,7 @@
 #include <sent/hmm_calc.h>
 #include <sent/util.h>
 
+#define JAMD_WITH_LIBJULIUS 1
 #include "../julius_amd/shim/jamd_flatten.h"
 
 typedef struct {
@@ -373,3 +374,18 @@ int jref_engine_info(void *h, int *info)
   info[9] = r->backtrellis->framelen;
   return 0;
 }
+
+/* Flatten the loaded recogniser's first-pass tables with the product's own
+ * reference-side shim (julius_amd/shim/jamd_flatten_lex.c) and write them as a
+ * lexicon blob.  Returns 0 or a JAMD_E* code. */
+int jref_engine_save_lexicon(void *h, const char *path)
+{
+  jref_eng *e = (jref_eng *)h;
+  jamd_flat_lexicon fl;
+  int rc = jamd_flatten_lexicon(e->recog->process_list, &fl);
+  if (rc != 0) return rc;
+  rc = jamd_lexicon_save(&fl.desc, path);
+  jamd_flat_lexicon_free(&fl);
+  return rc;
+}
+
