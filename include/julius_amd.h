@@ -253,6 +253,65 @@ typedef struct {
   short endtime;
 } jamd_trellis_atom;
 
+
+typedef struct jamd_lexicon jamd_lexicon;
+typedef struct jamd_beam    jamd_beam;
+
+/* Upload the first-pass tables.  Replaces, for the device, what
+ * get_back_trellis_init() reads from r->wchmm (libjulius/src/beam.c:1825).
+ * JAMD_EINVAL for inconsistent tables (a root without factoring value / successor word). */
+int  jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *d, jamd_lexicon **out);
+void jamd_lexicon_destroy(jamd_lexicon *l);
+
+/* First-pass status of one utterance */
+#define JAMD_PASS1_OK        0  /* J_RESULT_STATUS_SUCCESS                                   */
+#define JAMD_PASS1_FAIL      1  /* no sentence-end word survived (find_1pass_result(),        */
+                                /* beam.c:424-429 -> J_RESULT_STATUS_FAIL)                     */
+#define JAMD_PASS1_DIED      2  /* "no nodes left in beam" at frame died_at: _proceed()       */
+                                /* returned FALSE (beam.c:3012-3015); the caller segments     */
+#define JAMD_PASS1_OVERFLOW  3  /* more trellis atoms than atoms_per_utt                      */
+
+typedef struct {
+  int   status;          /* JAMD_PASS1_*                                              */
+  int   natom;           /* trellis atoms emitted                                     */
+  int   wnum;            /* r->pass1_wnum                                             */
+  float score;           /* r->pass1_score (best->backscore, beam.c:505)              */
+  int   died_at;         /* frame index for JAMD_PASS1_DIED, else -1                  */
+  int   ties;            /* exact score ties met by a max/selection:  */
+                         /* 0 => the result does not depend on visiting order         */
+  int   frames;          /* T                                                         */
+  int   max_tokens;      /* high-water mark of tokens alive in one frame              */
+  int   ties_node, ties_wordend, ties_cut;   /* ties by kind: Viterbi max at a node, best    */
+                         /* word end, rank cut                                        */
+  int   wseq[150];       /* r->pass1_wseq, MAXSEQNUM = 150 (libsent speech.h:50)      */
+} jamd_pass1_result;
+
+/* Work area for up to max_utts utterances decoded at once (FSBeam,
+ * libjulius/include/julius/recog.h:115-174, one per utterance).
+ * beam_width = r->trellis_beam_width (<= 65536), score_pruning_width =
+ * r->config->pass1.score_pruning_width (< 0 disables, beam.c:2954-2960),
+ * atoms_per_utt bounds the word trellis of one utterance. */
+int  jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float score_pruning_width,
+                      int max_utts, int atoms_per_utt, jamd_beam **out);
+void jamd_beam_destroy(jamd_beam *b);
+
+/* The whole first pass for nutt utterances at once: for each utterance
+ * get_back_trellis_init() (beam.c:1825), get_back_trellis_proceed() for
+ * t = 1..T-1 (beam.c:2663), get_back_trellis_end() (beam.c:3052) and
+ * find_1pass_result() (beam.c:372).  dev_scores holds the state score rows of
+ * all utterances back to back: utterance u owns rows utt_off[u]..utt_off[u+1])
+ * of [.][nstate] (what outprob_state() would return for every state: the output
+ * of jamd_gmm_outprob_dev / jamd_dnn_outprob_dev).  utt_off is a HOST array of
+ * nutt+1 ints.  Asynchronous on `stream`; results are read with
+ * jamd_beam_results() / jamd_beam_trellis(), which synchronise. */
+int  jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *utt_off,
+                         int nutt, void *stream);
+int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
+/* Word trellis of utterance u in emission order (last_tre indexes the same
+ * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:
+ * 218-267,468-477) is (endtime, wid). */
+int  jamd_beam_trellis(jamd_beam *b, int utt, jamd_trellis_atom *atoms, int cap, int *natom);
+
 #ifdef __cplusplus
 }
 #endif

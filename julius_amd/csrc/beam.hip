@@ -1,0 +1,700 @@
+// beam.hip -- first-pass token passing over the tree lexicon (K6) for gfx950.
+//
+// Replaces, for a BATCH of utterances in one launch, the reference's
+//   get_back_trellis_init()     libjulius/src/beam.c:1825  (+ init_nodescore :1552)
+//   get_back_trellis_proceed()  beam.c:2663   (non-multipath branch :2832-2900)
+//     beam_intra_word()/_core() beam.c:2154 / :2004
+//     save_trellis()            beam.c:2209
+//     beam_inter_word()         beam.c:2271
+//     beam_inter_word_factoring beam.c:2549
+//     sort_token_no_order()     beam.c:1492   (rank pruning)
+//   get_back_trellis_end()      beam.c:3052
+//   find_1pass_result()         beam.c:372    (+ trace_backptr :294)
+// and their callees outprob_style() (outprob_style.c:354), max_successor_prob()
+// / max_successor_prob_iw() (factoring_sub.c:942 / :1049) and the 2-gram access
+// functions (libsent/src/ngram/ngram_access.c:225-403).
+//
+// Execution model: ONE WORKGROUP PER UTTERANCE, persistent over all frames of
+// that utterance (the trellis is serial in t; utterances are independent, so a
+// batch fills the chip).  Per frame:
+//   A  every surviving token pushes its intra-word candidates, emits a trellis
+//      atom if it sits on a word end and records itself in the word-end list;
+//   B  word ends x isolated roots (2-gram) and best word end x shared roots
+//      (1-gram factoring) push the cross-word candidates;
+//   C  one thread per touched node takes the winner, rebuilds its payload from
+//      the winning candidate id, adds the acoustic score, tracks the frame max;
+//   D  rank pruning: radix select of the beam_width-th score + compaction.
+// "push" is a 64-bit atomicMax on nodekey[node] = (order-preserving score bits,
+// candidate id): the Viterbi max of propagate_token() (beam.c:1945) without any
+// ordering between candidates.  The first candidate that finds the key empty
+// registers the node in the frame's touched list, step C swaps the key back to
+// 0, so the node table is clean again without a clearing sweep (what
+// clear_tokens(), beam.c:1122, does on the CPU).
+//
+// Determinism / parity: every float is produced by the same sequence of fp32
+// operations as the reference (this file is compiled with -ffp-contract=off).
+// The only freedom is the visiting order, which matters only when two candidates
+// for the same node, two word ends, or two tokens at the rank cut have EXACTLY
+// equal scores; every such event is counted in jamd_pass1_result.ties.  With
+// ties == 0 the trellis is the reference's trellis bit for bit.
+#include "jamd_device.h"
+#include <type_traits>
+
+namespace {
+using namespace jamd;
+
+constexpr int NT = 512;                 // threads per utterance workgroup
+constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
+
+struct LexDev {
+  int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
+  int head_silwid, tail_silwid, ng_mode, ng_unk_id;
+  float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
+  const float *self_a, *next_a; const int *ac_off, *ac_to; const float *ac_a;
+  const int *stend, *scid; const unsigned char *out_kind; const int *out_id;
+  const int *lc_tab, *word_lc, *set_off, *set_states, *startnode;
+  const int *iso_stid, *shared_stid;
+  const float *wordend_a; const int *wton; const float *cprob; const unsigned char *is_transparent;
+  const int *word_head; const float *fscore; const int *scword;
+  const float *ng_uni_prob, *ng_uni_bo; const int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; const float *ng_bi_prob;
+};
+
+struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/beam.h:35-45
+  int node; float score; int last_tre; int last_cword;
+  float last_lscore; int last_wid; int pad0, pad1;   // last_wid = wid of atoms[last_tre] (-1 for bos)
+};
+
+struct Work {            // per-utterance slices are addressed with the strides below
+  unsigned long long *nodekey;   // [utt][nnode]
+  Tok *tok[2];                   // [utt][tok_cap]
+  int *surv;                     // [utt][tok_cap] indices into the previous token array
+  int *touched;                  // [utt][tok_cap] nodes touched this frame
+  int *welist;                   // [utt][beam]    words that ended this frame
+  int2 *we_of;                   // [utt][nword]   word -> (slot of its end token in prev, atom index)
+  int *slot_of[2];               // [utt][nnode]   node -> slot of its token in tok[i] (valid for live tokens only)
+  jamd_trellis_atom *atoms;      // [utt][atom_cap]
+  jamd_pass1_result *res;        // [utt]
+  int tok_cap, atom_cap, beam, nnode, nword;
+  float width;
+};
+
+// order-preserving map float -> u32 (larger float <=> larger unsigned)
+__device__ __forceinline__ unsigned ord(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unord(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// search_bigram(), ngram_access.c:225-247
+__device__ __forceinline__ int search_bigram(const LexDev &lx, int w_context, int w) {
+  int left = lx.ng_bi_bgn[w_context];
+  if (left < 0) return -1;
+  int right = left + lx.ng_bi_num[w_context] - 1;
+  while (left < right) {
+    const int mid = (left + right) / 2;
+    if (lx.ng_bi_wid[mid] < w) left = mid + 1; else right = mid;
+  }
+  return (lx.ng_bi_wid[left] == w) ? left : -1;
+}
+
+// ngram->bigram_prob as chosen by bi_prob_func_set(), ngram_access.c:288-466
+__device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
+  int n2; float prob;
+  if (lx.ng_mode == JAMD_NG_NORMAL || lx.ng_mode == JAMD_NG_ADDITIONAL_OLD) {
+    if ((n2 = search_bigram(lx, w1, w2)) >= 0) prob = lx.ng_bi_prob[n2];
+    else prob = lx.ng_uni_bo[w1] + lx.ng_uni_prob[w2];
+  } else if (lx.ng_mode == JAMD_NG_ADDITIONAL) {
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob[n2];
+    else prob = lx.ng_uni_bo[w1] + lx.ng_uni_prob[w2];
+  } else {
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob[n2];
+    else prob = lx.ng_uni_bo[w2] + lx.ng_uni_prob[w1];
+    prob = prob + lx.ng_uni_prob[w2] - lx.ng_uni_prob[w1];
+  }
+  if (w2 != lx.ng_unk_id) return prob;
+  return prob - lx.ng_unk_num_log;
+}
+
+// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING)
+__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int node) {
+  if (lastword < 0) return 0.0f;
+  const int scid = lx.scid[node];
+  if (scid < 0) return lx.fscore[-scid];
+  const int w = lx.scword[scid];
+  return bigram_prob(lx, lx.wton[lastword], lx.wton[w]) + lx.cprob[w];
+}
+
+// outprob_style(), outprob_style.c:354-486, with the name lookups replaced by
+// the flattened left-context table
+__device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, int node, int last_wid) {
+  const int id = lx.out_id[node];
+  const int kind = lx.out_kind[node];
+  int ent;
+  if (kind == JAMD_AS_STATE) return row[id];
+  if (kind == JAMD_AS_LSET) ent = ~id;
+  else ent = lx.lc_tab[(size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc[last_wid])];
+  if (ent >= 0) return row[ent];
+  ent = ~ent;
+  return cd_reduce(row, lx.set_states, lx.set_off[ent], lx.set_off[ent + 1], lx.cdset_method, lx.cdmax_num);
+}
+
+struct Shared {
+  unsigned long long we_best;       // (ord(score + wordend_a), welist index)
+  unsigned hist[256];
+  int n_new, n_we, n_atom, n_surv, ties, ties_we, ties_cut;
+  unsigned maxbits;
+  unsigned sel_digit, sel_need, sel_count;
+  int stop;
+};
+
+// candidate ids (low 32 bits of a node key) name the SOURCE of the transition, in
+// terms that do not depend on any scheduling order, so that (score, id) is a
+// canonical total order and the result is deterministic:
+//   intra-word     bit31 = 0            [30:0] = source node
+//   isolated root  bits[31:30] = 10     [29:0] = the word that ended (its end node is unique)
+//   shared root    bits[31:30] = 11     (the source is the frame's best word end)
+// The destination is the address of the key, so the arc is implied.
+// Returns the previous key when it holds the SAME score as this candidate (an
+// exact tie), else 0.
+__device__ __forceinline__ unsigned long long push(Shared &sh, unsigned long long *nodekey, int *touched,
+                                                   int node, float score, unsigned id) {
+  if (score <= JAMD_LOG_ZERO) return 0ull;                    // propagate_token() :1951
+  const unsigned long long key = ((unsigned long long)ord(score) << 32) | id;
+  const unsigned long long old = atomicMax(&nodekey[node], key);
+  if (old == 0ull) {
+    const int s = atomicAdd(&sh.n_new, 1);
+    touched[s] = node;
+    return 0ull;
+  }
+  return ((unsigned)(old >> 32) == (unsigned)(key >> 32) && old != key) ? old : 0ull;
+}
+
+__global__ void __launch_bounds__(NT)
+beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
+                  const int *__restrict__ utt_off) {
+  __shared__ Shared sh;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int t_begin = utt_off[u], T = utt_off[u + 1] - t_begin;
+  unsigned long long *nodekey = wk.nodekey + (size_t)u * wk.nnode;
+  Tok *cur = wk.tok[0] + (size_t)u * wk.tok_cap;
+  Tok *prev = wk.tok[1] + (size_t)u * wk.tok_cap;
+  int *surv = wk.surv + (size_t)u * wk.tok_cap;
+  int *touched = wk.touched + (size_t)u * wk.tok_cap;
+  int *welist = wk.welist + (size_t)u * wk.beam;
+  int2 *we_of = wk.we_of + (size_t)u * wk.nword;
+  int *slot_cur = wk.slot_of[0] + (size_t)u * wk.nnode;    // written with `cur`, read as `slot_prev` next frame
+  int *slot_prev = wk.slot_of[1] + (size_t)u * wk.nnode;
+  jamd_trellis_atom *atoms = wk.atoms + (size_t)u * wk.atom_cap;
+  jamd_pass1_result *res = wk.res + u;
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+
+  if (tid == 0) {
+    sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.stop = 0; sh.n_surv = 0;
+    res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO;
+    res->died_at = -1; res->ties = 0; res->frames = T; res->max_tokens = 0;
+  }
+  __syncthreads();
+  if (T <= 0) { if (tid == 0) res->status = JAMD_PASS1_FAIL; return; }
+
+  // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665)
+  if (tid == 0) {
+    const int node = lx.word_head[lx.head_silwid];
+    Tok nw;
+    float ls = (lx.scid[node] != 0) ? max_successor_prob(lx, -1, node) : 0.0f;
+    ls = ls * lmw + pen;
+    nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
+    nw.score = node_outprob(lx, scores + (size_t)t_begin * S, node, -1) + ls;
+    nw.pad0 = nw.pad1 = 0;
+    cur[0] = nw;
+    slot_cur[node] = 0;
+    surv[0] = 0;
+    sh.n_surv = 1;
+  }
+  float thr = JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
+  int max_tokens = 1;
+  __syncthreads();
+
+  for (int t = 1; t <= T; t++) {
+    // swap tl/tn (beam.c:2697-2698): `prev` now holds last frame's tokens, surv[] the kept ones
+    { Tok *x = cur; cur = prev; prev = x; }
+    { int *x = slot_cur; slot_cur = slot_prev; slot_prev = x; }
+    const int n_surv = sh.n_surv;
+    __syncthreads();
+    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); }
+    __syncthreads();
+    const bool last = (t == T);     // get_back_trellis_end(): word ends only, no pruning test
+
+    // ---- A: intra-word transitions + word-end atoms (main loop, beam.c:2838-2900)
+    for (int j = tid; j < n_surv; j += NT) {
+      const int slot = surv[j];
+      const Tok tk = prev[slot];
+      const int node = tk.node;
+      if (!last) {
+        if (tk.score <= JAMD_LOG_ZERO) continue;
+        if (tk.score < thr) continue;
+        // beam_intra_word() :2154-2180 -> beam_intra_word_core() :2004-2135
+        const int e0 = lx.ac_off[node], e1 = lx.ac_off[node + 1];
+        for (int k = 0; k < 2 + (e1 - e0); k++) {
+          int next_node; float a;
+          if (k == 0) { next_node = node; a = lx.self_a[node]; if (a == JAMD_LOG_ZERO) continue; }
+          else if (k == 1) { next_node = node + 1; a = lx.next_a[node]; if (a == JAMD_LOG_ZERO) continue; }
+          else { next_node = lx.ac_to[e0 + k - 2]; a = lx.ac_a[e0 + k - 2]; }
+          float tmpsum = tk.score + a;
+          const bool fac = next_node != node && lx.scid[next_node] != 0;
+          if (fac) {
+            const float ng = max_successor_prob(lx, tk.last_cword, next_node) * lmw + pen;
+            tmpsum -= tk.last_lscore;
+            tmpsum += ng;
+          }
+          const unsigned long long tie = push(sh, nodekey, touched, next_node, tmpsum, (unsigned)node);
+          if (tie != 0ull) {
+            // two different sources reach next_node with exactly the same score.
+            // Harmless when both carry the same history (same predecessor atom, context
+            // word and LM score) -- merging tree branches produce that; anything else is
+            // a genuine tie, resolved by the larger source id and counted.
+            bool same = false;
+            if (((unsigned)tie >> 31) == 0u) {
+              const Tok o = prev[slot_prev[(unsigned)tie]];
+              // the LM score is recomputed from last_cword on entering a factoring
+              // node from another node (see step C); otherwise it is inherited
+              const bool re_o = lx.scid[next_node] != 0 && next_node != o.node;
+              same = o.last_tre == tk.last_tre && o.last_cword == tk.last_cword &&
+                     (fac == re_o) && (fac || o.last_lscore == tk.last_lscore);
+            }
+            if (!same) atomicAdd(&sh.ties, 1);
+          }
+        }
+      }
+      const int sword = lx.stend[node];
+      if (sword >= 0) {
+        // save_trellis() :2209-2247
+        const int ai = atomicAdd(&sh.n_atom, 1);
+        if (ai < wk.atom_cap) {
+          jamd_trellis_atom a;
+          a.wid = sword; a.last_tre = tk.last_tre; a.backscore = tk.score; a.lscore = tk.last_lscore;
+          a.begintime = (short)((tk.last_tre < 0 ? -1 : atoms[tk.last_tre].endtime) + 1);
+          a.endtime = (short)(t - 1);
+          atoms[ai] = a;
+        }
+        if (!last && sword != lx.tail_silwid) {            // beam_inter_word() :2296-2313
+          welist[atomicAdd(&sh.n_we, 1)] = sword;
+          we_of[sword] = make_int2(slot, ai);
+          const float tmpprob = tk.score + lx.wordend_a[sword];
+          if (tmpprob > JAMD_LOG_ZERO) {
+            const unsigned long long key = ((unsigned long long)ord(tmpprob) << 32) | (unsigned)sword;
+            const unsigned long long old = atomicMax(&sh.we_best, key);
+            if (old != 0ull && (unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicAdd(&sh.ties_we, 1);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (last) break;
+
+    // ---- B1: word ends -> isolated roots with the 2-gram (beam_inter_word() :2334-2516)
+    {
+      const int n_we = sh.n_we, niso = lx.isolatenum;
+      const int total = n_we * niso;
+      for (int x = tid; x < total; x += NT) {
+        const int w = x / niso, i = x - w * niso;
+        const int sword = welist[w];
+        const Tok tk = prev[we_of[sword].x];
+        const bool tr = lx.is_transparent[sword] != 0;
+        const int last_word = tr ? tk.last_cword : sword;
+        const int next_node = lx.startnode[lx.iso_stid[i]];
+        const int wn = lx.scword[lx.scid[next_node]];
+        // one entry of max_successor_prob_iw()'s array (factoring_sub.c:1119-1143)
+        const float p = (last_word < 0) ? 0.0f
+                        : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+        float tmpsum = tk.score;
+        tmpsum += lx.wordend_a[sword];
+        const float ng = p * lmw + pen;
+        tmpsum += ng;
+        if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
+        if (push(sh, nodekey, touched, next_node, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+          atomicAdd(&sh.ties, 1);
+      }
+    }
+    // ---- B2: best word end -> shared roots with the 1-gram factoring value
+    //          (beam_inter_word_factoring() :2549-2637)
+    if (sh.we_best != 0ull) {
+      const unsigned long long kb = sh.we_best;
+      const float best_score = unord((unsigned)(kb >> 32));
+      const int sword = (int)(unsigned)kb;
+      const Tok tk = prev[we_of[sword].x];
+      const bool trans2 = lx.is_transparent[sword] && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword];
+      for (int r = tid; r < lx.nshared; r += NT) {
+        const int next_node = lx.startnode[lx.shared_stid[r]];
+        const float ng = lx.fscore[-lx.scid[next_node]] * lmw + pen;
+        float tmpsum = best_score;
+        tmpsum += ng;
+        if (trans2) tmpsum += lx.lm_penalty_trans;
+        if (tmpsum < thr) continue;                               // :2580
+        if (push(sh, nodekey, touched, next_node, tmpsum, 0xC0000000u) != 0ull) atomicAdd(&sh.ties, 1);
+      }
+    }
+    __syncthreads();
+
+    // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951)
+    const int n_new = sh.n_new;
+    if (n_new > max_tokens) max_tokens = n_new;
+    {
+      const float *__restrict__ row = scores + (size_t)(t_begin + t) * S;
+      unsigned mymax = ord(JAMD_LOG_ZERO);
+      for (int s = tid; s < n_new; s += NT) {
+        const int node = touched[s];
+        const unsigned long long key = atomicExch(&nodekey[node], 0ull);
+        const unsigned id = (unsigned)key;
+        const float score = unord((unsigned)(key >> 32));
+        Tok nw;
+        nw.node = node; nw.pad0 = nw.pad1 = 0;
+        if ((id >> 31) == 0u) {                      // intra-word, id = source node
+          const Tok tk = prev[slot_prev[id]];
+          nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
+          if (node != tk.node && lx.scid[node] != 0)      // beam_intra_word_core() :2069-2082
+            nw.last_lscore = max_successor_prob(lx, tk.last_cword, node) * lmw + pen;
+          else
+            nw.last_lscore = tk.last_lscore;
+        } else {
+          const bool iso = (id >> 30) == 2u;
+          const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
+          const int2 we = we_of[sword];
+          const Tok tk = prev[we.x];
+          const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+          nw.last_tre = we.y; nw.last_cword = last_word; nw.last_wid = sword;
+          if (iso) {                                       // beam_inter_word() :2430-2438
+            const int wn = lx.scword[lx.scid[node]];
+            const float p = (last_word < 0) ? 0.0f
+                            : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+            nw.last_lscore = p * lmw + pen;
+          } else {                                         // beam_inter_word_factoring() :2572-2573
+            nw.last_lscore = lx.fscore[-lx.scid[node]] * lmw + pen;
+          }
+        }
+        nw.score = score + node_outprob(lx, row, node, nw.last_wid);
+        cur[s] = nw;
+        slot_cur[node] = s;
+        const unsigned b = ord(nw.score);
+        if (b > mymax) mymax = b;
+      }
+      atomicMax(&sh.maxbits, mymax);
+    }
+    __syncthreads();
+    {
+      const float mx = unord(sh.maxbits);                          // score_pruning_max :2948
+      thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;  // :2954-2960
+    }
+    if (n_new == 0) {                                              // :3012-3015
+      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; sh.stop = 1; }
+      __syncthreads();
+      break;
+    }
+    if (sh.n_atom > wk.atom_cap) {
+      if (tid == 0) { res->status = JAMD_PASS1_OVERFLOW; sh.stop = 1; }
+      __syncthreads();
+      break;
+    }
+
+    // ---- D: rank pruning, sort_token_no_order() :1492 -> the top beam_width tokens
+    if (n_new <= wk.beam) {
+      for (int s = tid; s < n_new; s += NT) surv[s] = s;
+      if (tid == 0) sh.n_surv = n_new;
+      __syncthreads();
+    } else {
+      unsigned prefix = 0, need = (unsigned)wk.beam, count_eq = 0;
+      for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) sh.hist[tid] = 0;
+        __syncthreads();
+        for (int s = tid; s < n_new; s += NT) {
+          const unsigned b = ord(cur[s].score);
+          if (pass == 0 || (b >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(b >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+          // lane l owns digits 4l..4l+3; `above` = tokens with a larger digit
+          unsigned c[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) c[q] = sh.hist[4 * tid + q];
+          const unsigned mine = c[0] + c[1] + c[2] + c[3];
+          unsigned incl = mine;                         // inclusive suffix sum over lanes >= tid
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_down(incl, off, 64);
+            if (tid + off < 64) incl += o;
+          }
+          unsigned above = incl - mine;
+#pragma unroll
+          for (int q = 3; q >= 0; q--) {
+            if (above < need && need <= above + c[q]) {
+              sh.sel_digit = 4u * tid + q; sh.sel_need = need - above; sh.sel_count = c[q];
+            }
+            above += c[q];
+          }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sh.sel_digit;
+        need = sh.sel_need;
+        count_eq = sh.sel_count;
+        __syncthreads();
+      }
+      // prefix = score bits of the beam_width-th token; keep everything above it and
+      // `need` of the count_eq tokens equal to it
+      if (tid == 0) { sh.n_surv = 0; if (count_eq > need) sh.ties_cut += 1; }
+      __syncthreads();
+      for (int s = tid; s < n_new; s += NT) {
+        const unsigned b = ord(cur[s].score);
+        bool keep = b > prefix;
+        if (b == prefix) {
+          if (count_eq <= need) keep = true;
+          else {
+            // several tokens share the cut score: keep those on the smallest nodes
+            // (canonical; the reference keeps whichever its heap order left inside)
+            const int mynode = cur[s].node;
+            unsigned rank = 0;
+            for (int q = 0; q < n_new; q++) {
+              const Tok o = cur[q];
+              rank += (ord(o.score) == prefix && o.node < mynode) ? 1u : 0u;
+            }
+            keep = rank < need;
+          }
+        }
+        if (keep) surv[atomicAdd(&sh.n_surv, 1)] = s;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- find_1pass_result() :399-431 + trace_backptr() :294-340
+  const int natom = min(sh.n_atom, wk.atom_cap);
+  if (tid == 0) { sh.n_new = -1; }
+  __syncthreads();
+  if (res->status == JAMD_PASS1_OK) {
+    int best = -1;
+    for (int i = tid; i < natom; i += NT)
+      if (atoms[i].wid == lx.tail_silwid && atoms[i].backscore > JAMD_LOG_ZERO) best = i;  // ascending i
+    if (best >= 0) atomicMax(&sh.n_new, best);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    res->natom = natom; res->ties = sh.ties + sh.ties_we + sh.ties_cut; res->max_tokens = max_tokens;
+    res->ties_node = sh.ties; res->ties_wordend = sh.ties_we; res->ties_cut = sh.ties_cut;
+    if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
+    if (res->status == JAMD_PASS1_OK) {
+      const int best = sh.n_new;
+      if (best < 0) res->status = JAMD_PASS1_FAIL;
+      else {
+        int n = 0, a = best;
+        int rev[MAXSEQ];
+        rev[n++] = atoms[a].wid;
+        while (atoms[a].begintime > 0 && n < MAXSEQ) { a = atoms[a].last_tre; rev[n++] = atoms[a].wid; }
+        for (int k = 0; k < n; k++) res->wseq[k] = rev[n - 1 - k];
+        res->wnum = n; res->score = atoms[best].backscore;
+      }
+    }
+  }
+}
+
+template <typename T>
+int upload(T **dst, const T *src, size_t n) {
+  JAMD_HIP(hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)));
+  if (n) JAMD_HIP(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+  return JAMD_OK;
+}
+
+}  // namespace
+
+struct jamd_lexicon {
+  jamd_engine *eng = nullptr;
+  LexDev d{};
+  int maxfan = 2;
+  std::vector<void *> owned;
+};
+
+struct jamd_beam {
+  jamd_engine *eng = nullptr;
+  jamd_lexicon *lex = nullptr;
+  Work w{};
+  int max_utts = 0;
+  int *d_utt_off = nullptr;
+  std::vector<void *> owned;
+};
+
+extern "C" {
+
+int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon **out) {
+  if (!e || !h || !out) { jamd_set_error("jamd_lexicon_create: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  if (h->nnode <= 0 || h->nword <= 0 || h->startnum < 0 || h->head_silwid < 0 || h->head_silwid >= h->nword) {
+    jamd_set_error("jamd_lexicon_create: bad sizes (nnode=%d nword=%d head_silwid=%d)", h->nnode, h->nword,
+                   h->head_silwid);
+    return JAMD_EINVAL;
+  }
+  if (h->cdset_method == JAMD_IWCD_NBEST && (h->cdmax_num < 1 || h->cdmax_num > jamd::kNbestMax)) {
+    jamd_set_error("jamd_lexicon_create: cdmax_num=%d outside [1,%d]", h->cdmax_num, jamd::kNbestMax);
+    return JAMD_EINVAL;
+  }
+  int maxfan = 2;
+  for (int i = 0; i < h->nnode; i++) {
+    const int x = h->ac_off[i + 1] - h->ac_off[i];
+    if (2 + x > maxfan) maxfan = 2 + x;
+  }
+  std::vector<int> iso(h->isolatenum > 0 ? h->isolatenum : 0), shared;
+  for (int s = 0; s < h->startnum; s++) {
+    const int i = h->start2isolate[s];
+    if (i >= 0) {
+      if (i >= h->isolatenum) { jamd_set_error("jamd_lexicon_create: start2isolate out of range"); return JAMD_EINVAL; }
+      iso[i] = s;
+      const int sc = h->scid[h->startnode[s]];
+      if (sc <= 0 || sc >= h->nscword) { jamd_set_error("jamd_lexicon_create: isolated root without a successor word"); return JAMD_EINVAL; }
+    } else {
+      const int sc = h->scid[h->startnode[s]];
+      if (sc >= 0 || -sc >= h->nfscore) { jamd_set_error("jamd_lexicon_create: shared root without a factoring value"); return JAMD_EINVAL; }
+      shared.push_back(s);
+    }
+  }
+  if (h->nword >= (1 << 30)) { jamd_set_error("jamd_lexicon_create: nword=%d too large", h->nword); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  jamd_lexicon *l = new jamd_lexicon();
+  l->eng = e; l->maxfan = maxfan;
+  LexDev &d = l->d;
+  d.nnode = h->nnode; d.nword = h->nword; d.startnum = h->startnum; d.isolatenum = h->isolatenum;
+  d.nshared = (int)shared.size(); d.nlc = h->nlc; d.cdset_method = h->cdset_method; d.cdmax_num = h->cdmax_num;
+  d.head_silwid = h->head_silwid; d.tail_silwid = h->tail_silwid; d.ng_mode = h->ng_mode; d.ng_unk_id = h->ng_unk_id;
+  d.ng_unk_num_log = h->ng_unk_num_log; d.lm_weight = h->lm_weight; d.lm_penalty = h->lm_penalty;
+  d.lm_penalty_trans = h->lm_penalty_trans;
+  const int nac = h->ac_off[h->nnode], nset_states = h->nset ? h->set_off[h->nset] : 0;
+  int rc = JAMD_OK;
+#define UP(field, src, n)                                                              \
+  do {                                                                                 \
+    std::remove_const_t<std::remove_pointer_t<decltype(d.field)>> *p_ = nullptr;        \
+    if (rc == JAMD_OK) rc = upload(&p_, src, (size_t)(n));                              \
+    d.field = p_; if (p_) l->owned.push_back((void *)p_);                               \
+  } while (0)
+  UP(self_a, h->self_a, h->nnode); UP(next_a, h->next_a, h->nnode); UP(ac_off, h->ac_off, h->nnode + 1);
+  UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac); UP(stend, h->stend, h->nnode); UP(scid, h->scid, h->nnode);
+  UP(out_kind, h->out_kind, h->nnode); UP(out_id, h->out_id, h->nnode);
+  UP(lc_tab, h->lc_tab, (size_t)h->nlcrow * (h->nlc + 1)); UP(word_lc, h->word_lc, h->nword);
+  UP(set_off, h->set_off, h->nset + 1); UP(set_states, h->set_states, nset_states);
+  UP(startnode, h->startnode, h->startnum);
+  UP(iso_stid, iso.data(), iso.size()); UP(shared_stid, shared.data(), shared.size());
+  UP(wordend_a, h->wordend_a, h->nword); UP(wton, h->wton, h->nword); UP(cprob, h->cprob, h->nword);
+  UP(is_transparent, h->is_transparent, h->nword); UP(word_head, h->word_head, h->nword);
+  UP(fscore, h->fscore, h->nfscore); UP(scword, h->scword, h->nscword);
+  UP(ng_uni_prob, h->ng_uni_prob, h->ng_nword); UP(ng_uni_bo, h->ng_uni_bo, h->ng_nword);
+  UP(ng_bi_bgn, h->ng_bi_bgn, h->ng_nword); UP(ng_bi_num, h->ng_bi_num, h->ng_nword);
+  UP(ng_bi_wid, h->ng_bi_wid, h->ng_nbigram); UP(ng_bi_prob, h->ng_bi_prob, h->ng_nbigram);
+#undef UP
+  if (rc != JAMD_OK) { jamd_lexicon_destroy(l); return rc; }
+  *out = l;
+  return JAMD_OK;
+}
+
+void jamd_lexicon_destroy(jamd_lexicon *l) {
+  if (!l) return;
+  (void)hipSetDevice(l->eng->device);
+  for (void *p : l->owned) (void)hipFree(p);
+  delete l;
+}
+
+int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float score_pruning_width,
+                     int max_utts, int atoms_per_utt, jamd_beam **out) {
+  if (!e || !l || !out) { jamd_set_error("jamd_beam_create: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  if (beam_width < 1 || beam_width > 65536) {
+    jamd_set_error("jamd_beam_create: beam_width=%d outside [1,65536]", beam_width);
+    return JAMD_EINVAL;
+  }
+  if (max_utts < 1 || atoms_per_utt < 1) { jamd_set_error("jamd_beam_create: bad capacity"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  jamd_beam *b = new jamd_beam();
+  b->eng = e; b->lex = l; b->max_utts = max_utts;
+  Work &w = b->w;
+  w.beam = beam_width; w.width = score_pruning_width; w.nnode = l->d.nnode; w.nword = l->d.nword;
+  w.atom_cap = atoms_per_utt;
+  // every survivor reaches at most maxfan nodes, cross-word candidates only reach roots
+  w.tok_cap = beam_width * l->maxfan + l->d.startnum + 1;
+  const size_t U = (size_t)max_utts;
+  int rc = JAMD_OK;
+  auto alloc = [&](void **p, size_t bytes, bool zero) -> int {
+    JAMD_HIP(hipMalloc(p, bytes ? bytes : 4));
+    b->owned.push_back(*p);
+    if (zero) JAMD_HIP(hipMemset(*p, 0, bytes));
+    return JAMD_OK;
+  };
+  if (rc == JAMD_OK) rc = alloc((void **)&w.nodekey, U * w.nnode * sizeof(unsigned long long), true);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.tok[0], U * w.tok_cap * sizeof(Tok), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.tok[1], U * w.tok_cap * sizeof(Tok), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.surv, U * w.tok_cap * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.welist, U * w.beam * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.we_of, U * w.nword * sizeof(int2), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.slot_of[0], U * w.nnode * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.slot_of[1], U * w.nnode * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.atoms, U * w.atom_cap * sizeof(jamd_trellis_atom), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
+  if (rc == JAMD_OK) rc = alloc((void **)&b->d_utt_off, (U + 1) * sizeof(int), true);
+  if (rc != JAMD_OK) { jamd_beam_destroy(b); return rc; }
+  *out = b;
+  return JAMD_OK;
+}
+
+void jamd_beam_destroy(jamd_beam *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->eng->device);
+  for (void *p : b->owned) (void)hipFree(p);
+  delete b;
+}
+
+int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *utt_off, int nutt,
+                        void *stream) {
+  if (!b || !dev_scores || !utt_off || nstate <= 0) { jamd_set_error("jamd_beam_pass1_dev: bad argument"); return JAMD_EINVAL; }
+  if (nutt < 0 || nutt > b->max_utts) {
+    jamd_set_error("jamd_beam_pass1_dev: nutt=%d exceeds the work area (%d)", nutt, b->max_utts);
+    return JAMD_EINVAL;
+  }
+  for (int u = 0; u < nutt; u++) {
+    const int T = utt_off[u + 1] - utt_off[u];
+    if (T < 0 || T > 32767) {   // TRELLIS_ATOM times are short (trellis.h:32-33)
+      jamd_set_error("jamd_beam_pass1_dev: utterance %d has %d frames (limit 32767)", u, T);
+      return JAMD_EINVAL;
+    }
+  }
+  if (nutt == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  hipStream_t st = jamd_stream(b->eng, stream);
+  JAMD_HIP(hipMemcpyAsync(b->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), 0, st, b->lex->d, b->w, dev_scores, nstate,
+                     b->d_utt_off);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  return JAMD_OK;
+}
+
+int jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt) {
+  if (!b || !out || nutt < 0 || nutt > b->max_utts) { jamd_set_error("jamd_beam_results: bad argument"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  JAMD_HIP(hipDeviceSynchronize());
+  if (nutt) JAMD_HIP(hipMemcpy(out, b->w.res, sizeof(jamd_pass1_result) * nutt, hipMemcpyDeviceToHost));
+  return JAMD_OK;
+}
+
+int jamd_beam_trellis(jamd_beam *b, int utt, jamd_trellis_atom *atoms, int cap, int *natom) {
+  if (!b || !natom || utt < 0 || utt >= b->max_utts) { jamd_set_error("jamd_beam_trellis: bad argument"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  JAMD_HIP(hipDeviceSynchronize());
+  jamd_pass1_result r;
+  JAMD_HIP(hipMemcpy(&r, b->w.res + utt, sizeof(r), hipMemcpyDeviceToHost));
+  *natom = r.natom;
+  if (atoms) {
+    const int n = r.natom < cap ? r.natom : cap;
+    if (n > 0) JAMD_HIP(hipMemcpy(atoms, b->w.atoms + (size_t)utt * b->w.atom_cap, sizeof(jamd_trellis_atom) * n,
+                                  hipMemcpyDeviceToHost));
+  }
+  return JAMD_OK;
+}
+
+}  // extern "C"

@@ -22,7 +22,7 @@ struct jamd_cdset {
 
 namespace {
 
-constexpr int kNbestMax = 16;
+using jamd::kNbestMax;
 
 __global__ void __launch_bounds__(256)
 cdset_kernel(const float *__restrict__ scores, const int *__restrict__ off,
@@ -32,41 +32,7 @@ cdset_kernel(const float *__restrict__ scores, const int *__restrict__ off,
   const int t = blockIdx.y;
   if (i >= nset) return;
   const float *row = scores + (size_t)t * S;
-  const int a = off[i], b = off[i + 1];
-  float r;
-  if (method == JAMD_IWCD_MAX) {
-    float m = JAMD_LOG_ZERO;
-    for (int k = a; k < b; k++) { const float p = row[states[k]]; if (m < p) m = p; }
-    r = m;
-  } else if (method == JAMD_IWCD_AVG) {
-    float sum = 0.0f; int j = 0;
-    for (int k = a; k < b; k++) { const float p = row[states[k]]; if (p > JAMD_LOG_ZERO) { sum += p; j++; } }
-    r = sum / (float)j;
-  } else {
-    float best[kNbestMax];
-    int n = 0;
-#pragma unroll
-    for (int q = 0; q < kNbestMax; q++) best[q] = JAMD_LOG_ZERO;
-    for (int k = a; k < b; k++) {
-      const float p = row[states[k]];
-      if (p <= JAMD_LOG_ZERO) continue;
-      // position = number of kept values >= p when appending at the bottom
-      // (outprob.c:297: `prob <= maxprobs[n-1]`), else before the first smaller one
-      int pos = 0;
-#pragma unroll
-      for (int q = 0; q < kNbestMax; q++) pos += (q < n && best[q] >= p) ? 1 : 0;
-      if (pos >= nbest) continue;
-#pragma unroll
-      for (int q = kNbestMax - 1; q >= 1; q--) if (q > pos && q < nbest) best[q] = best[q - 1];
-#pragma unroll
-      for (int q = 0; q < kNbestMax; q++) if (q == pos) best[q] = p;
-      if (n < nbest) n++;
-    }
-    float sum = 0.0f;
-#pragma unroll
-    for (int q = 0; q < kNbestMax; q++) if (q < n) sum += best[q];
-    r = sum / (float)n;
-  }
+  const float r = jamd::cd_reduce(row, states, off[i], off[i + 1], method, nbest);
   cd[(size_t)t * nset + i] = r;
 }
 

@@ -92,4 +92,45 @@ __device__ __forceinline__ void topn_push(float (&sc)[NMAX], int (&id)[NMAX], in
   if (len < cap) len++;
 }
 
+// outprob_cd() reductions over one CD_State_Set given a row of state scores
+// (libsent/src/phmm/outprob.c:287-400); shared by the cdset kernel and the
+// first-pass kernel.  `states[a..b)` are the member state ids.
+constexpr int kNbestMax = 16;
+__device__ __forceinline__ float cd_reduce(const float *__restrict__ row, const int *__restrict__ states,
+                                           int a, int b, int method, int nbest) {
+  if (method == JAMD_IWCD_MAX) {                       // outprob_cd_max :332-344
+    float m = JAMD_LOG_ZERO;
+    for (int k = a; k < b; k++) { const float p = row[states[k]]; if (m < p) m = p; }
+    return m;
+  }
+  if (method == JAMD_IWCD_AVG) {                       // outprob_cd_avg :356-370
+    float sum = 0.0f; int j = 0;
+    for (int k = a; k < b; k++) { const float p = row[states[k]]; if (p > JAMD_LOG_ZERO) { sum += p; j++; } }
+    return sum / (float)j;
+  }
+  float best[kNbestMax];                               // outprob_cd_nbest :287-321
+  int n = 0;
+#pragma unroll
+  for (int q = 0; q < kNbestMax; q++) best[q] = JAMD_LOG_ZERO;
+  for (int k = a; k < b; k++) {
+    const float p = row[states[k]];
+    if (p <= JAMD_LOG_ZERO) continue;
+    // position = number of kept values >= p when appending at the bottom
+    // (outprob.c:297: `prob <= maxprobs[n-1]`), else before the first smaller one
+    int pos = 0;
+#pragma unroll
+    for (int q = 0; q < kNbestMax; q++) pos += (q < n && best[q] >= p) ? 1 : 0;
+    if (pos >= nbest) continue;
+#pragma unroll
+    for (int q = kNbestMax - 1; q >= 1; q--) if (q > pos && q < nbest) best[q] = best[q - 1];
+#pragma unroll
+    for (int q = 0; q < kNbestMax; q++) if (q == pos) best[q] = p;
+    if (n < nbest) n++;
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int q = 0; q < kNbestMax; q++) if (q < n) sum += best[q];
+  return sum / (float)n;
+}
+
 }  // namespace jamd

@@ -88,6 +88,13 @@ def load():
         "jamd_dnn_veclen": (ci, [vp]),
         "jamd_dnn_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
         "jamd_dnn_outprob_host": (ci, [vp, vp, ci, vp]),
+        "jamd_lexicon_create": (ci, [vp, vp, P(vp)]),
+        "jamd_lexicon_destroy": (None, [vp]),
+        "jamd_beam_create": (ci, [vp, vp, ci, cf, ci, ci, P(vp)]),
+        "jamd_beam_destroy": (None, [vp]),
+        "jamd_beam_pass1_dev": (ci, [vp, vp, ci, vp, ci, vp]),
+        "jamd_beam_results": (ci, [vp, vp, ci]),
+        "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -326,6 +333,95 @@ class Dnn:
     def close(self):
         if getattr(self, "h", None):
             load().jamd_dnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pass1Result(C.Structure):
+    """jamd_pass1_result (include/julius_amd.h)."""
+    _fields_ = [("status", C.c_int), ("natom", C.c_int), ("wnum", C.c_int), ("score", C.c_float),
+                ("died_at", C.c_int), ("ties", C.c_int), ("frames", C.c_int), ("max_tokens", C.c_int),
+                ("ties_node", C.c_int), ("ties_wordend", C.c_int), ("ties_cut", C.c_int),
+                ("wseq", C.c_int * 150)]
+
+
+class Lexicon:
+    """Device-resident first-pass tables (jamd_lexicon) from a lexicon dict
+    (julius_amd.lexblob.load)."""
+
+    def __init__(self, eng: Engine, lex: dict):
+        from . import lexblob
+        self.eng, self.lex = eng, lex
+        d, self._keep = lexblob.make_desc(lex)
+        h = C.c_void_p()
+        _check(load().jamd_lexicon_create(eng.h, C.byref(d), C.byref(h)), "jamd_lexicon_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_lexicon_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Beam:
+    """First-pass work area for a batch of utterances (jamd_beam)."""
+
+    def __init__(self, eng: Engine, lexicon: Lexicon, beam_width: int, score_pruning_width: float = -1.0,
+                 max_utts: int = 1, atoms_per_utt: int = 1 << 16):
+        self.eng, self.lexicon = eng, lexicon
+        self.max_utts, self.atoms_per_utt = max_utts, atoms_per_utt
+        h = C.c_void_p()
+        _check(load().jamd_beam_create(eng.h, lexicon.h, beam_width, score_pruning_width, max_utts,
+                                       atoms_per_utt, C.byref(h)), "jamd_beam_create")
+        self.h = h
+
+    def pass1_dev(self, dev_scores: int, nstate: int, utt_off, stream: int = 0):
+        off = _i32(utt_off)
+        self._nutt = len(off) - 1
+        _check(load().jamd_beam_pass1_dev(self.h, dev_scores, nstate, off.ctypes.data, self._nutt,
+                                          stream or None), "jamd_beam_pass1_dev")
+
+    def results(self, nutt=None):
+        n = self._nutt if nutt is None else nutt
+        arr = (Pass1Result * n)()
+        _check(load().jamd_beam_results(self.h, arr, n), "jamd_beam_results")
+        return list(arr)
+
+    def trellis(self, utt: int):
+        from . import lexblob
+        n = C.c_int()
+        _check(load().jamd_beam_trellis(self.h, utt, None, 0, C.byref(n)), "jamd_beam_trellis")
+        atoms = np.zeros(max(n.value, 1), dtype=lexblob.ATOM_DTYPE)
+        _check(load().jamd_beam_trellis(self.h, utt, atoms.ctypes.data, n.value, C.byref(n)), "jamd_beam_trellis")
+        return atoms[:n.value]
+
+    def pass1_host(self, score_list):
+        """Convenience for tests: list of [T_u][S] host score matrices -> (results, trellises)."""
+        S = score_list[0].shape[1]
+        off = np.zeros(len(score_list) + 1, np.int32)
+        off[1:] = np.cumsum([len(x) for x in score_list])
+        allsc = _f32(np.concatenate(score_list, axis=0))
+        d = DevBuf(self.eng, allsc.nbytes).upload(allsc)
+        self.pass1_dev(d.ptr, S, off)
+        res = self.results()
+        tre = [self.trellis(u) for u in range(len(score_list))]
+        d.free()
+        return res, tre
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_beam_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,108 @@
+"""GPU: the HIP first pass (beam.hip, through the C ABI) against the golden
+fixtures of the compiled reference, the oracle, and -- when oracle/_ref is
+present -- the reference recogniser itself.  Bit-exact trellis: word ids,
+begin/end frames, predecessor links and float scores.  (jamd_pass1_result.ties
+counts exact float ties, the only place where the engine's canonical rule and the
+reference's visiting order could pick different -- equally scored -- histories;
+these fixtures contain a few and still match.)"""
+import numpy as np
+import pytest
+
+from beamutil import assert_trellis_equal, assert_trellis_equal_modulo_ties, load_beam_golden, ref_task
+from julius_amd import lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz"])
+def test_golden_batch(engine, oracle, name):
+    """All utterances of a fixture in ONE launch (one workgroup each)."""
+    g = load_beam_golden(name)
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    res, tre = bm.pass1_host(scores)
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0 and r.frames == len(u["frames"])
+        assert_trellis_equal(atoms, u["trellis"])
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"])
+        assert r.score == u["score"]
+
+
+def test_end_to_end_device_flow(engine):
+    """HIP GMM scores stay on the device and feed the HIP beam: frames in,
+    pass-1 sentence out, identical to the reference's."""
+    g = load_beam_golden("beam_rank.npz")
+    gm = lib.Gmm(engine, g["am"])
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    frames = np.concatenate([u["frames"] for u in g["utts"]])
+    off = np.zeros(len(g["utts"]) + 1, np.int32)
+    off[1:] = np.cumsum([len(u["frames"]) for u in g["utts"]])
+    d_fr = lib.DevBuf(engine, frames.nbytes).upload(frames)
+    d_sc = lib.DevBuf(engine, 4 * len(frames) * gm.S)
+    gm.outprob_dev(d_fr.ptr, len(frames), d_sc.ptr)
+    bm.pass1_dev(d_sc.ptr, gm.S, off)
+    res = bm.results()
+    for i, (r, u) in enumerate(zip(res, g["utts"])):
+        assert r.status == 0
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"])
+        assert r.score == u["score"]
+        assert_trellis_equal(bm.trellis(i), u["trellis"])
+
+
+def test_beam_death(engine):
+    g = load_beam_golden("beam_score.npz")      # IWCD max: an all-LOG_ZERO set stays LOG_ZERO (no NaN)
+    S = len(g["am"]["st_off"]) - 1
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, 50, -1.0, max_utts=1)
+    res, _ = bm.pass1_host([np.full((5, S), -1000000.0, np.float32)])
+    assert res[0].status == 2 and res[0].died_at == 1
+
+
+def test_atom_overflow_is_reported(engine, oracle):
+    g = load_beam_golden("beam_rank.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], -1.0, max_utts=1, atoms_per_utt=50)
+    res, _ = bm.pass1_host([oracle.gmm_outprob(g["am"], g["utts"][0]["frames"])])
+    assert res[0].status == 3
+
+
+def test_work_area_is_reusable(engine, oracle):
+    """Two batches through the same jamd_beam: the node table must come back clean."""
+    g = load_beam_golden("beam_score.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=2)
+    sc = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    for pick in ([0, 1], [2, 0], [1]):
+        res, tre = bm.pass1_host([sc[i] for i in pick])
+        for r, atoms, i in zip(res, tre, pick):
+            assert r.status == 0
+            assert_trellis_equal(atoms, g["utts"][i]["trellis"])
+
+
+@pytest.mark.parametrize("seed,beam,extra,task_kw", [
+    (21, 300, ["-sepnum", "5"], {}),
+    (22, 30, ["-sepnum", "2"], {}),
+    (23, 600, ["-sepnum", "10", "-bs", "80"], dict(nword=300, nphone=12, S=200)),   # beam > 512 threads
+    (24, 100, ["-sepnum", "0", "-iwcd1", "avg"], {}),
+    (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),          # no rank pruning at all
+])
+def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
+    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    utts = [synth.make_utterance(task, nwords=2 + 3 * u, seed=100 * seed + u)[0] for u in range(4)]
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts))
+    res, tre = bm.pass1_host(scores)
+    for fr, sc, r, atoms in zip(utts, scores, res, tre):
+        oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, bs)
+        assert r.status == rc
+        from julius_amd import lexblob
+        assert_trellis_equal_modulo_ties(atoms, lexblob.canonical_trellis(oatoms), r.ties)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert_trellis_equal_modulo_ties(atoms, rtr, r.ties)
+        if rc == 0:
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore

@@ -1,0 +1,65 @@
+"""CPU: the first-pass oracle (oracle/jamd_oracle_beam.c) against
+  (1) the committed golden fixtures the compiled reference produced
+      (tools/make_golden.py beam), and
+  (2) the compiled reference itself on fresh seeded tasks (when oracle/_ref is built).
+Bit-exact: word ids, frame indices, predecessor links, float scores."""
+import numpy as np
+import pytest
+
+from beamutil import assert_trellis_equal, load_beam_golden, ref_task
+from julius_amd import lexblob, synth
+
+
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz"])
+def test_oracle_matches_golden(oracle, name):
+    g = load_beam_golden(name)
+    for u in g["utts"]:
+        sc = oracle.gmm_outprob(g["am"], u["frames"])
+        atoms, wseq, score, rc, died = oracle.beam_pass1(g["lex"], sc, g["beam_width"], g["score_pruning_width"])
+        assert rc == 0 and died == -1
+        assert_trellis_equal(atoms, u["trellis"])
+        assert np.array_equal(wseq, u["wseq"])
+        assert score == u["score"]
+
+
+def test_lexblob_roundtrip(tmp_path):
+    g = load_beam_golden("beam_rank.npz")
+    lexblob.save(g["lex"], tmp_path / "x.blob")
+    back = lexblob.load(tmp_path / "x.blob")
+    for k, v in g["lex"].items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(back[k], v), k
+        else:
+            assert back[k] == pytest.approx(v), k
+
+
+def test_beam_death_is_reported(oracle):
+    """All-LOG_ZERO acoustic scores kill every token: status 2 at frame 1
+    (get_back_trellis_proceed() returning FALSE, beam.c:3012-3015)."""
+    g = load_beam_golden("beam_score.npz")      # IWCD max: an all-LOG_ZERO set stays LOG_ZERO (no NaN)
+    S = len(g["am"]["st_off"]) - 1
+    sc = np.full((5, S), -1000000.0, np.float32)
+    atoms, wseq, score, rc, died = oracle.beam_pass1(g["lex"], sc, 50)
+    assert rc == 2 and died == 1 and len(wseq) == 0
+
+
+@pytest.mark.parametrize("seed,beam,extra", [
+    (11, 200, ["-sepnum", "5"]),
+    (12, 25, ["-sepnum", "2"]),                                # very narrow rank beam
+    (13, 150, ["-sepnum", "4", "-bs", "40"]),                  # score beam
+    (14, 100, ["-sepnum", "0", "-iwcd1", "avg"]),              # whole vocabulary in the tree
+    (15, 100, ["-sepnum", "3", "-iwcd1", "best", "2", "-lmp", "6.0", "-3.0"]),
+])
+def test_oracle_matches_reference_live(oracle, ref, tmp_path, seed, beam, extra):
+    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra)
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr, (wseq, score) = eng.recognize(tmp_path / "u.mfc")
+        sc = oracle.gmm_outprob(am, fr)
+        atoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, bs)
+        assert rc in (0, 1)
+        assert_trellis_equal(atoms, tr)
+        if rc == 0:
+            assert np.array_equal(owseq, wseq) and oscore == score

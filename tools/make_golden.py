@@ -105,5 +105,56 @@ def main():
          logistic_val=o.logistic_tbl()[::641])
 
 
+
+def beam_fixture(ref, tmp, name, seed, beam, extra, nutt=3, **task_kw):
+    """A complete first-pass case: the reference recogniser loads a synthetic
+    tied-state triphone task (hmmdefs + HMMList + dict + ARPA 2-gram), the
+    product-side shim flattens its lexicon (-> lexicon blob), and the reference's
+    own first pass produces the word trellis / pass-1 sentence per utterance."""
+    from julius_amd import lexblob
+    d = tmp / name
+    task = synth.make_triphone_task(d, seed=seed, **task_kw)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)] + list(extra)
+    eng = pyoracle.RefEngine(ref, args)
+    eng.save_lexicon(d / "lex.blob")
+    lex = lexblob.load(d / "lex.blob")
+    am = ref.am_load(task["hmmdefs"], task["hmmlist"])
+    model = am.export()
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    out = dict(beam_width=np.int32(eng.beam_width), score_pruning_width=np.float32(bs), nutt=np.int32(nutt),
+               args=np.array(" ".join(str(a) for a in args[10:])))
+    for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+        out["am_" + k] = model[k]
+    for k, v in lex.items():
+        out["lex_" + k] = np.asarray(v)
+    for u in range(nutt):
+        fr, _ = synth.make_utterance(task, nwords=4 + u, seed=1000 * seed + u)
+        synth.write_htk_param(d / "u.mfc", fr)
+        tr, (wseq, sc) = eng.recognize(d / "u.mfc")
+        out[f"u{u}_frames"] = fr
+        for k, v in tr.items():
+            out[f"u{u}_tr_{k}"] = v
+        out[f"u{u}_wseq"] = wseq
+        out[f"u{u}_score"] = np.float32(sc)
+    save(name + ".npz", **out)
+
+
+def main_beam():
+    ref = pyoracle.Ref()
+    tmp = Path(tempfile.mkdtemp())
+    # B1: rank beam only; lexicon tree with shared roots (factoring) and isolated roots
+    beam_fixture(ref, tmp, "beam_rank", seed=0, beam=120, extra=["-sepnum", "5"])
+    # B2: rank + score beam, IWCD max, different LM weights
+    beam_fixture(ref, tmp, "beam_score", seed=3, beam=80, extra=["-sepnum", "3", "-bs", "60", "-iwcd1", "max",
+                                                                  "-lmp", "5.0", "-1.0"])
+    # B3: every word separated from the tree (all roots isolated), IWCD avg, narrow beam
+    beam_fixture(ref, tmp, "beam_isolated", seed=4, beam=40, extra=["-iwcd1", "avg"], nword=40)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "beam":
+        main_beam()
+    else:
+        main()
+        main_beam()
