@@ -76,11 +76,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=16, help="utterances (x1000 frames) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn"],
-                    help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half")
+    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn", "e2e"],
+                    help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half; "
+                         "e2e = configs[2]: GMM outprob + HIP first pass on a 20k-word lexicon")
+    ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
+    ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
     args = ap.parse_args()
     if args.workload == "dnn":
         return main_dnn(args)
+    if args.workload == "e2e":
+        return main_e2e(args)
 
     import torch
     from julius_amd import lib, synth
@@ -242,6 +247,113 @@ def main_dnn(args):
                          "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel_ms": ms},
             "parity_spot_check": bool(np.array_equal(got, want))}
     print(json.dumps(line), flush=True)
+
+
+def main_e2e(args):
+    """configs[2]: tied-state triphone GMM (S=3000 x M=16 x D=39) + 20k-word tree
+    lexicon with 2-gram, outprob kernel + HIP first pass, end to end on the device:
+    frames in HBM -> [T][S] scores in HBM -> word trellis + pass-1 sentence.
+    One step = `--utts` utterances (one workgroup each) per GPU.  The lexicon is
+    synthetic (julius_amd.synth.make_lexicon, same structural rules as the
+    reference's builder); utterances follow random word sequences through it."""
+    import torch
+    from julius_amd import lib, synth
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
+    model = synth.make_gmm(S=S, M=M, D=D, seed=0)
+    nuniq = min(args.utts, 16)
+    uniq = [synth.make_lexicon_utterance(lex, model, nwords=30, seed=1000 * rank + u) for u in range(nuniq)]
+    utts = [uniq[u % nuniq][0] for u in range(args.utts)]
+    off = np.zeros(args.utts + 1, np.int32)
+    off[1:] = np.cumsum([len(x) for x in utts])
+    frames = np.concatenate(utts)
+    T = len(frames)
+    eng = lib.Engine(local_rank)
+    gmm = lib.Gmm(eng, model)
+    lx = lib.Lexicon(eng, lex)
+    bm = lib.Beam(eng, lx, args.beam, -1.0, max_utts=args.utts, atoms_per_utt=1 << 17)
+    d_fr = torch.from_numpy(frames).cuda()
+    d_sc = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+
+    def step():
+        gmm.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+        bm.pass1_dev(d_sc.data_ptr(), S, off, stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[3 * i].record(stream)
+        gmm.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+        ev[3 * i + 1].record(stream)
+        bm.pass1_dev(d_sc.data_ptr(), S, off, stream.cuda_stream)
+        ev[3 * i + 2].record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gmm_ms = float(np.mean([ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.steps)]))
+    beam_ms = float(np.mean([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)]))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        res = bm.results()
+        ok = sum(1 for r in res if r.status == 0)
+        correct = sum(1 for u, r in enumerate(res) if list(r.wseq[:r.wnum]) == uniq[u % nuniq][1])
+        total_frames = T * world * args.steps
+        tokens = float(np.mean([r.max_tokens for r in res]))
+        line = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * S / elapsed,
+                "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": total_frames / 100.0 / elapsed,
+                "config": {"workload": f"C3 (BASELINE.json configs[2]): GMM S={S} x M={M} x D={D} outprob + HIP first pass, "
+                                       f"{args.nword}-word tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram, "
+                                       f"beam {args.beam}, {args.utts} utterances ({T} frames) per GPU per step",
+                           "parallelism": f"utterance-sharded x{world}"},
+                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                             "traffic": None, "note": "irregular gather/scatter: no algorithmic-bytes roofline "
+                             "(SURVEY.md 8d); figure of merit is end-to-end frames/s",
+                             "gmm_kernel_ms": gmm_ms, "beam_kernel_ms": beam_ms,
+                             "beam_frames_per_s": T / (beam_ms * 1e-3),
+                             "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
+                "pass1": {"ok": ok, "sentence_correct": correct, "utts": len(res), "mean_peak_tokens": tokens,
+                          "ties": int(sum(r.ties for r in res)), "phase_us_utt0": list(res[0].phase_us)}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+            orc = pyoracle.Oracle()
+            fr0 = utts[0]
+            tt0 = time.perf_counter()
+            sc0 = orc.gmm_outprob(model, fr0)
+            tt1 = time.perf_counter()
+            atoms, wseq, score, rc, died = orc.beam_pass1(lex, sc0, args.beam, -1.0)
+            tt2 = time.perf_counter()
+            got = d_sc[:len(fr0)].cpu().numpy()
+            line["parity_spot_check"] = bool(np.array_equal(got, sc0)) and list(wseq) == list(res[0].wseq[:res[0].wnum]) \
+                and float(score) == float(res[0].score)
+            line["cpu_baseline"] = {"value": len(fr0) * S / (tt2 - tt0), "unit": "frame*states/s", "cores": 1,
+                                    "kind": "port", "rtf_inv": len(fr0) / 100.0 / (tt2 - tt0),
+                                    "sample": f"1 utterance of {len(fr0)} frames: oracle eager GMM scoring {tt1 - tt0:.2f} s + "
+                                              f"oracle first pass {tt2 - tt1:.2f} s on 1 of {os.cpu_count()} host cores"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -283,6 +283,8 @@ typedef struct {
   int   max_tokens;      /* high-water mark of tokens alive in one frame              */
   int   ties_node, ties_wordend, ties_cut;   /* ties by kind: Viterbi max at a node, best    */
                          /* word end, rank cut                                        */
+  int   phase_us[4];     /* device time spent in: A intra-word+atoms, B cross-word,   */
+                         /* C finalize+outprob, D rank pruning (microseconds)         */
   int   wseq[150];       /* r->pass1_wseq, MAXSEQNUM = 150 (libsent speech.h:50)      */
 } jamd_pass1_result;
 

@@ -213,6 +213,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     sh.n_surv = 1;
   }
   float thr = JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tc = wall_clock64();   // phase clocks (100 MHz), thread 0 only
+#define PHASE(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
   int max_tokens = 1;
   __syncthreads();
 
@@ -291,6 +293,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
     }
     __syncthreads();
+    PHASE(0);
     if (last) break;
 
     // ---- B1: word ends -> isolated roots with the 2-gram (beam_inter_word() :2334-2516)
@@ -336,6 +339,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
     }
     __syncthreads();
+    PHASE(1);
 
     // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951)
     const int n_new = sh.n_new;
@@ -382,6 +386,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       atomicMax(&sh.maxbits, mymax);
     }
     __syncthreads();
+    PHASE(2);
     {
       const float mx = unord(sh.maxbits);                          // score_pruning_max :2948
       thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;  // :2954-2960
@@ -465,6 +470,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
       __syncthreads();
     }
+    PHASE(3);
   }
   __syncthreads();
 
@@ -482,6 +488,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   if (tid == 0) {
     res->natom = natom; res->ties = sh.ties + sh.ties_we + sh.ties_cut; res->max_tokens = max_tokens;
     res->ties_node = sh.ties; res->ties_wordend = sh.ties_we; res->ties_cut = sh.ties_cut;
+    for (int i = 0; i < 4; i++) res->phase_us[i] = (int)(ph[i] / 100ull);
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
       const int best = sh.n_new;

@@ -108,7 +108,32 @@ __device__ __forceinline__ float cd_reduce(const float *__restrict__ row, const 
     for (int k = a; k < b; k++) { const float p = row[states[k]]; if (p > JAMD_LOG_ZERO) { sum += p; j++; } }
     return sum / (float)j;
   }
-  float best[kNbestMax];                               // outprob_cd_nbest :287-321
+  // outprob_cd_nbest :287-321 keeps a descending list of at most nbest values and
+  // returns their best-first float sum / n.  The kept multiset is simply the nbest
+  // largest values (ties do not change it), so for the usual small nbest a
+  // register insertion chain produces the identical sum.
+  if (nbest <= 4) {
+    float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
+    int n = 0;
+    for (int k = a; k < b; k++) {
+      float p = row[states[k]];
+      if (p <= JAMD_LOG_ZERO) continue;
+      n++;
+      float t;
+      if (p > b0) { t = b0; b0 = p; p = t; }
+      if (p > b1) { t = b1; b1 = p; p = t; }
+      if (p > b2) { t = b2; b2 = p; p = t; }
+      if (p > b3) { b3 = p; }
+    }
+    if (n > nbest) n = nbest;
+    float sum = 0.0f;
+    if (n > 0) sum += b0;
+    if (n > 1) sum += b1;
+    if (n > 2) sum += b2;
+    if (n > 3) sum += b3;
+    return sum / (float)n;
+  }
+  float best[kNbestMax];
   int n = 0;
 #pragma unroll
   for (int q = 0; q < kNbestMax; q++) best[q] = JAMD_LOG_ZERO;

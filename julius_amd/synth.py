@@ -322,3 +322,321 @@ def make_utterance(task, nwords=6, seed=0, frames_per_state=3, noise=0.7):
     st = np.repeat(np.array(seq), frames_per_state)
     fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
     return fr.astype(np.float32), [w for w, _ in ws]
+
+
+# ------------------------------------------------- synthetic tree lexicon (bench / scale tests)
+def make_lexicon(nword=20000, nphone=40, S=3000, seed=0, minlen=2, maxlen=8, sepnum=150, nshort=20,
+                 nbigram_per_word=20, defined_frac=0.9, lm_weight=8.0, lm_penalty=-2.0):
+    """A seeded tree lexicon + 2-gram in the flat form of jamd_lexicon_desc, built
+    directly (no reference code involved) with the same structural rules the
+    reference's builder applies, so that a 20k-word task of BASELINE.json's shape
+    exists on machines without the reference:
+
+      * every phone is three left-to-right nodes (self 0.6 / next 0.4, exit 0.3);
+      * words are merged into a prefix tree over their LOGICAL triphone names
+        (head "a+b", inner "a-b+c", tail "b-c"), so word ends are always leaves
+        (build_wchmm2(), libjulius/src/wchmm.c:1749; sharing test :417-430);
+      * the `sepnum` most frequent words and the one-phone words stay outside the
+        tree, as do <s> and </s>; <s> is not a cross-word target (wchmm.c:1585-1640);
+      * 1-gram factoring ids: a node whose successor-word set differs from its
+        predecessor's carries scid > 0 (one word: index into scword) or scid < 0
+        (several: index into fscore = max 1-gram of the set)
+        (libjulius/src/factoring_sub.c:345-468); roots with scid > 0 are the
+        "isolated" ones (make_iwcache_index(), factoring_sub.c:719-735);
+      * head phones are AS_RSET (row of the left-context table), tail phones
+        AS_LSET (state set over the right contexts), one-phone words AS_LRSET
+        (wchmm_add_word(), wchmm.c:1093-1128).
+
+    State ids index a pool of S tied states (per centre phone and state position).
+    """
+    rng = np.random.default_rng(seed)
+    per = S // nphone
+    ploc = max(per // 3, 1)
+    assert per >= 3
+    nsil = 2
+    W = nword + nsil                     # word 0 = <s>, word 1 = </s>
+    SILB, SILE = nphone, nphone + 1      # context classes of the two silence words
+    nlc = nphone + 2
+
+    def tri(l, c, r, loc):
+        return int(c * per + loc * ploc + ((l * 131 + r * 31 + 7) % ploc))
+
+    # ---- vocabulary -------------------------------------------------------------
+    seqs, seen = [], set()
+    while len(seqs) < nword:
+        n = 1 if len(seqs) < min(nshort, nphone // 2) else int(rng.integers(minlen, maxlen + 1))
+        ph = tuple(int(x) for x in rng.integers(0, nphone, size=n))
+        if ph in seen:
+            continue
+        seen.add(ph)
+        seqs.append(ph)
+    order = rng.permutation(nword)
+    seqs = [seqs[i] for i in order]
+    uni = np.log10(rng.dirichlet(np.full(W, 0.3)) + 1e-9).astype(np.float32)
+    uni[0] = uni[1] = np.float32(np.log10(0.05))          # sentence delimiters are frequent
+    bo = (-rng.uniform(0.1, 1.0, size=W)).astype(np.float32)
+    rank = np.argsort(-uni[nsil:])
+    separated = np.zeros(nword, bool)
+    separated[rank[:sepnum]] = True
+    for i, ph in enumerate(seqs):
+        if len(ph) == 1:
+            separated[i] = True
+
+    # ---- nodes --------------------------------------------------------------------
+    self_a, next_a, stend, scid, out_kind, out_id = [], [], [], [], [], []
+    ac = {}                                   # node -> list of (to, a)
+    LZ = np.float32(-1000000.0)
+    A_SELF, A_NEXT = np.float32(np.log10(0.6)), np.float32(np.log10(0.4))
+    A_SELF3, A_EXIT = np.float32(np.log10(0.7)), np.float32(np.log10(0.3))
+    rows, row_list, sets, set_list = {}, [], {}, []
+
+    def row_id(kind, key):
+        k = (kind, key)
+        if k not in rows:
+            rows[k] = len(row_list)
+            row_list.append(k)
+        return rows[k]
+
+    def set_id(key):
+        if key not in sets:
+            sets[key] = len(set_list)
+            set_list.append(key)
+        return sets[key]
+
+    def add_phone(spec):
+        """three nodes; returns first node id.  spec(loc) -> (out_kind, out_id)"""
+        first = len(self_a)
+        for loc in range(3):
+            self_a.append(A_SELF if loc < 2 else A_SELF3)
+            next_a.append(A_NEXT if loc < 2 else LZ)      # last state: linked by the caller
+            stend.append(-1)
+            scid.append(0)
+            k, i = spec(loc)
+            out_kind.append(k)
+            out_id.append(i)
+        return first
+
+    def phone_spec(ph, i):
+        L = len(ph)
+        c = ph[i]
+        if L == 1:
+            return lambda loc: (3, row_id("lr", (c, loc)))
+        if i == 0:
+            return lambda loc: (2, row_id("r", (c, ph[1], loc)))
+        if i == L - 1:
+            return lambda loc: (1, set_id((ph[i - 1], c, loc)))
+        return lambda loc: (0, tri(ph[i - 1], c, ph[i + 1], loc))
+
+    def link(frm_last, to_first):
+        if to_first == frm_last + 1:
+            next_a[frm_last] = A_EXIT
+        else:
+            ac.setdefault(frm_last, []).append((to_first, A_EXIT))
+
+    word_head = np.zeros(W, np.int32)
+    word_end = np.zeros(W, np.int32)
+    words_below = {}                           # first node of a tree edge -> list of words
+    trie = {}                                  # (parent_first_node or -1, logical name) -> first node
+    children = {}                              # parent edge first node (-1 root) -> count
+    roots = []                                 # first nodes of root edges, in creation order
+
+    def logical(ph, i):
+        L = len(ph)
+        if L == 1:
+            return ("m", ph[0])
+        if i == 0:
+            return ("h", ph[0], ph[1])
+        if i == L - 1:
+            return ("t", ph[i - 1], ph[i])
+        return ("i", ph[i - 1], ph[i], ph[i + 1])
+
+    def add_chain(w, ph, start_i, prev_last):
+        """append phones ph[start_i:] as new nodes after node prev_last (or as a root)"""
+        firsts = []
+        for i in range(start_i, len(ph)):
+            f = add_phone(phone_spec(ph, i))
+            if prev_last is not None:
+                link(prev_last, f)
+            prev_last = f + 2
+            firsts.append(f)
+        stend[prev_last] = w
+        word_end[w] = prev_last
+        return firsts
+
+    # silence words: single "phone" chains with plain states from the top of the pool
+    for w, base in ((0, S - 6), (1, S - 3)):
+        f = len(self_a)
+        for loc in range(3):
+            self_a.append(A_SELF if loc < 2 else A_SELF3)
+            next_a.append(A_NEXT if loc < 2 else LZ)
+            stend.append(-1); scid.append(0); out_kind.append(0); out_id.append(base + loc)
+        stend[f + 2] = w
+        word_head[w], word_end[w] = f, f + 2
+    single_roots = [(word_head[1], 1)]         # </s> is a cross-word target, <s> is not
+    edge_parent = {}
+    for wi, ph in enumerate(seqs):
+        w = wi + nsil
+        if separated[wi]:
+            firsts = add_chain(w, ph, 0, None)
+            word_head[w] = firsts[0]
+            single_roots.append((firsts[0], w))
+            continue
+        parent, depth, prev_last = -1, 0, None
+        while depth < len(ph) and (parent, logical(ph, depth)) in trie:
+            parent = trie[(parent, logical(ph, depth))]
+            words_below[parent].append(w)
+            prev_last = parent + 2
+            depth += 1
+        firsts = add_chain(w, ph, depth, prev_last)
+        p = parent
+        for i, f in zip(range(depth, len(ph)), firsts):
+            trie[(p, logical(ph, i))] = f
+            words_below[f] = [w]
+            edge_parent[f] = p
+            children[p] = children.get(p, 0) + 1
+            if p == -1:
+                roots.append(f)
+            p = f
+    # word_head for tree words = root edge containing the word
+    for f in roots:
+        for w in words_below[f]:
+            word_head[w] = f
+
+    # ---- factoring ids ----------------------------------------------------------------
+    fscore, scword = [LZ], [0]
+    def assign(f, ws):
+        if len(ws) == 1:
+            scid[f] = len(scword); scword.append(ws[0])
+        else:
+            scid[f] = -len(fscore); fscore.append(np.float32(max(uni[x] for x in ws)))
+    for f, ws in words_below.items():
+        p = edge_parent[f]
+        if p == -1 or len(words_below[p]) != len(ws):
+            assign(f, ws)
+    for f, w in single_roots:
+        assign(f, [w])
+    # <s>: its head is entered only at t = 0; the reference gives it a successor id too
+    assign(int(word_head[0]), [0])
+
+    startnode = np.array(roots + [f for f, _ in single_roots], np.int32)
+    s2i, niso = [], 0
+    for f in startnode:
+        if scid[f] >= 0:
+            s2i.append(niso); niso += 1
+        else:
+            s2i.append(-1)
+
+    # ---- context tables ---------------------------------------------------------------------
+    nset0 = len(set_list)
+    lc_tab = np.zeros((len(row_list), nlc + 1), np.int32)
+    for r, (kind, key) in enumerate(row_list):
+        for c in range(nlc + 1):
+            lctx = c if c < nphone else nphone - 1 - (c - nphone) % nphone   # silence / none: borrow a phone
+            if kind == "r":
+                ce, rc, loc = key
+                if c < nlc and rng.random() < defined_frac:
+                    lc_tab[r, c] = tri(lctx, ce, rc, loc)
+                else:
+                    lc_tab[r, c] = ~set_id(("rs", ce, rc, loc))
+            else:
+                ce, loc = key
+                lc_tab[r, c] = ~set_id(("lrs", ce, loc, c if c < nlc else -1))
+    set_off, set_states = [0], []
+    for key in set_list:
+        if key[0] == "rs":
+            _, ce, rc, loc = key
+            st = sorted({tri(l, ce, rc, loc) for l in range(nphone)})
+        elif key[0] == "lrs":
+            _, ce, loc, c = key
+            st = sorted({tri((c * 7 + r) % nphone, ce, r, loc) for r in range(nphone)})
+        else:
+            l, ce, loc = key
+            st = sorted({tri(l, ce, r, loc) for r in range(nphone)})
+        set_states += st
+        set_off.append(len(set_states))
+
+    # ---- words / LM -----------------------------------------------------------------------------
+    word_lc = np.zeros(W, np.int32)
+    word_lc[0], word_lc[1] = SILB, SILE
+    for wi, ph in enumerate(seqs):
+        word_lc[wi + nsil] = ph[-1]
+    n = len(self_a)
+    ac_off = np.zeros(n + 1, np.int32)
+    ac_to, ac_a = [], []
+    for i in range(n):
+        for to, a in ac.get(i, []):
+            ac_to.append(to); ac_a.append(a)
+        ac_off[i + 1] = len(ac_to)
+    wordend_a = np.full(W, A_EXIT, np.float32)
+    bgn = np.full(W, -1, np.int32); num = np.zeros(W, np.int32)
+    bw, bp = [], []
+    for w in range(W):
+        if w == 1:
+            continue
+        k = min(nbigram_per_word, W - 1)
+        js = np.unique(np.concatenate([[1], rng.choice(np.arange(2, W), size=k - 1, replace=False)]))
+        k = len(js)
+        ps = np.log10(rng.dirichlet(np.full(k, 1.0)) * 0.7 + 1e-9)
+        ps[0] = np.log10(0.1)                              # every word can end the sentence
+        bgn[w], num[w] = len(bw), k
+        bw += [int(j) for j in js]; bp += [float(p) for p in ps]
+    return dict(
+        nnode=n, nword=W, startnum=len(startnode), isolatenum=niso, nlc=nlc, nlcrow=len(row_list),
+        nset=len(set_list), cdset_method=2, cdmax_num=3, head_silwid=0, tail_silwid=1,
+        nfscore=len(fscore), nscword=len(scword), ng_mode=0, ng_nword=W, ng_nbigram=len(bw),
+        ng_unk_id=2147483647, ng_unk_num_log=0.0, lm_weight=float(lm_weight), lm_penalty=float(lm_penalty),
+        lm_penalty_trans=0.0,
+        self_a=np.array(self_a, np.float32), next_a=np.array(next_a, np.float32), ac_off=ac_off,
+        ac_to=np.array(ac_to, np.int32), ac_a=np.array(ac_a, np.float32), stend=np.array(stend, np.int32),
+        scid=np.array(scid, np.int32), out_kind=np.array(out_kind, np.uint8), out_id=np.array(out_id, np.int32),
+        lc_tab=lc_tab.reshape(-1), word_lc=word_lc, set_off=np.array(set_off, np.int32),
+        set_states=np.array(set_states, np.int32), startnode=startnode, start2isolate=np.array(s2i, np.int32),
+        wordend_a=wordend_a, wton=np.arange(W, dtype=np.int32), cprob=np.zeros(W, np.float32),
+        is_transparent=np.zeros(W, np.uint8), word_head=word_head, fscore=np.array(fscore, np.float32),
+        scword=np.array(scword, np.int32), ng_uni_prob=uni, ng_uni_bo=bo, ng_bi_bgn=bgn, ng_bi_num=num,
+        ng_bi_wid=np.array(bw, np.int32), ng_bi_prob=np.array(bp, np.float32))
+
+
+def make_lexicon_utterance(lex, model, nwords=8, seed=0, frames_per_state=3, noise=0.6):
+    """Frames that follow a random word sequence <s> w1 .. wn </s> through the
+    lexicon's own node chains (state centres + noise), so the first pass has a
+    real sentence to find.  Returns (frames [T][D], word ids)."""
+    rng = np.random.default_rng(seed)
+    W = lex["nword"]
+    ws = [0] + [int(x) for x in rng.integers(2, W, size=nwords)] + [1]
+    # predecessor map of the tree: walk back from each word's end node to its head
+    stend = lex["stend"]
+    end_of = np.full(W, -1, np.int64)
+    idx = np.nonzero(stend >= 0)[0]
+    end_of[stend[idx]] = idx
+    pred = {}
+    ac_off, ac_to = lex["ac_off"], lex["ac_to"]
+    src = np.repeat(np.arange(lex["nnode"]), np.diff(ac_off))
+    for s_, t_ in zip(src, ac_to):
+        pred[int(t_)] = int(s_)
+    set_off, set_states = lex["set_off"], lex["set_states"]
+    nlc = lex["nlc"]
+
+    def state_of(node, prev_word):
+        k, i = int(lex["out_kind"][node]), int(lex["out_id"][node])
+        if k == 0:
+            return i
+        col = nlc if prev_word < 0 else int(lex["word_lc"][prev_word])
+        ent = ~i if k == 1 else int(lex["lc_tab"][i * (nlc + 1) + col])
+        return ent if ent >= 0 else int(set_states[set_off[~ent]])
+
+    seq = []
+    for wi, w in enumerate(ws):
+        path, node = [], int(end_of[w])
+        while True:
+            path.append(node)
+            if node in pred:
+                node = pred[node]
+            elif node - 1 >= 0 and lex["next_a"][node - 1] > -1e5 and stend[node - 1] < 0 and node != int(lex["word_head"][w]):
+                node -= 1
+            else:
+                break
+        seq += [state_of(nd, ws[wi - 1] if wi > 0 else -1) for nd in reversed(path)]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
+    return fr.astype(np.float32), ws
