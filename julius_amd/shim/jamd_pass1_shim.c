@@ -1,0 +1,228 @@
+/*
+ * jamd_pass1_shim.c -- reference-side binding of the first-pass boundary (B).
+ *
+ * Compiled INSIDE the Julius tree against its own headers and linked IN PLACE OF
+ * libjulius/src/beam.c: it exports the complete symbol set of beam.o
+ *     get_back_trellis_init()     libjulius/src/beam.c:1825
+ *     get_back_trellis_proceed()  beam.c:2663
+ *     get_back_trellis_end()      beam.c:3052
+ *     finalize_1st_pass()         beam.c:3133
+ *     fsbeam_free()               beam.c:3179
+ * (prototypes: libjulius/include/julius/extern.h:57-61) so that libjulius' callers
+ * (pass1.c:234,242,503,567; instance.c:322) link unchanged.  Everything else of
+ * Julius -- loaders, front end, 2nd pass, output -- is untouched.
+ *
+ * How the frame-by-frame call pattern maps onto the batched engine: for buffered
+ * input (-input htkparam / rawfile, the benchmark path) the whole
+ * HTK_Param is already in memory when _init() is called, so _proceed() only
+ * acknowledges the frame and _end() runs acoustic scoring + the first pass on the
+ * device in one go, then rebuilds the BACKTRELLIS from the returned atoms with
+ * the reference's own allocator (bt_new / bt_store), and finalize_1st_pass()
+ * indexes it with bt_relocate_rw / bt_sort_rw exactly as the reference does.
+ *
+ * Supported configuration (anything else is refused loudly at _init()): N-gram
+ * LM, non-multipath GMM acoustic model with -gprune none|safe, no short-pause
+ * segmentation, buffered input.  The "no nodes left in beam" condition is
+ * reported by failing the utterance (J_RESULT_STATUS_FAIL) instead of segmenting.
+ */
+#include <stdlib.h>
+#include <string.h>
+#define JAMD_WITH_LIBJULIUS 1
+#include "jamd_flatten.h"
+
+typedef struct {
+  RecogProcess *r;             /* key */
+  WCHMM_INFO *wchmm;           /* lexicon the handles were built from */
+  HTK_HMM_INFO *hmminfo;
+  int beam_width; float bs_width;
+  jamd_gmm *gmm; jamd_lexicon *lex; jamd_beam *beam;
+  int nstate;
+} pass1_ctx;
+
+static jamd_engine *g_eng = NULL;
+static pass1_ctx g_ctx[16];
+static int g_nctx = 0;
+
+static void ctx_release(pass1_ctx *c)
+{
+  if (c->beam) jamd_beam_destroy(c->beam);
+  if (c->lex) jamd_lexicon_destroy(c->lex);
+  if (c->gmm) jamd_gmm_destroy(c->gmm);
+  c->beam = NULL; c->lex = NULL; c->gmm = NULL;
+}
+
+static pass1_ctx *ctx_get(RecogProcess *r)
+{
+  int i;
+  for (i = 0; i < g_nctx; i++) if (g_ctx[i].r == r) return &g_ctx[i];
+  if (g_nctx >= 16) return NULL;
+  memset(&g_ctx[g_nctx], 0, sizeof(pass1_ctx));
+  g_ctx[g_nctx].r = r;
+  return &g_ctx[g_nctx++];
+}
+
+static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
+{
+  int gprune, rc;
+  if (g_eng == NULL) {
+    const char *dev = getenv("JAMD_DEVICE");
+    if (jamd_engine_create(dev ? atoi(dev) : 0, &g_eng) != JAMD_OK) {
+      jlog("ERROR: jamd: %s\n", jamd_last_error());
+      return FALSE;
+    }
+  }
+  if (c->wchmm == r->wchmm && c->hmminfo == r->am->hmminfo && c->beam_width == r->trellis_beam_width &&
+      c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL) return TRUE;
+  ctx_release(c);
+  if (r->lmtype != LM_PROB || r->am->hmminfo->multipath || r->config->successive.enabled || r->am->dnn != NULL) {
+    jlog("ERROR: jamd: the device first pass covers N-gram LM, non-multipath GMM models, no -spsegment\n");
+    return FALSE;
+  }
+  switch (r->am->config->gprune_method) {      /* jconf.h:94, values hmm_calc.h:38-45 */
+  case GPRUNE_SEL_NONE: gprune = JAMD_GPRUNE_NONE; break;
+  case GPRUNE_SEL_SAFE: gprune = JAMD_GPRUNE_SAFE; break;
+  default:
+    jlog("ERROR: jamd: run with -gprune none or -gprune safe (heu/beam are frame-order dependent)\n");
+    return FALSE;
+  }
+  {
+    jamd_flat_gmm fg;
+    if (jamd_flatten_hmminfo(r->am->hmminfo, &fg) != 0) { jlog("ERROR: jamd: cannot flatten the acoustic model\n"); return FALSE; }
+    rc = jamd_gmm_create(g_eng, &fg.desc, gprune, r->am->hmmwrk.OP_gprune_num, &c->gmm);
+    c->nstate = fg.desc.nstate;
+    jamd_flat_gmm_free(&fg);
+    if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  }
+  {
+    jamd_flat_lexicon fl;
+    if (jamd_flatten_lexicon(r, &fl) != JAMD_OK) { jlog("ERROR: jamd: cannot flatten the tree lexicon\n"); return FALSE; }
+    rc = jamd_lexicon_create(g_eng, &fl.desc, &c->lex);
+    jamd_flat_lexicon_free(&fl);
+    if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  }
+  /* word trellis bound: a generous per-frame share of the beam, T <= 32767 */
+  rc = jamd_beam_create(g_eng, c->lex, r->trellis_beam_width, r->config->pass1.score_pruning_width, 1,
+                        1 << 20, &c->beam);
+  if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
+  c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
+  jlog("STAT: jamd: first pass on HIP device %d (beam %d, %d states, %d lexicon nodes)\n",
+       jamd_engine_device(g_eng), c->beam_width, c->nstate, r->wchmm->n);
+  return TRUE;
+}
+
+boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
+{
+  pass1_ctx *c = ctx_get(r);
+  FSBeam *d = &(r->pass1);
+  if (c == NULL || !ctx_prepare(c, r)) return FALSE;
+  bt_prepare(r->backtrellis);                         /* beam.c:1845 */
+  d->bos.wid = WORD_INVALID;                          /* init_nodescore(), beam.c:1581-1584 */
+  d->bos.begintime = d->bos.endtime = -1;
+  outprob_style_cache_init(r->wchmm);                 /* beam.c:1595: the 2nd pass reuses these caches */
+  r->have_interim = FALSE;
+  return TRUE;
+}
+
+boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boolean final_for_multipath)
+{
+  /* buffered input: the work is done in get_back_trellis_end() */
+  r->have_interim = FALSE;
+  return TRUE;
+}
+
+void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
+{
+  pass1_ctx *c = ctx_get(r);
+  FSBeam *d = &(r->pass1);
+  int T = param->samplenum, off[2], natom = 0, i;
+  float *frames, *d_frames = NULL, *d_scores = NULL;
+  jamd_pass1_result res;
+  jamd_trellis_atom *atoms = NULL;
+  TRELLIS_ATOM **made = NULL;
+
+  r->result.status = J_RESULT_STATUS_FAIL;            /* until proven otherwise */
+  d->wordend_best_score = LOG_ZERO;
+  if (c == NULL || c->beam == NULL || T <= 0) return;
+  frames = jamd_pack_param(param, 0, T);
+  off[0] = 0; off[1] = T;
+  if (frames == NULL ||
+      jamd_malloc(g_eng, sizeof(float) * (size_t)T * param->veclen, (void **)&d_frames) != JAMD_OK ||
+      jamd_malloc(g_eng, sizeof(float) * (size_t)T * c->nstate, (void **)&d_scores) != JAMD_OK ||
+      jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * (size_t)T * param->veclen) != JAMD_OK ||
+      jamd_gmm_outprob_dev(c->gmm, d_frames, T, d_scores, NULL) != JAMD_OK ||
+      jamd_beam_pass1_dev(c->beam, d_scores, c->nstate, off, 1, NULL) != JAMD_OK ||
+      jamd_beam_results(c->beam, &res, 1) != JAMD_OK) {
+    jlog("ERROR: jamd: first pass failed: %s\n", jamd_last_error());
+    goto done;
+  }
+  if (res.status == JAMD_PASS1_DIED)
+    jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
+  if (res.status == JAMD_PASS1_OVERFLOW) { jlog("ERROR: jamd: word trellis overflow\n"); goto done; }
+  natom = res.natom;
+  atoms = (jamd_trellis_atom *)malloc(sizeof(jamd_trellis_atom) * (natom > 0 ? natom : 1));
+  made = (TRELLIS_ATOM **)malloc(sizeof(TRELLIS_ATOM *) * (natom > 0 ? natom : 1));
+  if (jamd_beam_trellis(c->beam, 0, atoms, natom, &natom) != JAMD_OK) { natom = 0; goto done; }
+  /* save_trellis(), beam.c:2209-2247, for every atom the device emitted */
+  for (i = 0; i < natom; i++) {
+    TRELLIS_ATOM *tre = bt_new(r->backtrellis);
+    tre->wid = (WORD_ID)atoms[i].wid;
+    tre->backscore = atoms[i].backscore;
+    tre->begintime = atoms[i].begintime;
+    tre->endtime = atoms[i].endtime;
+    tre->last_tre = (atoms[i].last_tre < 0) ? &(d->bos) : made[atoms[i].last_tre];
+    tre->lscore = atoms[i].lscore;
+    tre->dfa_state = -1;
+    bt_store(r->backtrellis, tre);
+    made[i] = tre;
+  }
+  /* what find_1pass_result() (beam.c:372-510) leaves behind */
+  if (res.status == JAMD_PASS1_OK) {
+    r->result.status = J_RESULT_STATUS_SUCCESS;
+    r->result.num_frame = T;
+    for (i = 0; i < res.wnum; i++) r->pass1_wseq[i] = r->result.pass1.word[i] = (WORD_ID)res.wseq[i];
+    r->pass1_wnum = r->result.pass1.word_num = res.wnum;
+    r->pass1_score = r->result.pass1.score = res.score;
+    {                                                   /* trace_backptr(): total LM score */
+      LOGPROB lm = 0.0; int a;
+      for (a = natom - 1; a >= 0; a--)
+        if (atoms[a].wid == r->lm->winfo->tail_silwid && atoms[a].backscore == res.score) break;
+      for (; a >= 0; a = atoms[a].last_tre) { lm += atoms[a].lscore; if (atoms[a].begintime <= 0) break; }
+      r->result.pass1.score_lm = lm;
+      r->result.pass1.score_am = res.score - lm;
+    }
+  }
+done:
+  if (d_frames) jamd_free(g_eng, d_frames);
+  if (d_scores) jamd_free(g_eng, d_scores);
+  free(frames); free(atoms); free(made);
+}
+
+void finalize_1st_pass(RecogProcess *r, int len)
+{
+  BACKTRELLIS *backtrellis = r->backtrellis;
+  int status = r->result.status;
+  backtrellis->framelen = len;                        /* beam.c:3139-3145 */
+  bt_relocate_rw(backtrellis);
+  bt_sort_rw(backtrellis);
+  if (backtrellis->num == NULL) {
+    if (backtrellis->framelen > 0)
+      jlog("WARNING: %02d %s: input processed, but no survived word found\n", r->config->id, r->config->name);
+    r->result.status = J_RESULT_STATUS_FAIL;
+    return;
+  }
+  if (status != J_RESULT_STATUS_SUCCESS) {
+    jlog("WARNING: %02d %s: no tail silence word survived on the last frame, search failed\n",
+         r->config->id, r->config->name);
+    r->result.status = J_RESULT_STATUS_FAIL;
+  }
+}
+
+void fsbeam_free(FSBeam *d)
+{
+  int i;
+  for (i = 0; i < g_nctx; i++)
+    if (&(g_ctx[i].r->pass1) == d) { ctx_release(&g_ctx[i]); g_ctx[i] = g_ctx[--g_nctx]; break; }
+  if (d->pausemodelnames != NULL) { free(d->pausemodelnames); free(d->pausemodel); }
+  if (d->boslist != NULL) free(d->boslist);
+}

@@ -17,6 +17,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 ORACLE_SO = HERE / "liboracle.so"
 REF_SO = HERE / "_ref" / "libjref.so"
+REF_AMD_SO = HERE / "_ref" / "libjref_amd.so"   # same reference, first pass served by julius_amd/shim
 
 GPRUNE_NONE, GPRUNE_SAFE = 0, 1
 # reference enum (libsent/include/sent/hmm_calc.h:45)
@@ -167,11 +168,12 @@ class Oracle:
 class Ref:
     """The compiled reference (oracle/_ref/libjref.so)."""
 
-    def __init__(self, quiet=True):
-        if not REF_SO.exists():
+    def __init__(self, quiet=True, so=None):
+        so = so or REF_SO
+        if not so.exists():
             raise FileNotFoundError(
-                f"{REF_SO} missing: run `make -C oracle ref` where /root/reference is available")
-        self.lib = lib = C.CDLL(str(REF_SO))
+                f"{so} missing: run `make -C oracle ref` where /root/reference is available")
+        self.lib = lib = C.CDLL(str(so))
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double
         lib.jref_quiet.argtypes = [ci]
         lib.jref_am_load.restype = vp
@@ -377,3 +379,12 @@ class RefEngine:
         sc = C.c_float()
         k = lib.jref_engine_pass1(self.h, _p(wseq), C.byref(sc))
         return a, (wseq[:k].copy(), float(sc.value))
+
+    def final_result(self):
+        """(status, sentence-1 word ids, score) after the 2nd pass of the last recognize()."""
+        lib = self.ref.lib
+        lib.jref_engine_result.argtypes = [C.c_void_p] * 4
+        wseq = np.zeros(256, np.int32)
+        sc, st = C.c_float(), C.c_int()
+        k = lib.jref_engine_result(self.h, _p(wseq), C.byref(sc), C.byref(st))
+        return int(st.value), wseq[:k].copy(), float(sc.value)

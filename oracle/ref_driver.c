@@ -300,7 +300,24 @@ int jref_simd_avail(void) { return check_avail_simd(); }
 /* ------------------------------------------------- full-engine (pass 1) taps */
 #include <julius/juliuslib.h>
 
-typedef struct { Jconf *jconf; Recog *recog; } jref_eng;
+typedef struct {
+  Jconf *jconf; Recog *recog;
+  int res_status, res_wnum; float res_score; int res_wseq[MAXSEQNUM];   /* copied in CALLBACK_RESULT */
+} jref_eng;
+
+/* The result sentences are released right after CALLBACK_RESULT
+ * (libjulius/src/recogmain.c:1360-1367), so sentence 1 is copied here. */
+static void on_result(Recog *recog, void *data)
+{
+  jref_eng *e = (jref_eng *)data;
+  RecogProcess *r = recog->process_list;
+  int i;
+  e->res_status = r->result.status; e->res_wnum = 0; e->res_score = 0.0f;
+  if (r->result.status < 0 || r->result.sentnum <= 0 || r->result.sent == NULL) return;
+  e->res_wnum = r->result.sent[0].word_num;
+  for (i = 0; i < e->res_wnum; i++) e->res_wseq[i] = r->result.sent[0].word[i];
+  e->res_score = r->result.sent[0].score;
+}
 
 /* j_config_load_args_new() + j_create_instance_from_jconf() (the julius-simple
  * start-up sequence, julius-simple/julius-simple.c:250-270) */
@@ -312,6 +329,7 @@ void *jref_engine_create(int argc, char **argv)
   e->recog = j_create_instance_from_jconf(e->jconf);
   if (e->recog == NULL) { free(e); return NULL; }
   if (j_adin_init(e->recog) == FALSE) { free(e); return NULL; }
+  callback_add(e->recog, CALLBACK_RESULT, on_result, e);
   return e;
 }
 
@@ -389,3 +407,14 @@ int jref_engine_save_lexicon(void *h, const char *path)
   return rc;
 }
 
+
+/* Final result after the 2nd pass as captured by on_result(): sentence 1 and its
+ * score; *status gets r->result.status.  Returns the word count. */
+int jref_engine_result(void *h, int *wseq, float *score, int *status)
+{
+  jref_eng *e = (jref_eng *)h;
+  int i;
+  *status = e->res_status; *score = e->res_score;
+  for (i = 0; i < e->res_wnum; i++) wseq[i] = e->res_wseq[i];
+  return e->res_wnum;
+}

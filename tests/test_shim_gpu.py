@@ -1,0 +1,48 @@
+"""GPU: the reference's OWN recogniser running on top of the device first pass.
+
+oracle/_ref/libjref_amd.so is the unmodified reference with libjulius/src/beam.c
+left out and julius_amd/shim/jamd_pass1_shim.c (which exports beam.o's five
+symbols over the C ABI) linked in its place.  Front end, model loaders, 2nd pass
+(stack decoding over the word trellis) and result handling are the reference's.
+Checked against the plain reference (libjref.so) on the same inputs:
+  * the word trellis handed to the 2nd pass is identical (up to exact-tie cases),
+  * the pass-1 sentence and score are identical,
+  * the FINAL sentence (after the 2nd pass) and its score are identical."""
+import numpy as np
+import pytest
+
+from beamutil import assert_canonical_close
+from julius_amd import synth
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,beam,extra", [
+    (31, 200, ["-sepnum", "5"]),
+    (32, 100, ["-sepnum", "3", "-gprune", "safe", "-tmix", "3"]),
+    (33, 150, ["-sepnum", "8", "-bs", "70", "-lmp", "6.0", "-2.0"]),
+])
+def test_reference_two_pass_over_device_first_pass(ref, tmp_path, seed, beam, extra):
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    task = synth.make_triphone_task(tmp_path, seed=seed, nword=120, nphone=10, S=160)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-b", str(beam), "-b2", "30", "-n", "1", "-s", "500"]
+    if "-gprune" not in extra:
+        args += ["-gprune", "none"]
+    args += list(extra)
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = amd.final_result()
+        assert st1 == st0
+        assert np.array_equal(w1, w0) and s1 == s0                     # pass-1 best
+        assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
+        # the trellis the 2nd pass consumed: identical up to the rank-cut ties of DESIGN.md section 4
+        assert_canonical_close(tr1, tr0, max_diff=8)
