@@ -45,15 +45,21 @@ using namespace jamd;
 
 constexpr int NT = 512;                 // threads per utterance workgroup
 constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
+constexpr int kMaxDynLds = 96 * 1024;   // survivor state above this stays in global memory (160 KB LDS per CU)
 
 struct LexDev {
   int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
   int head_silwid, tail_silwid, ng_mode, ng_unk_id;
   float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
-  const float *self_a, *next_a; const int *ac_off, *ac_to; const float *ac_a;
-  const int *stend, *scid; const unsigned char *out_kind; const int *out_id;
-  const int *lc_tab, *word_lc, *set_off, *set_states, *startnode;
-  const int *iso_stid, *shared_stid;
+  // packed per-node records: one 16-byte load each
+  const int4 *node_a;         // [nnode] {self_a bits, next_a bits, ac_off, ac_end}   (wchmm->self_a/next_a/ac)
+  const int4 *node_b;         // [nnode] {stend, scid, out_id, out_kind}               (stend, state[].scid, outstyle)
+  const int *scid;            // [nnode] again, for the destination of a transition
+  const int *ac_to; const float *ac_a;
+  const int2 *iso_root;       // [isolatenum] {root node, successor word scword[scid[root]]}
+  const float2 *shared_root;  // [nshared]    {root node bits, fscore[-scid[root]]}
+  const int *word_end;        // [nword] node whose stend is the word
+  const int *lc_tab, *word_lc, *set_off, *set_states;
   const float *wordend_a; const int *wton; const float *cprob; const unsigned char *is_transparent;
   const int *word_head; const float *fscore; const int *scword;
   const float *ng_uni_prob, *ng_uni_bo; const int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; const float *ng_bi_prob;
@@ -65,15 +71,16 @@ struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/
 };
 
 struct Work {            // per-utterance slices are addressed with the strides below
-  unsigned long long *nodekey;   // [utt][nnode]
-  Tok *tok[2];                   // [utt][tok_cap]
-  int *surv;                     // [utt][tok_cap] indices into the previous token array
-  int *touched;                  // [utt][tok_cap] nodes touched this frame
-  int *welist;                   // [utt][beam]    words that ended this frame
-  int2 *we_of;                   // [utt][nword]   word -> (slot of its end token in prev, atom index)
-  int *slot_of[2];               // [utt][nnode]   node -> slot of its token in tok[i] (valid for live tokens only)
+  unsigned long long *nodekey;   // [utt][nnode]    Viterbi cells (0 = empty)
+  Tok *cur;                      // [utt][tok_cap]  tokens created this frame
+  unsigned *cur_key;             // [utt][tok_cap]  their order-preserving score bits (compact, for the rank select)
+  int *touched;                  // [utt][tok_cap]  nodes touched this frame
   jamd_trellis_atom *atoms;      // [utt][atom_cap]
   jamd_pass1_result *res;        // [utt]
+  // survivor state: lives in LDS when it fits (sv_bytes of dynamic shared memory),
+  // else in these per-utterance global arrays of the same layout
+  unsigned char *sv_global;      // [utt][sv_bytes]
+  int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
   int tok_cap, atom_cap, beam, nnode, nword;
   float width;
 };
@@ -117,10 +124,9 @@ __device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
   return prob - lx.ng_unk_num_log;
 }
 
-// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING)
-__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int node) {
+// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING), scid given
+__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int scid) {
   if (lastword < 0) return 0.0f;
-  const int scid = lx.scid[node];
   if (scid < 0) return lx.fscore[-scid];
   const int w = lx.scword[scid];
   return bigram_prob(lx, lx.wton[lastword], lx.wton[w]) + lx.cprob[w];
@@ -128,9 +134,7 @@ __device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastwo
 
 // outprob_style(), outprob_style.c:354-486, with the name lookups replaced by
 // the flattened left-context table
-__device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, int node, int last_wid) {
-  const int id = lx.out_id[node];
-  const int kind = lx.out_kind[node];
+__device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, int kind, int id, int last_wid) {
   int ent;
   if (kind == JAMD_AS_STATE) return row[id];
   if (kind == JAMD_AS_LSET) ent = ~id;
@@ -141,13 +145,32 @@ __device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, i
 }
 
 struct Shared {
-  unsigned long long we_best;       // (ord(score + wordend_a), welist index)
+  unsigned long long we_best;       // (ord(score + wordend_a), word that ended)
   unsigned hist[256];
-  int n_new, n_we, n_atom, n_surv, ties, ties_we, ties_cut;
+  int n_new, n_we, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
   unsigned maxbits;
   unsigned sel_digit, sel_need, sel_count;
-  int stop;
 };
+
+// node -> survivor index, open addressing (survivor nodes are distinct)
+__device__ __forceinline__ unsigned hslot(int node, int hmask) {
+  return ((unsigned)node * 2654435761u >> 7) & (unsigned)hmask;
+}
+__device__ __forceinline__ void hash_put(int *hkey, int *hval, int hmask, int node, int j) {
+  unsigned h = hslot(node, hmask);
+  while (atomicCAS(&hkey[h], -1, node) != -1) h = (h + 1) & (unsigned)hmask;
+  hval[h] = j;
+}
+__device__ __forceinline__ int hash_get(const int *hkey, const int *hval, int hmask, int node) {
+  unsigned h = hslot(node, hmask);
+  for (int guard = 0; guard <= hmask; guard++) {
+    const int k = hkey[h];
+    if (k == node) return hval[h];
+    if (k == -1) break;
+    h = (h + 1) & (unsigned)hmask;
+  }
+  return 0;   // unreachable for a live source
+}
 
 // candidate ids (low 32 bits of a node key) name the SOURCE of the transition, in
 // terms that do not depend on any scheduling order, so that (score, id) is a
@@ -175,41 +198,47 @@ __global__ void __launch_bounds__(NT)
 beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
                   const int *__restrict__ utt_off) {
   __shared__ Shared sh;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int t_begin = utt_off[u], T = utt_off[u + 1] - t_begin;
   unsigned long long *nodekey = wk.nodekey + (size_t)u * wk.nnode;
-  Tok *cur = wk.tok[0] + (size_t)u * wk.tok_cap;
-  Tok *prev = wk.tok[1] + (size_t)u * wk.tok_cap;
-  int *surv = wk.surv + (size_t)u * wk.tok_cap;
+  Tok *cur = wk.cur + (size_t)u * wk.tok_cap;
+  unsigned *cur_key = wk.cur_key + (size_t)u * wk.tok_cap;
   int *touched = wk.touched + (size_t)u * wk.tok_cap;
-  int *welist = wk.welist + (size_t)u * wk.beam;
-  int2 *we_of = wk.we_of + (size_t)u * wk.nword;
-  int *slot_cur = wk.slot_of[0] + (size_t)u * wk.nnode;    // written with `cur`, read as `slot_prev` next frame
-  int *slot_prev = wk.slot_of[1] + (size_t)u * wk.nnode;
   jamd_trellis_atom *atoms = wk.atoms + (size_t)u * wk.atom_cap;
   jamd_pass1_result *res = wk.res + u;
+  // survivor state of the previous frame (tokens, the atom each word end emitted, the
+  // frame's word-end list, node -> survivor hash)
+  unsigned char *svb = wk.use_lds ? dyn_lds : wk.sv_global + (size_t)u * wk.sv_bytes;
+  Tok *sv = (Tok *)svb;
+  int *sv_atom = (int *)(svb + (size_t)wk.beam * sizeof(Tok));
+  int *welist = sv_atom + wk.beam;
+  int *hkey = welist + wk.beam;
+  int *hval = hkey + wk.hsize;
+  const int hmask = wk.hsize - 1;
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
 
   if (tid == 0) {
-    sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.stop = 0; sh.n_surv = 0;
+    sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.n_surv = 0;
     res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO;
     res->died_at = -1; res->ties = 0; res->frames = T; res->max_tokens = 0;
   }
+  for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
   __syncthreads();
   if (T <= 0) { if (tid == 0) res->status = JAMD_PASS1_FAIL; return; }
 
   // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665)
   if (tid == 0) {
     const int node = lx.word_head[lx.head_silwid];
+    const int4 nr = lx.node_b[node];                 // {stend, scid, out_id, out_kind}
     Tok nw;
-    float ls = (lx.scid[node] != 0) ? max_successor_prob(lx, -1, node) : 0.0f;
+    float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
     ls = ls * lmw + pen;
     nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
-    nw.score = node_outprob(lx, scores + (size_t)t_begin * S, node, -1) + ls;
+    nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
     nw.pad0 = nw.pad1 = 0;
-    cur[0] = nw;
-    slot_cur[node] = 0;
-    surv[0] = 0;
+    sv[0] = nw;
+    hash_put(hkey, hval, hmask, node, 0);
     sh.n_surv = 1;
   }
   float thr = JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
@@ -219,9 +248,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   __syncthreads();
 
   for (int t = 1; t <= T; t++) {
-    // swap tl/tn (beam.c:2697-2698): `prev` now holds last frame's tokens, surv[] the kept ones
-    { Tok *x = cur; cur = prev; prev = x; }
-    { int *x = slot_cur; slot_cur = slot_prev; slot_prev = x; }
+    // tl/tn swap (beam.c:2697-2698): sv[] holds last frame's survivors
     const int n_surv = sh.n_surv;
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); }
@@ -230,23 +257,25 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 
     // ---- A: intra-word transitions + word-end atoms (main loop, beam.c:2838-2900)
     for (int j = tid; j < n_surv; j += NT) {
-      const int slot = surv[j];
-      const Tok tk = prev[slot];
+      const Tok tk = sv[j];
       const int node = tk.node;
+      const int4 na = lx.node_a[node];               // {self_a, next_a, ac_off, ac_end}
+      const int sword = lx.node_b[node].x;           // stend
       if (!last) {
         if (tk.score <= JAMD_LOG_ZERO) continue;
         if (tk.score < thr) continue;
         // beam_intra_word() :2154-2180 -> beam_intra_word_core() :2004-2135
-        const int e0 = lx.ac_off[node], e1 = lx.ac_off[node + 1];
+        const int e0 = na.z, e1 = na.w;
         for (int k = 0; k < 2 + (e1 - e0); k++) {
           int next_node; float a;
-          if (k == 0) { next_node = node; a = lx.self_a[node]; if (a == JAMD_LOG_ZERO) continue; }
-          else if (k == 1) { next_node = node + 1; a = lx.next_a[node]; if (a == JAMD_LOG_ZERO) continue; }
+          if (k == 0) { next_node = node; a = __int_as_float(na.x); if (a == JAMD_LOG_ZERO) continue; }
+          else if (k == 1) { next_node = node + 1; a = __int_as_float(na.y); if (a == JAMD_LOG_ZERO) continue; }
           else { next_node = lx.ac_to[e0 + k - 2]; a = lx.ac_a[e0 + k - 2]; }
           float tmpsum = tk.score + a;
-          const bool fac = next_node != node && lx.scid[next_node] != 0;
+          const int nscid = (next_node != node) ? lx.scid[next_node] : 0;
+          const bool fac = nscid != 0;
           if (fac) {
-            const float ng = max_successor_prob(lx, tk.last_cword, next_node) * lmw + pen;
+            const float ng = max_successor_prob(lx, tk.last_cword, nscid) * lmw + pen;
             tmpsum -= tk.last_lscore;
             tmpsum += ng;
           }
@@ -258,10 +287,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             // a genuine tie, resolved by the larger source id and counted.
             bool same = false;
             if (((unsigned)tie >> 31) == 0u) {
-              const Tok o = prev[slot_prev[(unsigned)tie]];
+              const Tok o = sv[hash_get(hkey, hval, hmask, (int)(unsigned)tie)];
               // the LM score is recomputed from last_cword on entering a factoring
               // node from another node (see step C); otherwise it is inherited
-              const bool re_o = lx.scid[next_node] != 0 && next_node != o.node;
+              const bool re_o = next_node != o.node && lx.scid[next_node] != 0;
               same = o.last_tre == tk.last_tre && o.last_cword == tk.last_cword &&
                      (fac == re_o) && (fac || o.last_lscore == tk.last_lscore);
             }
@@ -269,7 +298,6 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           }
         }
       }
-      const int sword = lx.stend[node];
       if (sword >= 0) {
         // save_trellis() :2209-2247
         const int ai = atomicAdd(&sh.n_atom, 1);
@@ -280,9 +308,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           a.endtime = (short)(t - 1);
           atoms[ai] = a;
         }
+        sv_atom[j] = ai;
         if (!last && sword != lx.tail_silwid) {            // beam_inter_word() :2296-2313
-          welist[atomicAdd(&sh.n_we, 1)] = sword;
-          we_of[sword] = make_int2(slot, ai);
+          welist[atomicAdd(&sh.n_we, 1)] = j;
           const float tmpprob = tk.score + lx.wordend_a[sword];
           if (tmpprob > JAMD_LOG_ZERO) {
             const unsigned long long key = ((unsigned long long)ord(tmpprob) << 32) | (unsigned)sword;
@@ -302,21 +330,20 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const int total = n_we * niso;
       for (int x = tid; x < total; x += NT) {
         const int w = x / niso, i = x - w * niso;
-        const int sword = welist[w];
-        const Tok tk = prev[we_of[sword].x];
+        const Tok tk = sv[welist[w]];
+        const int sword = lx.node_b[tk.node].x;
         const bool tr = lx.is_transparent[sword] != 0;
         const int last_word = tr ? tk.last_cword : sword;
-        const int next_node = lx.startnode[lx.iso_stid[i]];
-        const int wn = lx.scword[lx.scid[next_node]];
+        const int2 ir = lx.iso_root[i];                    // {root node, successor word}
         // one entry of max_successor_prob_iw()'s array (factoring_sub.c:1119-1143)
         const float p = (last_word < 0) ? 0.0f
-                        : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+                        : bigram_prob(lx, lx.wton[last_word], lx.wton[ir.y]) + lx.cprob[ir.y];
         float tmpsum = tk.score;
         tmpsum += lx.wordend_a[sword];
         const float ng = p * lmw + pen;
         tmpsum += ng;
         if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
-        if (push(sh, nodekey, touched, next_node, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+        if (push(sh, nodekey, touched, ir.x, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
           atomicAdd(&sh.ties, 1);
       }
     }
@@ -326,16 +353,16 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const unsigned long long kb = sh.we_best;
       const float best_score = unord((unsigned)(kb >> 32));
       const int sword = (int)(unsigned)kb;
-      const Tok tk = prev[we_of[sword].x];
+      const Tok tk = sv[hash_get(hkey, hval, hmask, lx.word_end[sword])];
       const bool trans2 = lx.is_transparent[sword] && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword];
       for (int r = tid; r < lx.nshared; r += NT) {
-        const int next_node = lx.startnode[lx.shared_stid[r]];
-        const float ng = lx.fscore[-lx.scid[next_node]] * lmw + pen;
+        const float2 sr = lx.shared_root[r];               // {root node (bits), fscore}
+        const float ng = sr.y * lmw + pen;
         float tmpsum = best_score;
         tmpsum += ng;
         if (trans2) tmpsum += lx.lm_penalty_trans;
         if (tmpsum < thr) continue;                               // :2580
-        if (push(sh, nodekey, touched, next_node, tmpsum, 0xC0000000u) != 0ull) atomicAdd(&sh.ties, 1);
+        if (push(sh, nodekey, touched, __float_as_int(sr.x), tmpsum, 0xC0000000u) != 0ull) atomicAdd(&sh.ties, 1);
       }
     }
     __syncthreads();
@@ -350,37 +377,38 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       for (int s = tid; s < n_new; s += NT) {
         const int node = touched[s];
         const unsigned long long key = atomicExch(&nodekey[node], 0ull);
+        const int4 nr = lx.node_b[node];             // {stend, scid, out_id, out_kind}
         const unsigned id = (unsigned)key;
         const float score = unord((unsigned)(key >> 32));
         Tok nw;
         nw.node = node; nw.pad0 = nw.pad1 = 0;
         if ((id >> 31) == 0u) {                      // intra-word, id = source node
-          const Tok tk = prev[slot_prev[id]];
+          const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
           nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
-          if (node != tk.node && lx.scid[node] != 0)      // beam_intra_word_core() :2069-2082
-            nw.last_lscore = max_successor_prob(lx, tk.last_cword, node) * lmw + pen;
+          if (node != tk.node && nr.y != 0)               // beam_intra_word_core() :2069-2082
+            nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y) * lmw + pen;
           else
             nw.last_lscore = tk.last_lscore;
         } else {
           const bool iso = (id >> 30) == 2u;
           const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
-          const int2 we = we_of[sword];
-          const Tok tk = prev[we.x];
+          const int j = hash_get(hkey, hval, hmask, lx.word_end[sword]);
+          const Tok tk = sv[j];
           const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
-          nw.last_tre = we.y; nw.last_cword = last_word; nw.last_wid = sword;
+          nw.last_tre = sv_atom[j]; nw.last_cword = last_word; nw.last_wid = sword;
           if (iso) {                                       // beam_inter_word() :2430-2438
-            const int wn = lx.scword[lx.scid[node]];
+            const int wn = lx.scword[nr.y];
             const float p = (last_word < 0) ? 0.0f
                             : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
             nw.last_lscore = p * lmw + pen;
           } else {                                         // beam_inter_word_factoring() :2572-2573
-            nw.last_lscore = lx.fscore[-lx.scid[node]] * lmw + pen;
+            nw.last_lscore = lx.fscore[-nr.y] * lmw + pen;
           }
         }
-        nw.score = score + node_outprob(lx, row, node, nw.last_wid);
+        nw.score = score + node_outprob(lx, row, nr.w, nr.z, nw.last_wid);
         cur[s] = nw;
-        slot_cur[node] = s;
         const unsigned b = ord(nw.score);
+        cur_key[s] = b;
         if (b > mymax) mymax = b;
       }
       atomicMax(&sh.maxbits, mymax);
@@ -392,29 +420,28 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;  // :2954-2960
     }
     if (n_new == 0) {                                              // :3012-3015
-      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; sh.stop = 1; }
+      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }
       __syncthreads();
       break;
     }
     if (sh.n_atom > wk.atom_cap) {
-      if (tid == 0) { res->status = JAMD_PASS1_OVERFLOW; sh.stop = 1; }
+      if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
       __syncthreads();
       break;
     }
 
-    // ---- D: rank pruning, sort_token_no_order() :1492 -> the top beam_width tokens
-    if (n_new <= wk.beam) {
-      for (int s = tid; s < n_new; s += NT) surv[s] = s;
-      if (tid == 0) sh.n_surv = n_new;
-      __syncthreads();
-    } else {
-      unsigned prefix = 0, need = (unsigned)wk.beam, count_eq = 0;
+    // ---- D: rank pruning, sort_token_no_order() :1492 -> the top beam_width tokens become
+    //         the next frame's survivors (copied into sv[], hashed by node)
+    unsigned prefix = 0, need = 0, count_eq = 0;
+    const bool prune = n_new > wk.beam;
+    if (prune) {
+      need = (unsigned)wk.beam;
       for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) sh.hist[tid] = 0;
         __syncthreads();
         for (int s = tid; s < n_new; s += NT) {
-          const unsigned b = ord(cur[s].score);
+          const unsigned b = cur_key[s];
           if (pass == 0 || (b >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(b >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -447,11 +474,15 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
       // prefix = score bits of the beam_width-th token; keep everything above it and
       // `need` of the count_eq tokens equal to it
-      if (tid == 0) { sh.n_surv = 0; if (count_eq > need) sh.ties_cut += 1; }
-      __syncthreads();
-      for (int s = tid; s < n_new; s += NT) {
-        const unsigned b = ord(cur[s].score);
-        bool keep = b > prefix;
+    }
+    for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
+    if (tid == 0) { sh.n_surv = 0; if (prune && count_eq > need) sh.ties_cut += 1; }
+    __syncthreads();
+    for (int s = tid; s < n_new; s += NT) {
+      bool keep = true;
+      if (prune) {
+        const unsigned b = cur_key[s];
+        keep = b > prefix;
         if (b == prefix) {
           if (count_eq <= need) keep = true;
           else {
@@ -459,30 +490,33 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             // (canonical; the reference keeps whichever its heap order left inside)
             const int mynode = cur[s].node;
             unsigned rank = 0;
-            for (int q = 0; q < n_new; q++) {
-              const Tok o = cur[q];
-              rank += (ord(o.score) == prefix && o.node < mynode) ? 1u : 0u;
-            }
+            for (int q = 0; q < n_new; q++)
+              rank += (cur_key[q] == prefix && cur[q].node < mynode) ? 1u : 0u;
             keep = rank < need;
           }
         }
-        if (keep) surv[atomicAdd(&sh.n_surv, 1)] = s;
       }
-      __syncthreads();
+      if (keep) {
+        const Tok me = cur[s];
+        const int j = atomicAdd(&sh.n_surv, 1);
+        sv[j] = me;
+        hash_put(hkey, hval, hmask, me.node, j);
+      }
     }
+    __syncthreads();
     PHASE(3);
   }
   __syncthreads();
 
   // ---- find_1pass_result() :399-431 + trace_backptr() :294-340
   const int natom = min(sh.n_atom, wk.atom_cap);
-  if (tid == 0) { sh.n_new = -1; }
+  if (tid == 0) sh.best_atom = -1;
   __syncthreads();
   if (res->status == JAMD_PASS1_OK) {
     int best = -1;
     for (int i = tid; i < natom; i += NT)
       if (atoms[i].wid == lx.tail_silwid && atoms[i].backscore > JAMD_LOG_ZERO) best = i;  // ascending i
-    if (best >= 0) atomicMax(&sh.n_new, best);
+    if (best >= 0) atomicMax(&sh.best_atom, best);
   }
   __syncthreads();
   if (tid == 0) {
@@ -491,7 +525,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     for (int i = 0; i < 4; i++) res->phase_us[i] = (int)(ph[i] / 100ull);
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
-      const int best = sh.n_new;
+      const int best = sh.best_atom;
       if (best < 0) res->status = JAMD_PASS1_FAIL;
       else {
         int n = 0, a = best;
@@ -581,13 +615,32 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     if (rc == JAMD_OK) rc = upload(&p_, src, (size_t)(n));                              \
     d.field = p_; if (p_) l->owned.push_back((void *)p_);                               \
   } while (0)
-  UP(self_a, h->self_a, h->nnode); UP(next_a, h->next_a, h->nnode); UP(ac_off, h->ac_off, h->nnode + 1);
-  UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac); UP(stend, h->stend, h->nnode); UP(scid, h->scid, h->nnode);
-  UP(out_kind, h->out_kind, h->nnode); UP(out_id, h->out_id, h->nnode);
+  std::vector<int4> na(h->nnode), nb(h->nnode);
+  std::vector<int> word_end(h->nword, -1);
+  for (int i = 0; i < h->nnode; i++) {
+    int sa, nx;
+    memcpy(&sa, &h->self_a[i], 4); memcpy(&nx, &h->next_a[i], 4);
+    na[i] = make_int4(sa, nx, h->ac_off[i], h->ac_off[i + 1]);
+    nb[i] = make_int4(h->stend[i], h->scid[i], h->out_id[i], (int)h->out_kind[i]);
+    if (h->stend[i] >= 0 && h->stend[i] < h->nword) word_end[h->stend[i]] = i;
+  }
+  std::vector<int2> iso_root(iso.size());
+  for (size_t i = 0; i < iso.size(); i++) {
+    const int node = h->startnode[iso[i]];
+    iso_root[i] = make_int2(node, h->scword[h->scid[node]]);
+  }
+  std::vector<float2> shared_root(shared.size());
+  for (size_t i = 0; i < shared.size(); i++) {
+    const int node = h->startnode[shared[i]];
+    float nf; memcpy(&nf, &node, 4);
+    shared_root[i] = make_float2(nf, h->fscore[-h->scid[node]]);
+  }
+  UP(node_a, na.data(), na.size()); UP(node_b, nb.data(), nb.size()); UP(scid, h->scid, h->nnode);
+  UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac);
+  UP(iso_root, iso_root.data(), iso_root.size()); UP(shared_root, shared_root.data(), shared_root.size());
+  UP(word_end, word_end.data(), word_end.size());
   UP(lc_tab, h->lc_tab, (size_t)h->nlcrow * (h->nlc + 1)); UP(word_lc, h->word_lc, h->nword);
   UP(set_off, h->set_off, h->nset + 1); UP(set_states, h->set_states, nset_states);
-  UP(startnode, h->startnode, h->startnum);
-  UP(iso_stid, iso.data(), iso.size()); UP(shared_stid, shared.data(), shared.size());
   UP(wordend_a, h->wordend_a, h->nword); UP(wton, h->wton, h->nword); UP(cprob, h->cprob, h->nword);
   UP(is_transparent, h->is_transparent, h->nword); UP(word_head, h->word_head, h->nword);
   UP(fscore, h->fscore, h->nfscore); UP(scword, h->scword, h->nscword);
@@ -632,17 +685,24 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     if (zero) JAMD_HIP(hipMemset(*p, 0, bytes));
     return JAMD_OK;
   };
+  // survivor state: Tok[beam] + atom[beam] + welist[beam] + hash keys/values[hsize]
+  w.hsize = 64; while (w.hsize < 2 * beam_width) w.hsize <<= 1;
+  w.sv_bytes = (int)(beam_width * (sizeof(Tok) + 2 * sizeof(int)) + (size_t)w.hsize * 2 * sizeof(int));
+  w.sv_bytes = (w.sv_bytes + 15) & ~15;
+  w.use_lds = w.sv_bytes <= kMaxDynLds ? 1 : 0;
   if (rc == JAMD_OK) rc = alloc((void **)&w.nodekey, U * w.nnode * sizeof(unsigned long long), true);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.tok[0], U * w.tok_cap * sizeof(Tok), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.tok[1], U * w.tok_cap * sizeof(Tok), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.surv, U * w.tok_cap * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.cur, U * w.tok_cap * sizeof(Tok), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.cur_key, U * w.tok_cap * sizeof(unsigned), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.welist, U * w.beam * sizeof(int), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.we_of, U * w.nword * sizeof(int2), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.slot_of[0], U * w.nnode * sizeof(int), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.slot_of[1], U * w.nnode * sizeof(int), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.atoms, U * w.atom_cap * sizeof(jamd_trellis_atom), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
+  if (rc == JAMD_OK && !w.use_lds) rc = alloc((void **)&w.sv_global, U * (size_t)w.sv_bytes, false);
+  if (rc == JAMD_OK && w.use_lds) {
+    hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        w.sv_bytes);
+    if (ae != hipSuccess) { jamd_set_error("jamd_beam_create: cannot reserve %d bytes of LDS: %s", w.sv_bytes,
+                                           hipGetErrorString(ae)); rc = JAMD_ENODEV; }
+  }
   if (rc == JAMD_OK) rc = alloc((void **)&b->d_utt_off, (U + 1) * sizeof(int), true);
   if (rc != JAMD_OK) { jamd_beam_destroy(b); return rc; }
   *out = b;
@@ -674,7 +734,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), 0, st, b->lex->d, b->w, dev_scores, nstate,
+  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w, dev_scores, nstate,
                      b->d_utt_off);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
