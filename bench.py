@@ -76,15 +76,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=16, help="utterances (x1000 frames) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn", "e2e"],
+    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn", "e2e", "e2e-dnn"],
                     help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half; "
-                         "e2e = configs[2]: GMM outprob + HIP first pass on a 20k-word lexicon")
+                         "e2e = configs[2]: GMM outprob + HIP first pass on a 20k-word lexicon; "
+                         "e2e-dnn = configs[3]: MFMA DNN outprob + HIP first pass")
     ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
     args = ap.parse_args()
     if args.workload == "dnn":
         return main_dnn(args)
-    if args.workload == "e2e":
+    if args.workload in ("e2e", "e2e-dnn"):
         return main_e2e(args)
 
     import torch
@@ -266,26 +267,41 @@ def main_e2e(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
-    model = synth.make_gmm(S=S, M=M, D=D, seed=0)
-    nuniq = min(args.utts, 16)
-    uniq = [synth.make_lexicon_utterance(lex, model, nwords=30, seed=1000 * rank + u) for u in range(nuniq)]
+    use_dnn = args.workload == "e2e-dnn"
+    eng = lib.Engine(local_rank)
+    if use_dnn:
+        # configs[3]: 528 -> 6 x 2048 -> 4000 senones; the lexicon's states index the DNN outputs.
+        # Random-init weights: the scores carry no sentence, the search runs with a saturated beam.
+        dnn = synth.make_dnn(seed=0)
+        NS = int(dnn["dims"][-1])
+        lex = synth.make_lexicon(nword=args.nword, nphone=40, S=NS, seed=0)
+        scorer = lib.Dnn(eng, dnn)
+        rng = np.random.default_rng(1000 + rank)
+        uniq = [(rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32), None)
+                for _ in range(min(args.utts, 16))]
+        what = f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob"
+    else:
+        NS = S
+        lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
+        model = synth.make_gmm(S=S, M=M, D=D, seed=0)
+        scorer = lib.Gmm(eng, model)
+        uniq = [synth.make_lexicon_utterance(lex, model, nwords=30, seed=1000 * rank + u) for u in range(min(args.utts, 16))]
+        what = f"GMM S={S} x M={M} x D={D} outprob"
+    nuniq = len(uniq)
     utts = [uniq[u % nuniq][0] for u in range(args.utts)]
     off = np.zeros(args.utts + 1, np.int32)
     off[1:] = np.cumsum([len(x) for x in utts])
     frames = np.concatenate(utts)
     T = len(frames)
-    eng = lib.Engine(local_rank)
-    gmm = lib.Gmm(eng, model)
     lx = lib.Lexicon(eng, lex)
     bm = lib.Beam(eng, lx, args.beam, -1.0, max_utts=args.utts, atoms_per_utt=1 << 17)
     d_fr = torch.from_numpy(frames).cuda()
-    d_sc = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
 
     def step():
-        gmm.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
-        bm.pass1_dev(d_sc.data_ptr(), S, off, stream.cuda_stream)
+        scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+        bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -297,9 +313,9 @@ def main_e2e(args):
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[3 * i].record(stream)
-        gmm.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+        scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
         ev[3 * i + 1].record(stream)
-        bm.pass1_dev(d_sc.data_ptr(), S, off, stream.cuda_stream)
+        bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
         ev[3 * i + 2].record(stream)
     torch.cuda.synchronize()
     if dist is not None:
@@ -315,21 +331,22 @@ def main_e2e(args):
     if rank == 0:
         res = bm.results()
         ok = sum(1 for r in res if r.status == 0)
-        correct = sum(1 for u, r in enumerate(res) if list(r.wseq[:r.wnum]) == uniq[u % nuniq][1])
+        correct = None if use_dnn else sum(1 for u, r in enumerate(res) if list(r.wseq[:r.wnum]) == uniq[u % nuniq][1])
         total_frames = T * world * args.steps
         tokens = float(np.mean([r.max_tokens for r in res]))
-        line = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * S / elapsed,
+        cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
+        line = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
                 "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": total_frames / 100.0 / elapsed,
-                "config": {"workload": f"C3 (BASELINE.json configs[2]): GMM S={S} x M={M} x D={D} outprob + HIP first pass, "
+                "config": {"workload": f"{cfg}: {what} + HIP first pass, "
                                        f"{args.nword}-word tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram, "
                                        f"beam {args.beam}, {args.utts} utterances ({T} frames) per GPU per step",
                            "parallelism": f"utterance-sharded x{world}"},
                 "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                              "traffic": None, "note": "irregular gather/scatter: no algorithmic-bytes roofline "
                              "(SURVEY.md 8d); figure of merit is end-to-end frames/s",
-                             "gmm_kernel_ms": gmm_ms, "beam_kernel_ms": beam_ms,
+                             "score_kernels_ms": gmm_ms, "beam_kernel_ms": beam_ms,
                              "beam_frames_per_s": T / (beam_ms * 1e-3),
                              "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
                 "pass1": {"ok": ok, "sentence_correct": correct, "utts": len(res), "mean_peak_tokens": tokens,
@@ -339,16 +356,20 @@ def main_e2e(args):
             orc = pyoracle.Oracle()
             fr0 = utts[0]
             tt0 = time.perf_counter()
-            sc0 = orc.gmm_outprob(model, fr0)
+            if use_dnn:
+                fr0 = fr0[:100]      # ~6 ms per frame on one core
+                sc0 = orc.dnn_outprob(dnn, fr0, pyoracle.DNN_FMA)
+            else:
+                sc0 = orc.gmm_outprob(model, fr0)
             tt1 = time.perf_counter()
             atoms, wseq, score, rc, died = orc.beam_pass1(lex, sc0, args.beam, -1.0)
             tt2 = time.perf_counter()
             got = d_sc[:len(fr0)].cpu().numpy()
-            line["parity_spot_check"] = bool(np.array_equal(got, sc0)) and list(wseq) == list(res[0].wseq[:res[0].wnum]) \
-                and float(score) == float(res[0].score)
-            line["cpu_baseline"] = {"value": len(fr0) * S / (tt2 - tt0), "unit": "frame*states/s", "cores": 1,
+            line["parity_spot_check"] = bool(np.array_equal(got, sc0)) and (use_dnn or (
+                list(wseq) == list(res[0].wseq[:res[0].wnum]) and float(score) == float(res[0].score)))
+            line["cpu_baseline"] = {"value": len(fr0) * NS / (tt2 - tt0), "unit": "frame*states/s", "cores": 1,
                                     "kind": "port", "rtf_inv": len(fr0) / 100.0 / (tt2 - tt0),
-                                    "sample": f"1 utterance of {len(fr0)} frames: oracle eager GMM scoring {tt1 - tt0:.2f} s + "
+                                    "sample": f"1 utterance of {len(fr0)} frames: oracle eager {'DNN' if use_dnn else 'GMM'} scoring {tt1 - tt0:.2f} s + "
                                               f"oracle first pass {tt2 - tt1:.2f} s on 1 of {os.cpu_count()} host cores"}
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -106,3 +106,49 @@ def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam,
         assert_trellis_equal_modulo_ties(atoms, rtr, r.ties)
         if rc == 0:
             assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+
+
+def test_dnn_scores_feed_the_beam(engine, oracle):
+    """configs[3] flow at a small size: MFMA DNN scores stay on the device and drive
+    the first pass; compared with the oracle DNN + oracle first pass (bit-exact scores,
+    identical trellis).  The lexicon is the synthetic one (julius_amd.synth.make_lexicon)."""
+    from julius_amd import lexblob
+    dnn = synth.make_dnn(dims=(48, 64, 64, 120), seed=5)
+    lex = synth.make_lexicon(nword=300, nphone=10, S=120, seed=5, sepnum=10)
+    rng = np.random.default_rng(5)
+    utts = [rng.normal(0, 1, (T, 48)).astype(np.float32) for T in (40, 75)]
+    net = lib.Dnn(engine, dnn)
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, 150, -1.0, max_utts=2)
+    frames = np.concatenate(utts)
+    off = np.array([0, 40, 115], np.int32)
+    d_fr = lib.DevBuf(engine, frames.nbytes).upload(frames)
+    d_sc = lib.DevBuf(engine, 4 * len(frames) * net.S)
+    net.outprob_dev(d_fr.ptr, len(frames), d_sc.ptr)
+    bm.pass1_dev(d_sc.ptr, net.S, off)
+    res = bm.results()
+    for u, fr in enumerate(utts):
+        sc = oracle.dnn_outprob(dnn, fr)
+        oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, 150, -1.0)
+        assert res[u].status == rc
+        assert_trellis_equal_modulo_ties(bm.trellis(u), lexblob.canonical_trellis(oatoms), res[u].ties)
+        if rc == 0:
+            assert list(res[u].wseq[:res[u].wnum]) == list(owseq) and res[u].score == oscore
+
+
+def test_full_size_lexicon_vs_oracle(engine, oracle):
+    """BASELINE-size lexicon (20 000 words, ~254k nodes, beam 800): the device first
+    pass against the CPU restatement on the same synthetic task."""
+    from julius_amd import lexblob
+    S = 3000
+    lex = synth.make_lexicon(nword=20000, nphone=40, S=S, seed=0)
+    model = synth.make_gmm(S=S, M=2, D=39, seed=0)
+    fr, ws = synth.make_lexicon_utterance(lex, model, nwords=6, seed=3)
+    sc = oracle.gmm_outprob(model, fr)
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, 800, -1.0, max_utts=1)
+    res, tre = bm.pass1_host([sc])
+    oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, 800, -1.0)
+    assert res[0].status == rc == 0
+    assert list(res[0].wseq[:res[0].wnum]) == list(owseq) == ws and res[0].score == oscore
+    assert_trellis_equal_modulo_ties(tre[0], lexblob.canonical_trellis(oatoms), res[0].ties_node + res[0].ties_cut + res[0].ties_wordend)
