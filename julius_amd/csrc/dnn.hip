@@ -20,10 +20,12 @@
 // accumulator; the price is 128 accumulator registers per wave tile.
 //
 // GEMM shape: C[t][o] = sum_k X[t][k] * W[o][k]  (both operands K-contiguous).
-// Block = 4 waves = 64 frames x 64 outputs, K slab 32 staged through LDS with
-// register prefetch of the next slab; LDS rows are pitched 36 floats so the
-// ds_read_b128 fragment reads (one 16-byte quad of k per lane) are conflict
-// free for the instruction's 16-lane groups (MI355X_MICROARCH.md, LDS).
+// Block = 4 waves = 64 frames x 64 outputs, K slab 64 staged through a DOUBLE-
+// BUFFERED LDS tile (one barrier per slab: the next slab is prefetched into
+// registers before the MFMAs of the current one and stored into the other
+// buffer after them); LDS rows are pitched 68 floats so the ds_read_b128
+// fragment reads (one 16-byte quad of k per lane) are conflict free for the
+// instruction's 16-lane groups (MI355X_MICROARCH.md, LDS).
 #include "jamd_device.h"
 
 struct jamd_dnn {
@@ -45,7 +47,7 @@ using namespace jamd;
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, KS = 32, PITCH = KS + 4;
+constexpr int BM = 64, BN = 64, KS = 64, PITCH = KS + 4;
 
 // ACT: 1 = table logistic (hidden layer), 0 = raw (output layer).
 template <int ACT>
@@ -53,8 +55,8 @@ __global__ void __launch_bounds__(256, 2)
 dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
                  const float *__restrict__ bias, const float *__restrict__ sig,
                  float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb) {
-  __shared__ __align__(16) float Xs[BM][PITCH];
-  __shared__ __align__(16) float Ws[BN][PITCH];
+  __shared__ __align__(16) float Xs[2][BM][PITCH];
+  __shared__ __align__(16) float Ws[2][BN][PITCH];
   // XCD-aware order: the dispatcher puts block b on XCD b % 8; consecutive
   // blocks of one XCD walk the N tiles of the same 64-frame strip so the strip
   // of X stays in that XCD's L2 while W streams.
@@ -67,31 +69,39 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
-  // staging: thread loads 2 float4 of X and 2 of W per slab: row = tid/8 (+32), quad = tid%8
-  const int lr = tid >> 3, lq = (tid & 7) * 4;
-  const float *xrow[2], *wrow[2];
-  bool wvalid[2];
+  // staging: per slab a thread loads 4 float4 of X and 4 of W: row = tid/16 (+16h), quad = tid%16
+  constexpr int NH = 4;
+  const int lr = tid >> 4, lq = (tid & 15) * 4;
+  const float *xrow[NH], *wrow[NH];
+  bool wvalid[NH];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    int tr = t0 + lr + 32 * h; if (tr > T - 1) tr = T - 1;
+  for (int h = 0; h < NH; h++) {
+    int tr = t0 + lr + 16 * h; if (tr > T - 1) tr = T - 1;
     xrow[h] = X + (size_t)tr * ldx;
-    int orow = o0 + lr + 32 * h; wvalid[h] = orow < N; if (orow > N - 1) orow = N - 1;
+    int orow = o0 + lr + 16 * h; wvalid[h] = orow < N; if (orow > N - 1) orow = N - 1;
     wrow[h] = W + (size_t)orow * K;
   }
-  auto gload = [&](int k0, f4v (&xa)[2], f4v (&wa)[2]) {
+  // K is a multiple of 8 (jamd_dnn_create), so a float4 is either fully inside a row or
+  // fully past its end; past-the-end quads are loaded from the last valid quad and zeroed
+  // with a select (zero padding keeps every chain exact: fma(0,0,acc) == acc) -- no
+  // branches, so the prefetch really overlaps the MFMAs.
+  auto gload = [&](int k0, f4v (&xa)[NH], f4v (&wa)[NH]) {
+    const int k = k0 + lq;
+    const int kk = (k < K) ? k : K - 4;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int k = k0 + lq;
-      if (k + 3 < K) {
-        xa[h] = *(const f4v *)(xrow[h] + k);
-        wa[h] = *(const f4v *)(wrow[h] + k);
-      } else {   // K tail: zero padding keeps every chain exact (fma(0,0,acc) == acc)
-        f4v xv = {0, 0, 0, 0}, wv = {0, 0, 0, 0};
+    for (int h = 0; h < NH; h++) {
+      xa[h] = *(const f4v *)(xrow[h] + kk);
+      wa[h] = *(const f4v *)(wrow[h] + kk);
+    }
+  };
+  // the zeroing select is applied here, AFTER the MFMAs of the current slab, so that the
+  // loads stay in flight behind them
+  auto lstore = [&](int buf, int k0, const f4v (&xa)[NH], const f4v (&wa)[NH]) {
+    const bool inside = k0 + lq < K;
 #pragma unroll
-        for (int c = 0; c < 4; c++) if (k + c < K) { xv[c] = xrow[h][k + c]; wv[c] = wrow[h][k + c]; }
-        xa[h] = xv; wa[h] = wv;
-      }
-      if (!wvalid[h]) wa[h] = f4v{0, 0, 0, 0};
+    for (int h = 0; h < NH; h++) {
+      *(f4v *)&Xs[buf][lr + 16 * h][lq] = inside ? xa[h] : f4v{0, 0, 0, 0};
+      *(f4v *)&Ws[buf][lr + 16 * h][lq] = (inside && wvalid[h]) ? wa[h] : f4v{0, 0, 0, 0};
     }
   };
 
@@ -101,32 +111,32 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[l][r] = 0.0f;
 
-  f4v xa[2], wa[2];
+  f4v xa[NH], wa[NH];
   gload(0, xa, wa);
+  lstore(0, 0, xa, wa);
+  __syncthreads();
   const int arow = wm + (lane & 31), brow = wn + (lane & 31), half = lane >> 5;
+  int cur = 0;
   for (int k0 = 0; k0 < K; k0 += KS) {
-    __syncthreads();   // previous slab fully consumed
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      *(f4v *)&Xs[lr + 32 * h][lq] = xa[h];
-      *(f4v *)&Ws[lr + 32 * h][lq] = wa[h];
-    }
-    __syncthreads();
-    if (k0 + KS < K) gload(k0 + KS, xa, wa);   // prefetch next slab into registers
+    const bool more = k0 + KS < K;
+    if (more) gload(k0 + KS, xa, wa);   // prefetch next slab into registers
 #pragma unroll
     for (int g = 0; g < KS; g += 16) {
       // lanes 0-31 take k = g+0..7, lanes 32-63 k = g+8..15: accumulator l sees
       // k = g+l then g+8+l -- ascending within its residue class mod 8
-      const f4v a0 = *(const f4v *)&Xs[arow][g + 8 * half];
-      const f4v a1 = *(const f4v *)&Xs[arow][g + 8 * half + 4];
-      const f4v b0 = *(const f4v *)&Ws[brow][g + 8 * half];
-      const f4v b1 = *(const f4v *)&Ws[brow][g + 8 * half + 4];
+      const f4v a0 = *(const f4v *)&Xs[cur][arow][g + 8 * half];
+      const f4v a1 = *(const f4v *)&Xs[cur][arow][g + 8 * half + 4];
+      const f4v b0 = *(const f4v *)&Ws[cur][brow][g + 8 * half];
+      const f4v b1 = *(const f4v *)&Ws[cur][brow][g + 8 * half + 4];
 #pragma unroll
       for (int l = 0; l < 4; l++) {
         acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[l], b0[l], acc[l], 0, 0, 0);
         acc[l + 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[l], b1[l], acc[l + 4], 0, 0, 0);
       }
     }
+    if (more) lstore(cur ^ 1, k0 + KS, xa, wa);  // the other buffer was last read one iteration ago
+    __syncthreads();
+    cur ^= 1;
   }
 
   // epilogue: lanes add 0..7 left to right, then the bias (calc_dnn_fma.c:53-60)
