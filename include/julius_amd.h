@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JAMD_ABI_VERSION 1
+#define JAMD_ABI_VERSION 2
 
 #define JAMD_OK        0
 #define JAMD_EINVAL   -1   /* bad argument / unsupported model feature        */
@@ -283,8 +283,9 @@ typedef struct {
   int   max_tokens;      /* high-water mark of tokens alive in one frame              */
   int   ties_node, ties_wordend, ties_cut;   /* ties by kind: Viterbi max at a node, best    */
                          /* word end, rank cut                                        */
-  int   phase_us[4];     /* device time spent in: A intra-word+atoms, B cross-word,   */
-                         /* C finalize+outprob, D rank pruning (microseconds)         */
+  int   phase_us[8];     /* device time spent in: A intra-word+atoms, B cross-word,   */
+                         /* C finalize+outprob, D rank pruning (microseconds); [4..6] */
+                         /* thread 0's share of C: key fetch, payload, outprob        */
   int   wseq[150];       /* r->pass1_wseq, MAXSEQNUM = 150 (libsent speech.h:50)      */
 } jamd_pass1_result;
 

@@ -43,7 +43,7 @@
 namespace {
 using namespace jamd;
 
-constexpr int NT = 512;                 // threads per utterance workgroup
+constexpr int NT = 1024;                // threads per utterance workgroup
 constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
 constexpr int kMaxDynLds = 96 * 1024;   // survivor state above this stays in global memory (160 KB LDS per CU)
 
@@ -146,10 +146,11 @@ __device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, i
 
 struct Shared {
   unsigned long long we_best;       // (ord(score + wordend_a), word that ended)
-  unsigned hist[256];
+  unsigned hist[2048];
   int n_new, n_we, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
-  unsigned maxbits;
+  unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
+  int eq_n, eq_node[128];           // tokens exactly on the rank cut (tie handling)
 };
 
 // node -> survivor index, open addressing (survivor nodes are distinct)
@@ -242,7 +243,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     sh.n_surv = 1;
   }
   float thr = JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
-  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tc = wall_clock64();   // phase clocks (100 MHz), thread 0 only
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tq = 0;   // phase clocks (100 MHz), thread 0 only
 #define PHASE(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
   int max_tokens = 1;
   __syncthreads();
@@ -251,7 +252,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     // tl/tn swap (beam.c:2697-2698): sv[] holds last frame's survivors
     const int n_surv = sh.n_surv;
     __syncthreads();
-    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); }
+    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
     __syncthreads();
     const bool last = (t == T);     // get_back_trellis_end(): word ends only, no pruning test
 
@@ -373,8 +374,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     if (n_new > max_tokens) max_tokens = n_new;
     {
       const float *__restrict__ row = scores + (size_t)(t_begin + t) * S;
-      unsigned mymax = ord(JAMD_LOG_ZERO);
+      unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
       for (int s = tid; s < n_new; s += NT) {
+        if (tid == 0) tq = wall_clock64();
         const int node = touched[s];
         const unsigned long long key = atomicExch(&nodekey[node], 0ull);
         const int4 nr = lx.node_b[node];             // {stend, scid, out_id, out_kind}
@@ -382,6 +384,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const float score = unord((unsigned)(key >> 32));
         Tok nw;
         nw.node = node; nw.pad0 = nw.pad1 = 0;
+        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[4] += n_ - tq + (nr.x & 0); tq = n_; }
         if ((id >> 31) == 0u) {                      // intra-word, id = source node
           const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
           nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
@@ -405,13 +408,17 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             nw.last_lscore = lx.fscore[-nr.y] * lmw + pen;
           }
         }
+        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[5] += n_ - tq + (__float_as_int(nw.last_lscore) & 0); tq = n_; }
         nw.score = score + node_outprob(lx, row, nr.w, nr.z, nw.last_wid);
+        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (__float_as_int(nw.score) & 0); tq = n_; }
         cur[s] = nw;
         const unsigned b = ord(nw.score);
         cur_key[s] = b;
         if (b > mymax) mymax = b;
+        if (b < mymin) mymin = b;
       }
       atomicMax(&sh.maxbits, mymax);
+      atomicMin(&sh.minbits, mymin);
     }
     __syncthreads();
     PHASE(2);
@@ -435,22 +442,31 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     unsigned prefix = 0, need = 0, count_eq = 0;
     const bool prune = n_new > wk.beam;
     if (prune) {
+      // radix select of the beam_width-th largest key.  All keys of a frame share their
+      // high bits (scores lie within a few hundred log units), so only the bits below the
+      // highest bit in which the frame's max and min differ are selected on, 11 at a time
+      // (typically 2-3 passes).
       need = (unsigned)wk.beam;
-      for (int pass = 0; pass < 4; pass++) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) sh.hist[tid] = 0;
+      const unsigned diff = sh.maxbits ^ sh.minbits;
+      int remaining = diff ? 32 - __clz(diff) : 0;       // number of varying low bits
+      prefix = remaining < 32 ? (sh.maxbits >> remaining) : 0u;
+      count_eq = (unsigned)n_new;
+      while (remaining > 0) {
+        const int w = remaining < 11 ? remaining : 11;
+        const int shift = remaining - w;
+        const unsigned dmask = (1u << w) - 1u;
+        for (int i = tid; i < 2048; i += NT) sh.hist[i] = 0;
         __syncthreads();
         for (int s = tid; s < n_new; s += NT) {
           const unsigned b = cur_key[s];
-          if (pass == 0 || (b >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(b >> shift) & 255u], 1u);
+          const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
+          if (hi == prefix) atomicAdd(&sh.hist[(b >> shift) & dmask], 1u);
         }
         __syncthreads();
         if (tid < 64) {
-          // lane l owns digits 4l..4l+3; `above` = tokens with a larger digit
-          unsigned c[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) c[q] = sh.hist[4 * tid + q];
-          const unsigned mine = c[0] + c[1] + c[2] + c[3];
+          // lane l owns digits 32l..32l+31; `above` = tokens with a larger digit
+          unsigned mine = 0;
+          for (int q = 0; q < 32; q++) mine += sh.hist[32 * tid + q];
           unsigned incl = mine;                         // inclusive suffix sum over lanes >= tid
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) {
@@ -458,40 +474,55 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             if (tid + off < 64) incl += o;
           }
           unsigned above = incl - mine;
-#pragma unroll
-          for (int q = 3; q >= 0; q--) {
-            if (above < need && need <= above + c[q]) {
-              sh.sel_digit = 4u * tid + q; sh.sel_need = need - above; sh.sel_count = c[q];
+          if (above < need && need <= above + mine) {   // the digit is in this lane's range
+            for (int q = 31; q >= 0; q--) {
+              const unsigned c = sh.hist[32 * tid + q];
+              if (above < need && need <= above + c) {
+                sh.sel_digit = 32u * tid + q; sh.sel_need = need - above; sh.sel_count = c;
+              }
+              above += c;
             }
-            above += c[q];
           }
         }
         __syncthreads();
-        prefix = (prefix << 8) | sh.sel_digit;
+        prefix = (prefix << w) | sh.sel_digit;
         need = sh.sel_need;
         count_eq = sh.sel_count;
-        __syncthreads();
+        remaining -= w;
       }
       // prefix = score bits of the beam_width-th token; keep everything above it and
       // `need` of the count_eq tokens equal to it
     }
     for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
-    if (tid == 0) { sh.n_surv = 0; if (prune && count_eq > need) sh.ties_cut += 1; }
+    const bool cut_tie = prune && count_eq > need;
+    if (tid == 0) { sh.n_surv = 0; sh.eq_n = 0; if (cut_tie) sh.ties_cut += 1; }
     __syncthreads();
+    if (cut_tie) {
+      // several tokens share the cut score: collect their nodes (a handful), then keep
+      // those on the smallest nodes (canonical; the reference keeps whichever its heap
+      // order left inside)
+      for (int s = tid; s < n_new; s += NT)
+        if (cur_key[s] == prefix) {
+          const int q = atomicAdd(&sh.eq_n, 1);
+          if (q < 128) sh.eq_node[q] = cur[s].node;
+        }
+      __syncthreads();
+    }
     for (int s = tid; s < n_new; s += NT) {
       bool keep = true;
       if (prune) {
         const unsigned b = cur_key[s];
         keep = b > prefix;
         if (b == prefix) {
-          if (count_eq <= need) keep = true;
+          if (!cut_tie) keep = true;
           else {
-            // several tokens share the cut score: keep those on the smallest nodes
-            // (canonical; the reference keeps whichever its heap order left inside)
             const int mynode = cur[s].node;
             unsigned rank = 0;
-            for (int q = 0; q < n_new; q++)
-              rank += (cur_key[q] == prefix && cur[q].node < mynode) ? 1u : 0u;
+            if (sh.eq_n <= 128) {
+              for (int q = 0; q < sh.eq_n; q++) rank += (sh.eq_node[q] < mynode) ? 1u : 0u;
+            } else {
+              for (int q = 0; q < n_new; q++) rank += (cur_key[q] == prefix && cur[q].node < mynode) ? 1u : 0u;
+            }
             keep = rank < need;
           }
         }
@@ -522,7 +553,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   if (tid == 0) {
     res->natom = natom; res->ties = sh.ties + sh.ties_we + sh.ties_cut; res->max_tokens = max_tokens;
     res->ties_node = sh.ties; res->ties_wordend = sh.ties_we; res->ties_cut = sh.ties_cut;
-    for (int i = 0; i < 4; i++) res->phase_us[i] = (int)(ph[i] / 100ull);
+    for (int i = 0; i < 8; i++) res->phase_us[i] = (int)(ph[i] / 100ull);
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
       const int best = sh.best_atom;

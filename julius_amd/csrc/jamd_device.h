@@ -115,16 +115,24 @@ __device__ __forceinline__ float cd_reduce(const float *__restrict__ row, const 
   if (nbest <= 4) {
     float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
     int n = 0;
-    for (int k = a; k < b; k++) {
-      float p = row[states[k]];
-      if (p <= JAMD_LOG_ZERO) continue;
+    auto ins = [&](float p) {
+      if (p <= JAMD_LOG_ZERO) return;
       n++;
       float t;
       if (p > b0) { t = b0; b0 = p; p = t; }
       if (p > b1) { t = b1; b1 = p; p = t; }
       if (p > b2) { t = b2; b2 = p; p = t; }
       if (p > b3) { b3 = p; }
+    };
+    int k = a;
+    // four members at a time: the id loads, then the score gathers, are independent, so
+    // their latencies overlap (the gathers are what this loop waits for)
+    for (; k + 4 <= b; k += 4) {
+      const int s0 = states[k], s1 = states[k + 1], s2 = states[k + 2], s3 = states[k + 3];
+      const float p0 = row[s0], p1 = row[s1], p2 = row[s2], p3 = row[s3];
+      ins(p0); ins(p1); ins(p2); ins(p3);
     }
+    for (; k < b; k++) ins(row[states[k]]);
     if (n > nbest) n = nbest;
     float sum = 0.0f;
     if (n > 0) sum += b0;

@@ -347,7 +347,7 @@ class Pass1Result(C.Structure):
     _fields_ = [("status", C.c_int), ("natom", C.c_int), ("wnum", C.c_int), ("score", C.c_float),
                 ("died_at", C.c_int), ("ties", C.c_int), ("frames", C.c_int), ("max_tokens", C.c_int),
                 ("ties_node", C.c_int), ("ties_wordend", C.c_int), ("ties_cut", C.c_int),
-                ("phase_us", C.c_int * 4),
+                ("phase_us", C.c_int * 8),
                 ("wseq", C.c_int * 150)]
 
 

@@ -64,6 +64,10 @@ static pass1_ctx *ctx_get(RecogProcess *r)
 static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
 {
   int gprune, rc;
+  if (jamd_abi_version() != JAMD_ABI_VERSION) {   /* header this shim was compiled with vs the loaded library */
+    jlog("ERROR: jamd: libjulius_amd.so has ABI %d, this shim was built for %d\n", jamd_abi_version(), JAMD_ABI_VERSION);
+    return FALSE;
+  }
   if (g_eng == NULL) {
     const char *dev = getenv("JAMD_DEVICE");
     if (jamd_engine_create(dev ? atoi(dev) : 0, &g_eng) != JAMD_OK) {

@@ -33,4 +33,4 @@ for it in range(3):
     res = bm.results()
     print(f"utts {nutt} frames {len(frames)} beam {beam}: gmm {1e3*(t1-t0):.2f} ms, beam {1e3*(t2-t1):.2f} ms "
           f"-> {len(frames)/(t2-t1):.3e} frames/s beam, {1e6*(t2-t1)/max(len(x) for x in utts):.1f} us/frame/utt; "
-          f"phases us {list(res[0].phase_us)} status {[r.status for r in res[:4]]} ties {[r.ties for r in res[:4]]} maxtok {res[0].max_tokens} natom {res[0].natom}")
+          f"phases us {list(res[0].phase_us)} status {[r.status for r in res[:4]]} ties(node,we,cut) {[(r.ties_node, r.ties_wordend, r.ties_cut) for r in res[:2]]} maxtok {res[0].max_tokens} natom {res[0].natom}")
