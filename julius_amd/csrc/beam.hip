@@ -173,6 +173,20 @@ __device__ __forceinline__ int hash_get(const int *hkey, const int *hval, int hm
   return 0;   // unreachable for a live source
 }
 
+// Wave-aggregated slot allocation: the active lanes that want a slot are counted with a
+// ballot, ONE lane bumps the shared counter, every lane takes base + its rank.  Cuts the
+// same-address LDS atomics (thousands per frame on n_new / n_atom / n_surv) by up to 64x.
+__device__ __forceinline__ int wave_alloc(int *counter, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (!want) return -1;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 // candidate ids (low 32 bits of a node key) name the SOURCE of the transition, in
 // terms that do not depend on any scheduling order, so that (score, id) is a
 // canonical total order and the result is deterministic:
@@ -187,8 +201,8 @@ __device__ __forceinline__ unsigned long long push(Shared &sh, unsigned long lon
   if (score <= JAMD_LOG_ZERO) return 0ull;                    // propagate_token() :1951
   const unsigned long long key = ((unsigned long long)ord(score) << 32) | id;
   const unsigned long long old = atomicMax(&nodekey[node], key);
+  const int s = wave_alloc(&sh.n_new, old == 0ull);
   if (old == 0ull) {
-    const int s = atomicAdd(&sh.n_new, 1);
     touched[s] = node;
     return 0ull;
   }
@@ -301,7 +315,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
       if (sword >= 0) {
         // save_trellis() :2209-2247
-        const int ai = atomicAdd(&sh.n_atom, 1);
+        const int ai = wave_alloc(&sh.n_atom, true);
         if (ai < wk.atom_cap) {
           jamd_trellis_atom a;
           a.wid = sword; a.last_tre = tk.last_tre; a.backscore = tk.score; a.lscore = tk.last_lscore;
@@ -529,7 +543,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
       if (keep) {
         const Tok me = cur[s];
-        const int j = atomicAdd(&sh.n_surv, 1);
+        const int j = wave_alloc(&sh.n_surv, true);
         sv[j] = me;
         hash_put(hkey, hval, hmask, me.node, j);
       }
