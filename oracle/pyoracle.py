@@ -380,6 +380,14 @@ class RefEngine:
         k = lib.jref_engine_pass1(self.h, _p(wseq), C.byref(sc))
         return a, (wseq[:k].copy(), float(sc.value))
 
+    def cache_fill(self):
+        """(defined, total) entries of the outprob cache after the last recognize()."""
+        lib = self.ref.lib
+        lib.jref_engine_cache_fill.argtypes = [C.c_void_p] * 3
+        a, b = C.c_int(), C.c_int()
+        lib.jref_engine_cache_fill(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def final_result(self):
         """(status, sentence-1 word ids, score) after the 2nd pass of the last recognize()."""
         lib = self.ref.lib

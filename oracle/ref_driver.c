@@ -418,3 +418,19 @@ int jref_engine_result(void *h, int *wseq, float *score, int *status)
   for (i = 0; i < e->res_wnum; i++) wseq[i] = e->res_wseq[i];
   return e->res_wnum;
 }
+
+/* How much of the [T][S] outprob cache holds a computed score after the last
+ * recognition (entries != LOG_UNDEF, libsent/src/phmm/outprob.c:68): the plain
+ * reference fills only what the search touched, the device shim fills all of it. */
+int jref_engine_cache_fill(void *h, int *defined, int *total)
+{
+  jref_eng *e = (jref_eng *)h;
+  HMMWork *wrk = &(e->recog->amlist->hmmwrk);
+  int T = e->recog->process_list->backtrellis->framelen, t, s, n = 0;
+  if (T > wrk->outprob_allocframenum) T = wrk->outprob_allocframenum;
+  for (t = 0; t < T; t++)
+    for (s = 0; s < wrk->statenum; s++)
+      if (wrk->outprob_cache[t][s] != (LOG_ZERO - 1)) n++;
+  *defined = n; *total = T * wrk->statenum;
+  return 0;
+}

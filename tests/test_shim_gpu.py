@@ -41,6 +41,11 @@ def test_reference_two_pass_over_device_first_pass(ref, tmp_path, seed, beam, ex
         st0, f0, fs0 = plain.final_result()
         tr1, (w1, s1) = amd.recognize(tmp_path / "u.mfc")
         st1, f1, fs1 = amd.final_result()
+        # the 2nd pass of the shimmed recogniser read device scores: its cache is completely filled,
+        # the plain reference's only where the search went
+        d1, n1 = amd.cache_fill()
+        d0, n0 = plain.cache_fill()
+        assert d1 == n1 == n0 and d0 < n0
         assert st1 == st0
         assert np.array_equal(w1, w0) and s1 == s0                     # pass-1 best
         assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
