@@ -309,6 +309,14 @@ void jamd_beam_destroy(jamd_beam *b);
  * jamd_beam_results() / jamd_beam_trellis(), which synchronise. */
 int  jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *utt_off,
                          int nutt, void *stream);
+/* Verification mode.  on != 0: later jamd_beam_pass1_dev() calls run the reference's
+ * SEQUENTIAL algorithm (same token creation order, same partial heap sort
+ * beam.c:1342-1516, first-writer-wins propagation) with one lane per utterance, so that
+ * the word trellis equals the reference's bit for bit even where exact score ties are
+ * broken by visiting order.  Two to three orders of magnitude slower per utterance;
+ * parallel only across the utterances of a batch.  Default is off (the frame-parallel
+ * kernel, identical whenever jamd_pass1_result.ties == 0). */
+int  jamd_beam_set_strict_order(jamd_beam *b, int on);
 int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
 /* Word trellis of utterance u in emission order (last_tre indexes the same
  * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:

@@ -59,6 +59,7 @@ struct LexDev {
   const int2 *iso_root;       // [isolatenum] {root node, successor word scword[scid[root]]}
   const float2 *shared_root;  // [nshared]    {root node bits, fscore[-scid[root]]}
   const int *word_end;        // [nword] node whose stend is the word
+  const int *startnode, *start2isolate;   // [startnum] as in wchmm (strict-order kernel walks them like beam.c)
   const int *lc_tab, *word_lc, *set_off, *set_states;
   const float *wordend_a; const int *wton; const float *cprob; const unsigned char *is_transparent;
   const int *word_head; const float *fscore; const int *scword;
@@ -584,6 +585,253 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// STRICT-ORDER first pass (verification mode, jamd_beam_set_strict_order()).
+//
+// The reference resolves exact score ties by its visiting order, which is the output of
+// a partial heap sort over token indices (beam.c:1342-1516) applied frame after frame; no
+// parallel schedule can reproduce that.  This kernel therefore runs the reference's
+// SEQUENTIAL algorithm -- same token creation order, same heap permutation, same
+// first-writer-wins propagation -- with ONE LANE PER UTTERANCE (parallel only across the
+// utterances of a batch).  It is two to three orders of magnitude slower per utterance
+// than beam_pass1_kernel and exists so that the word trellis can be checked bit for bit
+// against the reference in every case, ties included.  Same inputs, same result records.
+struct STok { int last_tre, last_cword; float last_lscore, score; int node; };
+
+struct StrictWork {
+  STok *tl[2];     // [utt][cap]   tlist[2]
+  int *ti[2];      // [utt][cap]   tindex[2]
+  int *token;      // [utt][nnode] node -> token id of the current list (-1 none)
+  int cap;
+};
+
+struct SBeam {
+  const LexDev *lx; const float *sc; int S;
+  STok *tl[2]; int *ti[2]; int tnum[2]; int *token; int cap;
+  int tn, tlx, n_start, n_end;
+  float thr, we_best_score; int we_best_node, we_best_tre, we_best_cword;
+  jamd_trellis_atom *atoms; int natom, atom_cap; bool overflow;
+};
+
+__device__ int s_create_token(SBeam &b) {                       // create_token() beam.c:1148
+  const int id = b.tnum[b.tn];
+  if (id + 1 >= b.cap) { b.overflow = true; return id > 0 ? id - 1 : 0; }
+  b.tnum[b.tn]++;
+  b.ti[b.tn][id] = id;
+  return id;
+}
+
+// sort_token_upward / _downward (beam.c:1342 / :1414): 1-based heap over tindex
+__device__ void s_sort(SBeam &b, int neednum, int totalnum, bool upward) {
+  STok *tl = b.tl[b.tn]; int *ti = b.ti[b.tn];
+#define SD_(A) ti[(A) - 1]
+#define SV_(A) (tl[ti[(A) - 1]].score)
+#define BEFORE_(x, y) (upward ? ((x) < (y)) : ((x) > (y)))
+#define STOP_(x, y) (upward ? ((x) >= (y)) : ((x) <= (y)))
+  int n, root, child, parent, s;
+  for (root = totalnum / 2; root >= 1; root--) {
+    s = SD_(root); parent = root;
+    while ((child = parent * 2) <= totalnum) {
+      if (child < totalnum && BEFORE_(SV_(child), SV_(child + 1))) child++;
+      if (STOP_(tl[s].score, SV_(child))) break;
+      SD_(parent) = SD_(child); parent = child;
+    }
+    SD_(parent) = s;
+  }
+  n = totalnum;
+  while (n > totalnum - neednum) {
+    s = SD_(n); SD_(n) = SD_(1); n--; parent = 1;
+    while ((child = parent * 2) <= n) {
+      if (child < n && BEFORE_(SV_(child), SV_(child + 1))) child++;
+      if (STOP_(tl[s].score, SV_(child))) break;
+      SD_(parent) = SD_(child); parent = child;
+    }
+    SD_(parent) = s;
+  }
+#undef SD_
+#undef SV_
+#undef BEFORE_
+#undef STOP_
+}
+__device__ void s_sort_no_order(SBeam &b, int neednum) {         // sort_token_no_order() :1492
+  const int totalnum = b.tnum[b.tn], restnum = totalnum - neednum;
+  if (neednum >= totalnum) { b.n_start = 0; b.n_end = totalnum - 1; }
+  else if (neednum < restnum) { s_sort(b, neednum, totalnum, true); b.n_start = totalnum - neednum; b.n_end = totalnum - 1; }
+  else { s_sort(b, restnum, totalnum, false); b.n_start = 0; b.n_end = neednum - 1; }
+}
+
+__device__ void s_propagate(SBeam &b, int next_node, float next_score, int last_tre, int last_cword,
+                            float last_lscore) {                 // propagate_token() :1945
+  if (next_score <= JAMD_LOG_ZERO) return;
+  int id = b.token[next_node];
+  if (id >= 0) {
+    STok &tk = b.tl[b.tn][id];
+    if (tk.score < next_score) { tk.last_tre = last_tre; tk.last_cword = last_cword; tk.last_lscore = last_lscore; tk.score = next_score; }
+  } else {
+    id = s_create_token(b);
+    STok &tk = b.tl[b.tn][id];
+    tk.last_tre = last_tre; tk.last_cword = last_cword; tk.last_lscore = last_lscore; tk.score = next_score;
+    tk.node = next_node; b.token[next_node] = id;
+  }
+}
+
+__device__ void s_intra_core(SBeam &b, const STok &tk, int next_node, float next_a) {   // :2004
+  const LexDev &lx = *b.lx;
+  float tmpsum = tk.score + next_a, ng = JAMD_LOG_ZERO;
+  const int nscid = (next_node != tk.node) ? lx.scid[next_node] : 0;
+  if (nscid != 0) {
+    ng = max_successor_prob(lx, tk.last_cword, nscid) * lx.lm_weight + lx.lm_penalty;
+    tmpsum -= tk.last_lscore;
+    tmpsum += ng;
+  }
+  if (ng == JAMD_LOG_ZERO) ng = tk.last_lscore;
+  s_propagate(b, next_node, tmpsum, tk.last_tre, tk.last_cword, ng);
+}
+
+__device__ int s_save_trellis(SBeam &b, const STok &tk, int sword, int t) {            // :2209
+  if (b.natom >= b.atom_cap) { b.overflow = true; return b.natom - 1; }
+  jamd_trellis_atom a;
+  a.wid = sword; a.backscore = tk.score; a.last_tre = tk.last_tre; a.lscore = tk.last_lscore;
+  a.begintime = (short)((tk.last_tre < 0 ? -1 : b.atoms[tk.last_tre].endtime) + 1);
+  a.endtime = (short)(t - 1);
+  b.atoms[b.natom] = a;
+  return b.natom++;
+}
+
+__global__ void __launch_bounds__(64)
+beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ scores, int S,
+                   const int *__restrict__ utt_off, int nutt) {
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  if (u >= nutt) return;
+  const int t_begin = utt_off[u], T = utt_off[u + 1] - t_begin;
+  jamd_pass1_result *res = wk.res + u;
+  SBeam b;
+  b.lx = &lx; b.sc = scores + (size_t)t_begin * S; b.S = S;
+  for (int i = 0; i < 2; i++) { b.tl[i] = sw.tl[i] + (size_t)u * sw.cap; b.ti[i] = sw.ti[i] + (size_t)u * sw.cap; b.tnum[i] = 0; }
+  b.token = sw.token + (size_t)u * wk.nnode; b.cap = sw.cap;
+  b.atoms = wk.atoms + (size_t)u * wk.atom_cap; b.natom = 0; b.atom_cap = wk.atom_cap; b.overflow = false;
+  res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO; res->died_at = -1;
+  res->ties = res->ties_node = res->ties_wordend = res->ties_cut = 0; res->frames = T; res->max_tokens = 0;
+  for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
+  if (T <= 0) { res->status = JAMD_PASS1_FAIL; return; }
+  for (int i = 0; i < wk.nnode; i++) b.token[i] = -1;               // init_nodescore() :1587-1590
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+  int status = JAMD_PASS1_OK, died_at = -1, max_tokens = 1;
+
+  b.tn = 0; b.tlx = 1;
+  {                                                                  // init_nodescore() :1622-1665
+    const int id = s_create_token(b);
+    STok &nw = b.tl[b.tn][id];
+    const int node = lx.word_head[lx.head_silwid];
+    const int4 nr = lx.node_b[node];
+    float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
+    ls = ls * lmw + pen;
+    nw.last_lscore = ls; nw.last_tre = -1; nw.last_cword = -1;
+    nw.score = node_outprob(lx, b.sc, nr.w, nr.z, -1) + ls;
+    nw.node = node; b.token[node] = id;
+  }
+  s_sort_no_order(b, wk.beam);
+  b.thr = JAMD_LOG_ZERO;
+
+  for (int t = 1; t < T; t++) {                                      // get_back_trellis_proceed() :2663
+    b.tlx = b.tn; b.tn = b.tn ? 0 : 1;
+    const int tl = b.tlx, tn = b.tn;
+    b.we_best_score = JAMD_LOG_ZERO;
+    for (int j = 0; j < b.tnum[tl]; j++) b.token[b.tl[tl][j].node] = -1;        // clear_tokens() :1122
+    for (int j = b.n_start; j <= b.n_end; j++) {
+      const STok tk = b.tl[tl][b.ti[tl][j]];
+      if (tk.score <= JAMD_LOG_ZERO) continue;
+      if (tk.score < b.thr) continue;
+      const int node = tk.node;
+      const int4 na = lx.node_a[node];
+      const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
+      if (a_self != JAMD_LOG_ZERO) s_intra_core(b, tk, node, a_self);           // beam_intra_word() :2154
+      if (a_next != JAMD_LOG_ZERO) s_intra_core(b, tk, node + 1, a_next);
+      for (int e = na.z; e < na.w; e++) s_intra_core(b, tk, lx.ac_to[e], lx.ac_a[e]);
+      const int sword = lx.node_b[node].x;
+      if (sword >= 0) {
+        const int tre = s_save_trellis(b, tk, sword, t);
+        if (sword != lx.tail_silwid) {                                          // beam_inter_word() :2271
+          const bool tr = lx.is_transparent[sword] != 0;
+          const int last_word = tr ? tk.last_cword : sword;
+          float tmpprob = tk.score + lx.wordend_a[sword];
+          if (b.we_best_score < tmpprob) {
+            b.we_best_score = tmpprob; b.we_best_node = node; b.we_best_tre = tre; b.we_best_cword = tk.last_cword;
+          }
+          for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+            if (lx.start2isolate[stid] == -1) continue;
+            const int next_node = lx.startnode[stid];
+            const int wn = lx.scword[lx.scid[next_node]];
+            const float p = (last_word < 0) ? 0.0f
+                            : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+            float tmpsum = tk.score;
+            tmpsum += lx.wordend_a[sword];
+            const float ng = p * lmw + pen;
+            tmpsum += ng;
+            if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
+            s_propagate(b, next_node, tmpsum, tre, last_word, ng);
+          }
+        }
+      }
+    }
+    if (b.we_best_score > JAMD_LOG_ZERO) {                                       // beam_inter_word_factoring() :2549
+      const int sword = lx.node_b[b.we_best_node].x;
+      const int last_word = lx.is_transparent[sword] ? b.we_best_cword : sword;
+      for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+        if (lx.start2isolate[stid] != -1) continue;
+        const int next_node = lx.startnode[stid];
+        const float ng = lx.fscore[-lx.scid[next_node]] * lmw + pen;
+        float tmpsum = b.we_best_score;
+        tmpsum += ng;
+        if (lx.is_transparent[sword] && b.we_best_cword >= 0 && lx.is_transparent[b.we_best_cword]) tmpsum += lx.lm_penalty_trans;
+        if (tmpsum < b.thr) continue;
+        s_propagate(b, next_node, tmpsum, b.we_best_tre, last_word, ng);
+      }
+    }
+    float pmax = JAMD_LOG_ZERO;
+    const float *row = b.sc + (size_t)t * S;
+    for (int j = 0; j < b.tnum[tn]; j++) {                                       // :2944-2951
+      STok &tk = b.tl[tn][b.ti[tn][j]];
+      const int4 nr = lx.node_b[tk.node];
+      const int lw = tk.last_tre < 0 ? -1 : b.atoms[tk.last_tre].wid;
+      tk.score += node_outprob(lx, row, nr.w, nr.z, lw);
+      if (pmax < tk.score) pmax = tk.score;
+    }
+    b.thr = (wk.width >= 0.0f) ? (pmax - wk.width) : JAMD_LOG_ZERO;
+    if (b.tnum[tn] > max_tokens) max_tokens = b.tnum[tn];
+    b.tnum[tl] = 0;
+    s_sort_no_order(b, wk.beam);
+    if (b.tnum[tn] == 0) { status = JAMD_PASS1_DIED; died_at = t; break; }
+    if (b.overflow) break;
+  }
+  if (status == JAMD_PASS1_OK && !b.overflow) {                                  // get_back_trellis_end() :3076
+    b.tlx = b.tn; b.tn = b.tn ? 0 : 1;
+    for (int j = b.n_start; j <= b.n_end; j++) {
+      const STok tk = b.tl[b.tlx][b.ti[b.tlx][j]];
+      const int sword = lx.node_b[tk.node].x;
+      if (sword >= 0) s_save_trellis(b, tk, sword, T);
+    }
+    int best = -1;                                                               // find_1pass_result() :399
+    for (int i = b.natom - 1; i >= 0; i--)
+      if (b.atoms[i].wid == lx.tail_silwid && b.atoms[i].backscore > JAMD_LOG_ZERO) { best = i; break; }
+    if (best >= 0 && b.atoms[best].endtime != b.atoms[b.natom - 1].endtime) {
+      // atoms are emitted in time order; `best` is already the tail word ending latest
+    }
+    if (best < 0) status = JAMD_PASS1_FAIL;
+    else {
+      int n = 0, a = best;
+      int rev[MAXSEQ];
+      rev[n++] = b.atoms[a].wid;
+      while (b.atoms[a].begintime > 0 && n < MAXSEQ) { a = b.atoms[a].last_tre; rev[n++] = b.atoms[a].wid; }
+      for (int k = 0; k < n; k++) res->wseq[k] = rev[n - 1 - k];
+      res->wnum = n; res->score = b.atoms[best].backscore;
+    }
+  }
+  if (b.overflow) status = JAMD_PASS1_OVERFLOW;
+  res->status = status; res->died_at = died_at; res->natom = b.natom; res->max_tokens = max_tokens;
+}
+
 template <typename T>
 int upload(T **dst, const T *src, size_t n) {
   JAMD_HIP(hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)));
@@ -606,6 +854,8 @@ struct jamd_beam {
   Work w{};
   int max_utts = 0;
   int *d_utt_off = nullptr;
+  bool strict = false;
+  StrictWork sw{};
   std::vector<void *> owned;
 };
 
@@ -684,6 +934,7 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac);
   UP(iso_root, iso_root.data(), iso_root.size()); UP(shared_root, shared_root.data(), shared_root.size());
   UP(word_end, word_end.data(), word_end.size());
+  UP(startnode, h->startnode, h->startnum); UP(start2isolate, h->start2isolate, h->startnum);
   UP(lc_tab, h->lc_tab, (size_t)h->nlcrow * (h->nlc + 1)); UP(word_lc, h->word_lc, h->nword);
   UP(set_off, h->set_off, h->nset + 1); UP(set_states, h->set_states, nset_states);
   UP(wordend_a, h->wordend_a, h->nword); UP(wton, h->wton, h->nword); UP(cprob, h->cprob, h->nword);
@@ -779,10 +1030,31 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w, dev_scores, nstate,
-                     b->d_utt_off);
+  if (b->strict)
+    hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
+                       nstate, b->d_utt_off, nutt);
+  else
+    hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w,
+                       dev_scores, nstate, b->d_utt_off);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  return JAMD_OK;
+}
+
+int jamd_beam_set_strict_order(jamd_beam *b, int on) {
+  if (!b) { jamd_set_error("jamd_beam_set_strict_order: NULL"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  if (on && b->sw.token == nullptr) {
+    const size_t U = (size_t)b->max_utts;
+    b->sw.cap = b->w.tok_cap + 2;
+    void *p = nullptr;
+    for (int i = 0; i < 2; i++) {
+      JAMD_HIP(hipMalloc(&p, U * b->sw.cap * sizeof(STok))); b->owned.push_back(p); b->sw.tl[i] = (STok *)p;
+      JAMD_HIP(hipMalloc(&p, U * b->sw.cap * sizeof(int))); b->owned.push_back(p); b->sw.ti[i] = (int *)p;
+    }
+    JAMD_HIP(hipMalloc(&p, U * b->w.nnode * sizeof(int))); b->owned.push_back(p); b->sw.token = (int *)p;
+  }
+  b->strict = on != 0;
   return JAMD_OK;
 }
 

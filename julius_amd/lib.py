@@ -94,6 +94,7 @@ def load():
         "jamd_beam_destroy": (None, [vp]),
         "jamd_beam_pass1_dev": (ci, [vp, vp, ci, vp, ci, vp]),
         "jamd_beam_results": (ci, [vp, vp, ci]),
+        "jamd_beam_set_strict_order": (ci, [vp, ci]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
     }
     for name, (res, args) in sig.items():
@@ -386,6 +387,9 @@ class Beam:
         _check(load().jamd_beam_create(eng.h, lexicon.h, beam_width, score_pruning_width, max_utts,
                                        atoms_per_utt, C.byref(h)), "jamd_beam_create")
         self.h = h
+
+    def set_strict_order(self, on: bool = True):
+        _check(load().jamd_beam_set_strict_order(self.h, 1 if on else 0), "jamd_beam_set_strict_order")
 
     def pass1_dev(self, dev_scores: int, nstate: int, utt_off, stream: int = 0):
         off = _i32(utt_off)

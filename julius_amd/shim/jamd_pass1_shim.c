@@ -108,6 +108,8 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   rc = jamd_beam_create(g_eng, c->lex, r->trellis_beam_width, r->config->pass1.score_pruning_width, 1,
                         1 << 20, &c->beam);
   if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0 &&
+      jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
   jlog("STAT: jamd: first pass on HIP device %d (beam %d, %d states, %d lexicon nodes)\n",

@@ -152,3 +152,41 @@ def test_full_size_lexicon_vs_oracle(engine, oracle):
     assert res[0].status == rc == 0
     assert list(res[0].wseq[:res[0].wnum]) == list(owseq) == ws and res[0].score == oscore
     assert_trellis_equal_modulo_ties(tre[0], lexblob.canonical_trellis(oatoms), res[0].ties_node + res[0].ties_cut + res[0].ties_wordend)
+
+
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz"])
+def test_strict_order_golden(engine, oracle, name):
+    """Strict-order mode (the reference's sequential visiting order, one lane per
+    utterance): EXACT equality with the reference's golden trellis, no tie caveat."""
+    g = load_beam_golden(name)
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    bm.set_strict_order(True)
+    res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0
+        assert_trellis_equal(atoms, u["trellis"])
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
+
+
+@pytest.mark.parametrize("seed,beam,extra,task_kw", [
+    (22, 30, ["-sepnum", "2"], {}),
+    (24, 100, ["-sepnum", "0", "-iwcd1", "avg"], {}),
+    (23, 600, ["-sepnum", "10", "-bs", "80"], dict(nword=300, nphone=12, S=200)),
+    (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),   # the case where the fast kernel's
+])                                                                              # tie rule dropped one atom of 34 842
+def test_strict_order_exact_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
+    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    utts = [synth.make_utterance(task, nwords=2 + 3 * u, seed=100 * seed + u)[0] for u in range(4)]
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 17)
+    bm.set_strict_order(True)
+    res, tre = bm.pass1_host(scores)
+    for fr, r, atoms in zip(utts, res, tre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert_trellis_equal(atoms, rtr)                      # exact, ties included
+        if r.status == 0:
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
