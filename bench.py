@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): tied-state
 triphone-sized GMM, S=3000 states x M=16 mixtures x D=39, outprob kernel only.
 One "step" = one pass of the GMM outprob path over one batch of
-`--utts` synthetic utterances x 1000 frames (seeded synthetic MFCC) already
+`--utts` (default 64) synthetic utterances x 1000 frames (seeded synthetic MFCC) already
 resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
 
   value   = frame*states scored per second, whole job (all ranks)
@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--utts", type=int, default=16, help="utterances (x1000 frames) per GPU per step")
+    ap.add_argument("--utts", type=int, default=64,
+                    help="utterances (x1000 frames) per GPU per step (64 = one GPU's share of the 512-utterance batch of configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn", "e2e", "e2e-dnn"],
                     help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half; "
