@@ -76,11 +76,15 @@ struct Work {            // per-utterance slices are addressed with the strides 
   Tok *cur;                      // [utt][tok_cap]  tokens created this frame
   unsigned *cur_key;             // [utt][tok_cap]  their order-preserving score bits (compact, for the rank select)
   int *touched;                  // [utt][tok_cap]  nodes touched this frame
+  int2 *arcq;                    // [utt][tok_cap]  work queue of (survivor, extra arc) pairs
   jamd_trellis_atom *atoms;      // [utt][atom_cap]
   jamd_pass1_result *res;        // [utt]
   // survivor state: lives in LDS when it fits (sv_bytes of dynamic shared memory),
   // else in these per-utterance global arrays of the same layout
   unsigned char *sv_global;      // [utt][sv_bytes]
+  unsigned long long *lmcache;   // [utt][nscword] (context N-gram id << 32 | prob bits): the reference's
+                                 // per-successor-id memo LM_PROB_CACHE (wchmm.h:117-149, factoring_sub.c:965-986)
+  int nscword;
   int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
   int tok_cap, atom_cap, beam, nnode, nword;
   float width;
@@ -125,12 +129,25 @@ __device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
   return prob - lx.ng_unk_num_log;
 }
 
-// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING), scid given
-__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int scid) {
+// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING), scid given.
+// `memo` is the per-utterance equivalent of the reference's lastwcache/probcache pair:
+// one (context, value) entry per successor id, a pure memo of the 2-gram lookup.  A token
+// waiting in front of a branch asks for the same pair every frame, so nearly every call
+// is one 8-byte load instead of a binary search.  Entries are written as single 64-bit
+// words, so concurrent writers cannot tear them; NULL disables the memo.
+__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int scid,
+                                                    unsigned long long *memo = nullptr) {
   if (lastword < 0) return 0.0f;
   if (scid < 0) return lx.fscore[-scid];
+  const int ctx = lx.wton[lastword];
+  if (memo) {
+    const unsigned long long m = memo[scid];
+    if ((int)(unsigned)(m >> 32) == ctx) return __uint_as_float((unsigned)m);
+  }
   const int w = lx.scword[scid];
-  return bigram_prob(lx, lx.wton[lastword], lx.wton[w]) + lx.cprob[w];
+  const float p = bigram_prob(lx, ctx, lx.wton[w]) + lx.cprob[w];
+  if (memo) memo[scid] = ((unsigned long long)(unsigned)ctx << 32) | __float_as_uint(p);
+  return p;
 }
 
 // outprob_style(), outprob_style.c:354-486, with the name lookups replaced by
@@ -145,10 +162,17 @@ __device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, i
   return cd_reduce(row, lx.set_states, lx.set_off[ent], lx.set_off[ent + 1], lx.cdset_method, lx.cdmax_num);
 }
 
+// the state (>= 0) or ~state-set (< 0) that outprob_style() scores for a node
+__device__ __forceinline__ int outprob_entry(const LexDev &lx, int kind, int id, int last_wid) {
+  if (kind == JAMD_AS_STATE) return id;
+  if (kind == JAMD_AS_LSET) return ~id;
+  return lx.lc_tab[(size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc[last_wid])];
+}
+
 struct Shared {
   unsigned long long we_best;       // (ord(score + wordend_a), word that ended)
   unsigned hist[2048];
-  int n_new, n_we, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
+  int n_new, n_we, n_arc, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
   int eq_n, eq_node[128];           // tokens exactly on the rank cut (tie handling)
@@ -221,6 +245,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   Tok *cur = wk.cur + (size_t)u * wk.tok_cap;
   unsigned *cur_key = wk.cur_key + (size_t)u * wk.tok_cap;
   int *touched = wk.touched + (size_t)u * wk.tok_cap;
+  int2 *arcq = wk.arcq + (size_t)u * wk.tok_cap;       // extra arcs of this frame's survivors: (survivor, arc)
   jamd_trellis_atom *atoms = wk.atoms + (size_t)u * wk.atom_cap;
   jamd_pass1_result *res = wk.res + u;
   // survivor state of the previous frame (tokens, the atom each word end emitted, the
@@ -233,6 +258,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   int *hval = hkey + wk.hsize;
   const int hmask = wk.hsize - 1;
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+  unsigned long long *memo = wk.lmcache + (size_t)u * wk.nscword;
 
   if (tid == 0) {
     sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.n_surv = 0;
@@ -240,6 +266,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     res->died_at = -1; res->ties = 0; res->frames = T; res->max_tokens = 0;
   }
   for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
+  for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;   // context -1: never matches
   __syncthreads();
   if (T <= 0) { if (tid == 0) res->status = JAMD_PASS1_FAIL; return; }
 
@@ -267,10 +294,39 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     // tl/tn swap (beam.c:2697-2698): sv[] holds last frame's survivors
     const int n_surv = sh.n_surv;
     __syncthreads();
-    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
+    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
     __syncthreads();
     const bool last = (t == T);     // get_back_trellis_end(): word ends only, no pruning test
 
+    // one intra-word candidate of token tk: score, LM factoring update, push, tie accounting
+    auto intra_candidate = [&](const Tok &tk, int next_node, float a) {
+      const int node = tk.node;
+      float tmpsum = tk.score + a;
+      const int nscid = (next_node != node) ? lx.scid[next_node] : 0;
+      const bool fac = nscid != 0;
+      if (fac) {
+        const float ng = max_successor_prob(lx, tk.last_cword, nscid, memo) * lmw + pen;
+        tmpsum -= tk.last_lscore;
+        tmpsum += ng;
+      }
+      const unsigned long long tie = push(sh, nodekey, touched, next_node, tmpsum, (unsigned)node);
+      if (tie != 0ull) {
+        // two different sources reach next_node with exactly the same score.
+        // Harmless when both carry the same history (same predecessor atom, context
+        // word and LM score) -- merging tree branches produce that; anything else is
+        // a genuine tie, resolved by the larger source id and counted.
+        bool same = false;
+        if (((unsigned)tie >> 31) == 0u) {
+          const Tok o = sv[hash_get(hkey, hval, hmask, (int)(unsigned)tie)];
+          // the LM score is recomputed from last_cword on entering a factoring
+          // node from another node (see step C); otherwise it is inherited
+          const bool re_o = next_node != o.node && lx.scid[next_node] != 0;
+          same = o.last_tre == tk.last_tre && o.last_cword == tk.last_cword &&
+                 (fac == re_o) && (fac || o.last_lscore == tk.last_lscore);
+        }
+        if (!same) atomicAdd(&sh.ties, 1);
+      }
+    };
     // ---- A: intra-word transitions + word-end atoms (main loop, beam.c:2838-2900)
     for (int j = tid; j < n_surv; j += NT) {
       const Tok tk = sv[j];
@@ -280,38 +336,19 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       if (!last) {
         if (tk.score <= JAMD_LOG_ZERO) continue;
         if (tk.score < thr) continue;
-        // beam_intra_word() :2154-2180 -> beam_intra_word_core() :2004-2135
+        // beam_intra_word() :2154-2180 -> beam_intra_word_core() :2004-2135.  The self loop and
+        // the `next` arc are handled here; the extra arcs of branching nodes (up to tens per
+        // node) go to a work queue so that no lane walks them alone.
         const int e0 = na.z, e1 = na.w;
-        for (int k = 0; k < 2 + (e1 - e0); k++) {
+        if (e1 > e0) {
+          const int base = atomicAdd(&sh.n_arc, e1 - e0);
+          for (int e = e0; e < e1; e++) arcq[base + e - e0] = make_int2(j, e);
+        }
+        for (int k = 0; k < 2; k++) {
           int next_node; float a;
           if (k == 0) { next_node = node; a = __int_as_float(na.x); if (a == JAMD_LOG_ZERO) continue; }
-          else if (k == 1) { next_node = node + 1; a = __int_as_float(na.y); if (a == JAMD_LOG_ZERO) continue; }
-          else { next_node = lx.ac_to[e0 + k - 2]; a = lx.ac_a[e0 + k - 2]; }
-          float tmpsum = tk.score + a;
-          const int nscid = (next_node != node) ? lx.scid[next_node] : 0;
-          const bool fac = nscid != 0;
-          if (fac) {
-            const float ng = max_successor_prob(lx, tk.last_cword, nscid) * lmw + pen;
-            tmpsum -= tk.last_lscore;
-            tmpsum += ng;
-          }
-          const unsigned long long tie = push(sh, nodekey, touched, next_node, tmpsum, (unsigned)node);
-          if (tie != 0ull) {
-            // two different sources reach next_node with exactly the same score.
-            // Harmless when both carry the same history (same predecessor atom, context
-            // word and LM score) -- merging tree branches produce that; anything else is
-            // a genuine tie, resolved by the larger source id and counted.
-            bool same = false;
-            if (((unsigned)tie >> 31) == 0u) {
-              const Tok o = sv[hash_get(hkey, hval, hmask, (int)(unsigned)tie)];
-              // the LM score is recomputed from last_cword on entering a factoring
-              // node from another node (see step C); otherwise it is inherited
-              const bool re_o = next_node != o.node && lx.scid[next_node] != 0;
-              same = o.last_tre == tk.last_tre && o.last_cword == tk.last_cword &&
-                     (fac == re_o) && (fac || o.last_lscore == tk.last_lscore);
-            }
-            if (!same) atomicAdd(&sh.ties, 1);
-          }
+          else { next_node = node + 1; a = __int_as_float(na.y); if (a == JAMD_LOG_ZERO) continue; }
+          intra_candidate(tk, next_node, a);
         }
       }
       if (sword >= 0) {
@@ -337,6 +374,14 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
     }
     __syncthreads();
+    if (!last) {                                   // drain the extra-arc queue, one arc per thread
+      const int n_arc = sh.n_arc;
+      for (int q = tid; q < n_arc; q += NT) {
+        const int2 it = arcq[q];
+        intra_candidate(sv[it.x], lx.ac_to[it.y], lx.ac_a[it.y]);
+      }
+      __syncthreads();
+    }
     PHASE(0);
     if (last) break;
 
@@ -382,6 +427,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
     }
     __syncthreads();
+    if (tid == 0) sh.n_arc = 0;                    // the queue now collects state-set reductions
     PHASE(1);
 
     // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951)
@@ -404,7 +450,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
           nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
           if (node != tk.node && nr.y != 0)               // beam_intra_word_core() :2069-2082
-            nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y) * lmw + pen;
+            nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y, memo) * lmw + pen;
           else
             nw.last_lscore = tk.last_lscore;
         } else {
@@ -424,13 +470,82 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           }
         }
         if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[5] += n_ - tq + (__float_as_int(nw.last_lscore) & 0); tq = n_; }
-        nw.score = score + node_outprob(lx, row, nr.w, nr.z, nw.last_wid);
-        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (__float_as_int(nw.score) & 0); tq = n_; }
+        // outprob_style(), outprob_style.c:354-486: a plain state score is added here; a
+        // state-set reduction (tens of gathers) is deferred to the cooperative drain below
+        const int ent = outprob_entry(lx, nr.w, nr.z, nw.last_wid);
+        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (ent & 0); tq = n_; }
+        if (ent >= 0) {
+          nw.score = score + row[ent];
+          const unsigned b = ord(nw.score);
+          cur_key[s] = b;
+          if (b > mymax) mymax = b;
+          if (b < mymin) mymin = b;
+        } else {
+          nw.score = score;
+          arcq[atomicAdd(&sh.n_arc, 1)] = make_int2(s, ~ent);     // (token, state set); arcq is free again
+        }
         cur[s] = nw;
-        const unsigned b = ord(nw.score);
-        cur_key[s] = b;
-        if (b > mymax) mymax = b;
-        if (b < mymin) mymin = b;
+      }
+      __syncthreads();
+      // drain: four lanes per (token, set) item, each reduces every fourth member, then the
+      // partial results are merged through shuffles (outprob_cd(), outprob.c:287-400)
+      const int n_set = sh.n_arc;
+      const int sub = tid & 3, lane = tid & 63;
+      for (int q0 = 0; q0 < n_set; q0 += NT / 4) {
+        const int q = q0 + (tid >> 2);
+        const bool act = q < n_set;
+        const int2 it = act ? arcq[q] : make_int2(0, 0);
+        const int a = act ? lx.set_off[it.y] : 0, bnd = act ? lx.set_off[it.y + 1] : 0;
+        float r;
+        if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
+          float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
+          int n = 0;
+          auto ins = [&](float p) {
+            float t_;
+            if (p > b0) { t_ = b0; b0 = p; p = t_; }
+            if (p > b1) { t_ = b1; b1 = p; p = t_; }
+            if (p > b2) { t_ = b2; b2 = p; p = t_; }
+            if (p > b3) { b3 = p; }
+          };
+          for (int m = a + sub; m < bnd; m += 4) {
+            const float p = row[lx.set_states[m]];
+            if (p > JAMD_LOG_ZERO) { n++; ins(p); }
+          }
+          // merge the four partial top lists into the group's first lane (values <= LOG_ZERO are
+          // padding and never displace anything)
+#pragma unroll
+          for (int src = 1; src < 4; src++) {
+            const int from = (lane & ~3) + src;
+            const float c0 = __shfl(b0, from, 64), c1 = __shfl(b1, from, 64), c2 = __shfl(b2, from, 64),
+                        c3 = __shfl(b3, from, 64);
+            const int cn = __shfl(n, from, 64);
+            if (sub == 0) { ins(c0); ins(c1); ins(c2); ins(c3); n += cn; }
+          }
+          if (n > lx.cdmax_num) n = lx.cdmax_num;
+          float sum = 0.0f;
+          if (n > 0) sum += b0;
+          if (n > 1) sum += b1;
+          if (n > 2) sum += b2;
+          if (n > 3) sum += b3;
+          r = sum / (float)n;
+        } else if (lx.cdset_method == JAMD_IWCD_MAX) {
+          float m_ = JAMD_LOG_ZERO;
+          for (int m = a + sub; m < bnd; m += 4) { const float p = row[lx.set_states[m]]; if (m_ < p) m_ = p; }
+#pragma unroll
+          for (int src = 1; src < 4; src++) { const float c = __shfl(m_, (lane & ~3) + src, 64); if (m_ < c) m_ = c; }
+          r = m_;
+        } else {
+          // average (member-order float sum) and long N-best lists: one lane, reference order
+          r = (act && sub == 0) ? cd_reduce(row, lx.set_states, a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
+        }
+        if (act && sub == 0) {
+          const float sc = cur[it.x].score + r;
+          cur[it.x].score = sc;
+          const unsigned b = ord(sc);
+          cur_key[it.x] = b;
+          if (b > mymax) mymax = b;
+          if (b < mymin) mymin = b;
+        }
       }
       atomicMax(&sh.maxbits, mymax);
       atomicMin(&sh.minbits, mymin);
@@ -844,7 +959,7 @@ int upload(T **dst, const T *src, size_t n) {
 struct jamd_lexicon {
   jamd_engine *eng = nullptr;
   LexDev d{};
-  int maxfan = 2;
+  int maxfan = 2, nscword = 0;
   std::vector<void *> owned;
 };
 
@@ -895,7 +1010,7 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   if (h->nword >= (1 << 30)) { jamd_set_error("jamd_lexicon_create: nword=%d too large", h->nword); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(e->device));
   jamd_lexicon *l = new jamd_lexicon();
-  l->eng = e; l->maxfan = maxfan;
+  l->eng = e; l->maxfan = maxfan; l->nscword = h->nscword;
   LexDev &d = l->d;
   d.nnode = h->nnode; d.nword = h->nword; d.startnum = h->startnum; d.isolatenum = h->isolatenum;
   d.nshared = (int)shared.size(); d.nlc = h->nlc; d.cdset_method = h->cdset_method; d.cdmax_num = h->cdmax_num;
@@ -990,9 +1105,12 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur, U * w.tok_cap * sizeof(Tok), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur_key, U * w.tok_cap * sizeof(unsigned), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.arcq, U * w.tok_cap * sizeof(int2), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.atoms, U * w.atom_cap * sizeof(jamd_trellis_atom), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
   if (rc == JAMD_OK && !w.use_lds) rc = alloc((void **)&w.sv_global, U * (size_t)w.sv_bytes, false);
+  w.nscword = l->nscword > 0 ? l->nscword : 1;
+  if (rc == JAMD_OK) rc = alloc((void **)&w.lmcache, U * (size_t)w.nscword * sizeof(unsigned long long), false);
   if (rc == JAMD_OK && w.use_lds) {
     hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         w.sv_bytes);
