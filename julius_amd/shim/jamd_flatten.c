@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include "jamd_flatten.h"
+#include <sent/speech.h>   /* OUTPROB_CACHE_PERIOD */
+#include <sent/util.h>     /* mymalloc, mybmalloc2 */
 
 /* open-addressing pointer -> index map for density de-duplication */
 typedef struct { const void **key; int *val; size_t cap; } pmap;
@@ -123,4 +125,32 @@ float *jamd_pack_param(const HTK_Param *param, int t0, int t1)
   float *buf = (float *)malloc(sizeof(float) * (size_t)(t1 - t0 > 0 ? t1 - t0 : 1) * D);
   for (t = t0; t < t1; t++) memcpy(buf + (size_t)(t - t0) * D, param->parvec[t], sizeof(float) * D);
   return buf;
+}
+
+/* Make outprob_cache[0..t0+n) exist (same growth rule and allocator as the static
+ * outprob_cache_extend(), libsent/src/phmm/outprob.c:109-142) and copy n rows of device
+ * scores in, starting at frame t0: every later outprob_state(t, s) for those frames is a
+ * cache hit (outprob.c:245-247) on values bit-identical to calc_mix()'s. */
+#define JAMD_LOG_UNDEF (LOG_ZERO - 1)      /* outprob.c:68 */
+int jamd_fill_outprob_cache(HMMWork *wrk, const float *scores, int t0, int n, int S)
+{
+  int t, s, T = t0 + n;
+  if (S != wrk->statenum || t0 < 0 || n < 0) return JAMD_EINVAL;
+  if (T > wrk->outprob_allocframenum) {
+    int newnum = T, size;
+    LOGPROB *tmpp;
+    if (newnum < wrk->outprob_allocframenum + OUTPROB_CACHE_PERIOD) newnum = wrk->outprob_allocframenum + OUTPROB_CACHE_PERIOD;
+    size = (newnum - wrk->outprob_allocframenum) * wrk->statenum;
+    if (wrk->outprob_cache == NULL) wrk->outprob_cache = (LOGPROB **)mymalloc(sizeof(LOGPROB *) * newnum);
+    else wrk->outprob_cache = (LOGPROB **)myrealloc(wrk->outprob_cache, sizeof(LOGPROB *) * newnum);
+    tmpp = (LOGPROB *)mybmalloc2(sizeof(LOGPROB) * size, &(wrk->croot));
+    for (t = wrk->outprob_allocframenum; t < newnum; t++) {
+      wrk->outprob_cache[t] = &(tmpp[(t - wrk->outprob_allocframenum) * wrk->statenum]);
+      for (s = 0; s < wrk->statenum; s++) wrk->outprob_cache[t][s] = JAMD_LOG_UNDEF;
+    }
+    wrk->outprob_allocframenum = newnum;
+  }
+  for (t = t0; t < T; t++) memcpy(wrk->outprob_cache[t], scores + (size_t)(t - t0) * S, sizeof(float) * S);
+  wrk->OP_time = -1;      /* force outprob_state() to re-latch last_cache for its frame */
+  return JAMD_OK;
 }

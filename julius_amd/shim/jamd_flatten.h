@@ -41,6 +41,11 @@ void jamd_flat_gmm_free(jamd_flat_gmm *f);
  * libsent/src/anlz/param_malloc.c:52-77) into one [T][veclen] block. */
 float *jamd_pack_param(const HTK_Param *param, int t0, int t1);
 
+/* Copy n rows of [.][S] device scores into wrk->outprob_cache starting at frame t0 (growing
+ * the cache like the reference's static outprob_cache_extend()), so that later outprob_state()
+ * calls for those frames are cache hits. */
+int  jamd_fill_outprob_cache(HMMWork *wrk, const float *scores, int t0, int n, int S);
+
 
 /* ---- first pass: tree lexicon + LM tables (jamd_flatten_lex.c) ------------- */
 #ifdef JAMD_WITH_LIBJULIUS   /* needs <julius/julius.h>; the GMM part above only needs libsent */

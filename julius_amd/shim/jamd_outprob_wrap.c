@@ -1,0 +1,156 @@
+/*
+ * jamd_outprob_wrap.c -- reference-side binding of the SCORING boundary (O).
+ *
+ * Linked into Julius with GNU ld's symbol wrapping
+ *     -Wl,--wrap=outprob_state,--wrap=outprob_cd,--wrap=outprob,
+ *         --wrap=outprob_prepare,--wrap=outprob_free
+ * so that every call libjulius makes into libsent's scoring entry points
+ *     outprob_state()   libsent/src/phmm/outprob.c:184   (from outprob_style.c:380-485)
+ *     outprob_cd()      outprob.c:383
+ *     outprob()         outprob.c:414                    (2nd pass, search_bestfirst_v1.c:939-1212)
+ *     outprob_prepare() outprob_init.c:210               (recogmain.c:1156, once per utterance)
+ *     outprob_free()    outprob_init.c:231
+ * passes through here first.  Nothing of Julius is edited or removed: libsent's own objects
+ * stay linked and are what finally answers each call -- but for a supported configuration
+ * the whole [T][S] score matrix of the utterance has by then been computed on the device
+ * (jamd_gmm_outprob_host) and copied into wrk->outprob_cache, so the answer is a cache
+ * hit.  Julius' CPU beam, its grammar / N-gram handling, multipath models, the 2nd pass:
+ * all unchanged, all consuming device scores that are bit-identical to calc_mix() /
+ * calc_tied_mix().
+ *
+ * Supported: GMM acoustic models (plain or tied-mixture), single stream, -gprune none
+ * or -gprune safe.  Anything else (heu/beam pruning, GMS, multi-stream, DNN, -input
+ * outprob) is left to libsent's CPU code with one log line -- those paths are outside
+ * the engine's scope.  A supported configuration without a usable
+ * gfx950 device is a hard error (exit), as in the reference's own CUDA path
+ * (libsent/src/phmm/calc_dnn_cuda.cu:22-32).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jamd_flatten.h"
+#include <sent/util.h>
+
+LOGPROB __real_outprob_state(HMMWork *wrk, int t, HTK_HMM_State *stateinfo, HTK_Param *param);
+LOGPROB __real_outprob_cd(HMMWork *wrk, int t, CD_State_Set *lset, HTK_Param *param);
+LOGPROB __real_outprob(HMMWork *wrk, int t, HMM_STATE *hmmstate, HTK_Param *param);
+boolean __real_outprob_prepare(HMMWork *wrk, int framenum);
+void    __real_outprob_free(HMMWork *wrk);
+
+typedef struct {
+  HMMWork *wrk;
+  int state;                 /* 0 = not examined, 1 = device, 2 = left to libsent */
+  jamd_gmm *gmm;
+  int nstate;
+  const HTK_Param *param;    /* utterance the cache was filled for */
+  int filled;                /* frames [0, filled) are in the cache */
+} wrap_ctx;
+
+static jamd_engine *g_eng = NULL;
+static wrap_ctx g_ctx[16];
+static int g_nctx = 0;
+
+static wrap_ctx *ctx_get(HMMWork *wrk)
+{
+  int i;
+  for (i = 0; i < g_nctx; i++) if (g_ctx[i].wrk == wrk) return &g_ctx[i];
+  if (g_nctx >= 16) return NULL;
+  memset(&g_ctx[g_nctx], 0, sizeof(wrap_ctx));
+  g_ctx[g_nctx].wrk = wrk;
+  return &g_ctx[g_nctx++];
+}
+
+static void die(const char *what)
+{
+  jlog("Error: jamd: %s: %s\n", what, jamd_last_error());
+  fprintf(stderr, "jamd: %s: %s\n", what, jamd_last_error());
+  exit(1);
+}
+
+static void examine(wrap_ctx *c)
+{
+  HMMWork *wrk = c->wrk;
+  int gprune;
+  jamd_flat_gmm fg;
+  c->state = 2;
+  if (wrk->OP_dnn != NULL || wrk->OP_gshmm != NULL || wrk->OP_nstream != 1) {
+    jlog("Stat: jamd: DNN / GMS / multi-stream scoring stays on libsent's CPU code\n");
+    return;
+  }
+  if (wrk->compute_gaussset == gprune_none) gprune = JAMD_GPRUNE_NONE;
+  else if (wrk->compute_gaussset == gprune_safe) gprune = JAMD_GPRUNE_SAFE;
+  else {
+    jlog("Stat: jamd: this -gprune method depends on the previous frame; scoring stays on libsent's CPU code\n");
+    return;
+  }
+  if (jamd_abi_version() != JAMD_ABI_VERSION) die("ABI mismatch between shim and libjulius_amd.so");
+  if (g_eng == NULL) {
+    const char *dev = getenv("JAMD_DEVICE");
+    if (jamd_engine_create(dev ? atoi(dev) : 0, &g_eng) != JAMD_OK) die("no usable gfx950 device");
+  }
+  if (jamd_flatten_hmminfo(wrk->OP_hmminfo, &fg) != 0) die("cannot flatten the acoustic model");
+  if (jamd_gmm_create(g_eng, &fg.desc, gprune, wrk->OP_gprune_num, &c->gmm) != JAMD_OK) die("jamd_gmm_create");
+  c->nstate = fg.desc.nstate;
+  jamd_flat_gmm_free(&fg);
+  c->state = 1;
+  jlog("Stat: jamd: acoustic scoring on HIP device %d (%d states)\n", jamd_engine_device(g_eng), c->nstate);
+}
+
+/* Score every frame of `param` that is not in the cache yet. */
+static void ensure(HMMWork *wrk, HTK_Param *param)
+{
+  wrap_ctx *c = ctx_get(wrk);
+  int T, n;
+  float *fr, *sc;
+  if (c == NULL || param == NULL || param->is_outprob) return;
+  if (c->state == 0) examine(c);
+  if (c->state != 1) return;
+  T = param->samplenum;
+  if (c->param != param) { c->param = param; c->filled = 0; }
+  if (c->filled >= T) return;
+  n = T - c->filled;
+  fr = jamd_pack_param(param, c->filled, T);
+  sc = (float *)malloc(sizeof(float) * (size_t)n * c->nstate);
+  if (fr == NULL || sc == NULL) die("out of memory");
+  if (jamd_gmm_outprob_host(c->gmm, fr, n, sc) != JAMD_OK) die("jamd_gmm_outprob_host");
+  if (jamd_fill_outprob_cache(wrk, sc, c->filled, n, c->nstate) != JAMD_OK) die("cache layout mismatch");
+  c->filled = T;
+  free(fr); free(sc);
+}
+
+LOGPROB __wrap_outprob_state(HMMWork *wrk, int t, HTK_HMM_State *stateinfo, HTK_Param *param)
+{
+  ensure(wrk, param);
+  return __real_outprob_state(wrk, t, stateinfo, param);
+}
+
+LOGPROB __wrap_outprob_cd(HMMWork *wrk, int t, CD_State_Set *lset, HTK_Param *param)
+{
+  ensure(wrk, param);
+  return __real_outprob_cd(wrk, t, lset, param);
+}
+
+LOGPROB __wrap_outprob(HMMWork *wrk, int t, HMM_STATE *hmmstate, HTK_Param *param)
+{
+  ensure(wrk, param);
+  return __real_outprob(wrk, t, hmmstate, param);
+}
+
+boolean __wrap_outprob_prepare(HMMWork *wrk, int framenum)
+{
+  wrap_ctx *c = ctx_get(wrk);
+  if (c != NULL) { c->param = NULL; c->filled = 0; }      /* outprob_cache_prepare() wipes the cache */
+  return __real_outprob_prepare(wrk, framenum);
+}
+
+void __wrap_outprob_free(HMMWork *wrk)
+{
+  int i;
+  for (i = 0; i < g_nctx; i++)
+    if (g_ctx[i].wrk == wrk) {
+      if (g_ctx[i].gmm) jamd_gmm_destroy(g_ctx[i].gmm);
+      g_ctx[i] = g_ctx[--g_nctx];
+      break;
+    }
+  __real_outprob_free(wrk);
+}

@@ -117,33 +117,6 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   return TRUE;
 }
 
-/* Make outprob_cache[0..T) exist (same growth rule and allocator as the static
- * outprob_cache_extend(), libsent/src/phmm/outprob.c:109-142) and copy the device scores
- * in: every later outprob_state(t, s) -- bt_discount_pescore() and the whole 2nd pass --
- * is then a cache hit (outprob.c:245-247) on values bit-identical to calc_mix()'s. */
-#define JAMD_LOG_UNDEF (LOG_ZERO - 1)      /* outprob.c:68 */
-static void fill_outprob_cache(HMMWork *wrk, const float *scores, int T, int S)
-{
-  int t, s;
-  if (S != wrk->statenum) return;
-  if (T > wrk->outprob_allocframenum) {
-    int newnum = T, size;
-    LOGPROB *tmpp;
-    if (newnum < wrk->outprob_allocframenum + OUTPROB_CACHE_PERIOD) newnum = wrk->outprob_allocframenum + OUTPROB_CACHE_PERIOD;
-    size = (newnum - wrk->outprob_allocframenum) * wrk->statenum;
-    if (wrk->outprob_cache == NULL) wrk->outprob_cache = (LOGPROB **)mymalloc(sizeof(LOGPROB *) * newnum);
-    else wrk->outprob_cache = (LOGPROB **)myrealloc(wrk->outprob_cache, sizeof(LOGPROB *) * newnum);
-    tmpp = (LOGPROB *)mybmalloc2(sizeof(LOGPROB) * size, &(wrk->croot));
-    for (t = wrk->outprob_allocframenum; t < newnum; t++) {
-      wrk->outprob_cache[t] = &(tmpp[(t - wrk->outprob_allocframenum) * wrk->statenum]);
-      for (s = 0; s < wrk->statenum; s++) wrk->outprob_cache[t][s] = JAMD_LOG_UNDEF;
-    }
-    wrk->outprob_allocframenum = newnum;
-  }
-  for (t = 0; t < T; t++) memcpy(wrk->outprob_cache[t], scores + (size_t)t * S, sizeof(float) * S);
-  wrk->OP_time = -1;      /* force outprob_state() to re-latch last_cache for its frame */
-}
-
 boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
 {
   pass1_ctx *c = ctx_get(r);
@@ -196,7 +169,7 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
     float *host_scores = (float *)malloc(sizeof(float) * (size_t)T * c->nstate);
     if (host_scores != NULL &&
         jamd_memcpy_d2h(g_eng, host_scores, d_scores, sizeof(float) * (size_t)T * c->nstate) == JAMD_OK)
-      fill_outprob_cache(&(r->am->hmmwrk), host_scores, T, c->nstate);
+      jamd_fill_outprob_cache(&(r->am->hmmwrk), host_scores, 0, T, c->nstate);
     free(host_scores);
   }
   if (res.status == JAMD_PASS1_OVERFLOW) { jlog("ERROR: jamd: word trellis overflow\n"); goto done; }

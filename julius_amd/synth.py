@@ -640,3 +640,50 @@ def make_lexicon_utterance(lex, model, nwords=8, seed=0, frames_per_state=3, noi
     st = np.repeat(np.array(seq), frames_per_state)
     fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
     return fr.astype(np.float32), ws
+
+
+# --------------------------------------------------- grammar task (BASELINE configs[0] shape)
+def make_grammar_task(workdir, nphone=12, nword=100, nbook=2, K=64, D=39, seed=0, maxlen=4):
+    """Tied-mixture monophone GMM-HMM (HTK ascii, <TMix> codebooks) + an `nword`-word
+    loop grammar in Julius' DFA format: <s> WORD+ </s>.  The automaton is written
+    reversed, as mkdfa.pl emits it (libsent/src/dfa/rddfa.c:141-200): state 0 consumes
+    the sentence-final category.  Returns paths and the word list."""
+    workdir = Path(workdir)
+    workdir.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    S = 3 * (nphone + 2)
+    model = make_tied_gmm(S=S, nbook=nbook, K=K, D=D, seed=seed + 1)
+    names = [f"p{i}" for i in range(nphone)] + ["silB", "silE"]
+    phones = [(names[i], (3 * i, 3 * i + 1, 3 * i + 2)) for i in range(nphone + 2)]
+    write_hmmdefs(workdir / "hmmdefs", model, phones=phones)
+    words, seen = [], set()
+    while len(words) < nword:
+        ph = tuple(int(x) for x in rng.integers(0, nphone, size=int(rng.integers(1, maxlen + 1))))
+        if ph in seen:
+            continue
+        seen.add(ph)
+        words.append((f"W{len(words):03d}", ph))
+    # categories: 0 = </s>, 1 = words, 2 = <s>
+    dl = ["0 [</s>] silE", "2 [<s>] silB"] + [f"1 [{w}] " + " ".join(f"p{p}" for p in ph) for w, ph in words]
+    (workdir / "g.dict").write_text("\n".join(dl) + "\n")
+    (workdir / "g.dfa").write_text("0 0 1 0 0\n1 1 1 0 0\n1 2 2 0 0\n2 -1 -1 1 0\n")
+    # state centres for utterance synthesis: mean of each state's heaviest codebook Gaussian
+    off = model["st_off"]
+    centre = np.stack([model["mean"][model["ent_dens"][off[s] + int(np.argmax(model["weight"][off[s]:off[s + 1]]))]]
+                       for s in range(S)])
+    return dict(dir=workdir, hmmdefs=workdir / "hmmdefs", dfa=workdir / "g.dfa", dict=workdir / "g.dict",
+                model=model, words=words, nphone=nphone, centre=centre)
+
+
+def make_grammar_utterance(task, nwords=4, seed=0, frames_per_state=3, noise=0.5):
+    rng = np.random.default_rng(seed)
+    n = task["nphone"]
+    ws = [task["words"][int(i)] for i in rng.integers(0, len(task["words"]), size=nwords)]
+    seq = [3 * n, 3 * n + 1, 3 * n + 2]
+    for _, ph in ws:
+        for p in ph:
+            seq += [3 * p, 3 * p + 1, 3 * p + 2]
+    seq += [3 * (n + 1), 3 * (n + 1) + 1, 3 * (n + 1) + 2]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = task["centre"][st] + rng.normal(0, noise, size=(len(st), task["centre"].shape[1]))
+    return fr.astype(np.float32), [w for w, _ in ws]

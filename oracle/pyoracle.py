@@ -18,6 +18,7 @@ HERE = Path(__file__).resolve().parent
 ORACLE_SO = HERE / "liboracle.so"
 REF_SO = HERE / "_ref" / "libjref.so"
 REF_AMD_SO = HERE / "_ref" / "libjref_amd.so"   # same reference, first pass served by julius_amd/shim
+REF_O_SO = HERE / "_ref" / "libjref_o.so"       # same reference (own beam), scoring entry points wrapped (boundary O)
 
 GPRUNE_NONE, GPRUNE_SAFE = 0, 1
 # reference enum (libsent/include/sent/hmm_calc.h:45)

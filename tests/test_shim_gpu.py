@@ -58,3 +58,56 @@ def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, s
                 assert np.array_equal(tr1[k], tr0[k]), k
         else:
             assert_canonical_close(tr1, tr0, max_diff=8)
+
+
+# ------------------------------------------------------------------ boundary O (scoring only)
+def _compare_exact(plain, wrapped, mfc):
+    tr0, (w0, s0) = plain.recognize(mfc)
+    st0, f0, fs0 = plain.final_result()
+    d0, n0 = plain.cache_fill()
+    tr1, (w1, s1) = wrapped.recognize(mfc)
+    st1, f1, fs1 = wrapped.final_result()
+    d1, n1 = wrapped.cache_fill()
+    assert d1 == n1 == n0 and d0 < n0            # every (t, s) came from the device
+    assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0
+    assert np.array_equal(f1, f0) and fs1 == fs0
+    for k in tr0:                                # the reference's own beam: no tie caveat, exact
+        assert np.array_equal(tr1[k], tr0[k]), k
+
+
+@pytest.mark.parametrize("seed,beam,extra", [
+    (41, 200, ["-sepnum", "5", "-gprune", "none"]),
+    (42, 100, ["-sepnum", "3", "-gprune", "safe", "-tmix", "3", "-iwcd1", "max"]),
+])
+def test_reference_search_over_device_scores(ref, tmp_path, seed, beam, extra):
+    """libjref_o.so: the complete reference (CPU beam, 2nd pass) with outprob_state/_cd/outprob/
+    outprob_prepare/outprob_free wrapped by julius_amd/shim/jamd_outprob_wrap.c.  Identical
+    trellis, pass-1 and final results; the outprob cache is filled entirely by the device."""
+    if not pyoracle.REF_O_SO.exists():
+        pytest.skip("oracle/_ref/libjref_o.so not built")
+    task = synth.make_triphone_task(tmp_path, seed=seed, nword=120, nphone=10, S=160)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-b", str(beam), "-b2", "30", "-n", "1", "-s", "500"] + list(extra)
+    plain = pyoracle.RefEngine(ref, args)
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_O_SO), args)
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        _compare_exact(plain, wrapped, tmp_path / "u.mfc")
+
+
+def test_c1_tied_mixture_grammar_over_device_scores(ref, tmp_path):
+    """BASELINE configs[0] shape on the GPU: tied-mixture monophone GMM-HMM + a 100-word DFA
+    grammar.  The grammar search is the reference's; the tied-mixture scoring (codebook
+    top-N cache + per-state re-weighting, calc_tied_mix.c:162) runs on the device."""
+    if not pyoracle.REF_O_SO.exists():
+        pytest.skip("oracle/_ref/libjref_o.so not built")
+    task = synth.make_grammar_task(tmp_path, seed=7)
+    args = ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam",
+            "-gprune", "safe", "-tmix", "2", "-b", "200"]
+    plain = pyoracle.RefEngine(ref, args)
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_O_SO), args)
+    for u in range(3):
+        fr, _ = synth.make_grammar_utterance(task, nwords=3 + u, seed=u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        _compare_exact(plain, wrapped, tmp_path / "u.mfc")
