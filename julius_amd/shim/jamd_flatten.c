@@ -154,3 +154,27 @@ int jamd_fill_outprob_cache(HMMWork *wrk, const float *scores, int t0, int n, in
   wrk->OP_time = -1;      /* force outprob_state() to re-latch last_cache for its frame */
   return JAMD_OK;
 }
+
+int jamd_flatten_dnn(DNNData *dnn, jamd_flat_dnn *out)
+{
+  int nl = dnn->hnum + 1, l;
+  memset(out, 0, sizeof(*out));
+  out->dims = (int *)malloc(sizeof(int) * (nl + 1));
+  out->w = (const float **)malloc(sizeof(float *) * nl);
+  out->b = (const float **)malloc(sizeof(float *) * nl);
+  for (l = 0; l < dnn->hnum; l++) {
+    out->dims[l] = dnn->h[l].in;
+    if (l > 0 && dnn->h[l].in != dnn->h[l - 1].out) return JAMD_EINVAL;
+    out->w[l] = dnn->h[l].w; out->b[l] = dnn->h[l].b;
+  }
+  out->dims[dnn->hnum] = dnn->o.in;
+  out->dims[nl] = dnn->o.out;
+  if (dnn->hnum > 0 && dnn->o.in != dnn->h[dnn->hnum - 1].out) return JAMD_EINVAL;
+  out->w[dnn->hnum] = dnn->o.w; out->b[dnn->hnum] = dnn->o.b;
+  out->desc.nlayer = nl; out->desc.dims = out->dims;
+  out->desc.w = out->w; out->desc.b = out->b;
+  out->desc.state_prior = dnn->state_prior;      /* log10 already applied by dnn_setup() (calc_dnn.c:699-703) */
+  return JAMD_OK;
+}
+
+void jamd_flat_dnn_free(jamd_flat_dnn *f) { free(f->dims); free((void *)f->w); free((void *)f->b); memset(f, 0, sizeof(*f)); }

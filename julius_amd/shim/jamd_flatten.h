@@ -14,6 +14,7 @@
 #include <sent/htk_param.h>
 #include <sent/hmm.h>
 #include <sent/hmm_calc.h>
+#include <sent/dnn.h>
 #include "julius_amd.h"
 
 #ifdef __cplusplus
@@ -40,6 +41,16 @@ void jamd_flat_gmm_free(jamd_flat_gmm *f);
 /* Pack HTK_Param rows (each parvec[t] is a separate allocation,
  * libsent/src/anlz/param_malloc.c:52-77) into one [T][veclen] block. */
 float *jamd_pack_param(const HTK_Param *param, int t0, int t1);
+
+/* DNNData (libsent/include/sent/dnn.h:41-74) -> jamd_dnn_desc.  The weight matrices are
+ * already contiguous [out][in] float arrays, so the descriptor points straight into the
+ * DNNData (nothing is copied; `f` only owns the small pointer tables). */
+typedef struct {
+  jamd_dnn_desc desc;
+  int *dims; const float **w; const float **b;
+} jamd_flat_dnn;
+int  jamd_flatten_dnn(DNNData *dnn, jamd_flat_dnn *out);
+void jamd_flat_dnn_free(jamd_flat_dnn *f);
 
 /* Copy n rows of [.][S] device scores into wrk->outprob_cache starting at frame t0 (growing
  * the cache like the reference's static outprob_cache_extend()), so that later outprob_state()

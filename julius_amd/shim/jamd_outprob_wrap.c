@@ -19,8 +19,8 @@
  * calc_tied_mix().
  *
  * Supported: GMM acoustic models (plain or tied-mixture), single stream, -gprune none
- * or -gprune safe.  Anything else (heu/beam pruning, GMS, multi-stream, DNN, -input
- * outprob) is left to libsent's CPU code with one log line -- those paths are outside
+ * or -gprune safe; DNN acoustic models (-dnnconf).  Anything else (heu/beam pruning, GMS,
+ * multi-stream, -input outprob) is left to libsent's CPU code with one log line -- those paths are outside
  * the engine's scope.  A supported configuration without a usable
  * gfx950 device is a hard error (exit), as in the reference's own CUDA path
  * (libsent/src/phmm/calc_dnn_cuda.cu:22-32).
@@ -41,6 +41,7 @@ typedef struct {
   HMMWork *wrk;
   int state;                 /* 0 = not examined, 1 = device, 2 = left to libsent */
   jamd_gmm *gmm;
+  jamd_dnn *dnn;
   int nstate;
   const HTK_Param *param;    /* utterance the cache was filled for */
   int filled;                /* frames [0, filled) are in the cache */
@@ -73,8 +74,23 @@ static void examine(wrap_ctx *c)
   int gprune;
   jamd_flat_gmm fg;
   c->state = 2;
-  if (wrk->OP_dnn != NULL || wrk->OP_gshmm != NULL || wrk->OP_nstream != 1) {
-    jlog("Stat: jamd: DNN / GMS / multi-stream scoring stays on libsent's CPU code\n");
+  if (wrk->OP_gshmm != NULL || (wrk->OP_dnn == NULL && wrk->OP_nstream != 1)) {
+    jlog("Stat: jamd: GMS / multi-stream scoring stays on libsent's CPU code\n");
+    return;
+  }
+  if (jamd_abi_version() != JAMD_ABI_VERSION) die("ABI mismatch between shim and libjulius_amd.so");
+  if (g_eng == NULL) {
+    const char *dev = getenv("JAMD_DEVICE");
+    if (jamd_engine_create(dev ? atoi(dev) : 0, &g_eng) != JAMD_OK) die("no usable gfx950 device");
+  }
+  if (wrk->OP_dnn != NULL) {                /* dnn_calc_outprob(), calc_dnn.c:774, for whole utterances */
+    jamd_flat_dnn fd;
+    if (jamd_flatten_dnn(wrk->OP_dnn, &fd) != JAMD_OK) die("cannot flatten the DNN");
+    if (jamd_dnn_create(g_eng, &fd.desc, &c->dnn) != JAMD_OK) die("jamd_dnn_create");
+    c->nstate = fd.desc.dims[fd.desc.nlayer];
+    jamd_flat_dnn_free(&fd);
+    c->state = 1;
+    jlog("Stat: jamd: DNN scoring on HIP device %d (%d outputs)\n", jamd_engine_device(g_eng), c->nstate);
     return;
   }
   if (wrk->compute_gaussset == gprune_none) gprune = JAMD_GPRUNE_NONE;
@@ -82,11 +98,6 @@ static void examine(wrap_ctx *c)
   else {
     jlog("Stat: jamd: this -gprune method depends on the previous frame; scoring stays on libsent's CPU code\n");
     return;
-  }
-  if (jamd_abi_version() != JAMD_ABI_VERSION) die("ABI mismatch between shim and libjulius_amd.so");
-  if (g_eng == NULL) {
-    const char *dev = getenv("JAMD_DEVICE");
-    if (jamd_engine_create(dev ? atoi(dev) : 0, &g_eng) != JAMD_OK) die("no usable gfx950 device");
   }
   if (jamd_flatten_hmminfo(wrk->OP_hmminfo, &fg) != 0) die("cannot flatten the acoustic model");
   if (jamd_gmm_create(g_eng, &fg.desc, gprune, wrk->OP_gprune_num, &c->gmm) != JAMD_OK) die("jamd_gmm_create");
@@ -112,7 +123,10 @@ static void ensure(HMMWork *wrk, HTK_Param *param)
   fr = jamd_pack_param(param, c->filled, T);
   sc = (float *)malloc(sizeof(float) * (size_t)n * c->nstate);
   if (fr == NULL || sc == NULL) die("out of memory");
-  if (jamd_gmm_outprob_host(c->gmm, fr, n, sc) != JAMD_OK) die("jamd_gmm_outprob_host");
+  if (c->dnn != NULL) {
+    if (param->veclen != jamd_dnn_veclen(c->dnn)) die("feature vectors are not spliced to the DNN input length");
+    if (jamd_dnn_outprob_host(c->dnn, fr, n, sc) != JAMD_OK) die("jamd_dnn_outprob_host");
+  } else if (jamd_gmm_outprob_host(c->gmm, fr, n, sc) != JAMD_OK) die("jamd_gmm_outprob_host");
   if (jamd_fill_outprob_cache(wrk, sc, c->filled, n, c->nstate) != JAMD_OK) die("cache layout mismatch");
   c->filled = T;
   free(fr); free(sc);
@@ -149,6 +163,7 @@ void __wrap_outprob_free(HMMWork *wrk)
   for (i = 0; i < g_nctx; i++)
     if (g_ctx[i].wrk == wrk) {
       if (g_ctx[i].gmm) jamd_gmm_destroy(g_ctx[i].gmm);
+      if (g_ctx[i].dnn) jamd_dnn_destroy(g_ctx[i].dnn);
       g_ctx[i] = g_ctx[--g_nctx];
       break;
     }

@@ -111,3 +111,45 @@ def test_c1_tied_mixture_grammar_over_device_scores(ref, tmp_path):
         fr, _ = synth.make_grammar_utterance(task, nwords=3 + u, seed=u)
         synth.write_htk_param(tmp_path / "u.mfc", fr)
         _compare_exact(plain, wrapped, tmp_path / "u.mfc")
+
+
+def test_c4_dnn_over_device_scores(ref, tmp_path):
+    """DNN-HMM (-dnnconf) through the scoring wrapper: dnn_calc_outprob()'s work is done by the
+    MFMA kernels for the whole utterance, Julius' own first and second pass consume the cache.
+    Bit-identical trellis and results require the reference to run its FMA kernel (it picks
+    the best SIMD path of the host CPU)."""
+    if not pyoracle.REF_O_SO.exists():
+        pytest.skip("oracle/_ref/libjref_o.so not built")
+    if b"FMA" not in ref.lib.jref_simd_string():
+        pytest.skip("reference built without its FMA kernel")
+    task = synth.make_triphone_task(tmp_path, seed=51, nword=80, nphone=8, S=120)
+    S, IN, H = 120, 48, 64
+    dnn = synth.make_dnn(dims=(IN, H, H, S), seed=51)
+    for l, (w, b) in enumerate(zip(dnn["w"], dnn["b"])):
+        synth.write_npy(tmp_path / f"W{l}.npy", w)
+        synth.write_npy(tmp_path / f"b{l}.npy", np.asarray(b).reshape(-1, 1))
+    with open(tmp_path / "prior", "w") as f:
+        for i, v in enumerate(dnn["prior_lin"]):
+            f.write(f"{i} {float(v):.9e}\n")
+    (tmp_path / "dnn.conf").write_text(
+        f"feature_type USER\nfeature_len {IN}\ncontext_len 1\ninput_nodes {IN}\noutput_nodes {S}\n"
+        f"hidden_nodes {H}\nhidden_layers 2\nW1 W0.npy\nW2 W1.npy\nB1 b0.npy\nB2 b1.npy\noutput_W W2.npy\n"
+        f"output_B b2.npy\nstate_prior prior\nstate_prior_factor 1.0\nstate_prior_log10nize yes\nnum_threads 1\n")
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-dnnconf", tmp_path / "dnn.conf", "-input", "htkparam", "-notypecheck", "-b", "150", "-b2", "30",
+            "-n", "1", "-s", "500", "-sepnum", "4"]
+    plain = pyoracle.RefEngine(ref, args)
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_O_SO), args)
+    rng = np.random.default_rng(51)
+    for u in range(3):
+        fr = rng.normal(0, 1, (60 + 40 * u, IN)).astype(np.float32)
+        synth.write_htk_param(tmp_path / "u.mfc", fr, parmkind=synth.PARM_USER)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = plain.final_result()
+        tr1, (w1, s1) = wrapped.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = wrapped.final_result()
+        d1, n1 = wrapped.cache_fill()
+        assert d1 == n1
+        assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0 and np.array_equal(f1, f0) and fs1 == fs0
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k
