@@ -21,8 +21,8 @@
  * indexes it with bt_relocate_rw / bt_sort_rw exactly as the reference does.
  *
  * Supported configuration (anything else is refused loudly at _init()): N-gram
- * LM, non-multipath GMM acoustic model with -gprune none|safe, no short-pause
- * segmentation, buffered input.  The "no nodes left in beam" condition is
+ * LM, non-multipath acoustic model -- GMM with -gprune none|safe, or DNN (-dnnconf) --
+ * no short-pause segmentation, buffered input.  The "no nodes left in beam" condition is
  * reported by failing the utterance (J_RESULT_STATUS_FAIL) instead of segmenting.
  */
 #include <stdlib.h>
@@ -35,7 +35,7 @@ typedef struct {
   WCHMM_INFO *wchmm;           /* lexicon the handles were built from */
   HTK_HMM_INFO *hmminfo;
   int beam_width; float bs_width;
-  jamd_gmm *gmm; jamd_lexicon *lex; jamd_beam *beam;
+  jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam;
   int nstate;
 } pass1_ctx;
 
@@ -48,7 +48,8 @@ static void ctx_release(pass1_ctx *c)
   if (c->beam) jamd_beam_destroy(c->beam);
   if (c->lex) jamd_lexicon_destroy(c->lex);
   if (c->gmm) jamd_gmm_destroy(c->gmm);
-  c->beam = NULL; c->lex = NULL; c->gmm = NULL;
+  if (c->dnn) jamd_dnn_destroy(c->dnn);
+  c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL;
 }
 
 static pass1_ctx *ctx_get(RecogProcess *r)
@@ -63,7 +64,7 @@ static pass1_ctx *ctx_get(RecogProcess *r)
 
 static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
 {
-  int gprune, rc;
+  int gprune = JAMD_GPRUNE_NONE, rc;
   if (jamd_abi_version() != JAMD_ABI_VERSION) {   /* header this shim was compiled with vs the loaded library */
     jlog("ERROR: jamd: libjulius_amd.so has ABI %d, this shim was built for %d\n", jamd_abi_version(), JAMD_ABI_VERSION);
     return FALSE;
@@ -78,24 +79,33 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   if (c->wchmm == r->wchmm && c->hmminfo == r->am->hmminfo && c->beam_width == r->trellis_beam_width &&
       c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL) return TRUE;
   ctx_release(c);
-  if (r->lmtype != LM_PROB || r->am->hmminfo->multipath || r->config->successive.enabled || r->am->dnn != NULL) {
-    jlog("ERROR: jamd: the device first pass covers N-gram LM, non-multipath GMM models, no -spsegment\n");
+  if (r->lmtype != LM_PROB || r->am->hmminfo->multipath || r->config->successive.enabled) {
+    jlog("ERROR: jamd: the device first pass covers N-gram LM, non-multipath models, no -spsegment\n");
     return FALSE;
   }
-  switch (r->am->config->gprune_method) {      /* jconf.h:94, values hmm_calc.h:38-45 */
-  case GPRUNE_SEL_NONE: gprune = JAMD_GPRUNE_NONE; break;
-  case GPRUNE_SEL_SAFE: gprune = JAMD_GPRUNE_SAFE; break;
-  default:
-    jlog("ERROR: jamd: run with -gprune none or -gprune safe (heu/beam are frame-order dependent)\n");
-    return FALSE;
-  }
-  {
-    jamd_flat_gmm fg;
-    if (jamd_flatten_hmminfo(r->am->hmminfo, &fg) != 0) { jlog("ERROR: jamd: cannot flatten the acoustic model\n"); return FALSE; }
-    rc = jamd_gmm_create(g_eng, &fg.desc, gprune, r->am->hmmwrk.OP_gprune_num, &c->gmm);
-    c->nstate = fg.desc.nstate;
-    jamd_flat_gmm_free(&fg);
+  if (r->am->dnn != NULL) {                    /* DNN-HMM: dnn_calc_outprob() for the whole utterance */
+    jamd_flat_dnn fd;
+    if (jamd_flatten_dnn(r->am->dnn, &fd) != JAMD_OK) { jlog("ERROR: jamd: cannot flatten the DNN\n"); return FALSE; }
+    rc = jamd_dnn_create(g_eng, &fd.desc, &c->dnn);
+    c->nstate = fd.desc.dims[fd.desc.nlayer];
+    jamd_flat_dnn_free(&fd);
     if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  } else {
+    switch (r->am->config->gprune_method) {      /* jconf.h:94, values hmm_calc.h:38-45 */
+    case GPRUNE_SEL_NONE: gprune = JAMD_GPRUNE_NONE; break;
+    case GPRUNE_SEL_SAFE: gprune = JAMD_GPRUNE_SAFE; break;
+    default:
+      jlog("ERROR: jamd: run with -gprune none or -gprune safe (heu/beam are frame-order dependent)\n");
+      return FALSE;
+    }
+    {
+      jamd_flat_gmm fg;
+      if (jamd_flatten_hmminfo(r->am->hmminfo, &fg) != 0) { jlog("ERROR: jamd: cannot flatten the acoustic model\n"); return FALSE; }
+      rc = jamd_gmm_create(g_eng, &fg.desc, gprune, r->am->hmmwrk.OP_gprune_num, &c->gmm);
+      c->nstate = fg.desc.nstate;
+      jamd_flat_gmm_free(&fg);
+      if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+    }
   }
   {
     jamd_flat_lexicon fl;
@@ -156,7 +166,8 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
       jamd_malloc(g_eng, sizeof(float) * (size_t)T * param->veclen, (void **)&d_frames) != JAMD_OK ||
       jamd_malloc(g_eng, sizeof(float) * (size_t)T * c->nstate, (void **)&d_scores) != JAMD_OK ||
       jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * (size_t)T * param->veclen) != JAMD_OK ||
-      jamd_gmm_outprob_dev(c->gmm, d_frames, T, d_scores, NULL) != JAMD_OK ||
+      (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, T, d_scores, NULL)
+              : jamd_gmm_outprob_dev(c->gmm, d_frames, T, d_scores, NULL)) != JAMD_OK ||
       jamd_beam_pass1_dev(c->beam, d_scores, c->nstate, off, 1, NULL) != JAMD_OK ||
       jamd_beam_results(c->beam, &res, 1) != JAMD_OK) {
     jlog("ERROR: jamd: first pass failed: %s\n", jamd_last_error());

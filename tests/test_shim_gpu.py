@@ -113,13 +113,16 @@ def test_c1_tied_mixture_grammar_over_device_scores(ref, tmp_path):
         _compare_exact(plain, wrapped, tmp_path / "u.mfc")
 
 
-def test_c4_dnn_over_device_scores(ref, tmp_path):
+@pytest.mark.parametrize("so,strict", [("o", False), ("amd", True)])
+def test_c4_dnn_over_device_scores(ref, tmp_path, monkeypatch, so, strict):
     """DNN-HMM (-dnnconf) through the scoring wrapper: dnn_calc_outprob()'s work is done by the
     MFMA kernels for the whole utterance, Julius' own first and second pass consume the cache.
     Bit-identical trellis and results require the reference to run its FMA kernel (it picks
     the best SIMD path of the host CPU)."""
-    if not pyoracle.REF_O_SO.exists():
-        pytest.skip("oracle/_ref/libjref_o.so not built")
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if strict else "0")   # "amd": device first pass too (exact order)
+    lib_so = pyoracle.REF_O_SO if so == "o" else pyoracle.REF_AMD_SO
+    if not lib_so.exists():
+        pytest.skip(f"{lib_so} not built")
     if b"FMA" not in ref.lib.jref_simd_string():
         pytest.skip("reference built without its FMA kernel")
     task = synth.make_triphone_task(tmp_path, seed=51, nword=80, nphone=8, S=120)
@@ -139,7 +142,7 @@ def test_c4_dnn_over_device_scores(ref, tmp_path):
             "-dnnconf", tmp_path / "dnn.conf", "-input", "htkparam", "-notypecheck", "-b", "150", "-b2", "30",
             "-n", "1", "-s", "500", "-sepnum", "4"]
     plain = pyoracle.RefEngine(ref, args)
-    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_O_SO), args)
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=lib_so), args)
     rng = np.random.default_rng(51)
     for u in range(3):
         fr = rng.normal(0, 1, (60 + 40 * u, IN)).astype(np.float32)
