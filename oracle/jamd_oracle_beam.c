@@ -14,12 +14,11 @@
  * spsegment).  Paths below are relative to the reference root.
  *
  * Parity status: PINNED against the compiled reference (oracle/_ref) by
- * tests/test_beam_oracle_vs_ref.py and the fixtures under tests/golden/.
+ * tests/test_beam_oracle.py and the fixtures under tests/golden/.
  */
 #include <stdlib.h>
 #include <string.h>
 #include "jamd_oracle.h"
-#include "../include/julius_amd.h"
 
 typedef struct {          /* TOKEN2, libjulius/include/julius/beam.h:35-45 */
   int   last_tre;         /* index into atoms[], -1 = FSBeam.bos */
