@@ -99,7 +99,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: always rendezvous
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -213,6 +213,11 @@ def main_dnn(args):
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dnn = synth.make_dnn(seed=0)
     T = args.utts * FRAMES_PER_UTT
     frames = np.random.default_rng(100 + rank).normal(0, 1, (T, 528)).astype(np.float32)
@@ -225,6 +230,9 @@ def main_dnn(args):
     for _ in range(args.warmup):
         net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
@@ -232,23 +240,38 @@ def main_dnn(args):
         net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
         b.record(stream)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dims = [int(x) for x in dnn["dims"]]
     flops = 2.0 * T * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     from oracle import pyoracle
     tt = np.array([0, T // 2, T - 1])
     want = pyoracle.Oracle().dnn_outprob(dnn, frames[tt], pyoracle.DNN_FMA)
     got = d_out[torch.from_numpy(tt).cuda()].cpu().numpy()
-    line = {"metric": "frames_x_states_scored_per_sec", "value": T * args.steps * net.S / elapsed,
+    line = {"metric": "frames_x_states_scored_per_sec", "value": T * world * args.steps * net.S / elapsed,
             "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": T * args.steps / 100.0 / elapsed,
-            "config": {"workload": f"C4 scoring half (BASELINE.json configs[3]): DNN {dims}, {T} frames per step"},
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": T * world * args.steps / 100.0 / elapsed,
+            "config": {"workload": f"C4 scoring half (BASELINE.json configs[3]): DNN {dims}, {T} frames per GPU per step",
+                       "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel_ms": ms},
             "parity_spot_check": bool(np.array_equal(got, want))}
     print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main_e2e(args):
@@ -264,7 +287,7 @@ def main_e2e(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: always rendezvous
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
