@@ -43,6 +43,25 @@ def load(path) -> dict:
     return lex
 
 
+def load_gmm(path) -> dict:
+    """Acoustic-model blob written by jamd_gmm_save() -> the model dict lib.Gmm takes."""
+    raw = Path(path).read_bytes()
+    if raw[:8] != b"JAMDGMM1":
+        raise ValueError(f"{path}: not a JAMDGMM1 blob")
+    (nrec,) = struct.unpack_from("<i", raw, 8)
+    pos, rec = 12, {}
+    for _ in range(nrec):
+        name = raw[pos:pos + 24].split(b"\0", 1)[0].decode()
+        dtype, count = struct.unpack_from("<ii", raw, pos + 24)
+        pos += 32
+        rec[name] = np.frombuffer(raw, dtype=_DT[dtype], count=count, offset=pos).copy()
+        pos += 4 * count
+    S, D, G, E, nbook, nstream = (int(x) for x in rec.pop("ints"))
+    return dict(mean=rec["mean"].reshape(G, D), ivar=rec["ivar"].reshape(G, D), gconst=rec["gconst"],
+                st_off=rec["st_off"], ent_dens=rec["ent_dens"], ent_logw=rec["ent_logw"],
+                st_book=rec.get("st_book") if nbook > 0 else None, nbook=nbook, nstream=nstream)
+
+
 def save(lex: dict, path) -> None:
     """Same format as jamd_lexicon_save() (used to commit small golden fixtures)."""
     out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS))]

@@ -8,6 +8,7 @@
  *   GCODEBOOK {num, d[], id}                  htk_hmm.h:196-201
  *   HTK_HMM_Dens {mean, var->vec, gconst}     htk_hmm.h:120-131
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "jamd_flatten.h"
@@ -178,3 +179,35 @@ int jamd_flatten_dnn(DNNData *dnn, jamd_flat_dnn *out)
 }
 
 void jamd_flat_dnn_free(jamd_flat_dnn *f) { free(f->dims); free((void *)f->w); free((void *)f->b); memset(f, 0, sizeof(*f)); }
+
+/* ---- acoustic-model blob ---------------------------------------------------------------
+ * Same container as the lexicon blob (jamd_flatten_lex.c): magic "JAMDGMM1", int32 nrec,
+ * then records {char name[24], int32 dtype (0 int32, 1 float32), int32 count, payload}.
+ * Lets batch workers load the flattened model without linking Julius. */
+static int gmm_put(FILE *f, const char *name, int dtype, int count, const void *data)
+{
+  char nm[24];
+  memset(nm, 0, sizeof(nm)); strncpy(nm, name, sizeof(nm) - 1);
+  if (fwrite(nm, 1, 24, f) != 24 || fwrite(&dtype, 4, 1, f) != 1 || fwrite(&count, 4, 1, f) != 1) return -1;
+  if (count > 0 && fwrite(data, 4, (size_t)count, f) != (size_t)count) return -1;
+  return 0;
+}
+
+int jamd_gmm_save(const jamd_gmm_desc *d, const char *path)
+{
+  FILE *f = fopen(path, "wb");
+  int nrec = d->st_book ? 8 : 7, rc = 0, ints[6];
+  if (f == NULL) return JAMD_EINVAL;
+  ints[0] = d->nstate; ints[1] = d->veclen; ints[2] = d->ndens; ints[3] = d->nentry; ints[4] = d->nbook; ints[5] = d->nstream;
+  fwrite("JAMDGMM1", 1, 8, f); fwrite(&nrec, 4, 1, f);
+  rc |= gmm_put(f, "ints", 0, 6, ints);
+  rc |= gmm_put(f, "mean", 1, d->ndens * d->veclen, d->mean);
+  rc |= gmm_put(f, "ivar", 1, d->ndens * d->veclen, d->ivar);
+  rc |= gmm_put(f, "gconst", 1, d->ndens, d->gconst);
+  rc |= gmm_put(f, "st_off", 0, d->nstate + 1, d->st_off);
+  rc |= gmm_put(f, "ent_dens", 0, d->nentry, d->ent_dens);
+  rc |= gmm_put(f, "ent_logw", 1, d->nentry, d->ent_logw);
+  if (d->st_book) rc |= gmm_put(f, "st_book", 0, d->nstate, d->st_book);
+  if (fclose(f) != 0) rc = -1;
+  return rc ? JAMD_EINVAL : JAMD_OK;
+}

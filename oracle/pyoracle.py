@@ -282,6 +282,10 @@ class RefAM:
             m["st_book"] = None
         return m
 
+    def save_blob(self, path):
+        self.ref.lib.jref_am_save.argtypes = [C.c_void_p, C.c_char_p]
+        assert self.ref.lib.jref_am_save(self.h, str(path).encode()) == 0
+
     def outprob(self, frames, want_out=True):
         fr = _f32(frames)
         T = fr.shape[0]

@@ -71,6 +71,7 @@ void jref_am_free(void *h)
   free(a);
 }
 
+int jref_am_save(void *h, const char *path);
 static int ensure_flat(jref_am *a)
 {
   if (a->have_flat) return 0;
@@ -433,4 +434,12 @@ int jref_engine_cache_fill(void *h, int *defined, int *total)
       if (wrk->outprob_cache[t][s] != (LOG_ZERO - 1)) n++;
   *defined = n; *total = T * wrk->statenum;
   return 0;
+}
+
+/* The loaded acoustic model through the product shim's blob writer (jamd_gmm_save). */
+int jref_am_save(void *h, const char *path)
+{
+  jref_am *a = (jref_am *)h;
+  if (ensure_flat(a) != 0) return -1;
+  return jamd_gmm_save(&a->flat.desc, path);
 }

@@ -65,3 +65,20 @@ def test_dnn(ref, oracle, tmp_path, dims):
     r = ref.dnn_load(dnn, tmp_path)
     fr = np.random.default_rng(1).normal(0, 1.5, (15, dims[0])).astype(np.float32)
     assert np.array_equal(oracle.dnn_outprob(dnn, fr, po.DNN_FMA), r.outprob(fr))
+
+
+def test_gmm_blob_roundtrip(ref, tmp_path):
+    """jamd_gmm_save() (reference-side shim) -> lexblob.load_gmm(): the same arrays the
+    in-memory export gives, for a plain and a tied-mixture model."""
+    from julius_amd import lexblob
+    for name, m in (("plain", synth.make_gmm(S=12, M=3, D=39, seed=5, ragged=True)),
+                    ("tied", synth.make_tied_gmm(S=12, nbook=2, K=8, D=39, seed=6))):
+        synth.write_hmmdefs(tmp_path / name, m)
+        am = ref.am_load(tmp_path / name)
+        am.save_blob(tmp_path / f"{name}.blob")
+        a, b = am.export(), lexblob.load_gmm(tmp_path / f"{name}.blob")
+        for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+        assert (a["st_book"] is None) == (b["st_book"] is None) and a["nbook"] == b["nbook"]
+        if a["st_book"] is not None:
+            assert np.array_equal(a["st_book"], b["st_book"])
