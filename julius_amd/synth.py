@@ -220,7 +220,7 @@ def write_npy(path, a):
 
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
-                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False):
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0):
     """Write a complete synthetic recognition task the reference can load:
     tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
     forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
@@ -274,7 +274,10 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
             continue
         seen.add(ph)
         words.append((f"W{len(words):04d}", ph))
-    dl = ["<s> [] silB", "</s> [] silE"] + [f"{w} [{w}] " + " ".join(ph) for w, ph in words]
+    # the first `ntransparent` words are written {transparent} (libsent/src/voca/voca_load_htkdict.c:463-468):
+    # the LM context skips them
+    dl = ["<s> [] silB", "</s> [] silE"] + [
+        (f"{w} {{{w}}} " if i < ntransparent else f"{w} [{w}] ") + " ".join(ph) for i, (w, ph) in enumerate(words)]
     (workdir / "dict").write_text("\n".join(dl) + "\n")
     # forward 2-gram ARPA (log10), entries in 1-gram order
     vocab = ["<s>", "</s>"] + [w for w, _ in words]

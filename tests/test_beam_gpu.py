@@ -87,6 +87,7 @@ def test_work_area_is_reusable(engine, oracle):
     (23, 600, ["-sepnum", "10", "-bs", "80"], dict(nword=300, nphone=12, S=200)),   # beam > 512 threads
     (24, 100, ["-sepnum", "0", "-iwcd1", "avg"], {}),
     (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),          # no rank pruning at all
+    (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),          # transparent words
 ])
 def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
@@ -174,7 +175,8 @@ def test_strict_order_golden(engine, oracle, name):
     (24, 100, ["-sepnum", "0", "-iwcd1", "avg"], {}),
     (23, 600, ["-sepnum", "10", "-bs", "80"], dict(nword=300, nphone=12, S=200)),
     (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),   # the case where the fast kernel's
-])                                                                              # tie rule dropped one atom of 34 842
+    (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),   # tie rule dropped one atom of 34 842;
+])                                                                              # transparent words
 def test_strict_order_exact_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
     bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0

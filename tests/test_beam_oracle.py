@@ -49,9 +49,12 @@ def test_beam_death_is_reported(oracle):
     (13, 150, ["-sepnum", "4", "-bs", "40"]),                  # score beam
     (14, 100, ["-sepnum", "0", "-iwcd1", "avg"]),              # whole vocabulary in the tree
     (15, 100, ["-sepnum", "3", "-iwcd1", "best", "2", "-lmp", "6.0", "-3.0"]),
+    (16, 150, ["-sepnum", "4", "-transp", "-1.5"]),            # transparent words (task built with ntransparent=12)
 ])
 def test_oracle_matches_reference_live(oracle, ref, tmp_path, seed, beam, extra):
-    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra)
+    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **(dict(ntransparent=12) if "-transp" in extra else {}))
+    if "-transp" in extra:
+        assert int(np.sum(lex["is_transparent"])) == 12 and lex["lm_penalty_trans"] == -1.5
     bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
     for u in range(3):
         fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)
