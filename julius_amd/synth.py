@@ -220,7 +220,7 @@ def write_npy(path, a):
 
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
-                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0):
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0):
     """Write a complete synthetic recognition task the reference can load:
     tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
     forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
@@ -279,8 +279,12 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
     dl = ["<s> [] silB", "</s> [] silE"] + [
         (f"{w} {{{w}}} " if i < ntransparent else f"{w} [{w}] ") + " ".join(ph) for i, (w, ph) in enumerate(words)]
     (workdir / "dict").write_text("\n".join(dl) + "\n")
-    # forward 2-gram ARPA (log10), entries in 1-gram order
-    vocab = ["<s>", "</s>"] + [w for w, _ in words]
+    # forward 2-gram ARPA (log10), entries in 1-gram order.  With nunk > 0 the last `nunk`
+    # dictionary words are left out of the LM and an <unk> entry is added: the reference maps
+    # them to it and divides its probability among them (unk_num_log,
+    # libsent/src/ngram/init_ngram.c; used by libsent/src/ngram/ngram_access.c:296-306)
+    lm_words = [w for w, _ in words][:len(words) - nunk] if nunk > 0 else [w for w, _ in words]
+    vocab = ["<s>", "</s>"] + (["<unk>"] if nunk > 0 else []) + lm_words
     V = len(vocab)
     uni = rng.dirichlet(np.full(V, 1.0))
     uni = np.log10(uni)

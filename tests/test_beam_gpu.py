@@ -88,6 +88,7 @@ def test_work_area_is_reusable(engine, oracle):
     (24, 100, ["-sepnum", "0", "-iwcd1", "avg"], {}),
     (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),          # no rank pruning at all
     (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),          # transparent words
+    (27, 150, ["-sepnum", "4"], dict(nunk=10)),                                     # words outside the LM -> <unk>
 ])
 def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
@@ -192,3 +193,27 @@ def test_strict_order_exact_vs_reference_live(engine, oracle, ref, tmp_path, see
         assert_trellis_equal(atoms, rtr)                      # exact, ties included
         if r.status == 0:
             assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+
+
+@pytest.mark.parametrize("beam", [1, 7, 120])
+def test_edge_lengths_in_one_batch(engine, oracle, beam):
+    """Utterances of 1, 2, 3 frames, a normal one and beam widths down to 1 in one launch
+    (get_back_trellis_init() alone, one _proceed(), ...), against the oracle."""
+    from julius_amd import lexblob
+    g = load_beam_golden("beam_rank.npz")
+    sc_full = oracle.gmm_outprob(g["am"], g["utts"][0]["frames"])
+    scores = [sc_full[:1], sc_full[:2], sc_full[:3], sc_full]
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, beam, -1.0, max_utts=len(scores))
+    for strict in (False, True):
+        bm.set_strict_order(strict)
+        res, tre = bm.pass1_host(scores)
+        for sc, r, atoms in zip(scores, res, tre):
+            oatoms, owseq, oscore, rc, died = oracle.beam_pass1(g["lex"], sc, beam, -1.0)
+            assert r.status == rc and r.frames == len(sc)
+            if strict:
+                assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+            else:
+                assert_trellis_equal_modulo_ties(atoms, lexblob.canonical_trellis(oatoms), r.ties)
+            if rc == 0:
+                assert list(r.wseq[:r.wnum]) == list(owseq) and r.score == oscore

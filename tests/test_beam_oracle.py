@@ -50,9 +50,14 @@ def test_beam_death_is_reported(oracle):
     (14, 100, ["-sepnum", "0", "-iwcd1", "avg"]),              # whole vocabulary in the tree
     (15, 100, ["-sepnum", "3", "-iwcd1", "best", "2", "-lmp", "6.0", "-3.0"]),
     (16, 150, ["-sepnum", "4", "-transp", "-1.5"]),            # transparent words (task built with ntransparent=12)
+    (17, 150, ["-sepnum", "4", "-unk"]),                       # 10 dictionary words outside the LM -> <unk>
 ])
 def test_oracle_matches_reference_live(oracle, ref, tmp_path, seed, beam, extra):
-    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **(dict(ntransparent=12) if "-transp" in extra else {}))
+    kw = dict(ntransparent=12) if "-transp" in extra else dict(nunk=10) if "-unk" in extra else {}
+    extra = [x for x in extra if x != "-unk"]
+    eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **kw)
+    if "nunk" in kw:
+        assert lex["ng_unk_id"] < lex["ng_nword"] and lex["ng_unk_num_log"] == pytest.approx(1.0)   # log10(10)
     if "-transp" in extra:
         assert int(np.sum(lex["is_transparent"])) == 12 and lex["lm_penalty_trans"] == -1.5
     bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
