@@ -305,8 +305,33 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
         for i, j, p in big:
             f.write(f"{p:.6f}\t{vocab[i]} {vocab[j]}\n")
         f.write("\n\\end\\\n")
+    rl = None
+    if with_rl3:
+        # backward (RL) 3-gram for the reference's standard "-nlr 2-gram -nrl 3-gram" set-up: the
+        # first pass then reads the forward 2-gram through bi_prob_additional() (RL index, LR
+        # probabilities in the additional area; libsent/src/ngram/ngram_access.c:351).  Every
+        # forward 2-gram (a b) needs its reversed tuple (b a) among the RL 2-grams
+        # (ngram_read_arpa.c:305-318); tuples are sorted in 1-gram order.
+        rl2 = sorted({(j, i) for i, j, _ in big})
+        rl3 = []
+        for (j, i) in rl2[::3]:
+            ks = [k for (i2, k) in rl2 if i2 == i][:2]
+            rl3 += [(j, i, k) for k in ks]
+        rl3 = sorted(set(rl3))
+        rl = workdir / "lm_rl.arpa"
+        with open(rl, "w") as f:
+            f.write(f"\\data\\\nngram 1={V}\nngram 2={len(rl2)}\nngram 3={len(rl3)}\n\n\\1-grams:\n")
+            for i in range(V):
+                f.write(f"{uni[i]:.6f}\t{vocab[i]}\t{-rng.uniform(0.1, 1.0):.6f}\n")
+            f.write("\n\\2-grams:\n")
+            for j, i in rl2:
+                f.write(f"{-rng.uniform(0.2, 2.0):.6f}\t{vocab[j]} {vocab[i]}\t{-rng.uniform(0.1, 0.8):.6f}\n")
+            f.write("\n\\3-grams:\n")
+            for j, i, k in rl3:
+                f.write(f"{-rng.uniform(0.2, 2.0):.6f}\t{vocab[j]} {vocab[i]} {vocab[k]}\n")
+            f.write("\n\\end\\\n")
     return dict(dir=workdir, hmmdefs=workdir / "hmmdefs", hmmlist=workdir / "hmmlist", dict=workdir / "dict",
-                arpa=workdir / "lm.arpa", model=model, words=words, vocab=vocab, phones=phones)
+                arpa=workdir / "lm.arpa", arpa_rl=rl, model=model, words=words, vocab=vocab, phones=phones)
 
 
 def make_utterance(task, nwords=6, seed=0, frames_per_state=3, noise=0.7):

@@ -36,9 +36,9 @@ def ref_task(ref, tmpdir, seed, beam, extra=(), **task_kw):
     """Synthetic triphone task loaded by the compiled reference: (RefEngine, lex dict, flat AM, task)."""
     from oracle import pyoracle
     task = synth.make_triphone_task(tmpdir, seed=seed, **task_kw)
-    eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"],
-                                   "-nlr", task["arpa"], "-input", "htkparam", "-1pass", "-gprune", "none",
-                                   "-b", str(beam)] + list(extra))
+    lm = ["-nlr", task["arpa"]] + (["-nrl", task["arpa_rl"]] if task.get("arpa_rl") else [])
+    eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"]] + lm +
+                             ["-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)] + list(extra))
     eng.save_lexicon(tmpdir / "lex.blob")
     lex = lexblob.load(tmpdir / "lex.blob")
     am = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()

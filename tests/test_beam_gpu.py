@@ -89,6 +89,7 @@ def test_work_area_is_reusable(engine, oracle):
     (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),          # no rank pruning at all
     (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),          # transparent words
     (27, 150, ["-sepnum", "4"], dict(nunk=10)),                                     # words outside the LM -> <unk>
+    (28, 150, ["-sepnum", "4"], dict(with_rl3=True)),                               # LR 2-gram + RL 3-gram (additional area)
 ])
 def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)

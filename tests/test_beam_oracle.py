@@ -51,11 +51,15 @@ def test_beam_death_is_reported(oracle):
     (15, 100, ["-sepnum", "3", "-iwcd1", "best", "2", "-lmp", "6.0", "-3.0"]),
     (16, 150, ["-sepnum", "4", "-transp", "-1.5"]),            # transparent words (task built with ntransparent=12)
     (17, 150, ["-sepnum", "4", "-unk"]),                       # 10 dictionary words outside the LM -> <unk>
+    (18, 150, ["-sepnum", "4", "-rl3"]),                       # forward 2-gram + backward 3-gram: bi_prob_additional()
 ])
 def test_oracle_matches_reference_live(oracle, ref, tmp_path, seed, beam, extra):
-    kw = dict(ntransparent=12) if "-transp" in extra else dict(nunk=10) if "-unk" in extra else {}
-    extra = [x for x in extra if x != "-unk"]
+    kw = (dict(ntransparent=12) if "-transp" in extra else dict(nunk=10) if "-unk" in extra
+          else dict(with_rl3=True) if "-rl3" in extra else {})
+    extra = [x for x in extra if x not in ("-unk", "-rl3")]
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **kw)
+    if "with_rl3" in kw:
+        assert lex["ng_mode"] == 2            # JAMD_NG_ADDITIONAL
     if "nunk" in kw:
         assert lex["ng_unk_id"] < lex["ng_nword"] and lex["ng_unk_num_log"] == pytest.approx(1.0)   # log10(10)
     if "-transp" in extra:

@@ -23,14 +23,19 @@ pytestmark = pytest.mark.gpu
     (31, 200, ["-sepnum", "5"]),
     (32, 100, ["-sepnum", "3", "-gprune", "safe", "-tmix", "3"]),
     (33, 150, ["-sepnum", "8", "-bs", "70", "-lmp", "6.0", "-2.0"]),
+    (34, 150, ["-sepnum", "5", "-rl3"]),       # forward 2-gram for pass 1 + backward 3-gram for the reference's pass 2
 ])
 def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, seed, beam, extra, strict):
     monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if strict else "0")
     if not pyoracle.REF_AMD_SO.exists():
         pytest.skip("oracle/_ref/libjref_amd.so not built")
-    task = synth.make_triphone_task(tmp_path, seed=seed, nword=120, nphone=10, S=160)
-    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
-            "-input", "htkparam", "-b", str(beam), "-b2", "30", "-n", "1", "-s", "500"]
+    rl3 = "-rl3" in extra
+    extra = [x for x in extra if x != "-rl3"]
+    task = synth.make_triphone_task(tmp_path, seed=seed, nword=120, nphone=10, S=160, with_rl3=rl3)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"]]
+    if rl3:
+        args += ["-nrl", task["arpa_rl"]]
+    args += ["-input", "htkparam", "-b", str(beam), "-b2", "30", "-n", "1", "-s", "500"]
     if "-gprune" not in extra:
         args += ["-gprune", "none"]
     args += list(extra)
