@@ -45,7 +45,7 @@ using namespace jamd;
 
 constexpr int NT = 1024;                // threads per utterance workgroup
 constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
-constexpr int kMaxDynLds = 96 * 1024;   // survivor state above this stays in global memory (160 KB LDS per CU)
+constexpr int kMaxDynLds = 144 * 1024;  // survivor state above this stays in global memory (160 KB LDS per CU, ~10 KB static)
 
 struct LexDev {
   int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
