@@ -21,6 +21,8 @@ frames = np.concatenate(utts)
 eng = lib.Engine(0)
 gm = lib.Gmm(eng, model); lx = lib.Lexicon(eng, lex)
 bm = lib.Beam(eng, lx, beam, -1.0, max_utts=nutt, atoms_per_utt=1 << 17)
+if len(sys.argv) > 4 and sys.argv[4] == "strict":
+    bm.set_strict_order(True)
 d_fr = torch.from_numpy(frames).cuda()
 d_sc = torch.empty((len(frames), S), dtype=torch.float32, device="cuda")
 st = torch.cuda.Stream()
