@@ -309,6 +309,20 @@ void jamd_beam_destroy(jamd_beam *b);
  * jamd_beam_results() / jamd_beam_trellis(), which synchronise. */
 int  jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *utt_off,
                          int nutt, void *stream);
+/* Streaming form of jamd_beam_pass1_dev() for input that arrives in pieces (Julius calls
+ * get_back_trellis_proceed() once per frame, libjulius/src/pass1.c:242; live audio never has
+ * the whole utterance).  jamd_beam_stream_begin() opens a session for utterance slots
+ * 0..nutt-1; each jamd_beam_stream_push_dev() advances every utterance by the rows
+ * chunk_off[u]..chunk_off[u+1]) of dev_scores (any number of frames, zero included) and keeps
+ * the search state on the device; `final` != 0 additionally runs get_back_trellis_end() and the
+ * traceback, after which jamd_beam_results()/jamd_beam_trellis() return exactly what one
+ * jamd_beam_pass1_dev() call over the concatenated rows would.  jamd_beam_results() may also
+ * be called between pushes (natom / frames so far).  In strict-order mode a session must
+ * consist of one final push. */
+int  jamd_beam_stream_begin(jamd_beam *b, int nutt);
+int  jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *chunk_off,
+                               int nutt, int final, void *stream);
+
 /* Verification mode.  on != 0: later jamd_beam_pass1_dev() calls run the reference's
  * SEQUENTIAL algorithm (same token creation order, same partial heap sort
  * beam.c:1342-1516, first-writer-wins propagation) with one lane per utterance, so that

@@ -71,7 +71,13 @@ struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/
   float last_lscore; int last_wid; int pad0, pad1;   // last_wid = wid of atoms[last_tre] (-1 for bos)
 };
 
+struct StreamState {     // what a streaming utterance carries from one launch to the next
+  int started, active, frames_done, n_surv, n_atom, ties, ties_we, ties_cut, max_tokens;
+  float thr;
+};
+
 struct Work {            // per-utterance slices are addressed with the strides below
+  StreamState *stream;           // [utt] (allocated by jamd_beam_stream_begin)
   unsigned long long *nodekey;   // [utt][nnode]    Viterbi cells (0 = empty)
   Tok *cur;                      // [utt][tok_cap]  tokens created this frame
   unsigned *cur_key;             // [utt][tok_cap]  their order-preserving score bits (compact, for the rank select)
@@ -236,11 +242,19 @@ __device__ __forceinline__ unsigned long long push(Shared &sh, unsigned long lon
 
 __global__ void __launch_bounds__(NT)
 beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
-                  const int *__restrict__ utt_off) {
+                  const int *__restrict__ utt_off, int smode) {
   __shared__ Shared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   const int u = blockIdx.x, tid = threadIdx.x;
-  const int t_begin = utt_off[u], T = utt_off[u + 1] - t_begin;
+  // smode 0: whole utterances.  smode 1 / 2: streaming -- this launch advances every utterance
+  // by the rows utt_off[u]..utt_off[u+1]) of `scores`; 2 = also run get_back_trellis_end() and
+  // the traceback.  The state between launches lives in wk.stream[u] and wk.sv_global.
+  const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
+  StreamState *ss = smode ? wk.stream + u : nullptr;
+  const bool resume = smode && ss->started;
+  const int base = resume ? ss->frames_done : 0;            // absolute index of this launch's first row
+  const int T = base + nrows;                                // frames seen so far
+  const bool finish = smode != 1;                            // run the end phase after the last row
   unsigned long long *nodekey = wk.nodekey + (size_t)u * wk.nnode;
   Tok *cur = wk.cur + (size_t)u * wk.tok_cap;
   unsigned *cur_key = wk.cur_key + (size_t)u * wk.tok_cap;
@@ -260,37 +274,57 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
   unsigned long long *memo = wk.lmcache + (size_t)u * wk.nscword;
 
-  if (tid == 0) {
-    sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.n_surv = 0;
-    res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO;
-    res->died_at = -1; res->ties = 0; res->frames = T; res->max_tokens = 0;
+  if (resume) {
+    if (!ss->active) return;                                 // died / overflowed / finished earlier
+    if (wk.use_lds) {                                        // survivor image back into LDS
+      const uint4 *src = (const uint4 *)(wk.sv_global + (size_t)u * wk.sv_bytes);
+      uint4 *dst = (uint4 *)dyn_lds;
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+    }
+    if (tid == 0) {
+      sh.n_atom = ss->n_atom; sh.ties = ss->ties; sh.ties_we = ss->ties_we; sh.ties_cut = ss->ties_cut;
+      sh.n_surv = ss->n_surv;
+    }
+    __syncthreads();
+  } else {
+    if (tid == 0) {
+      sh.n_atom = 0; sh.ties = 0; sh.ties_we = 0; sh.ties_cut = 0; sh.n_surv = 0;
+      res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO;
+      res->died_at = -1; res->ties = 0; res->frames = T; res->max_tokens = 0;
+      for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
+    }
+    for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
+    for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;   // context -1: never matches
+    __syncthreads();
+    if (nrows <= 0) {                                        // nothing to start from yet
+      if (tid == 0) { if (smode != 1) res->status = JAMD_PASS1_FAIL; if (ss) { ss->started = 0; ss->active = 1; } }
+      return;
+    }
+    // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665)
+    if (tid == 0) {
+      const int node = lx.word_head[lx.head_silwid];
+      const int4 nr = lx.node_b[node];                 // {stend, scid, out_id, out_kind}
+      Tok nw;
+      float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
+      ls = ls * lmw + pen;
+      nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
+      nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
+      nw.pad0 = nw.pad1 = 0;
+      sv[0] = nw;
+      hash_put(hkey, hval, hmask, node, 0);
+      sh.n_surv = 1;
+    }
   }
-  for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
-  for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;   // context -1: never matches
-  __syncthreads();
-  if (T <= 0) { if (tid == 0) res->status = JAMD_PASS1_FAIL; return; }
-
-  // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665)
-  if (tid == 0) {
-    const int node = lx.word_head[lx.head_silwid];
-    const int4 nr = lx.node_b[node];                 // {stend, scid, out_id, out_kind}
-    Tok nw;
-    float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
-    ls = ls * lmw + pen;
-    nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
-    nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
-    nw.pad0 = nw.pad1 = 0;
-    sv[0] = nw;
-    hash_put(hkey, hval, hmask, node, 0);
-    sh.n_surv = 1;
-  }
-  float thr = JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
+  float thr = resume ? ss->thr : JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tq = 0;   // phase clocks (100 MHz), thread 0 only
 #define PHASE(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
-  int max_tokens = 1;
+  int max_tokens = resume ? ss->max_tokens : 1;
+  bool stopped = false;
   __syncthreads();
 
-  for (int t = 1; t <= T; t++) {
+  // frames base+1 .. T-1 of this launch are propagated into (frame `base` itself when resuming);
+  // t == T is the end phase and only runs when finishing
+  for (int t = resume ? base : 1; t <= (finish ? T : T - 1); t++) {
     // tl/tn swap (beam.c:2697-2698): sv[] holds last frame's survivors
     const int n_surv = sh.n_surv;
     __syncthreads();
@@ -434,7 +468,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     const int n_new = sh.n_new;
     if (n_new > max_tokens) max_tokens = n_new;
     {
-      const float *__restrict__ row = scores + (size_t)(t_begin + t) * S;
+      const float *__restrict__ row = scores + (size_t)(t_begin + t - base) * S;
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
       for (int s = tid; s < n_new; s += NT) {
         if (tid == 0) tq = wall_clock64();
@@ -558,11 +592,13 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     }
     if (n_new == 0) {                                              // :3012-3015
       if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }
+      stopped = true;
       __syncthreads();
       break;
     }
     if (sh.n_atom > wk.atom_cap) {
       if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
+      stopped = true;
       __syncthreads();
       break;
     }
@@ -669,6 +705,24 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   }
   __syncthreads();
 
+  if (smode == 1) {            // not finished: park the state for the next launch
+    if (wk.use_lds && !stopped) {
+      uint4 *dst = (uint4 *)(wk.sv_global + (size_t)u * wk.sv_bytes);
+      const uint4 *src = (const uint4 *)dyn_lds;
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+    }
+    if (tid == 0) {
+      ss->started = 1; ss->active = stopped ? 0 : 1; ss->frames_done = T; ss->n_surv = sh.n_surv; ss->thr = thr;
+      ss->n_atom = sh.n_atom; ss->ties = sh.ties; ss->ties_we = sh.ties_we; ss->ties_cut = sh.ties_cut;
+      ss->max_tokens = max_tokens;
+      res->natom = min(sh.n_atom, wk.atom_cap); res->frames = T; res->max_tokens = max_tokens;
+      res->ties = sh.ties + sh.ties_we + sh.ties_cut;
+      for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    }
+    return;
+  }
+  if (ss && tid == 0) { ss->active = 0; ss->started = 1; ss->frames_done = T; }
+
   // ---- find_1pass_result() :399-431 + trace_backptr() :294-340
   const int natom = min(sh.n_atom, wk.atom_cap);
   if (tid == 0) sh.best_atom = -1;
@@ -683,7 +737,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   if (tid == 0) {
     res->natom = natom; res->ties = sh.ties + sh.ties_we + sh.ties_cut; res->max_tokens = max_tokens;
     res->ties_node = sh.ties; res->ties_wordend = sh.ties_we; res->ties_cut = sh.ties_cut;
-    for (int i = 0; i < 8; i++) res->phase_us[i] = (int)(ph[i] / 100ull);
+    for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    res->frames = T;
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
       const int best = sh.best_atom;
@@ -970,6 +1025,8 @@ struct jamd_beam {
   int max_utts = 0;
   int *d_utt_off = nullptr;
   bool strict = false;
+  int streaming = 0;               // utterances of the open streaming session, 0 = none
+  int stream_pushes = 0;
   StrictWork sw{};
   std::vector<void *> owned;
 };
@@ -1153,9 +1210,56 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
                        nstate, b->d_utt_off, nutt);
   else
     hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w,
-                       dev_scores, nstate, b->d_utt_off);
+                       dev_scores, nstate, b->d_utt_off, 0);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  return JAMD_OK;
+}
+
+int jamd_beam_stream_begin(jamd_beam *b, int nutt) {
+  if (!b || nutt < 1 || nutt > b->max_utts) { jamd_set_error("jamd_beam_stream_begin: bad argument"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  void *p = nullptr;
+  if (b->w.stream == nullptr) {
+    JAMD_HIP(hipMalloc(&p, sizeof(StreamState) * (size_t)b->max_utts)); b->owned.push_back(p); b->w.stream = (StreamState *)p;
+  }
+  if (b->w.sv_global == nullptr) {     // parking space for the LDS-resident survivor state between launches
+    JAMD_HIP(hipMalloc(&p, (size_t)b->max_utts * b->w.sv_bytes)); b->owned.push_back(p); b->w.sv_global = (unsigned char *)p;
+  }
+  JAMD_HIP(hipMemsetAsync(b->w.stream, 0, sizeof(StreamState) * (size_t)nutt, b->eng->stream));
+  JAMD_HIP(hipStreamSynchronize(b->eng->stream));
+  b->streaming = nutt; b->stream_pushes = 0;
+  return JAMD_OK;
+}
+
+int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *chunk_off, int nutt,
+                              int final, void *stream) {
+  if (!b || !chunk_off || nstate <= 0 || (!dev_scores && chunk_off[nutt > 0 ? nutt : 0] > 0)) {
+    jamd_set_error("jamd_beam_stream_push_dev: bad argument"); return JAMD_EINVAL;
+  }
+  if (b->streaming <= 0 || nutt != b->streaming) {
+    jamd_set_error("jamd_beam_stream_push_dev: call jamd_beam_stream_begin(b, %d) first", nutt); return JAMD_ESTATE;
+  }
+  for (int u = 0; u < nutt; u++)
+    if (chunk_off[u + 1] < chunk_off[u]) { jamd_set_error("jamd_beam_stream_push_dev: chunk_off must be non-decreasing"); return JAMD_EINVAL; }
+  if (b->strict) {
+    // the strict-order kernel keeps no state between launches: one push carrying everything
+    if (!final || b->stream_pushes != 0) {
+      jamd_set_error("jamd_beam_stream_push_dev: strict-order mode needs the whole utterance in one final push");
+      return JAMD_ESTATE;
+    }
+    b->streaming = 0;
+    return jamd_beam_pass1_dev(b, dev_scores, nstate, chunk_off, nutt, stream);
+  }
+  b->stream_pushes++;
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  hipStream_t st = jamd_stream(b->eng, stream);
+  JAMD_HIP(hipMemcpyAsync(b->d_utt_off, chunk_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w,
+                     dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { jamd_set_error("jamd_beam_stream_push_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  if (final) b->streaming = 0;
   return JAMD_OK;
 }
 

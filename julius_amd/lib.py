@@ -95,6 +95,8 @@ def load():
         "jamd_beam_pass1_dev": (ci, [vp, vp, ci, vp, ci, vp]),
         "jamd_beam_results": (ci, [vp, vp, ci]),
         "jamd_beam_set_strict_order": (ci, [vp, ci]),
+        "jamd_beam_stream_begin": (ci, [vp, ci]),
+        "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
     }
     for name, (res, args) in sig.items():
@@ -390,6 +392,15 @@ class Beam:
 
     def set_strict_order(self, on: bool = True):
         _check(load().jamd_beam_set_strict_order(self.h, 1 if on else 0), "jamd_beam_set_strict_order")
+
+    def stream_begin(self, nutt: int):
+        self._nutt = nutt
+        _check(load().jamd_beam_stream_begin(self.h, nutt), "jamd_beam_stream_begin")
+
+    def stream_push_dev(self, dev_scores: int, nstate: int, chunk_off, final: bool = False, stream: int = 0):
+        off = _i32(chunk_off)
+        _check(load().jamd_beam_stream_push_dev(self.h, dev_scores or None, nstate, off.ctypes.data, len(off) - 1,
+                                                1 if final else 0, stream or None), "jamd_beam_stream_push_dev")
 
     def pass1_dev(self, dev_scores: int, nstate: int, utt_off, stream: int = 0):
         off = _i32(utt_off)

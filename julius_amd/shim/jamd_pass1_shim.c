@@ -12,11 +12,12 @@
  * (pass1.c:234,242,503,567; instance.c:322) link unchanged.  Everything else of
  * Julius -- loaders, front end, 2nd pass, output -- is untouched.
  *
- * How the frame-by-frame call pattern maps onto the batched engine: for buffered
- * input (-input htkparam / rawfile, the benchmark path) the whole
- * HTK_Param is already in memory when _init() is called, so _proceed() only
- * acknowledges the frame and _end() runs acoustic scoring + the first pass on the
- * device in one go, then rebuilds the BACKTRELLIS from the returned atoms with
+ * How the frame-by-frame call pattern maps onto the batched engine: _init() opens a
+ * streaming session on the device (jamd_beam_stream_begin), _proceed(t) may hand the
+ * frames that have arrived so far to it (every JAMD_STREAM_CHUNK frames: live input), and
+ * _end() pushes the rest with the final flag.  For buffered input (-input htkparam /
+ * rawfile, the benchmark path) the default is one push at _end(): scoring
+ * and the whole first pass in one go.  _end() then rebuilds the BACKTRELLIS from the returned atoms with
  * the reference's own allocator (bt_new / bt_store), and finalize_1st_pass()
  * indexes it with bt_relocate_rw / bt_sort_rw exactly as the reference does.
  *
@@ -37,6 +38,11 @@ typedef struct {
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam;
   int nstate;
+  /* streaming state of the current utterance */
+  int chunk;                   /* JAMD_STREAM_CHUNK: push every this many frames from _proceed(); 0 = all at _end() */
+  int pushed;                  /* frames already handed to the device */
+  int failed;
+  float *host_scores; int host_cap;   /* [pushed][nstate] rows kept for the 2nd pass's cache */
 } pass1_ctx;
 
 static jamd_engine *g_eng = NULL;
@@ -49,6 +55,7 @@ static void ctx_release(pass1_ctx *c)
   if (c->lex) jamd_lexicon_destroy(c->lex);
   if (c->gmm) jamd_gmm_destroy(c->gmm);
   if (c->dnn) jamd_dnn_destroy(c->dnn);
+  free(c->host_scores); c->host_scores = NULL; c->host_cap = 0;
   c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL;
 }
 
@@ -137,13 +144,67 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   d->bos.begintime = d->bos.endtime = -1;
   outprob_style_cache_init(r->wchmm);                 /* beam.c:1595: the 2nd pass reuses these caches */
   r->have_interim = FALSE;
+  c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
+  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) c->chunk = 0;   /* one final push */
+  c->pushed = 0; c->failed = 0;
+  if (jamd_beam_stream_begin(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   return TRUE;
+}
+
+/* Score frames [c->pushed, upto) and advance the device search by them; `final` also runs
+ * get_back_trellis_end() + traceback on the device. */
+static boolean push_frames(pass1_ctx *c, RecogProcess *r, HTK_Param *param, int upto, int final)
+{
+  int n = upto - c->pushed, off[2];
+  float *frames = NULL, *d_frames = NULL, *d_scores = NULL;
+  boolean ok = FALSE;
+  const boolean keep = !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL;
+  off[0] = 0; off[1] = n;
+  if (n > 0) {
+    frames = jamd_pack_param(param, c->pushed, upto);
+    if (frames == NULL ||
+        jamd_malloc(g_eng, sizeof(float) * (size_t)n * param->veclen, (void **)&d_frames) != JAMD_OK ||
+        jamd_malloc(g_eng, sizeof(float) * (size_t)n * c->nstate, (void **)&d_scores) != JAMD_OK ||
+        jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * (size_t)n * param->veclen) != JAMD_OK ||
+        (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, n, d_scores, NULL)
+                : jamd_gmm_outprob_dev(c->gmm, d_frames, n, d_scores, NULL)) != JAMD_OK) goto out;
+    if (keep) {                                      /* rows for the reference's outprob cache (2nd pass) */
+      if (upto > c->host_cap) {
+        c->host_cap = upto + 1024;
+        c->host_scores = (float *)realloc(c->host_scores, sizeof(float) * (size_t)c->host_cap * c->nstate);
+      }
+      if (c->host_scores == NULL ||
+          jamd_memcpy_d2h(g_eng, c->host_scores + (size_t)c->pushed * c->nstate, d_scores,
+                          sizeof(float) * (size_t)n * c->nstate) != JAMD_OK) goto out;
+    }
+  }
+  if (jamd_beam_stream_push_dev(c->beam, d_scores, c->nstate, off, 1, final, NULL) != JAMD_OK) goto out;
+  if (jamd_engine_sync(g_eng) != JAMD_OK) goto out;
+  c->pushed = upto;
+  ok = TRUE;
+out:
+  if (!ok) { jlog("ERROR: jamd: first pass failed: %s\n", jamd_last_error()); c->failed = 1; }
+  if (d_frames) jamd_free(g_eng, d_frames);
+  if (d_scores) jamd_free(g_eng, d_scores);
+  free(frames);
+  return ok;
 }
 
 boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boolean final_for_multipath)
 {
-  /* buffered input: the work is done in get_back_trellis_end() */
+  /* Frame t is available.  With JAMD_STREAM_CHUNK = n the device search advances every n frames
+   * (live input); by default everything is pushed at get_back_trellis_end() (buffered input). */
+  pass1_ctx *c = ctx_get(r);
   r->have_interim = FALSE;
+  if (c == NULL || c->beam == NULL || c->failed) return FALSE;
+  if (c->chunk > 0 && t + 1 - c->pushed >= c->chunk) {
+    jamd_pass1_result res;
+    if (!push_frames(c, r, param, t + 1, 0)) return FALSE;
+    if (jamd_beam_results(c->beam, &res, 1) == JAMD_OK && res.status == JAMD_PASS1_DIED) {
+      jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
+      return FALSE;                                   /* beam.c:3012-3015: the caller segments the input */
+    }
+  }
   return TRUE;
 }
 
@@ -151,38 +212,19 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
 {
   pass1_ctx *c = ctx_get(r);
   FSBeam *d = &(r->pass1);
-  int T = param->samplenum, off[2], natom = 0, i;
-  float *frames, *d_frames = NULL, *d_scores = NULL;
+  int T = param->samplenum, natom = 0, i;
   jamd_pass1_result res;
   jamd_trellis_atom *atoms = NULL;
   TRELLIS_ATOM **made = NULL;
 
   r->result.status = J_RESULT_STATUS_FAIL;            /* until proven otherwise */
   d->wordend_best_score = LOG_ZERO;
-  if (c == NULL || c->beam == NULL || T <= 0) return;
-  frames = jamd_pack_param(param, 0, T);
-  off[0] = 0; off[1] = T;
-  if (frames == NULL ||
-      jamd_malloc(g_eng, sizeof(float) * (size_t)T * param->veclen, (void **)&d_frames) != JAMD_OK ||
-      jamd_malloc(g_eng, sizeof(float) * (size_t)T * c->nstate, (void **)&d_scores) != JAMD_OK ||
-      jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * (size_t)T * param->veclen) != JAMD_OK ||
-      (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, T, d_scores, NULL)
-              : jamd_gmm_outprob_dev(c->gmm, d_frames, T, d_scores, NULL)) != JAMD_OK ||
-      jamd_beam_pass1_dev(c->beam, d_scores, c->nstate, off, 1, NULL) != JAMD_OK ||
-      jamd_beam_results(c->beam, &res, 1) != JAMD_OK) {
-    jlog("ERROR: jamd: first pass failed: %s\n", jamd_last_error());
-    goto done;
-  }
+  if (c == NULL || c->beam == NULL || T <= 0 || c->failed) return;
+  if (!push_frames(c, r, param, T, 1) || jamd_beam_results(c->beam, &res, 1) != JAMD_OK) goto done;
   if (res.status == JAMD_PASS1_DIED)
     jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
-  if (!r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL) {
-    /* hand the [T][S] score matrix to the reference's cache for the 2nd pass */
-    float *host_scores = (float *)malloc(sizeof(float) * (size_t)T * c->nstate);
-    if (host_scores != NULL &&
-        jamd_memcpy_d2h(g_eng, host_scores, d_scores, sizeof(float) * (size_t)T * c->nstate) == JAMD_OK)
-      jamd_fill_outprob_cache(&(r->am->hmmwrk), host_scores, 0, T, c->nstate);
-    free(host_scores);
-  }
+  if (c->host_scores != NULL && !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL)
+    jamd_fill_outprob_cache(&(r->am->hmmwrk), c->host_scores, 0, T, c->nstate);   /* 2nd pass = cache hits */
   if (res.status == JAMD_PASS1_OVERFLOW) { jlog("ERROR: jamd: word trellis overflow\n"); goto done; }
   natom = res.natom;
   atoms = (jamd_trellis_atom *)malloc(sizeof(jamd_trellis_atom) * (natom > 0 ? natom : 1));
@@ -218,9 +260,7 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
     }
   }
 done:
-  if (d_frames) jamd_free(g_eng, d_frames);
-  if (d_scores) jamd_free(g_eng, d_scores);
-  free(frames); free(atoms); free(made);
+  free(atoms); free(made);
 }
 
 void finalize_1st_pass(RecogProcess *r, int len)

@@ -218,3 +218,39 @@ def test_edge_lengths_in_one_batch(engine, oracle, beam):
                 assert_trellis_equal_modulo_ties(atoms, lexblob.canonical_trellis(oatoms), r.ties)
             if rc == 0:
                 assert list(r.wseq[:r.wnum]) == list(owseq) and r.score == oscore
+
+
+@pytest.mark.parametrize("chunks", [[1] * 40 + [10000], [7, 1, 50, 0, 3, 10000], [10000]])
+def test_streaming_equals_one_shot(engine, oracle, chunks):
+    """jamd_beam_stream_*: the utterances arrive in pieces (frame by frame, ragged chunks,
+    empty pushes); the word trellis and the pass-1 result equal the one-shot call's."""
+    g = load_beam_golden("beam_score.npz")
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    S = scores[0].shape[1]
+    lx = lib.Lexicon(engine, g["lex"])
+    one = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(scores))
+    res1, tre1 = one.pass1_host(scores)
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(scores))
+    bm.stream_begin(len(scores))
+    pos = [0] * len(scores)
+    for ci, c in enumerate(chunks):
+        # utterances advance by different amounts: utterance u gets c + u frames (until it runs out)
+        part, off = [], [0]
+        for u, sc in enumerate(scores):
+            n = min(len(sc) - pos[u], (c + u) if c else 0)
+            part.append(sc[pos[u]:pos[u] + n]); pos[u] += n; off.append(off[-1] + n)
+        final = ci == len(chunks) - 1
+        rows = np.concatenate(part) if off[-1] else np.zeros((1, S), np.float32)
+        d = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(d.ptr, S, np.array(off, np.int32), final=final)
+        mid = bm.results(len(scores))
+        assert all(r.frames == p for r, p in zip(mid, pos))
+        d.free()
+    res2 = bm.results(len(scores))
+    for u in range(len(scores)):
+        a, b = res1[u], res2[u]
+        assert (a.status, a.natom, a.wnum, a.score, a.frames) == (b.status, b.natom, b.wnum, b.score, b.frames)
+        assert list(a.wseq[:a.wnum]) == list(b.wseq[:b.wnum])
+        from julius_amd import lexblob
+        assert_trellis_equal(bm.trellis(u), lexblob.canonical_trellis(tre1[u]))
+        assert_trellis_equal(bm.trellis(u), g["utts"][u]["trellis"])

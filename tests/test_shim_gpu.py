@@ -18,7 +18,7 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("strict", [False, True, "stream"])
 @pytest.mark.parametrize("seed,beam,extra", [
     (31, 200, ["-sepnum", "5"]),
     (32, 100, ["-sepnum", "3", "-gprune", "safe", "-tmix", "3"]),
@@ -26,7 +26,9 @@ pytestmark = pytest.mark.gpu
     (34, 150, ["-sepnum", "5", "-rl3"]),       # forward 2-gram for pass 1 + backward 3-gram for the reference's pass 2
 ])
 def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, seed, beam, extra, strict):
-    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if strict else "0")
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if strict is True else "0")
+    # "stream": the shim advances the device search every 25 frames from get_back_trellis_proceed()
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "25" if strict == "stream" else "0")
     if not pyoracle.REF_AMD_SO.exists():
         pytest.skip("oracle/_ref/libjref_amd.so not built")
     rl3 = "-rl3" in extra
@@ -58,7 +60,7 @@ def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, s
         assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
         # the trellis the 2nd pass consumed: identical -- exactly in strict-order mode, up to the
         # exact-score ties of DESIGN.md section 4 with the frame-parallel kernel
-        if strict:
+        if strict is True:
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
         else:
