@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JAMD_ABI_VERSION 2
+#define JAMD_ABI_VERSION 3
 
 #define JAMD_OK        0
 #define JAMD_EINVAL   -1   /* bad argument / unsupported model feature        */
@@ -177,14 +177,17 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * that outprob_style() (libjulius/src/outprob_style.c:354) resolves by name
  * lookups, the LM factoring tables (libjulius/src/factoring_sub.c:345-468) and
  * the forward 2-gram the beam reads through ngram->bigram_prob
- * (libsent/src/ngram/ngram_access.c:288-403).  N-gram LM, non-multipath models,
- * 1-gram factoring (the reference's default "fast" setup).  All indices are
+ * (libsent/src/ngram/ngram_access.c:288-403).  N-gram LM with 1-gram factoring (the
+ * reference's default "fast" setup) or DFA grammar with per-category trees; non-multipath models.  All indices are
  * 32-bit; WORD_INVALID is -1 here.  Built by jamd_flatten_lexicon()
  * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess. */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
 #define JAMD_AS_LSET  1   /* AS_LSET   wchmm.h:106: out_id = state-set id                */
 #define JAMD_AS_RSET  2   /* AS_RSET   wchmm.h:107: out_id = row of lc_tab               */
 #define JAMD_AS_LRSET 3   /* AS_LRSET  wchmm.h:108: out_id = row of lc_tab               */
+
+#define JAMD_LM_NGRAM 0   /* LM_PROB  */
+#define JAMD_LM_DFA   1   /* LM_DFA, LM_DFA_GRAMMAR with the default per-category tree */
 
 #define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */
 #define JAMD_NG_ADDITIONAL_OLD 1  /* bi_prob_additional_oldbin() ngram_access.c:320 */
@@ -238,6 +241,19 @@ typedef struct {
   const float *ng_bi_prob;             /* d[1].prob, or p_2 for the ADDITIONAL modes              */
   /* FSBeam local copies (libjulius/include/julius/recog.h:147-150) */
   float lm_weight, lm_penalty, lm_penalty_trans;
+  /* ---- grammar (DFA) mode, lm_type == JAMD_LM_DFA: per-category tree lexicon
+   * (wchmm->category_tree), category-pair constraint at the word boundaries
+   * (beam_inter_word(), libjulius/src/beam.c:2404-2412; dfa_cp(), libsent/src/dfa/cpair.c),
+   * no LM factoring inside words.  For N-gram mode these are 0 / NULL.  In grammar mode
+   * `wton` holds the category of each word. */
+  int lm_type;                         /* JAMD_LM_NGRAM / JAMD_LM_DFA                              */
+  int ncat;                            /* dfa->term_num                                            */
+  const unsigned char *cat_pair;       /* [ncat][ncat] dfa_cp(dfa, c1, c2): c2 may follow c1       */
+  const int   *start2wid;              /* [startnum] wchmm->start2wid (a word of the root's tree)  */
+  int ninit;                           /* initial tokens of init_nodescore() (beam.c:1669-1757):   */
+  const int   *init_node;              /* [ninit] distinct word-head nodes in creation order       */
+  const float *init_lscore;            /* [ninit] penalty1 + cprob of the first word reaching it   */
+  float penalty1;                      /* r->config->lmp.penalty1                                  */
 } jamd_lexicon_desc;
 
 /* One emitted word-trellis record (TRELLIS_ATOM, libjulius/include/julius/

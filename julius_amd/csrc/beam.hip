@@ -64,6 +64,11 @@ struct LexDev {
   const float *wordend_a; const int *wton; const float *cprob; const unsigned char *is_transparent;
   const int *word_head; const float *fscore; const int *scword;
   const float *ng_uni_prob, *ng_uni_bo; const int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; const float *ng_bi_prob;
+  // grammar (per-category trees): category-pair matrix, each root's category, the initial tokens
+  int lm_type, ncat, ninit; float penalty1;
+  const unsigned char *cat_pair;   // [ncat][ncat]  dfa_cp()
+  const int *root_cat;             // [startnum]    wton[start2wid[root]]
+  const int *init_node; const float *init_lscore;   // [ninit]
 };
 
 struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/beam.h:35-45
@@ -222,8 +227,10 @@ __device__ __forceinline__ int wave_alloc(int *counter, bool want) {
 // terms that do not depend on any scheduling order, so that (score, id) is a
 // canonical total order and the result is deterministic:
 //   intra-word     bit31 = 0            [30:0] = source node
-//   isolated root  bits[31:30] = 10     [29:0] = the word that ended (its end node is unique)
-//   shared root    bits[31:30] = 11     (the source is the frame's best word end)
+//   isolated root  bits[31:30] = 10     [29:0] = the word that ended (its end node is unique);
+//                                       with a grammar every root is entered this way
+//   shared root    bits[31:30] = 11     (the source is the frame's best word end);
+//                                       with a grammar: [29:0] = index of an initial token
 // The destination is the address of the key, so the arc is implied.
 // Returns the previous key when it holds the SAME score as this candidate (an
 // exact tie), else 0.
@@ -272,6 +279,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   int *hval = hkey + wk.hsize;
   const int hmask = wk.hsize - 1;
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+  const bool dfa = lx.lm_type == JAMD_LM_DFA;
   unsigned long long *memo = wk.lmcache + (size_t)u * wk.nscword;
 
   if (resume) {
@@ -300,8 +308,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       if (tid == 0) { if (smode != 1) res->status = JAMD_PASS1_FAIL; if (ss) { ss->started = 0; ss->active = 1; } }
       return;
     }
-    // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665)
-    if (tid == 0) {
+    // ---- get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665).
+    // With a grammar the initial tokens (one per word that may start a sentence, :1669-1757)
+    // enter through the finalize and rank-pruning steps of a pseudo frame 0 below.
+    if (tid == 0 && !dfa) {
       const int node = lx.word_head[lx.head_silwid];
       const int4 nr = lx.node_b[node];                 // {stend, scid, out_id, out_kind}
       Tok nw;
@@ -324,7 +334,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 
   // frames base+1 .. T-1 of this launch are propagated into (frame `base` itself when resuming);
   // t == T is the end phase and only runs when finishing
-  for (int t = resume ? base : 1; t <= (finish ? T : T - 1); t++) {
+  for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
     // tl/tn swap (beam.c:2697-2698): sv[] holds last frame's survivors
     const int n_surv = sh.n_surv;
     __syncthreads();
@@ -399,7 +409,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         if (!last && sword != lx.tail_silwid) {            // beam_inter_word() :2296-2313
           welist[atomicAdd(&sh.n_we, 1)] = j;
           const float tmpprob = tk.score + lx.wordend_a[sword];
-          if (tmpprob > JAMD_LOG_ZERO) {
+          if (!dfa && tmpprob > JAMD_LOG_ZERO) {
             const unsigned long long key = ((unsigned long long)ord(tmpprob) << 32) | (unsigned)sword;
             const unsigned long long old = atomicMax(&sh.we_best, key);
             if (old != 0ull && (unsigned)(old >> 32) == (unsigned)(key >> 32)) atomicAdd(&sh.ties_we, 1);
@@ -420,7 +430,30 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     if (last) break;
 
     // ---- B1: word ends -> isolated roots with the 2-gram (beam_inter_word() :2334-2516)
-    {
+    if (dfa) {
+      // grammar: every word end x every root whose category may follow (category-pair
+      // constraint, beam_inter_word() :2404-2412), word insertion penalty + the ended word's
+      // in-class score as the LM score (:2452-2461)
+      const int n_we = sh.n_we, nroot = lx.startnum;
+      const int total = n_we * nroot;
+      for (int x = tid; x < total; x += NT) {
+        const int w = x / nroot, r = x - w * nroot;
+        const Tok tk = sv[welist[w]];
+        const int sword = lx.node_b[tk.node].x;
+        if (!lx.cat_pair[lx.wton[sword] * lx.ncat + lx.root_cat[r]]) continue;
+        const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+        float tmpsum = tk.score;
+        tmpsum += lx.wordend_a[sword];
+        float ng = lx.penalty1;
+        ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+        tmpsum += ng;
+        if (push(sh, nodekey, touched, lx.startnode[r], tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+          atomicAdd(&sh.ties, 1);
+      }
+      if (t == 0)          // pseudo frame 0: the initial tokens (init_nodescore(), beam.c:1669-1757)
+        for (int e = tid; e < lx.ninit; e += NT)
+          push(sh, nodekey, touched, lx.init_node[e], lx.init_lscore[e], 0xC0000000u | (unsigned)e);
+    } else {
       const int n_we = sh.n_we, niso = lx.isolatenum;
       const int total = n_we * niso;
       for (int x = tid; x < total; x += NT) {
@@ -444,7 +477,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     }
     // ---- B2: best word end -> shared roots with the 1-gram factoring value
     //          (beam_inter_word_factoring() :2549-2637)
-    if (sh.we_best != 0ull) {
+    if (!dfa && sh.we_best != 0ull) {
       const unsigned long long kb = sh.we_best;
       const float best_score = unord((unsigned)(kb >> 32));
       const int sword = (int)(unsigned)kb;
@@ -487,6 +520,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y, memo) * lmw + pen;
           else
             nw.last_lscore = tk.last_lscore;
+        } else if (dfa && (id >> 30) == 3u) {        // an initial token of the grammar
+          nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1;
+          nw.last_lscore = lx.init_lscore[id & 0x3fffffffu];
         } else {
           const bool iso = (id >> 30) == 2u;
           const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
@@ -494,7 +530,11 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           const Tok tk = sv[j];
           const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
           nw.last_tre = sv_atom[j]; nw.last_cword = last_word; nw.last_wid = sword;
-          if (iso) {                                       // beam_inter_word() :2430-2438
+          if (dfa) {                                       // beam_inter_word() :2452-2461
+            float ng = lx.penalty1;
+            ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+            nw.last_lscore = ng;
+          } else if (iso) {                                // beam_inter_word() :2430-2438
             const int wn = lx.scword[nr.y];
             const float p = (last_word < 0) ? 0.0f
                             : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
@@ -727,7 +767,26 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   const int natom = min(sh.n_atom, wk.atom_cap);
   if (tid == 0) sh.best_atom = -1;
   __syncthreads();
-  if (res->status == JAMD_PASS1_OK) {
+  if (res->status == JAMD_PASS1_OK && dfa) {
+    // grammar (:433-455): the best word on the latest frame where a word survived; equal scores
+    // go to the smaller word id (rw[t] is sorted by word id and the test is a strict <)
+    if (tid == 0) { sh.n_arc = -1; sh.we_best = 0ull; }
+    __syncthreads();
+    int lt = -1;
+    for (int i = tid; i < natom; i += NT)
+      if (atoms[i].backscore > JAMD_LOG_ZERO && atoms[i].endtime > lt) lt = atoms[i].endtime;
+    if (lt >= 0) atomicMax(&sh.n_arc, lt);
+    __syncthreads();
+    lt = sh.n_arc;
+    for (int i = tid; i < natom; i += NT)
+      if (atoms[i].endtime == lt && atoms[i].backscore > JAMD_LOG_ZERO)
+        atomicMax(&sh.we_best, ((unsigned long long)ord(atoms[i].backscore) << 32) | (0xffffffffu - (unsigned)atoms[i].wid));
+    __syncthreads();
+    const unsigned long long kb = sh.we_best;
+    for (int i = tid; i < natom; i += NT)      // (frame, word) names one atom: a word has one end node
+      if (kb != 0ull && atoms[i].endtime == lt && (unsigned)atoms[i].wid == 0xffffffffu - (unsigned)kb &&
+          ord(atoms[i].backscore) == (unsigned)(kb >> 32)) sh.best_atom = i;
+  } else if (res->status == JAMD_PASS1_OK) {
     int best = -1;
     for (int i = tid; i < natom; i += NT)
       if (atoms[i].wid == lx.tail_silwid && atoms[i].backscore > JAMD_LOG_ZERO) best = i;  // ascending i
@@ -890,7 +949,18 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
   int status = JAMD_PASS1_OK, died_at = -1, max_tokens = 1;
 
   b.tn = 0; b.tlx = 1;
-  {                                                                  // init_nodescore() :1622-1665
+  const bool dfa = lx.lm_type == JAMD_LM_DFA;
+  if (dfa) {                                                         // init_nodescore() :1669-1757
+    for (int e = 0; e < lx.ninit; e++) {
+      const int id = s_create_token(b);
+      STok &nw = b.tl[b.tn][id];
+      const int node = lx.init_node[e];
+      const int4 nr = lx.node_b[node];
+      nw.last_lscore = lx.init_lscore[e]; nw.last_tre = -1; nw.last_cword = -1;
+      nw.score = node_outprob(lx, b.sc, nr.w, nr.z, -1) + nw.last_lscore;
+      nw.node = node; b.token[node] = id;
+    }
+  } else {                                                           // init_nodescore() :1622-1665
     const int id = s_create_token(b);
     STok &nw = b.tl[b.tn][id];
     const int node = lx.word_head[lx.head_silwid];
@@ -922,7 +992,18 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
       const int sword = lx.node_b[node].x;
       if (sword >= 0) {
         const int tre = s_save_trellis(b, tk, sword, t);
-        if (sword != lx.tail_silwid) {                                          // beam_inter_word() :2271
+        if (dfa) {                                                              // beam_inter_word(), grammar branch
+          const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+          for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+            if (!lx.cat_pair[lx.wton[sword] * lx.ncat + lx.root_cat[stid]]) continue;      // :2404-2412
+            float tmpsum = tk.score;
+            tmpsum += lx.wordend_a[sword];
+            float ng = lx.penalty1;                                             // :2452-2461
+            ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+            tmpsum += ng;
+            s_propagate(b, lx.startnode[stid], tmpsum, tre, last_word, ng);
+          }
+        } else if (sword != lx.tail_silwid) {                                   // beam_inter_word() :2271
           const bool tr = lx.is_transparent[sword] != 0;
           const int last_word = tr ? tk.last_cword : sword;
           float tmpprob = tk.score + lx.wordend_a[sword];
@@ -945,7 +1026,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
         }
       }
     }
-    if (b.we_best_score > JAMD_LOG_ZERO) {                                       // beam_inter_word_factoring() :2549
+    if (!dfa && b.we_best_score > JAMD_LOG_ZERO) {                               // beam_inter_word_factoring() :2549
       const int sword = lx.node_b[b.we_best_node].x;
       const int last_word = lx.is_transparent[sword] ? b.we_best_cword : sword;
       for (int stid = lx.startnum - 1; stid >= 0; stid--) {
@@ -983,10 +1064,19 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
       if (sword >= 0) s_save_trellis(b, tk, sword, T);
     }
     int best = -1;                                                               // find_1pass_result() :399
-    for (int i = b.natom - 1; i >= 0; i--)
-      if (b.atoms[i].wid == lx.tail_silwid && b.atoms[i].backscore > JAMD_LOG_ZERO) { best = i; break; }
-    if (best >= 0 && b.atoms[best].endtime != b.atoms[b.natom - 1].endtime) {
-      // atoms are emitted in time order; `best` is already the tail word ending latest
+    if (dfa) {                                                                   // :433-455
+      int lt = -1;
+      for (int i = b.natom - 1; i >= 0 && lt < 0; i--) if (b.atoms[i].backscore > JAMD_LOG_ZERO) lt = b.atoms[i].endtime;
+      for (int i = 0; i < b.natom; i++) {        // atoms are emitted in time order
+        const jamd_trellis_atom &a = b.atoms[i];
+        if (a.endtime != lt || !(a.backscore > JAMD_LOG_ZERO)) continue;
+        if (best < 0 || b.atoms[best].backscore < a.backscore ||
+            (b.atoms[best].backscore == a.backscore && a.wid < b.atoms[best].wid)) best = i;
+      }
+    } else {
+      // atoms are emitted in time order: the first hit from the back is the tail word ending latest
+      for (int i = b.natom - 1; i >= 0; i--)
+        if (b.atoms[i].wid == lx.tail_silwid && b.atoms[i].backscore > JAMD_LOG_ZERO) { best = i; break; }
     }
     if (best < 0) status = JAMD_PASS1_FAIL;
     else {
@@ -1036,7 +1126,13 @@ extern "C" {
 int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon **out) {
   if (!e || !h || !out) { jamd_set_error("jamd_lexicon_create: NULL argument"); return JAMD_EINVAL; }
   *out = nullptr;
-  if (h->nnode <= 0 || h->nword <= 0 || h->startnum < 0 || h->head_silwid < 0 || h->head_silwid >= h->nword) {
+  const bool dfa = h->lm_type == JAMD_LM_DFA;
+  if (h->lm_type != JAMD_LM_NGRAM && !dfa) { jamd_set_error("jamd_lexicon_create: lm_type=%d", h->lm_type); return JAMD_EINVAL; }
+  if (dfa && (h->ncat <= 0 || h->ninit < 0 || !h->cat_pair || !h->start2wid || (h->ninit > 0 && (!h->init_node || !h->init_lscore)))) {
+    jamd_set_error("jamd_lexicon_create: grammar descriptor incomplete (ncat=%d ninit=%d)", h->ncat, h->ninit);
+    return JAMD_EINVAL;
+  }
+  if (h->nnode <= 0 || h->nword <= 0 || h->startnum < 0 || (!dfa && (h->head_silwid < 0 || h->head_silwid >= h->nword))) {
     jamd_set_error("jamd_lexicon_create: bad sizes (nnode=%d nword=%d head_silwid=%d)", h->nnode, h->nword,
                    h->head_silwid);
     return JAMD_EINVAL;
@@ -1051,7 +1147,7 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     if (2 + x > maxfan) maxfan = 2 + x;
   }
   std::vector<int> iso(h->isolatenum > 0 ? h->isolatenum : 0), shared;
-  for (int s = 0; s < h->startnum; s++) {
+  for (int s = 0; s < h->startnum && !dfa; s++) {
     const int i = h->start2isolate[s];
     if (i >= 0) {
       if (i >= h->isolatenum) { jamd_set_error("jamd_lexicon_create: start2isolate out of range"); return JAMD_EINVAL; }
@@ -1115,6 +1211,23 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   UP(ng_uni_prob, h->ng_uni_prob, h->ng_nword); UP(ng_uni_bo, h->ng_uni_bo, h->ng_nword);
   UP(ng_bi_bgn, h->ng_bi_bgn, h->ng_nword); UP(ng_bi_num, h->ng_bi_num, h->ng_nword);
   UP(ng_bi_wid, h->ng_bi_wid, h->ng_nbigram); UP(ng_bi_prob, h->ng_bi_prob, h->ng_nbigram);
+  d.lm_type = h->lm_type; d.ncat = dfa ? h->ncat : 0; d.ninit = dfa ? h->ninit : 0; d.penalty1 = dfa ? h->penalty1 : 0.0f;
+  if (dfa) {
+    std::vector<int> root_cat(h->startnum);
+    for (int s = 0; s < h->startnum; s++) {
+      const int w = h->start2wid[s];
+      if (w < 0 || w >= h->nword || h->wton[w] < 0 || h->wton[w] >= h->ncat) {
+        jamd_set_error("jamd_lexicon_create: root %d has no valid category", s); rc = JAMD_EINVAL; break;
+      }
+      root_cat[s] = h->wton[w];
+    }
+    for (int w = 0; w < h->nword && rc == JAMD_OK; w++)
+      if (h->wton[w] < 0 || h->wton[w] >= h->ncat) { jamd_set_error("jamd_lexicon_create: word %d outside the categories", w); rc = JAMD_EINVAL; }
+    for (int e = 0; e < h->ninit && rc == JAMD_OK; e++)
+      if (h->init_node[e] < 0 || h->init_node[e] >= h->nnode) { jamd_set_error("jamd_lexicon_create: bad initial node"); rc = JAMD_EINVAL; }
+    UP(cat_pair, h->cat_pair, (size_t)h->ncat * h->ncat); UP(root_cat, root_cat.data(), root_cat.size());
+    UP(init_node, h->init_node, h->ninit); UP(init_lscore, h->init_lscore, h->ninit);
+  }
 #undef UP
   if (rc != JAMD_OK) { jamd_lexicon_destroy(l); return rc; }
   *out = l;
@@ -1144,7 +1257,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   w.beam = beam_width; w.width = score_pruning_width; w.nnode = l->d.nnode; w.nword = l->d.nword;
   w.atom_cap = atoms_per_utt;
   // every survivor reaches at most maxfan nodes, cross-word candidates only reach roots
-  w.tok_cap = beam_width * l->maxfan + l->d.startnum + 1;
+  w.tok_cap = beam_width * l->maxfan + l->d.startnum + l->d.ninit + 1;
   const size_t U = (size_t)max_utts;
   int rc = JAMD_OK;
   auto alloc = [&](void **p, size_t bytes, bool zero) -> int {

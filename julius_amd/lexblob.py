@@ -14,8 +14,9 @@ import numpy as np
 _DT = {0: np.int32, 1: np.float32, 2: np.uint8}
 _INTS = ["nnode", "nword", "startnum", "isolatenum", "nlc", "nlcrow", "nset", "cdset_method", "cdmax_num",
          "head_silwid", "tail_silwid", "nfscore", "nscword", "ng_mode", "ng_nword", "ng_nbigram", "ng_unk_id",
-         "_reserved"]
-_FLOATS = ["ng_unk_num_log", "lm_weight", "lm_penalty", "lm_penalty_trans"]
+         "_reserved", "lm_type", "ncat", "ninit"]
+_FLOATS = ["ng_unk_num_log", "lm_weight", "lm_penalty", "lm_penalty_trans", "penalty1"]
+DFA_ARRAYS = ["cat_pair", "start2wid", "init_node", "init_lscore"]
 ARRAYS = ["self_a", "next_a", "ac_off", "ac_to", "ac_a", "stend", "scid", "out_kind", "out_id", "lc_tab",
           "word_lc", "set_off", "set_states", "startnode", "start2isolate", "wordend_a", "wton", "cprob",
           "is_transparent", "word_head", "fscore", "scword", "ng_uni_prob", "ng_uni_bo", "ng_bi_bgn",
@@ -64,7 +65,7 @@ def load_gmm(path) -> dict:
 
 def save(lex: dict, path) -> None:
     """Same format as jamd_lexicon_save() (used to commit small golden fixtures)."""
-    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS))]
+    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if lex.get("lm_type", 0) == 1 else 0))]
 
     def put(name, arr):
         arr = np.ascontiguousarray(arr)
@@ -73,9 +74,12 @@ def save(lex: dict, path) -> None:
         out.append(name.encode().ljust(24, b"\0") + struct.pack("<ii", code, arr.size) + b + b"\0" * (-len(b) % 4))
 
     put("ints", np.array([lex.get(k, 0) for k in _INTS], dtype=np.int32))
-    put("floats", np.array([lex[k] for k in _FLOATS], dtype=np.float32))
+    put("floats", np.array([lex.get(k, 0.0) for k in _FLOATS], dtype=np.float32))
     for k in ARRAYS:
         put(k, lex[k])
+    if lex.get("lm_type", 0) == 1:
+        for k in DFA_ARRAYS:
+            put(k, lex[k])
     Path(path).write_bytes(b"".join(out))
 
 
@@ -100,6 +104,8 @@ class LexiconDesc(_C.Structure):
         ("ng_uni_prob", _vp), ("ng_uni_bo", _vp), ("ng_bi_bgn", _vp), ("ng_bi_num", _vp), ("ng_bi_wid", _vp),
         ("ng_bi_prob", _vp),
         ("lm_weight", _cf), ("lm_penalty", _cf), ("lm_penalty_trans", _cf),
+        ("lm_type", _ci), ("ncat", _ci), ("cat_pair", _vp), ("start2wid", _vp),
+        ("ninit", _ci), ("init_node", _vp), ("init_lscore", _vp), ("penalty1", _cf),
     ]
 
 
@@ -118,13 +124,16 @@ def make_desc(lex: dict):
     keep = {}
     d = LexiconDesc()
     scalars = {n for n, t in LexiconDesc._fields_ if t is not _vp}
+    dflt = {"lm_type": 0, "ncat": 0, "ninit": 0, "penalty1": 0.0, "cat_pair": np.zeros(1, np.uint8),
+            "start2wid": np.zeros(1, np.int32), "init_node": np.zeros(1, np.int32), "init_lscore": np.zeros(1, np.float32)}
     for name, ctype in LexiconDesc._fields_:
+        val = lex.get(name, dflt.get(name))           # fixtures written before grammar mode lack the DFA fields
         if name in scalars:
-            setattr(d, name, lex[name])
+            setattr(d, name, val)
         else:
-            want = {"out_kind": np.uint8, "is_transparent": np.uint8}.get(
-                name, np.float32 if np.asarray(lex[name]).dtype.kind == "f" else np.int32)
-            a = np.ascontiguousarray(lex[name], dtype=want)
+            want = {"out_kind": np.uint8, "is_transparent": np.uint8, "cat_pair": np.uint8}.get(
+                name, np.float32 if np.asarray(val).dtype.kind == "f" else np.int32)
+            a = np.ascontiguousarray(val, dtype=want)
             if a.size == 0:
                 a = np.zeros(1, dtype=want)
             keep[name] = a

@@ -76,11 +76,13 @@ typedef struct {
   float *wordend_a; int *wton; float *cprob; unsigned char *is_transparent; int *word_head;
   float *fscore; int *scword;
   float *ng_uni_prob, *ng_uni_bo; int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; float *ng_bi_prob;
+  unsigned char *cat_pair; int *start2wid, *init_node; float *init_lscore;
 } jamd_flat_lexicon;
 
 /* Walk r->wchmm (after j_final_fusion()) and fill `out`.  JAMD_EINVAL for the
- * configurations the device beam does not cover (grammar LM, multipath models,
- * user LM plugin, 24-bit compacted 2-gram index). */
+ * configurations the device beam does not cover (isolated-word LM, grammars with a
+ * forward DFA or without per-category trees, multipath models, user LM plugin, 24-bit
+ * compacted 2-gram index). */
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
 void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
 /* Write the descriptor as a self-describing blob of named arrays (the format

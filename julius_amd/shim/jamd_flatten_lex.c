@@ -89,15 +89,21 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   char **lcname = NULL; int nlc = 0;
   int *word_lc;
   pmap rows; ivec rowkey_kind; ivec lc_tab;
-  typedef struct { HMM_Logical *hmm; short loc; unsigned char kind; } rowkey;
+  typedef struct { HMM_Logical *hmm; short loc; unsigned char kind; int cat; } rowkey;
   rowkey *rk = NULL; int nrk = 0, caprk = 0;
   char rbuf[MAX_HMMNAME_LEN], cbuf[MAX_HMMNAME_LEN];
 
   memset(out, 0, sizeof(*out));
-  if (r->lmtype != LM_PROB || ng == NULL) return JAMD_EINVAL;      /* N-gram only (for now) */
+  const int dfa_mode = (r->lmtype == LM_DFA);
   if (hmminfo->multipath) return JAMD_EINVAL;
-  if (wchmm->category_tree) return JAMD_EINVAL;
-  if (r->lmvar == LM_NGRAM_USER) return JAMD_EINVAL;
+  if (dfa_mode) {                     /* grammar: per-category trees, no forward DFA, no isolated-word mode */
+    if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL || wchmm->dfa_forward != NULL)
+      return JAMD_EINVAL;
+  } else {
+    if (r->lmtype != LM_PROB || ng == NULL) return JAMD_EINVAL;
+    if (wchmm->category_tree) return JAMD_EINVAL;
+    if (r->lmvar == LM_NGRAM_USER) return JAMD_EINVAL;
+  }
 
   memset(&sr, 0, sizeof(sr)); pmap_init(&sr.sets, 1024); ivec_push(&sr.set_off, 0);
   memset(&rowkey_kind, 0, sizeof(rowkey_kind)); memset(&lc_tab, 0, sizeof(lc_tab));
@@ -130,7 +136,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
         }
       }
       out->stend[i] = (wchmm->stend[i] == WORD_INVALID) ? -1 : (int)wchmm->stend[i];
-      out->scid[i] = wchmm->state[i].scid;
+      out->scid[i] = dfa_mode ? 0 : wchmm->state[i].scid;   /* per-category trees carry no factoring data */
     }
     out->ac_off[n] = an;
     out->ac_to = ato.v ? ato.v : NEW(int, 1);
@@ -149,12 +155,15 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
     case AS_RSET: case AS_LRSET: {
       HMM_Logical *base = (kind == AS_RSET) ? wchmm->state[i].out.rset->hmm : wchmm->state[i].out.lrset->hmm;
       short loc = (kind == AS_RSET) ? wchmm->state[i].out.rset->state_loc : wchmm->state[i].out.lrset->state_loc;
+      /* with per-category trees a one-phone word's state set also depends on its category
+       * (lcdset_lookup_with_category(), outprob_style.c:144, :452-458) */
+      const int cat = (kind == AS_LRSET && wchmm->category_tree) ? (int)wchmm->state[i].out.lrset->category : -1;
       int row = -1;
-      for (k = 0; k < nrk; k++) if (rk[k].hmm == base && rk[k].loc == loc && rk[k].kind == kind) { row = k; break; }
+      for (k = 0; k < nrk; k++) if (rk[k].hmm == base && rk[k].loc == loc && rk[k].kind == kind && rk[k].cat == cat) { row = k; break; }
       if (row < 0) {
         int c;
         if (nrk == caprk) { caprk = caprk ? caprk * 2 : 256; rk = (rowkey *)realloc(rk, sizeof(rowkey) * caprk); }
-        rk[nrk].hmm = base; rk[nrk].loc = loc; rk[nrk].kind = kind; row = nrk++;
+        rk[nrk].hmm = base; rk[nrk].loc = loc; rk[nrk].kind = kind; rk[nrk].cat = cat; row = nrk++;
         for (c = 0; c <= nlc; c++) {          /* column nlc: last_wid == WORD_INVALID */
           HMM_Logical *rhmm = base, *ohmm;
           int ent;
@@ -164,9 +173,16 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
             else ent = rhmm->body.defined->s[loc]->id;
           } else {                                                 /* outprob_style.c:440-478 */
             CD_Set *lcd;
-            strcpy(rbuf, base->name);
-            if (c < nlc) add_left_context(rbuf, lcname[c]);
-            lcd = lcdset_lookup_by_hmmname(hmminfo, rbuf);
+            if (wchmm->category_tree) {
+              if (c < nlc && (ohmm = get_left_context_HMM(base, lcname[c], hmminfo)) != NULL)
+                lcd = lcdset_lookup_with_category(wchmm, ohmm, (WORD_ID)cat);
+              else
+                lcd = lcdset_lookup_with_category(wchmm, base, (WORD_ID)cat);
+            } else {
+              strcpy(rbuf, base->name);
+              if (c < nlc) add_left_context(rbuf, lcname[c]);
+              lcd = lcdset_lookup_by_hmmname(hmminfo, rbuf);
+            }
             if (lcd != NULL) ent = ~set_id(&sr, &(lcd->stateset[loc]));
             else if (base->is_pseudo) ent = ~set_id(&sr, &(base->body.pseudo->stateset[loc]));
             else ent = base->body.defined->s[loc]->id;
@@ -185,7 +201,10 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
 
   /* ---- roots, words ------------------------------------------------------------ */
   out->startnode = NEW(int, wchmm->startnum); out->start2isolate = NEW(int, wchmm->startnum);
-  for (i = 0; i < wchmm->startnum; i++) { out->startnode[i] = wchmm->startnode[i]; out->start2isolate[i] = wchmm->start2isolate[i]; }
+  for (i = 0; i < wchmm->startnum; i++) {
+    out->startnode[i] = wchmm->startnode[i];
+    out->start2isolate[i] = (!dfa_mode && wchmm->start2isolate) ? wchmm->start2isolate[i] : -1;
+  }
   out->wordend_a = NEW(float, W); out->wton = NEW(int, W); out->cprob = NEW(float, W);
   out->is_transparent = NEW(unsigned char, W); out->word_head = NEW(int, W);
   for (w = 0; w < W; w++) {
@@ -195,12 +214,16 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   out->word_lc = word_lc;
 
   /* ---- factoring ------------------------------------------------------------------ */
-  out->fscore = NEW(float, wchmm->fsnum); for (i = 0; i < wchmm->fsnum; i++) out->fscore[i] = wchmm->fscore[i];
-  out->scword = NEW(int, wchmm->scnum);
-  for (i = 1; i < wchmm->scnum; i++) out->scword[i] = wchmm->scword[i];
+  if (dfa_mode) {                       /* fsnum / scnum are never set with per-category trees (wchmm.c:1938) */
+    out->fscore = NEW(float, 1); out->scword = NEW(int, 1);
+  } else {
+    out->fscore = NEW(float, wchmm->fsnum); for (i = 0; i < wchmm->fsnum; i++) out->fscore[i] = wchmm->fscore[i];
+    out->scword = NEW(int, wchmm->scnum);
+    for (i = 1; i < wchmm->scnum; i++) out->scword[i] = wchmm->scword[i];
+  }
 
   /* ---- forward 2-gram (bi_prob_func_set(), ngram_access.c:449-466) --------------------- */
-  {
+  if (!dfa_mode) {
     int V = ng->max_word_num;
     NGRAM_TUPLE_INFO *t2 = &(ng->d[1]);
     const float *bo, *bp;
@@ -220,12 +243,43 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
     for (i = 0; i < (int)t2->totalnum; i++) { out->ng_bi_wid[i] = t2->nnid2wid[i]; out->ng_bi_prob[i] = bp[i]; }
     d->ng_nword = V; d->ng_nbigram = t2->totalnum;
     d->ng_unk_id = (int)ng->unk_id; d->ng_unk_num_log = ng->unk_num_log;
+  } else {
+    /* ---- grammar: category pairs, roots' categories, initial tokens (beam.c:1669-1757) ---- */
+    DFA_INFO *dfa = wchmm->dfa;
+    MULTIGRAM *m;
+    int C = dfa->term_num, c1, c2, t, iw, ninit = 0;
+    int *seen = NEW(int, n);
+    out->ng_uni_prob = NEW(float, 1); out->ng_uni_bo = NEW(float, 1); out->ng_bi_bgn = NEW(int, 1);
+    out->ng_bi_num = NEW(int, 1); out->ng_bi_wid = NEW(int, 1); out->ng_bi_prob = NEW(float, 1);
+    out->cat_pair = NEW(unsigned char, C * C);
+    for (c1 = 0; c1 < C; c1++) for (c2 = 0; c2 < C; c2++) out->cat_pair[c1 * C + c2] = dfa_cp(dfa, c1, c2) ? 1 : 0;
+    out->start2wid = NEW(int, wchmm->startnum);
+    for (i = 0; i < wchmm->startnum; i++) out->start2wid[i] = wchmm->start2wid[i];
+    out->init_node = NEW(int, W); out->init_lscore = NEW(float, W);
+    for (m = r->lm->grammars; m; m = m->next) {
+      if (!m->active) continue;
+      for (t = m->cate_begin; t < m->cate_begin + m->dfa->term_num; t++) {
+        if (dfa_cp_begin(dfa, t) != TRUE) continue;
+        for (iw = 0; iw < dfa->term.wnum[t]; iw++) {
+          int wid = dfa->term.tw[t][iw], node = wchmm->offset[wid][0];
+          if (seen[node]) continue;                    /* node_exist_token(), beam.c:1717 */
+          seen[node] = 1;
+          out->init_node[ninit] = node;
+          out->init_lscore[ninit] = r->config->lmp.penalty1 + winfo->cprob[wid];   /* beam.c:1724-1727 */
+          ninit++;
+        }
+      }
+    }
+    free(seen);
+    d->lm_type = JAMD_LM_DFA; d->ncat = C; d->ninit = ninit; d->penalty1 = r->config->lmp.penalty1;
+    d->cat_pair = out->cat_pair; d->start2wid = out->start2wid; d->init_node = out->init_node; d->init_lscore = out->init_lscore;
+    d->ng_unk_id = -1;
   }
 
   /* ---- descriptor ------------------------------------------------------------------------- */
   out->lc_tab = lc_tab.v ? lc_tab.v : NEW(int, 1);
   out->set_off = sr.set_off.v; out->set_states = sr.set_states.v ? sr.set_states.v : NEW(int, 1);
-  d->nnode = n; d->nword = W; d->startnum = wchmm->startnum; d->isolatenum = wchmm->isolatenum;
+  d->nnode = n; d->nword = W; d->startnum = wchmm->startnum; d->isolatenum = dfa_mode ? 0 : wchmm->isolatenum;
   d->self_a = out->self_a; d->next_a = out->next_a; d->ac_off = out->ac_off; d->ac_to = out->ac_to; d->ac_a = out->ac_a;
   d->stend = out->stend; d->scid = out->scid; d->out_kind = out->out_kind; d->out_id = out->out_id;
   d->nlc = nlc; d->nlcrow = nrk; d->lc_tab = out->lc_tab; d->word_lc = out->word_lc;
@@ -238,7 +292,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   d->is_transparent = out->is_transparent; d->word_head = out->word_head;
   d->head_silwid = (winfo->head_silwid == WORD_INVALID) ? -1 : (int)winfo->head_silwid;
   d->tail_silwid = (winfo->tail_silwid == WORD_INVALID) ? -1 : (int)winfo->tail_silwid;
-  d->nfscore = wchmm->fsnum; d->nscword = wchmm->scnum; d->fscore = out->fscore; d->scword = out->scword;
+  d->nfscore = dfa_mode ? 1 : wchmm->fsnum; d->nscword = dfa_mode ? 1 : wchmm->scnum; d->fscore = out->fscore; d->scword = out->scword;
   d->ng_uni_prob = out->ng_uni_prob; d->ng_uni_bo = out->ng_uni_bo; d->ng_bi_bgn = out->ng_bi_bgn;
   d->ng_bi_num = out->ng_bi_num; d->ng_bi_wid = out->ng_bi_wid; d->ng_bi_prob = out->ng_bi_prob;
   d->lm_weight = r->config->lmp.lm_weight; d->lm_penalty = r->config->lmp.lm_penalty;
@@ -255,7 +309,7 @@ void jamd_flat_lexicon_free(jamd_flat_lexicon *f)
   free(f->set_states); free(f->startnode); free(f->start2isolate); free(f->wordend_a); free(f->wton);
   free(f->cprob); free(f->is_transparent); free(f->word_head); free(f->fscore); free(f->scword);
   free(f->ng_uni_prob); free(f->ng_uni_bo); free(f->ng_bi_bgn); free(f->ng_bi_num); free(f->ng_bi_wid);
-  free(f->ng_bi_prob);
+  free(f->ng_bi_prob); free(f->cat_pair); free(f->start2wid); free(f->init_node); free(f->init_lscore);
   memset(f, 0, sizeof(*f));
 }
 
@@ -278,19 +332,20 @@ static int put_rec(FILE *f, const char *name, int dtype, int count, const void *
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");
-  int nrec = 30, rc = 0;
-  int ints[18]; float floats[4];
+  int nrec = 30 + (d->lm_type == JAMD_LM_DFA ? 4 : 0), rc = 0;
+  int ints[21]; float floats[5];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nnode; ints[1] = d->nword; ints[2] = d->startnum; ints[3] = d->isolatenum;
   ints[4] = d->nlc; ints[5] = d->nlcrow; ints[6] = d->nset; ints[7] = d->cdset_method; ints[8] = d->cdmax_num;
   ints[9] = d->head_silwid; ints[10] = d->tail_silwid; ints[11] = d->nfscore; ints[12] = d->nscword;
   ints[13] = d->ng_mode; ints[14] = d->ng_nword; ints[15] = d->ng_nbigram; ints[16] = d->ng_unk_id; ints[17] = 0;
+  ints[18] = d->lm_type; ints[19] = d->ncat; ints[20] = d->ninit; floats[4] = d->penalty1;
   floats[0] = d->ng_unk_num_log; floats[1] = d->lm_weight; floats[2] = d->lm_penalty; floats[3] = d->lm_penalty_trans;
   fwrite("JAMDLEX1", 1, 8, f); fwrite(&nrec, 4, 1, f);
 #define I32(nm, p, n) rc |= put_rec(f, nm, 0, (n), (p))
 #define F32(nm, p, n) rc |= put_rec(f, nm, 1, (n), (p))
 #define U8(nm, p, n)  rc |= put_rec(f, nm, 2, (n), (p))
-  I32("ints", ints, 18); F32("floats", floats, 4);
+  I32("ints", ints, 21); F32("floats", floats, 5);
   F32("self_a", d->self_a, d->nnode); F32("next_a", d->next_a, d->nnode);
   I32("ac_off", d->ac_off, d->nnode + 1); I32("ac_to", d->ac_to, d->ac_off[d->nnode]); F32("ac_a", d->ac_a, d->ac_off[d->nnode]);
   I32("stend", d->stend, d->nnode); I32("scid", d->scid, d->nnode);
@@ -304,6 +359,10 @@ int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
   F32("ng_uni_prob", d->ng_uni_prob, d->ng_nword); F32("ng_uni_bo", d->ng_uni_bo, d->ng_nword);
   I32("ng_bi_bgn", d->ng_bi_bgn, d->ng_nword); I32("ng_bi_num", d->ng_bi_num, d->ng_nword);
   I32("ng_bi_wid", d->ng_bi_wid, d->ng_nbigram); F32("ng_bi_prob", d->ng_bi_prob, d->ng_nbigram);
+  if (d->lm_type == JAMD_LM_DFA) {
+    U8("cat_pair", d->cat_pair, d->ncat * d->ncat); I32("start2wid", d->start2wid, d->startnum);
+    I32("init_node", d->init_node, d->ninit); F32("init_lscore", d->init_lscore, d->ninit);
+  }
 #undef I32
 #undef F32
 #undef U8

@@ -38,6 +38,7 @@ typedef struct {
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam;
   int nstate;
+  int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
   /* streaming state of the current utterance */
   int chunk;                   /* JAMD_STREAM_CHUNK: push every this many frames from _proceed(); 0 = all at _end() */
   int pushed;                  /* frames already handed to the device */
@@ -83,11 +84,14 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       return FALSE;
     }
   }
+  /* a grammar update rebuilds the lexicon tree (multigram_build()); the sizes and the DFA pointer
+   * also catch most rebuilt trees that landed on the old address */
   if (c->wchmm == r->wchmm && c->hmminfo == r->am->hmminfo && c->beam_width == r->trellis_beam_width &&
-      c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL) return TRUE;
+      c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL &&
+      c->nnode == r->wchmm->n && c->nword == r->wchmm->winfo->num && c->dfa == (void *)r->wchmm->dfa) return TRUE;
   ctx_release(c);
-  if (r->lmtype != LM_PROB || r->am->hmminfo->multipath || r->config->successive.enabled) {
-    jlog("ERROR: jamd: the device first pass covers N-gram LM, non-multipath models, no -spsegment\n");
+  if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || r->am->hmminfo->multipath || r->config->successive.enabled) {
+    jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
     return FALSE;
   }
   if (r->am->dnn != NULL) {                    /* DNN-HMM: dnn_calc_outprob() for the whole utterance */
@@ -128,6 +132,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0 &&
       jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
+  c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
   c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
   jlog("STAT: jamd: first pass on HIP device %d (beam %d, %d states, %d lexicon nodes)\n",
        jamd_engine_device(g_eng), c->beam_width, c->nstate, r->wchmm->n);
@@ -252,8 +257,8 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
     r->pass1_score = r->result.pass1.score = res.score;
     {                                                   /* trace_backptr(): total LM score */
       LOGPROB lm = 0.0; int a;
-      for (a = natom - 1; a >= 0; a--)
-        if (atoms[a].wid == r->lm->winfo->tail_silwid && atoms[a].backscore == res.score) break;
+      for (a = natom - 1; a >= 0; a--)     /* the atom the device traced back from: the sentence's last word */
+        if (atoms[a].wid == res.wseq[res.wnum - 1] && atoms[a].backscore == res.score) break;
       for (; a >= 0; a = atoms[a].last_tre) { lm += atoms[a].lscore; if (atoms[a].begintime <= 0) break; }
       r->result.pass1.score_lm = lm;
       r->result.pass1.score_am = res.score - lm;
@@ -277,8 +282,11 @@ void finalize_1st_pass(RecogProcess *r, int len)
     return;
   }
   if (status != J_RESULT_STATUS_SUCCESS) {
-    jlog("WARNING: %02d %s: no tail silence word survived on the last frame, search failed\n",
-         r->config->id, r->config->name);
+    if (r->lmtype == LM_DFA)
+      jlog("WARNING: %02d %s: no sentence-end word survived on last beam\n", r->config->id, r->config->name);
+    else
+      jlog("WARNING: %02d %s: no tail silence word survived on the last frame, search failed\n",
+           r->config->id, r->config->name);
     r->result.status = J_RESULT_STATUS_FAIL;
   }
 }

@@ -719,3 +719,64 @@ def make_grammar_utterance(task, nwords=4, seed=0, frames_per_state=3, noise=0.5
     st = np.repeat(np.array(seq), frames_per_state)
     fr = task["centre"][st] + rng.normal(0, noise, size=(len(st), task["centre"].shape[1]))
     return fr.astype(np.float32), [w for w, _ in ws]
+
+
+def make_triphone_grammar(task, ncat=3, seed=0, wrap=True):
+    """A DFA grammar over the words of a triphone task (make_triphone_task): word category
+    c may be followed by category c+1 or c+2 (mod ncat); a sentence is <s> WORD+ </s>.  One
+    lexicon tree per category with cross-word triphones, so one-phone words get category-aware
+    state sets (lcdset_register_with_category(), libjulius/src/wchmm.c:1068-1110).  The automaton
+    is written reversed as mkdfa.pl emits it.  Categories: 0 = </s>, 1 = <s>, 2.. = words.
+    wrap=False drops <s>/</s> from the sentences (they stay in the dictionary), so that every word
+    may start one: many initial tokens (init_nodescore(), libjulius/src/beam.c:1669-1757)."""
+    rng = np.random.default_rng(seed + 77)
+    workdir = Path(task["dir"])
+    words = task["words"]
+    cat = [int(rng.integers(0, ncat)) for _ in words]
+    dl = ["0 [</s>] silE", "1 [<s>] silB"] + [f"{2 + c} [{w}] " + " ".join(ph) for (w, ph), c in zip(words, cat)]
+    (workdir / "g.dict").write_text("\n".join(dl) + "\n")
+    # reversed automaton: 0 --</s>--> E(1); E --cat j--> R_j (2+j); R_j --cat i (i may precede j)--> R_i;
+    # R_j --<s>--> F; F accepts
+    F = 2 + ncat
+    lines = ["0 0 1 0 0"] + [f"1 {2 + j} {2 + j} 0 0" for j in range(ncat)]
+    if not wrap:         # state 0 = sentence end, any word category may be last; any R_j accepts
+        lines = [f"0 {2 + j} {2 + j} 0 0" for j in range(ncat)] + ["1 0 1 0 0", "1 1 1 0 0"]   # state 1: unreachable, keeps <s>,</s> declared
+    for j in range(ncat):
+        for i in range(ncat):
+            if (i + 1) % ncat == j or (i + 2) % ncat == j:
+                lines.append(f"{2 + j} {2 + i} {2 + i} 0 0")
+        lines.append(f"{2 + j} 1 {F} 0 0" if wrap else f"{2 + j} -1 -1 1 0")
+    if wrap:
+        lines.append(f"{F} -1 -1 1 0")
+    (workdir / "g.dfa").write_text("\n".join(lines) + "\n")
+    g = dict(task)
+    g.update(dfa=workdir / "g.dfa", gdict=workdir / "g.dict", word_cat=cat, ncat=ncat, wrap=wrap)
+    return g
+
+
+def make_triphone_grammar_utterance(g, nwords=4, seed=0, frames_per_state=3, noise=0.7):
+    """Frames following a random sentence the grammar of make_triphone_grammar() accepts."""
+    rng = np.random.default_rng(seed)
+    ncat = g["ncat"]
+    by_cat = [[i for i, c in enumerate(g["word_cat"]) if c == k] for k in range(ncat)]
+    c = int(rng.integers(0, ncat))
+    ids = []
+    for _ in range(nwords):
+        if not by_cat[c]:
+            c = (c + 1) % ncat
+            continue
+        ids.append(int(rng.choice(by_cat[c])))
+        c = (c + int(rng.integers(1, 3))) % ncat
+    model = g["model"]
+    S = len(model["st_off"]) - 1
+    per = (S - 6) // len(g["phones"])
+    seq = [S - 6, S - 5, S - 4] if g.get("wrap", True) else []
+    for i in ids:
+        for p in g["words"][i][1]:
+            base = g["phones"].index(p) * per
+            seq += [int(base + rng.integers(0, per)) for _ in range(3)]
+    if g.get("wrap", True):
+        seq += [S - 3, S - 2, S - 1]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
+    return fr.astype(np.float32), [g["words"][i][0] for i in ids]

@@ -9,7 +9,7 @@
  * step -- including the partial heap sort that decides the iteration order of
  * the surviving tokens -- so that its word trellis is the reference's word
  * trellis even where Viterbi ties are broken by visiting order.  Scope: N-gram
- * LM, non-multipath models, the reference's default "fast" configuration
+ * LM or DFA grammar with per-category trees, non-multipath models, the reference's default "fast" configuration
  * (UNIGRAM_FACTORING, PASS1_IWCD, SCORE_PRUNING; no WPAIR / WORD_GRAPH /
  * spsegment).  Paths below are relative to the reference root.
  *
@@ -217,7 +217,8 @@ static void intra_word_core(beam *b, int j, int next_node, float next_a)
   const jamd_lexicon_desc *lx = b->lx;
   tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];       /* copy: the list may be realloc'ed */
   float tmpsum = tk.score + next_a, ngram_score_cache = JO_LOG_ZERO;
-  if (next_node != tk.node && lx->scid[next_node] != 0) {
+  /* with per-category trees (grammar) the whole factoring block is skipped: beam.c:2029 */
+  if (lx->lm_type == JAMD_LM_NGRAM && next_node != tk.node && lx->scid[next_node] != 0) {
     ngram_score_cache = max_successor_prob(lx, tk.last_cword, next_node) * lx->lm_weight + lx->lm_penalty;
     tmpsum -= tk.last_lscore;
     tmpsum += ngram_score_cache;
@@ -279,6 +280,27 @@ static void inter_word(beam *b, int j, int tre)
   }
 }
 
+/* beam_inter_word(), grammar branch (LM_DFA with category tree, no forward DFA):
+ * category-pair test per root (beam.c:2404-2412), word insertion penalty + delayed class
+ * penalty of the previous word (:2452-2461) */
+static void inter_word_dfa(beam *b, int j, int tre)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+  int sword = lx->stend[tk.node], stid;
+  int last_word = lx->is_transparent[sword] ? tk.last_cword : sword;
+  float tmpsum, ngram_score_cache;
+  for (stid = lx->startnum - 1; stid >= 0; stid--) {
+    if (!lx->cat_pair[lx->wton[sword] * lx->ncat + lx->wton[lx->start2wid[stid]]]) continue;
+    tmpsum = tk.score;
+    tmpsum += lx->wordend_a[sword];
+    ngram_score_cache = lx->penalty1;
+    ngram_score_cache += lx->cprob[last_word];
+    tmpsum += ngram_score_cache;
+    propagate_token(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
+  }
+}
+
 /* beam_inter_word_factoring(), beam.c:2549-2637 */
 static void inter_word_factoring(beam *b)
 {
@@ -334,7 +356,17 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
   }
   b->token = (int *)malloc(sizeof(int) * lx->nnode);
   for (i = 0; i < lx->nnode; i++) b->token[i] = -1;
-  {                                                        /* init_nodescore :1622-1665 */
+  if (lx->lm_type == JAMD_LM_DFA) {                        /* init_nodescore :1669-1757 */
+    int e;
+    for (e = 0; e < lx->ninit; e++) {
+      int id = create_token(b);
+      tok *nw = &b->tlist[b->tn][id];
+      node = lx->init_node[e];
+      nw->last_tre = -1; nw->last_cword = -1; nw->last_lscore = lx->init_lscore[e];
+      nw->score = outprob_style(b, node, -1, 0) + nw->last_lscore;
+      b->token[node] = id; nw->node = node;
+    }
+  } else {                                                 /* init_nodescore :1622-1665 */
     int id = create_token(b);
     tok *nw = &b->tlist[b->tn][id];
     node = lx->word_head[lx->head_silwid];
@@ -361,10 +393,11 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
       intra_word(b, j);
       if (lx->stend[tk.node] >= 0) {
         int tre = save_trellis(b, &tk, t);
-        inter_word(b, j, tre);
+        if (lx->lm_type == JAMD_LM_DFA) inter_word_dfa(b, j, tre);
+        else inter_word(b, j, tre);
       }
     }
-    if (b->wordend_best_score > JO_LOG_ZERO) inter_word_factoring(b);
+    if (lx->lm_type == JAMD_LM_NGRAM && b->wordend_best_score > JO_LOG_ZERO) inter_word_factoring(b);
     b->score_pruning_max = JO_LOG_ZERO;
     for (j = 0; j < b->tnum[tn]; j++) {                                       /* :2944-2951 */
       tok *tk = &b->tlist[tn][b->tindex[tn][j]];
@@ -390,6 +423,18 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
     {
       int best = -1, last_time;
       for (last_time = T - 1; last_time >= 0 && best < 0; last_time--) {
+        if (lx->lm_type == JAMD_LM_DFA) {
+          /* grammar (:433-455): the best word on the latest frame that has one; rw[t] is sorted
+           * by word id and the test is a strict <, so ties go to the smaller word id */
+          float maxscore = JO_LOG_ZERO;
+          for (i = 0; i < b->natom; i++)
+            if (atoms[i].endtime == last_time &&
+                (maxscore < atoms[i].backscore || (maxscore == atoms[i].backscore && best >= 0 && atoms[i].wid < atoms[best].wid))) {
+              maxscore = atoms[i].backscore; best = i;
+            }
+          if (maxscore == JO_LOG_ZERO) best = -1;
+          continue;
+        }
         for (i = 0; i < b->natom; i++)
           if (atoms[i].endtime == last_time && atoms[i].wid == lx->tail_silwid && atoms[i].backscore > JO_LOG_ZERO) {
             best = i; break;

@@ -45,6 +45,19 @@ def ref_task(ref, tmpdir, seed, beam, extra=(), **task_kw):
     return eng, lex, am, task
 
 
+def ref_grammar_task(ref, tmpdir, seed, beam, extra=(), ncat=3, wrap=True, **task_kw):
+    """Cross-word triphone task under a DFA grammar (synth.make_triphone_grammar) loaded by the
+    compiled reference: (RefEngine, lex dict, flat AM, task)."""
+    from oracle import pyoracle
+    task = synth.make_triphone_grammar(synth.make_triphone_task(tmpdir, seed=seed, **task_kw), ncat=ncat, seed=seed, wrap=wrap)
+    eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+                                   "-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)] + list(extra))
+    eng.save_lexicon(tmpdir / "lex.blob")
+    lex = lexblob.load(tmpdir / "lex.blob")
+    am = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
+    return eng, lex, am, task
+
+
 def assert_trellis_equal_modulo_ties(atoms, want, ties):
     """Exact when the engine met no score tie.  With ties > 0 the engine's canonical
     rule (larger source id) and the reference's visiting order may keep different --

@@ -8,7 +8,8 @@ these fixtures contain a few and still match.)"""
 import numpy as np
 import pytest
 
-from beamutil import assert_trellis_equal, assert_trellis_equal_modulo_ties, load_beam_golden, ref_task
+from beamutil import (assert_trellis_equal, assert_trellis_equal_modulo_ties, load_beam_golden, ref_grammar_task,
+                      ref_task)
 from julius_amd import lib, synth
 
 pytestmark = pytest.mark.gpu
@@ -157,7 +158,8 @@ def test_full_size_lexicon_vs_oracle(engine, oracle):
     assert_trellis_equal_modulo_ties(tre[0], lexblob.canonical_trellis(oatoms), res[0].ties_node + res[0].ties_cut + res[0].ties_wordend)
 
 
-@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz"])
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz",
+                                  "beam_grammar.npz", "beam_grammar_free.npz"])
 def test_strict_order_golden(engine, oracle, name):
     """Strict-order mode (the reference's sequential visiting order, one lane per
     utterance): EXACT equality with the reference's golden trellis, no tie caveat."""
@@ -254,3 +256,59 @@ def test_streaming_equals_one_shot(engine, oracle, chunks):
         from julius_amd import lexblob
         assert_trellis_equal(bm.trellis(u), lexblob.canonical_trellis(tre1[u]))
         assert_trellis_equal(bm.trellis(u), g["utts"][u]["trellis"])
+
+
+@pytest.mark.parametrize("name", ["beam_grammar.npz", "beam_grammar_free.npz"])
+def test_grammar_golden_batch(engine, oracle, name):
+    """DFA grammar, one lexicon tree per category: initial tokens from every sentence-initial
+    word, category-pair constraint at every word boundary, best word on the last frame."""
+    g = load_beam_golden(name)
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    res, tre = bm.pass1_host(scores)
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0 and r.frames == len(u["frames"])
+        assert_trellis_equal_modulo_ties(atoms, u["trellis"], r.ties)
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"])
+        assert r.score == u["score"]
+    # the same utterances pushed in pieces
+    lens = [len(x) for x in scores]
+    bm.stream_begin(len(scores))
+    done = [0] * len(scores)
+    while any(d < n for d, n in zip(done, lens)):
+        take = [min(13, n - d) for d, n in zip(done, lens)]
+        rows = np.concatenate([sc[d:d + k] for sc, d, k in zip(scores, done, take)])
+        off = np.zeros(len(scores) + 1, np.int32)
+        off[1:] = np.cumsum(take)
+        done = [d + k for d, k in zip(done, take)]
+        buf = lib.DevBuf(engine, max(rows.nbytes, 4)).upload(rows)
+        bm.stream_push_dev(buf.ptr, rows.shape[1], off, final=all(d >= n for d, n in zip(done, lens)))
+    for i, (r, r0, atoms) in enumerate(zip(bm.results(), res, tre)):
+        assert (r.status, r.wnum, r.score, r.natom) == (r0.status, r0.wnum, r0.score, r0.natom)
+        assert np.array_equal(bm.trellis(i), atoms)
+
+
+@pytest.mark.parametrize("seed,beam,extra,wrap", [
+    (41, 150, ["-penalty1", "-2.0"], True),
+    (42, 50, ["-iwcd1", "max", "-bs", "70"], False),
+    (43, 1500, ["-iwcd1", "avg"], False),                      # no rank pruning
+])
+@pytest.mark.parametrize("strict", [False, True])
+def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, wrap, strict):
+    eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, extra, wrap=wrap, nword=90)
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(4)]
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 16)
+    bm.set_strict_order(strict)
+    res, tre = bm.pass1_host(scores)
+    for fr, r, atoms in zip(utts, res, tre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        if strict:
+            assert_trellis_equal(atoms, rtr)
+        else:
+            assert_trellis_equal_modulo_ties(atoms, rtr, r.ties)
+        assert r.status == 0 and np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore

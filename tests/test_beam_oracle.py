@@ -6,11 +6,12 @@ Bit-exact: word ids, frame indices, predecessor links, float scores."""
 import numpy as np
 import pytest
 
-from beamutil import assert_trellis_equal, load_beam_golden, ref_task
+from beamutil import assert_trellis_equal, load_beam_golden, ref_grammar_task, ref_task
 from julius_amd import lexblob, synth
 
 
-@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz"])
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz",
+                                  "beam_grammar.npz", "beam_grammar_free.npz"])
 def test_oracle_matches_golden(oracle, name):
     g = load_beam_golden(name)
     for u in g["utts"]:
@@ -75,3 +76,45 @@ def test_oracle_matches_reference_live(oracle, ref, tmp_path, seed, beam, extra)
         assert_trellis_equal(atoms, tr)
         if rc == 0:
             assert np.array_equal(owseq, wseq) and oscore == score
+
+
+@pytest.mark.parametrize("seed,beam,extra,wrap", [
+    (31, 120, ["-penalty1", "-2.0"], True),                              # <s> WORD+ </s>, N-best state sets (default)
+    (32, 60, ["-iwcd1", "max", "-bs", "70"], True),
+    (33, 40, ["-iwcd1", "avg", "-penalty1", "-1.0"], False),             # any word may start: 60+ initial tokens > beam
+])
+def test_oracle_matches_reference_grammar(oracle, ref, tmp_path, seed, beam, extra, wrap):
+    """DFA grammar with per-category lexicon trees (beam.c grammar branches: init_nodescore()
+    :1669-1757, beam_inter_word() category-pair test :2404-2412, find_1pass_result() :433-455)."""
+    eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, extra, wrap=wrap, nword=70)
+    assert lex["lm_type"] == 1 and lex["ncat"] == 5 and (lex["ninit"] == 1) == wrap
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    for u in range(3):
+        fr, _ = synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        sc = oracle.gmm_outprob(am, fr)
+        atoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, bs)
+        assert rc == 0
+        assert_trellis_equal(atoms, rtr)
+        assert np.array_equal(wseq, rwseq) and score == rscore
+
+
+def test_oracle_matches_reference_c1_grammar(oracle, ref, tmp_path):
+    """BASELINE configs[0] shape: tied-mixture monophones + 100-word loop grammar."""
+    from oracle import pyoracle
+    task = synth.make_grammar_task(tmp_path, seed=3)
+    eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam",
+                                   "-1pass", "-gprune", "safe", "-tmix", "2", "-b", "150"])
+    eng.save_lexicon(tmp_path / "lex.blob")
+    lex = lexblob.load(tmp_path / "lex.blob")
+    am = ref.am_load(task["hmmdefs"], gprune="safe", gprune_num=2).export()
+    for u in range(3):
+        fr, _ = synth.make_grammar_utterance(task, nwords=2 + u, seed=u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        sc = oracle.gmm_outprob(am, fr, pyoracle.GPRUNE_SAFE, 2)
+        atoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, -1.0)
+        assert rc == 0
+        assert_trellis_equal(atoms, rtr)
+        assert np.array_equal(wseq, rwseq) and score == rscore

@@ -163,3 +163,46 @@ def test_c4_dnn_over_device_scores(ref, tmp_path, monkeypatch, so, strict):
         assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0 and np.array_equal(f1, f0) and fs1 == fs0
         for k in tr0:
             assert np.array_equal(tr1[k], tr0[k]), k
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict", "stream"])
+@pytest.mark.parametrize("kind", ["c1", "triphone", "free"])
+def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kind, mode):
+    """Grammar recognition (-dfa) with the FIRST PASS ON THE DEVICE: per-category lexicon trees,
+    category-pair constraint, then the reference's own DFA-driven 2nd pass over the trellis the
+    shim rebuilt.  c1 = BASELINE configs[0] shape (tied-mixture monophones, 100-word loop
+    grammar); triphone = cross-word triphones with category-aware state sets; free = any word
+    may start a sentence (dozens of initial tokens)."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "20" if mode == "stream" else "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    if kind == "c1":
+        task = synth.make_grammar_task(tmp_path, seed=9)
+        args = ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam",
+                "-gprune", "safe", "-tmix", "2", "-b", "200", "-penalty1", "-1.0"]
+        utts = [synth.make_grammar_utterance(task, nwords=3 + u, seed=u)[0] for u in range(3)]
+    else:
+        task = synth.make_triphone_grammar(synth.make_triphone_task(tmp_path, seed=61, nword=90, nphone=10, S=160),
+                                           ncat=3, seed=61, wrap=(kind == "triphone"))
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+                "-input", "htkparam", "-gprune", "none", "-b", "150", "-penalty1", "-2.0", "-b2", "30", "-n", "1", "-s", "500"]
+        utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=6100 + u)[0] for u in range(3)]
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    for fr in utts:
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = amd.final_result()
+        d1, n1 = amd.cache_fill()
+        assert d1 == n1                                                # 2nd pass = cache hits on device scores
+        assert st1 == st0
+        assert np.array_equal(w1, w0) and s1 == s0                     # pass-1 best
+        assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
+        if mode == "strict":
+            for k in tr0:
+                assert np.array_equal(tr1[k], tr0[k]), k
+        else:
+            assert_canonical_close(tr1, tr0, max_diff=8)

@@ -140,6 +140,37 @@ def beam_fixture(ref, tmp, name, seed, beam, extra, nutt=3, **task_kw):
     save(name + ".npz", **out)
 
 
+def grammar_fixture(ref, tmp, name, seed, beam, extra, nutt=3, ncat=3, wrap=True, **task_kw):
+    """First pass under a DFA grammar (one lexicon tree per category, category-pair constraint
+    between words): cross-word triphone task + the grammar of synth.make_triphone_grammar()."""
+    from julius_amd import lexblob
+    d = tmp / name
+    task = synth.make_triphone_grammar(synth.make_triphone_task(d, seed=seed, **task_kw), ncat=ncat, seed=seed, wrap=wrap)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+            "-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)] + list(extra)
+    eng = pyoracle.RefEngine(ref, args)
+    eng.save_lexicon(d / "lex.blob")
+    lex = lexblob.load(d / "lex.blob")
+    model = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    out = dict(beam_width=np.int32(eng.beam_width), score_pruning_width=np.float32(bs), nutt=np.int32(nutt),
+               args=np.array(" ".join(str(a) for a in args[10:])))
+    for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+        out["am_" + k] = model[k]
+    for k, v in lex.items():
+        out["lex_" + k] = np.asarray(v)
+    for u in range(nutt):
+        fr, _ = synth.make_triphone_grammar_utterance(task, nwords=3 + u, seed=1000 * seed + u)
+        synth.write_htk_param(d / "u.mfc", fr)
+        tr, (wseq, sc) = eng.recognize(d / "u.mfc")
+        out[f"u{u}_frames"] = fr
+        for k, v in tr.items():
+            out[f"u{u}_tr_{k}"] = v
+        out[f"u{u}_wseq"] = wseq
+        out[f"u{u}_score"] = np.float32(sc)
+    save(name + ".npz", **out)
+
+
 def main_beam():
     ref = pyoracle.Ref()
     tmp = Path(tempfile.mkdtemp())
@@ -150,6 +181,12 @@ def main_beam():
                                                                   "-lmp", "5.0", "-1.0"])
     # B3: every word separated from the tree (all roots isolated), IWCD avg, narrow beam
     beam_fixture(ref, tmp, "beam_isolated", seed=4, beam=40, extra=["-iwcd1", "avg"], nword=40)
+    # B4: DFA grammar, per-category trees, word insertion penalty, N-best state sets
+    grammar_fixture(ref, tmp, "beam_grammar", seed=6, beam=100, extra=["-penalty1", "-2.0", "-iwcd1", "best", "3"],
+                    nword=50)
+    # B5: grammar whose sentences may start with any word: more initial tokens than the beam is wide
+    grammar_fixture(ref, tmp, "beam_grammar_free", seed=7, beam=30, extra=["-penalty1", "-1.0", "-iwcd1", "max", "-bs", "80"],
+                    nword=70, wrap=False)
 
 
 if __name__ == "__main__":
