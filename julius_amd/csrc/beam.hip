@@ -629,6 +629,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     {
       const float mx = unord(sh.maxbits);                          // score_pruning_max :2948
       thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;  // :2954-2960
+      if (t == 0) thr = JAMD_LOG_ZERO;                             // get_back_trellis_init() sets no score threshold
     }
     if (n_new == 0) {                                              // :3012-3015
       if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }

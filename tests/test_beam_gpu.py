@@ -8,7 +8,7 @@ these fixtures contain a few and still match.)"""
 import numpy as np
 import pytest
 
-from beamutil import (assert_trellis_equal, assert_trellis_equal_modulo_ties, load_beam_golden, ref_grammar_task,
+from beamutil import (assert_grammar_fast, assert_trellis_equal, assert_trellis_equal_modulo_ties, load_beam_golden, ref_grammar_task,
                       ref_task)
 from julius_amd import lib, synth
 
@@ -269,9 +269,7 @@ def test_grammar_golden_batch(engine, oracle, name):
     res, tre = bm.pass1_host(scores)
     for r, atoms, u in zip(res, tre, g["utts"]):
         assert r.status == 0 and r.frames == len(u["frames"])
-        assert_trellis_equal_modulo_ties(atoms, u["trellis"], r.ties)
-        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"])
-        assert r.score == u["score"]
+        assert_grammar_fast(atoms, u["trellis"], r, u["wseq"], u["score"])
     # the same utterances pushed in pieces
     lens = [len(x) for x in scores]
     bm.stream_begin(len(scores))
@@ -286,7 +284,8 @@ def test_grammar_golden_batch(engine, oracle, name):
         bm.stream_push_dev(buf.ptr, rows.shape[1], off, final=all(d >= n for d, n in zip(done, lens)))
     for i, (r, r0, atoms) in enumerate(zip(bm.results(), res, tre)):
         assert (r.status, r.wnum, r.score, r.natom) == (r0.status, r0.wnum, r0.score, r0.natom)
-        assert np.array_equal(bm.trellis(i), atoms)
+        from julius_amd import lexblob
+        assert_trellis_equal(bm.trellis(i), lexblob.canonical_trellis(atoms))   # emission order within a frame is free
 
 
 @pytest.mark.parametrize("seed,beam,extra,wrap", [
@@ -307,8 +306,9 @@ def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, ex
     for fr, r, atoms in zip(utts, res, tre):
         synth.write_htk_param(tmp_path / "u.mfc", fr)
         rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert r.status == 0
         if strict:
             assert_trellis_equal(atoms, rtr)
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
         else:
-            assert_trellis_equal_modulo_ties(atoms, rtr, r.ties)
-        assert r.status == 0 and np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+            assert_grammar_fast(atoms, rtr, r, rwseq, rscore)

