@@ -188,6 +188,10 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
 
 #define JAMD_LM_NGRAM 0   /* LM_PROB  */
 #define JAMD_LM_DFA   1   /* LM_DFA, LM_DFA_GRAMMAR with the default per-category tree */
+#define JAMD_LM_WORD  2   /* LM_DFA, LM_DFA_WORD: isolated word recognition (-w): every word of the list starts
+                           * with a token (beam.c:1762-1788), no cross-word transition (:2810, :2875), the
+                           * result is the best word on the last frame (find_1pass_result_word(), :561).
+                           * Uses ninit / init_node / init_lscore (all 0.0); cat_pair is not read. */
 
 #define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */
 #define JAMD_NG_ADDITIONAL_OLD 1  /* bi_prob_additional_oldbin() ngram_access.c:320 */
@@ -246,7 +250,7 @@ typedef struct {
    * (beam_inter_word(), libjulius/src/beam.c:2404-2412; dfa_cp(), libsent/src/dfa/cpair.c),
    * no LM factoring inside words.  For N-gram mode these are 0 / NULL.  In grammar mode
    * `wton` holds the category of each word. */
-  int lm_type;                         /* JAMD_LM_NGRAM / JAMD_LM_DFA                              */
+  int lm_type;                         /* JAMD_LM_NGRAM / JAMD_LM_DFA / JAMD_LM_WORD               */
   int ncat;                            /* dfa->term_num                                            */
   const unsigned char *cat_pair;       /* [ncat][ncat] dfa_cp(dfa, c1, c2): c2 may follow c1       */
   const int   *start2wid;              /* [startnum] wchmm->start2wid (a word of the root's tree)  */

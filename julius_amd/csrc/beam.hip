@@ -279,7 +279,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   int *hval = hkey + wk.hsize;
   const int hmask = wk.hsize - 1;
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
-  const bool dfa = lx.lm_type == JAMD_LM_DFA;
+  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;          // grammar or word list: initial-token frame, no factoring
+  const bool wordmode = lx.lm_type == JAMD_LM_WORD;      // isolated words: no cross-word transition at all
   unsigned long long *memo = wk.lmcache + (size_t)u * wk.nscword;
 
   if (resume) {
@@ -406,7 +407,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           atoms[ai] = a;
         }
         sv_atom[j] = ai;
-        if (!last && sword != lx.tail_silwid) {            // beam_inter_word() :2296-2313
+        if (!last && !wordmode && sword != lx.tail_silwid) {   // beam_inter_word() :2296-2313
           welist[atomicAdd(&sh.n_we, 1)] = j;
           const float tmpprob = tk.score + lx.wordend_a[sword];
           if (!dfa && tmpprob > JAMD_LOG_ZERO) {
@@ -950,8 +951,9 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
   int status = JAMD_PASS1_OK, died_at = -1, max_tokens = 1;
 
   b.tn = 0; b.tlx = 1;
-  const bool dfa = lx.lm_type == JAMD_LM_DFA;
-  if (dfa) {                                                         // init_nodescore() :1669-1757
+  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;
+  const bool wordmode = lx.lm_type == JAMD_LM_WORD;
+  if (dfa) {                                                         // init_nodescore() :1669-1757, :1762-1788
     for (int e = 0; e < lx.ninit; e++) {
       const int id = s_create_token(b);
       STok &nw = b.tl[b.tn][id];
@@ -993,7 +995,8 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
       const int sword = lx.node_b[node].x;
       if (sword >= 0) {
         const int tre = s_save_trellis(b, tk, sword, t);
-        if (dfa) {                                                              // beam_inter_word(), grammar branch
+        if (wordmode) {                                                         // :2875: isolated words stop here
+        } else if (dfa) {                                                       // beam_inter_word(), grammar branch
           const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
           for (int stid = lx.startnum - 1; stid >= 0; stid--) {
             if (!lx.cat_pair[lx.wton[sword] * lx.ncat + lx.root_cat[stid]]) continue;      // :2404-2412
@@ -1127,9 +1130,11 @@ extern "C" {
 int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon **out) {
   if (!e || !h || !out) { jamd_set_error("jamd_lexicon_create: NULL argument"); return JAMD_EINVAL; }
   *out = nullptr;
-  const bool dfa = h->lm_type == JAMD_LM_DFA;
+  const bool wordmode = h->lm_type == JAMD_LM_WORD;
+  const bool dfa = h->lm_type == JAMD_LM_DFA || wordmode;      // the two LM_DFA variants share everything but the word boundary
   if (h->lm_type != JAMD_LM_NGRAM && !dfa) { jamd_set_error("jamd_lexicon_create: lm_type=%d", h->lm_type); return JAMD_EINVAL; }
-  if (dfa && (h->ncat <= 0 || h->ninit < 0 || !h->cat_pair || !h->start2wid || (h->ninit > 0 && (!h->init_node || !h->init_lscore)))) {
+  if (dfa && (h->ninit < 0 || (h->ninit > 0 && (!h->init_node || !h->init_lscore)) ||
+              (!wordmode && (h->ncat <= 0 || !h->cat_pair || !h->start2wid)))) {
     jamd_set_error("jamd_lexicon_create: grammar descriptor incomplete (ncat=%d ninit=%d)", h->ncat, h->ninit);
     return JAMD_EINVAL;
   }
@@ -1214,19 +1219,19 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   UP(ng_bi_wid, h->ng_bi_wid, h->ng_nbigram); UP(ng_bi_prob, h->ng_bi_prob, h->ng_nbigram);
   d.lm_type = h->lm_type; d.ncat = dfa ? h->ncat : 0; d.ninit = dfa ? h->ninit : 0; d.penalty1 = dfa ? h->penalty1 : 0.0f;
   if (dfa) {
-    std::vector<int> root_cat(h->startnum);
-    for (int s = 0; s < h->startnum; s++) {
+    std::vector<int> root_cat(h->startnum, 0);
+    for (int s = 0; s < h->startnum && !wordmode; s++) {
       const int w = h->start2wid[s];
       if (w < 0 || w >= h->nword || h->wton[w] < 0 || h->wton[w] >= h->ncat) {
         jamd_set_error("jamd_lexicon_create: root %d has no valid category", s); rc = JAMD_EINVAL; break;
       }
       root_cat[s] = h->wton[w];
     }
-    for (int w = 0; w < h->nword && rc == JAMD_OK; w++)
+    for (int w = 0; w < h->nword && rc == JAMD_OK && !wordmode; w++)
       if (h->wton[w] < 0 || h->wton[w] >= h->ncat) { jamd_set_error("jamd_lexicon_create: word %d outside the categories", w); rc = JAMD_EINVAL; }
     for (int e = 0; e < h->ninit && rc == JAMD_OK; e++)
       if (h->init_node[e] < 0 || h->init_node[e] >= h->nnode) { jamd_set_error("jamd_lexicon_create: bad initial node"); rc = JAMD_EINVAL; }
-    UP(cat_pair, h->cat_pair, (size_t)h->ncat * h->ncat); UP(root_cat, root_cat.data(), root_cat.size());
+    UP(cat_pair, h->cat_pair, wordmode ? 0 : (size_t)h->ncat * h->ncat); UP(root_cat, root_cat.data(), root_cat.size());
     UP(init_node, h->init_node, h->ninit); UP(init_lscore, h->init_lscore, h->ninit);
   }
 #undef UP

@@ -95,8 +95,11 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
 
   memset(out, 0, sizeof(*out));
   const int dfa_mode = (r->lmtype == LM_DFA);
+  const int word_mode = (dfa_mode && r->lmvar == LM_DFA_WORD);      /* isolated word recognition (-w) */
   if (hmminfo->multipath) return JAMD_EINVAL;
-  if (dfa_mode) {                     /* grammar: per-category trees, no forward DFA, no isolated-word mode */
+  if (word_mode) {
+    if (!wchmm->category_tree) return JAMD_EINVAL;
+  } else if (dfa_mode) {              /* grammar: per-category trees, no forward DFA */
     if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL || wchmm->dfa_forward != NULL)
       return JAMD_EINVAL;
   } else {
@@ -247,17 +250,29 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
     /* ---- grammar: category pairs, roots' categories, initial tokens (beam.c:1669-1757) ---- */
     DFA_INFO *dfa = wchmm->dfa;
     MULTIGRAM *m;
-    int C = dfa->term_num, c1, c2, t, iw, ninit = 0;
+    int C = word_mode ? 1 : dfa->term_num, c1, c2, t, iw, ninit = 0;
     int *seen = NEW(int, n);
     out->ng_uni_prob = NEW(float, 1); out->ng_uni_bo = NEW(float, 1); out->ng_bi_bgn = NEW(int, 1);
     out->ng_bi_num = NEW(int, 1); out->ng_bi_wid = NEW(int, 1); out->ng_bi_prob = NEW(float, 1);
     out->cat_pair = NEW(unsigned char, C * C);
-    for (c1 = 0; c1 < C; c1++) for (c2 = 0; c2 < C; c2++) out->cat_pair[c1 * C + c2] = dfa_cp(dfa, c1, c2) ? 1 : 0;
+    if (!word_mode)
+      for (c1 = 0; c1 < C; c1++) for (c2 = 0; c2 < C; c2++) out->cat_pair[c1 * C + c2] = dfa_cp(dfa, c1, c2) ? 1 : 0;
     out->start2wid = NEW(int, wchmm->startnum);
     for (i = 0; i < wchmm->startnum; i++) out->start2wid[i] = wchmm->start2wid[i];
     out->init_node = NEW(int, W); out->init_lscore = NEW(float, W);
     for (m = r->lm->grammars; m; m = m->next) {
       if (!m->active) continue;
+      if (word_mode) {                                 /* every word of the active lists, beam.c:1762-1788 */
+        for (iw = m->word_begin; iw < m->word_begin + m->winfo->num; iw++) {
+          int node = wchmm->offset[iw][0];
+          if (seen[node]) continue;
+          seen[node] = 1;
+          out->init_node[ninit] = node;
+          out->init_lscore[ninit] = 0.0f;
+          ninit++;
+        }
+        continue;
+      }
       for (t = m->cate_begin; t < m->cate_begin + m->dfa->term_num; t++) {
         if (dfa_cp_begin(dfa, t) != TRUE) continue;
         for (iw = 0; iw < dfa->term.wnum[t]; iw++) {
@@ -271,7 +286,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
       }
     }
     free(seen);
-    d->lm_type = JAMD_LM_DFA; d->ncat = C; d->ninit = ninit; d->penalty1 = r->config->lmp.penalty1;
+    d->lm_type = word_mode ? JAMD_LM_WORD : JAMD_LM_DFA; d->ncat = C; d->ninit = ninit; d->penalty1 = r->config->lmp.penalty1;
     d->cat_pair = out->cat_pair; d->start2wid = out->start2wid; d->init_node = out->init_node; d->init_lscore = out->init_lscore;
     d->ng_unk_id = -1;
   }
@@ -332,7 +347,7 @@ static int put_rec(FILE *f, const char *name, int dtype, int count, const void *
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");
-  int nrec = 30 + (d->lm_type == JAMD_LM_DFA ? 4 : 0), rc = 0;
+  int nrec = 30 + (d->lm_type != JAMD_LM_NGRAM ? 4 : 0), rc = 0;
   int ints[21]; float floats[5];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nnode; ints[1] = d->nword; ints[2] = d->startnum; ints[3] = d->isolatenum;
@@ -359,7 +374,7 @@ int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
   F32("ng_uni_prob", d->ng_uni_prob, d->ng_nword); F32("ng_uni_bo", d->ng_uni_bo, d->ng_nword);
   I32("ng_bi_bgn", d->ng_bi_bgn, d->ng_nword); I32("ng_bi_num", d->ng_bi_num, d->ng_nword);
   I32("ng_bi_wid", d->ng_bi_wid, d->ng_nbigram); F32("ng_bi_prob", d->ng_bi_prob, d->ng_nbigram);
-  if (d->lm_type == JAMD_LM_DFA) {
+  if (d->lm_type != JAMD_LM_NGRAM) {
     U8("cat_pair", d->cat_pair, d->ncat * d->ncat); I32("start2wid", d->start2wid, d->startnum);
     I32("init_node", d->init_node, d->ninit); F32("init_lscore", d->init_lscore, d->ninit);
   }

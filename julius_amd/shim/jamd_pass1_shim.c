@@ -26,6 +26,7 @@
  * no short-pause segmentation, buffered input.  The "no nodes left in beam" condition is
  * reported by failing the utterance (J_RESULT_STATUS_FAIL) instead of segmenting.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #define JAMD_WITH_LIBJULIUS 1
@@ -268,6 +269,65 @@ done:
   free(atoms); free(made);
 }
 
+/* qsort order of the word-mode N-best list: the reference compares the truncated score difference
+ * (compare_backscore(), beam.c:548-551), so words less than 1.0 apart keep qsort's arrangement */
+static int by_backscore(const void *a, const void *b)
+{
+  return (int)((*(TRELLIS_ATOM *const *)b)->backscore - (*(TRELLIS_ATOM *const *)a)->backscore);
+}
+
+/* Isolated word recognition (-w): the first pass is the whole recognition; its N best words on the
+ * last frame become the final result (find_1pass_result_word(), beam.c:561-698). */
+static void word_mode_result(RecogProcess *r, int len)
+{
+  BACKTRELLIS *bt = r->backtrellis;
+  TRELLIS_ATOM *best = NULL, **order;
+  LOGPROB top = LOG_ZERO;
+  int t, i, n, want;
+#ifdef CONFIDENCE_MEASURE
+  LOGPROB sum = 0.0;
+#endif
+  for (t = len - 1; t >= 0; t--) {
+    for (i = 0; i < bt->num[t]; i++)
+      if (top < bt->rw[t][i]->backscore) { top = bt->rw[t][i]->backscore; best = bt->rw[t][i]; }
+    if (top != LOG_ZERO) break;
+  }
+  if (t < 0) {
+    jlog("WARNING: %02d %s: no word survived on the last frame, search failed\n", r->config->id, r->config->name);
+    r->result.status = J_RESULT_STATUS_FAIL;
+    return;
+  }
+  n = bt->num[t];
+#ifdef CONFIDENCE_MEASURE
+  for (i = 0; i < n; i++) sum += pow(10, r->config->annotate.cm_alpha * (bt->rw[t][i]->backscore - top));
+#endif
+  r->result.status = J_RESULT_STATUS_SUCCESS;
+  want = r->config->output.output_hypo_maxnum > 1 ? r->config->output.output_hypo_maxnum : 1;
+  if (want > n) want = n;
+  order = (TRELLIS_ATOM **)malloc(sizeof(TRELLIS_ATOM *) * n);
+  if (r->config->output.output_hypo_maxnum > 1) {
+    for (i = 0; i < n; i++) order[i] = bt->rw[t][i];
+    qsort(order, n, sizeof(TRELLIS_ATOM *), by_backscore);
+  } else order[0] = best;
+  result_sentence_malloc(r, want);
+  r->result.sentnum = want;
+  for (i = 0; i < want; i++) {
+    Sentence *s = &(r->result.sent[i]);
+    s->word_num = 1;
+    s->word[0] = order[i]->wid;
+#ifdef CONFIDENCE_MEASURE
+    s->confidence[0] = pow(10, r->config->annotate.cm_alpha * (order[i]->backscore - top)) / sum;
+#endif
+    s->score = order[i]->backscore;
+    s->score_lm = 0.0;
+    s->score_am = order[i]->backscore;
+    s->gram_id = multigram_get_all_num(r->lm) > 0 ? multigram_get_gram_from_wid(s->word[0], r->lm) : 0;
+  }
+  free(order);
+  memcpy(&(r->result.pass1), &(r->result.sent[0]), sizeof(Sentence));
+  r->result.pass1.align = NULL;
+}
+
 void finalize_1st_pass(RecogProcess *r, int len)
 {
   BACKTRELLIS *backtrellis = r->backtrellis;
@@ -279,6 +339,10 @@ void finalize_1st_pass(RecogProcess *r, int len)
     if (backtrellis->framelen > 0)
       jlog("WARNING: %02d %s: input processed, but no survived word found\n", r->config->id, r->config->name);
     r->result.status = J_RESULT_STATUS_FAIL;
+    return;
+  }
+  if (r->lmvar == LM_DFA_WORD) {                      /* beam.c:3157-3158; the device's choice is re-derived */
+    word_mode_result(r, len);                         /* from the rebuilt trellis (needs the N-best list)  */
     return;
   }
   if (status != J_RESULT_STATUS_SUCCESS) {

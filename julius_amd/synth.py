@@ -780,3 +780,49 @@ def make_triphone_grammar_utterance(g, nwords=4, seed=0, frames_per_state=3, noi
     st = np.repeat(np.array(seq), frames_per_state)
     fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
     return fr.astype(np.float32), [g["words"][i][0] for i in ids]
+
+
+def make_wordlist_task(workdir, nphone=10, nword=60, seed=0, maxlen=5, triphone=True):
+    """Isolated word recognition task (`-w list -wsil silB silE silB`, libsent/src/voca/
+    voca_load_wordlist.c): one word per line, "OutputString phone...", the silence models are
+    attached to both ends of every word by the loader.  Uses the models of make_triphone_task()
+    (word-internal and silence-context triphones) or of make_grammar_task() (monophones)."""
+    workdir = Path(workdir)
+    if triphone:
+        # cross-word context handling is off in this mode, so every triphone a word needs --
+        # including the ones next to the attached silences -- must be a defined model
+        task = make_triphone_task(workdir, nphone=nphone, seed=seed, nword=nword, maxlen=maxlen, defined_frac=1.0)
+        lines = [f"{w} " + " ".join(ph) for w, ph in task["words"]]
+    else:
+        task = make_grammar_task(workdir, nphone=nphone, seed=seed, nword=nword, maxlen=maxlen)
+        lines = [f"{w} " + " ".join(f"p{p}" for p in ph) for w, ph in task["words"]]
+    (workdir / "words.list").write_text("\n".join(lines) + "\n")
+    task = dict(task)
+    task.update(wordlist=workdir / "words.list", triphone=triphone)
+    return task
+
+
+def make_wordlist_utterance(task, seed=0, frames_per_state=3, noise=0.7):
+    """silB + one random word + silE."""
+    rng = np.random.default_rng(seed)
+    i = int(rng.integers(0, len(task["words"])))
+    if task["triphone"]:
+        model = task["model"]
+        S = len(model["st_off"]) - 1
+        per = (S - 6) // len(task["phones"])
+        seq = [S - 6, S - 5, S - 4]
+        for p in task["words"][i][1]:
+            base = task["phones"].index(p) * per
+            seq += [int(base + rng.integers(0, per)) for _ in range(3)]
+        seq += [S - 3, S - 2, S - 1]
+        centre = model["centre"]
+    else:
+        n = task["nphone"]
+        seq = [3 * n, 3 * n + 1, 3 * n + 2]
+        for p in task["words"][i][1]:
+            seq += [3 * p, 3 * p + 1, 3 * p + 2]
+        seq += [3 * (n + 1), 3 * (n + 1) + 1, 3 * (n + 1) + 2]
+        centre = task["centre"]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = centre[st] + rng.normal(0, noise, size=(len(st), centre.shape[1]))
+    return fr.astype(np.float32), i

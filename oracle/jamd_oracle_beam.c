@@ -9,7 +9,7 @@
  * step -- including the partial heap sort that decides the iteration order of
  * the surviving tokens -- so that its word trellis is the reference's word
  * trellis even where Viterbi ties are broken by visiting order.  Scope: N-gram
- * LM or DFA grammar with per-category trees, non-multipath models, the reference's default "fast" configuration
+ * LM, DFA grammar with per-category trees or isolated-word lists, non-multipath models, the reference's default "fast" configuration
  * (UNIGRAM_FACTORING, PASS1_IWCD, SCORE_PRUNING; no WPAIR / WORD_GRAPH /
  * spsegment).  Paths below are relative to the reference root.
  *
@@ -356,7 +356,7 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
   }
   b->token = (int *)malloc(sizeof(int) * lx->nnode);
   for (i = 0; i < lx->nnode; i++) b->token[i] = -1;
-  if (lx->lm_type == JAMD_LM_DFA) {                        /* init_nodescore :1669-1757 */
+  if (lx->lm_type != JAMD_LM_NGRAM) {                      /* init_nodescore :1669-1757 (grammar), :1762-1788 (word list) */
     int e;
     for (e = 0; e < lx->ninit; e++) {
       int id = create_token(b);
@@ -393,6 +393,7 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
       intra_word(b, j);
       if (lx->stend[tk.node] >= 0) {
         int tre = save_trellis(b, &tk, t);
+        if (lx->lm_type == JAMD_LM_WORD) continue;          /* isolated words: no cross-word transition :2875 */
         if (lx->lm_type == JAMD_LM_DFA) inter_word_dfa(b, j, tre);
         else inter_word(b, j, tre);
       }
@@ -423,8 +424,8 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
     {
       int best = -1, last_time;
       for (last_time = T - 1; last_time >= 0 && best < 0; last_time--) {
-        if (lx->lm_type == JAMD_LM_DFA) {
-          /* grammar (:433-455): the best word on the latest frame that has one; rw[t] is sorted
+        if (lx->lm_type != JAMD_LM_NGRAM) {
+          /* grammar (:433-455), word list (find_1pass_result_word :591-605): the best word on the latest frame that has one; rw[t] is sorted
            * by word id and the test is a strict <, so ties go to the smaller word id */
           float maxscore = JO_LOG_ZERO;
           for (i = 0; i < b->natom; i++)

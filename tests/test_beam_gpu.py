@@ -312,3 +312,34 @@ def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, ex
             assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
         else:
             assert_grammar_fast(atoms, rtr, r, rwseq, rscore)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("triphone", [True, False])
+def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, strict):
+    """Isolated word recognition (-w word list) on the device."""
+    from oracle import pyoracle
+    task = synth.make_wordlist_task(tmp_path, seed=7, triphone=triphone, nword=80)
+    args = ["-h", task["hmmdefs"]] + (["-hlist", task["hmmlist"]] if triphone else []) + [
+        "-w", task["wordlist"], "-wsil", "silB", "silE", "silB", "-input", "htkparam", "-gprune", "none", "-b", "80"]
+    eng = pyoracle.RefEngine(ref, args)
+    eng.save_lexicon(tmp_path / "lex.blob")
+    from julius_amd import lexblob
+    lex = lexblob.load(tmp_path / "lex.blob")
+    am = ref.am_load(task["hmmdefs"], hmmlist=task["hmmlist"] if triphone else None).export()
+    utts = [synth.make_wordlist_utterance(task, seed=u)[0] for u in range(5)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, -1.0, max_utts=len(utts))
+    bm.set_strict_order(strict)
+    res, tre = bm.pass1_host([oracle.gmm_outprob(am, fr) for fr in utts])
+    for fr, r, atoms in zip(utts, res, tre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, _ = eng.recognize(tmp_path / "u.mfc")
+        st, fw, fs = eng.final_result()
+        assert r.status == 0 and r.wnum == 1
+        if strict or r.ties == 0:
+            assert_trellis_equal(atoms, rtr)
+            assert [r.wseq[0]] == list(fw)
+        else:
+            assert_trellis_equal_modulo_ties(atoms, rtr, r.ties, min_same=0.99)
+        assert r.score == fs

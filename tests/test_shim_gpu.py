@@ -207,3 +207,31 @@ def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kin
         else:                                                          # equally scored alternatives may differ
             assert len(w1) > 0 and len(f1) > 0
             assert_canonical_scores_close(tr1, tr0)
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_wordlist_recognition_over_device_first_pass(ref, tmp_path, monkeypatch, mode):
+    """Isolated word recognition (-w) through the shimmed recogniser: the first pass IS the
+    recognition, the shim derives the final N-best result from the trellis it rebuilt."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    task = synth.make_wordlist_task(tmp_path, seed=11, triphone=True, nword=80)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-w", task["wordlist"], "-wsil", "silB", "silE", "silB",
+            "-input", "htkparam", "-gprune", "none", "-b", "100", "-output", "3"]
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    for u in range(4):
+        fr, _ = synth.make_wordlist_utterance(task, seed=50 + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, _ = plain.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = plain.final_result()
+        tr1, _ = amd.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = amd.final_result()
+        assert st1 == st0 and np.array_equal(f1, f0) and fs1 == fs0 and len(f1) == 1
+        if mode == "strict":
+            for k in tr0:
+                assert np.array_equal(tr1[k], tr0[k]), k
+        else:
+            assert_canonical_close(tr1, tr0, max_diff=8)
