@@ -80,7 +80,7 @@ typedef struct {
 } jamd_flat_lexicon;
 
 /* Walk r->wchmm (after j_final_fusion()) and fill `out`.  JAMD_EINVAL for the
- * configurations the device beam does not cover (isolated-word LM, grammars with a
+ * configurations the device beam does not cover (grammars with a
  * forward DFA or without per-category trees, multipath models, user LM plugin, 24-bit
  * compacted 2-gram index). */
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
@@ -88,6 +88,19 @@ void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
 /* Write the descriptor as a self-describing blob of named arrays (the format
  * julius_amd/lexblob.py and jamd_lexicon_load() read). */
 int  jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path);
+
+/* ---- batch of buffered inputs through the first-pass shim (jamd_pass1_shim.c) ----------------
+ * Replaces the one-launch-per-utterance pattern of get_back_trellis() / decode_proceed()
+ * (libjulius/src/pass1.c:111-317, :615-736) for file lists: queue every input, decode them all
+ * in one device launch, then run Julius' usual per-input loop, which finds each first pass done.
+ *   for (f in files) { j_open_stream(recog, f); jamd_pass1_prefetch_add(r, recog->mfcclist->param); }
+ *   jamd_pass1_prefetch_run(r);
+ *   for (f in files) { j_open_stream(recog, f); j_recognize_stream(recog); }       // unchanged loop
+ * Inputs are recognised by length + content hash, so un-queued inputs simply take the normal path. */
+int  jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param);
+int  jamd_pass1_prefetch_run(RecogProcess *r);
+int  jamd_pass1_prefetch_served(RecogProcess *r);   /* inputs served from the batch so far */
+void jamd_pass1_prefetch_clear(RecogProcess *r);
 #endif
 
 #ifdef __cplusplus

@@ -45,14 +45,34 @@ typedef struct {
   int pushed;                  /* frames already handed to the device */
   int failed;
   float *host_scores; int host_cap;   /* [pushed][nstate] rows kept for the 2nd pass's cache */
+  /* batch-of-utterances first pass: inputs queued by jamd_pass1_prefetch_add(), decoded in
+   * one launch by jamd_pass1_prefetch_run(), served to get_back_trellis_*() by content */
+  struct pre_entry *pre; int npre, pre_cap;
+  int hit;                     /* entry serving the current utterance, -1 = none */
 } pass1_ctx;
+
+typedef struct pre_entry {
+  unsigned long long key; int T, veclen;            /* identity of the input: length + content hash */
+  float *frames;                                   /* [T][veclen], until the batch ran */
+  int done, used;
+  jamd_pass1_result res; jamd_trellis_atom *atoms; int natom;
+  float *scores;                                   /* [T][nstate] for the 2nd pass, NULL with -1pass */
+} pre_entry;
 
 static jamd_engine *g_eng = NULL;
 static pass1_ctx g_ctx[16];
 static int g_nctx = 0;
 
+static void pre_clear(pass1_ctx *c)
+{
+  int i;
+  for (i = 0; i < c->npre; i++) { free(c->pre[i].frames); free(c->pre[i].atoms); free(c->pre[i].scores); }
+  free(c->pre); c->pre = NULL; c->npre = c->pre_cap = 0; c->hit = -1;
+}
+
 static void ctx_release(pass1_ctx *c)
 {
+  pre_clear(c);
   if (c->beam) jamd_beam_destroy(c->beam);
   if (c->lex) jamd_lexicon_destroy(c->lex);
   if (c->gmm) jamd_gmm_destroy(c->gmm);
@@ -140,6 +160,126 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   return TRUE;
 }
 
+/* ---- batch of utterances ---------------------------------------------------------
+ * A driver that holds many buffered inputs (a file list) queues them, lets the device decode them
+ * all in one launch -- one workgroup per utterance, the regime the first-pass kernel is built for --
+ * and then runs Julius' normal per-input loop: get_back_trellis_init() recognises each input by
+ * length + content hash and get_back_trellis_end() hands over the stored trellis instead of
+ * launching anything.  Inputs that were not queued (or whose trellis overflowed) take the normal path. */
+static unsigned long long frames_hash(const float *f, size_t n)
+{
+  const unsigned char *p = (const unsigned char *)f;
+  unsigned long long h = 1469598103934665603ull;
+  size_t i;
+  for (i = 0; i < n * sizeof(float); i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+int jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param)
+{
+  pass1_ctx *c = ctx_get(r);
+  pre_entry *e;
+  if (c == NULL || param == NULL || param->samplenum <= 0 || !ctx_prepare(c, r)) return JAMD_EINVAL;
+  if (c->npre == c->pre_cap) {
+    c->pre_cap = c->pre_cap ? 2 * c->pre_cap : 64;
+    c->pre = (pre_entry *)realloc(c->pre, sizeof(pre_entry) * c->pre_cap);
+  }
+  e = &c->pre[c->npre];
+  memset(e, 0, sizeof(*e));
+  e->T = param->samplenum; e->veclen = param->veclen;
+  e->frames = jamd_pack_param(param, 0, e->T);
+  if (e->frames == NULL) return JAMD_EINVAL;
+  e->key = frames_hash(e->frames, (size_t)e->T * e->veclen);
+  c->npre++;
+  return JAMD_OK;
+}
+
+/* one launch over entries [first, first+n): score all frames, run the first pass, fetch everything */
+static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int keep)
+{
+  jamd_beam *bb = NULL;
+  float *frames = NULL, *d_frames = NULL, *d_scores = NULL;
+  jamd_pass1_result *res = NULL;
+  int *off = (int *)malloc(sizeof(int) * (n + 1)), u, rc = JAMD_EINVAL, veclen = c->pre[first].veclen;
+  size_t total = 0;
+  off[0] = 0;
+  for (u = 0; u < n; u++) { total += (size_t)c->pre[first + u].T; off[u + 1] = (int)total; }
+  frames = (float *)malloc(sizeof(float) * total * veclen);
+  res = (jamd_pass1_result *)malloc(sizeof(jamd_pass1_result) * n);
+  if (frames == NULL || res == NULL) goto out;
+  for (u = 0; u < n; u++)
+    memcpy(frames + (size_t)off[u] * veclen, c->pre[first + u].frames, sizeof(float) * (size_t)c->pre[first + u].T * veclen);
+  if (jamd_beam_create(g_eng, c->lex, c->beam_width, c->bs_width, n, 1 << 19, &bb) != JAMD_OK) goto out;
+  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0 &&
+      jamd_beam_set_strict_order(bb, 1) != JAMD_OK) goto out;
+  if (jamd_malloc(g_eng, sizeof(float) * total * veclen, (void **)&d_frames) != JAMD_OK ||
+      jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores) != JAMD_OK ||
+      jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||
+      (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, (int)total, d_scores, NULL)
+              : jamd_gmm_outprob_dev(c->gmm, d_frames, (int)total, d_scores, NULL)) != JAMD_OK ||
+      jamd_beam_pass1_dev(bb, d_scores, c->nstate, off, n, NULL) != JAMD_OK ||
+      jamd_engine_sync(g_eng) != JAMD_OK || jamd_beam_results(bb, res, n) != JAMD_OK) goto out;
+  for (u = 0; u < n; u++) {
+    pre_entry *e = &c->pre[first + u];
+    e->res = res[u];
+    e->done = -1;                                     /* unusable unless everything below succeeds */
+    if (res[u].status == JAMD_PASS1_OVERFLOW) continue;   /* the normal path has the larger trellis area */
+    e->natom = res[u].natom;
+    e->atoms = (jamd_trellis_atom *)malloc(sizeof(jamd_trellis_atom) * (e->natom > 0 ? e->natom : 1));
+    if (e->atoms == NULL || jamd_beam_trellis(bb, u, e->atoms, e->natom, &e->natom) != JAMD_OK) continue;
+    if (keep) {
+      e->scores = (float *)malloc(sizeof(float) * (size_t)e->T * c->nstate);
+      if (e->scores == NULL ||
+          jamd_memcpy_d2h(g_eng, e->scores, d_scores + (size_t)off[u] * c->nstate,
+                          sizeof(float) * (size_t)e->T * c->nstate) != JAMD_OK) continue;
+    }
+    e->done = 1;
+  }
+  rc = JAMD_OK;
+out:
+  if (rc != JAMD_OK) jlog("ERROR: jamd: batch first pass failed: %s\n", jamd_last_error());
+  for (u = 0; u < n; u++) { free(c->pre[first + u].frames); c->pre[first + u].frames = NULL; if (rc != JAMD_OK) c->pre[first + u].done = -1; }
+  if (bb) jamd_beam_destroy(bb);
+  if (d_frames) jamd_free(g_eng, d_frames);
+  if (d_scores) jamd_free(g_eng, d_scores);
+  free(frames); free(res); free(off);
+  return rc;
+}
+
+int jamd_pass1_prefetch_run(RecogProcess *r)
+{
+  pass1_ctx *c = ctx_get(r);
+  const int keep = !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL;
+  int first = 0, rc = JAMD_OK, nrun = 0;
+  if (c == NULL || c->beam == NULL) return JAMD_EINVAL;
+  while (first < c->npre) {                           /* launches of <= 256 utterances / 2^18 frames */
+    int n = 0; size_t fr = 0;
+    if (c->pre[first].done != 0) { first++; continue; }
+    while (first + n < c->npre && c->pre[first + n].done == 0 && n < 256 &&
+           c->pre[first + n].veclen == c->pre[first].veclen &&
+           (n == 0 || fr + (size_t)c->pre[first + n].T <= ((size_t)1 << 18))) { fr += (size_t)c->pre[first + n].T; n++; }
+    if (prefetch_chunk(c, r, first, n, keep) != JAMD_OK) rc = JAMD_EINVAL;
+    first += n; nrun += n;
+  }
+  jlog("STAT: jamd: batch first pass over %d queued inputs\n", nrun);
+  return rc;
+}
+
+/* number of queued inputs whose stored first pass has been handed to Julius so far */
+int jamd_pass1_prefetch_served(RecogProcess *r)
+{
+  pass1_ctx *c = ctx_get(r);
+  int i, n = 0;
+  for (i = 0; c != NULL && i < c->npre; i++) n += c->pre[i].used;
+  return n;
+}
+
+void jamd_pass1_prefetch_clear(RecogProcess *r)
+{
+  pass1_ctx *c = ctx_get(r);
+  if (c != NULL) pre_clear(c);
+}
+
 boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
 {
   pass1_ctx *c = ctx_get(r);
@@ -152,7 +292,19 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   r->have_interim = FALSE;
   c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
   if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) c->chunk = 0;   /* one final push */
-  c->pushed = 0; c->failed = 0;
+  c->pushed = 0; c->failed = 0; c->hit = -1;
+  if (c->npre > 0 && param->samplenum > 0) {          /* decoded ahead in a batch? */
+    float *fr = jamd_pack_param(param, 0, param->samplenum);
+    if (fr != NULL) {
+      const unsigned long long key = frames_hash(fr, (size_t)param->samplenum * param->veclen);
+      int i;
+      for (i = 0; i < c->npre; i++)
+        if (c->pre[i].done == 1 && !c->pre[i].used && c->pre[i].T == param->samplenum &&
+            c->pre[i].veclen == param->veclen && c->pre[i].key == key) { c->hit = i; break; }
+      free(fr);
+    }
+    if (c->hit >= 0) return TRUE;
+  }
   if (jamd_beam_stream_begin(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   return TRUE;
 }
@@ -203,6 +355,7 @@ boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boole
   pass1_ctx *c = ctx_get(r);
   r->have_interim = FALSE;
   if (c == NULL || c->beam == NULL || c->failed) return FALSE;
+  if (c->hit >= 0) return TRUE;                       /* served from the batch at _end() */
   if (c->chunk > 0 && t + 1 - c->pushed >= c->chunk) {
     jamd_pass1_result res;
     if (!push_frames(c, r, param, t + 1, 0)) return FALSE;
@@ -226,16 +379,30 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
   r->result.status = J_RESULT_STATUS_FAIL;            /* until proven otherwise */
   d->wordend_best_score = LOG_ZERO;
   if (c == NULL || c->beam == NULL || T <= 0 || c->failed) return;
-  if (!push_frames(c, r, param, T, 1) || jamd_beam_results(c->beam, &res, 1) != JAMD_OK) goto done;
-  if (res.status == JAMD_PASS1_DIED)
-    jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
-  if (c->host_scores != NULL && !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL)
-    jamd_fill_outprob_cache(&(r->am->hmmwrk), c->host_scores, 0, T, c->nstate);   /* 2nd pass = cache hits */
-  if (res.status == JAMD_PASS1_OVERFLOW) { jlog("ERROR: jamd: word trellis overflow\n"); goto done; }
-  natom = res.natom;
-  atoms = (jamd_trellis_atom *)malloc(sizeof(jamd_trellis_atom) * (natom > 0 ? natom : 1));
-  made = (TRELLIS_ATOM **)malloc(sizeof(TRELLIS_ATOM *) * (natom > 0 ? natom : 1));
-  if (jamd_beam_trellis(c->beam, 0, atoms, natom, &natom) != JAMD_OK) { natom = 0; goto done; }
+  if (c->hit >= 0) {                                  /* decoded ahead by jamd_pass1_prefetch_run() */
+    pre_entry *e = &c->pre[c->hit];
+    res = e->res; natom = e->natom;
+    atoms = e->atoms; e->atoms = NULL;                /* ownership moves here (freed below) */
+    e->used = 1;
+    if (res.status == JAMD_PASS1_DIED)
+      jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
+    if (e->scores != NULL) {
+      jamd_fill_outprob_cache(&(r->am->hmmwrk), e->scores, 0, T, c->nstate);
+      free(e->scores); e->scores = NULL;
+    }
+    made = (TRELLIS_ATOM **)malloc(sizeof(TRELLIS_ATOM *) * (natom > 0 ? natom : 1));
+  } else {
+    if (!push_frames(c, r, param, T, 1) || jamd_beam_results(c->beam, &res, 1) != JAMD_OK) goto done;
+    if (res.status == JAMD_PASS1_DIED)
+      jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
+    if (c->host_scores != NULL && !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL)
+      jamd_fill_outprob_cache(&(r->am->hmmwrk), c->host_scores, 0, T, c->nstate);   /* 2nd pass = cache hits */
+    if (res.status == JAMD_PASS1_OVERFLOW) { jlog("ERROR: jamd: word trellis overflow\n"); goto done; }
+    natom = res.natom;
+    atoms = (jamd_trellis_atom *)malloc(sizeof(jamd_trellis_atom) * (natom > 0 ? natom : 1));
+    made = (TRELLIS_ATOM **)malloc(sizeof(TRELLIS_ATOM *) * (natom > 0 ? natom : 1));
+    if (jamd_beam_trellis(c->beam, 0, atoms, natom, &natom) != JAMD_OK) { natom = 0; goto done; }
+  }
   /* save_trellis(), beam.c:2209-2247, for every atom the device emitted */
   for (i = 0; i < natom; i++) {
     TRELLIS_ATOM *tre = bt_new(r->backtrellis);

@@ -385,6 +385,21 @@ class RefEngine:
         k = lib.jref_engine_pass1(self.h, _p(wseq), C.byref(sc))
         return a, (wseq[:k].copy(), float(sc.value))
 
+    def prefetch(self, mfcfiles):
+        """Batch driver of the first-pass shim build (libjref_amd.so): decode all inputs in one
+        device launch; the recognize() calls that follow find their first pass done."""
+        lib = self.ref.lib
+        arr = (C.c_char_p * len(mfcfiles))(*[str(f).encode() for f in mfcfiles])
+        lib.jref_engine_prefetch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
+        n = lib.jref_engine_prefetch(self.h, arr, len(mfcfiles))
+        if n != len(mfcfiles):
+            raise RuntimeError(f"batch first pass failed ({n})")
+
+    def prefetch_served(self):
+        lib = self.ref.lib
+        lib.jref_engine_prefetch_served.argtypes = [C.c_void_p]
+        return int(lib.jref_engine_prefetch_served(self.h))
+
     def cache_fill(self):
         """(defined, total) entries of the outprob cache after the last recognize()."""
         lib = self.ref.lib

@@ -349,6 +349,33 @@ int jref_engine_recognize(void *h, const char *mfcfile)
   return n;
 }
 
+/* Batch driver (only in the build that links the first-pass shim, libjref_amd.so): queue the
+ * inputs, decode them all in one device launch; the following jref_engine_recognize() calls find
+ * their first pass done.  The three entry points live in julius_amd/shim/jamd_pass1_shim.c. */
+extern int jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param) __attribute__((weak));
+extern int jamd_pass1_prefetch_run(RecogProcess *r) __attribute__((weak));
+extern void jamd_pass1_prefetch_clear(RecogProcess *r) __attribute__((weak));
+
+extern int jamd_pass1_prefetch_served(RecogProcess *r) __attribute__((weak));
+int jref_engine_prefetch_served(void *h)
+{
+  return jamd_pass1_prefetch_served ? jamd_pass1_prefetch_served(((jref_eng *)h)->recog->process_list) : -2;
+}
+
+int jref_engine_prefetch(void *h, const char **mfcfiles, int n)
+{
+  jref_eng *e = (jref_eng *)h;
+  RecogProcess *r = e->recog->process_list;
+  int i;
+  if (!jamd_pass1_prefetch_add || !jamd_pass1_prefetch_run) return -2;
+  jamd_pass1_prefetch_clear(r);
+  for (i = 0; i < n; i++) {
+    if (j_open_stream(e->recog, (char *)mfcfiles[i]) != 0) return -1;
+    if (jamd_pass1_prefetch_add(r, e->recog->mfcclist->param) != 0) return -1;
+  }
+  return jamd_pass1_prefetch_run(r) == 0 ? n : -1;
+}
+
 /* Copy the sorted word trellis (bt->rw[t][i]) out: per atom wid, begintime,
  * endtime, backscore, lscore and the (wid, endtime) of its predecessor
  * (-1,-1 for the sentence start). */

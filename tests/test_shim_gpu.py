@@ -240,3 +240,50 @@ def test_wordlist_recognition_over_device_first_pass(ref, tmp_path, monkeypatch,
             # searches keep different (equally good) ones: the best word's score must still agree closely
             assert abs(fs1 - fs0) <= 0.01 * abs(fs0)
             assert_canonical_scores_close(tr1, tr0, min_common=0.8, min_same=0.9)
+
+
+@pytest.mark.parametrize("lm", ["ngram", "grammar"])
+def test_batch_driver_equals_per_utterance(ref, tmp_path, monkeypatch, lm):
+    """a file list decoded in ONE device launch (jamd_pass1_prefetch_add/_run), then the
+    reference's unchanged per-input loop, which finds every first pass done.  Same trellis, pass-1
+    and final results as the one-launch-per-utterance path of the same build, and the same final
+    sentences as the plain reference; inputs that were not queued still work."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    if lm == "ngram":
+        task = synth.make_triphone_task(tmp_path, seed=71, nword=120, nphone=10, S=160)
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                "-input", "htkparam", "-gprune", "none", "-b", "200", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5"]
+        utts = [synth.make_utterance(task, nwords=2 + u % 5, seed=7100 + u)[0] for u in range(9)]
+    else:
+        task = synth.make_triphone_grammar(synth.make_triphone_task(tmp_path, seed=72, nword=90, nphone=10, S=160), ncat=3, seed=72)
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+                "-input", "htkparam", "-gprune", "none", "-b", "200", "-penalty1", "-2.0", "-b2", "30", "-n", "1", "-s", "500"]
+        utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + u % 4, seed=7200 + u)[0] for u in range(9)]
+    files = []
+    for u, fr in enumerate(utts):
+        files.append(tmp_path / f"u{u}.mfc")
+        synth.write_htk_param(files[-1], fr)
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    single = []
+    for f in files:                                   # one launch per utterance
+        tr, p1 = amd.recognize(f)
+        single.append((tr, p1, amd.final_result(), amd.cache_fill()))
+    amd.prefetch(files[:7])                           # the last two inputs are deliberately not queued
+    for f, (tr0, p10, fin0, cf0) in zip(files, single):
+        tr1, p11 = amd.recognize(f)
+        fin1 = amd.final_result()
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k  # the same kernel decoded it: identical, atom for atom
+        assert np.array_equal(p11[0], p10[0]) and p11[1] == p10[1]
+        assert fin1[0] == fin0[0] and np.array_equal(fin1[1], fin0[1]) and fin1[2] == fin0[2]
+        assert amd.cache_fill() == cf0
+        plain.recognize(f)
+        st, fw, fs = plain.final_result()
+        assert st == fin1[0] and fs == fin1[2]
+        if lm == "ngram":
+            assert np.array_equal(fw, fin1[1])
+    assert amd.prefetch_served() == 7                 # the queued inputs really came from the batch launch
