@@ -86,7 +86,7 @@ struct Work {            // per-utterance slices are addressed with the strides 
   unsigned long long *nodekey;   // [utt][nnode]    Viterbi cells (0 = empty)
   Tok *cur;                      // [utt][tok_cap]  tokens created this frame
   unsigned *cur_key;             // [utt][tok_cap]  their order-preserving score bits (compact, for the rank select)
-  int *touched;                  // [utt][tok_cap]  nodes touched this frame
+  int2 *touched;                 // [utt][tok_cap]  nodes touched this frame: {node, LDS cell slot or -1 = nodekey[]}
   int2 *arcq;                    // [utt][tok_cap]  work queue of (survivor, extra arc) pairs
   jamd_trellis_atom *atoms;      // [utt][atom_cap]
   jamd_pass1_result *res;        // [utt]
@@ -97,6 +97,8 @@ struct Work {            // per-utterance slices are addressed with the strides 
                                  // per-successor-id memo LM_PROB_CACHE (wchmm.h:117-149, factoring_sub.c:965-986)
   int nscword;
   int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
+  int cell_slots;                // LDS Viterbi cells of the current frame (power of two, 0 = all cells in nodekey[])
+  int lds_bytes;                 // dynamic LDS per workgroup: sv_bytes + 12 * cell_slots
   int tok_cap, atom_cap, beam, nnode, nword;
   float width;
 };
@@ -234,20 +236,56 @@ __device__ __forceinline__ int wave_alloc(int *counter, bool want) {
 // The destination is the address of the key, so the arc is implied.
 // Returns the previous key when it holds the SAME score as this candidate (an
 // exact tie), else 0.
-__device__ __forceinline__ unsigned long long push(Shared &sh, unsigned long long *nodekey, int *touched,
-                                                   int node, float score, unsigned id) {
+// Where the Viterbi cells of the frame being built live.  A frame touches a few thousand of the
+// lexicon's 10^5..10^6 nodes; with hundreds of utterances in flight the direct-indexed nodekey[]
+// tables (2 MB each) fall out of every cache and each push becomes a random DRAM read-modify-write.
+// The cells therefore live in an LDS hash table keyed by node (open addressing, claimed with a CAS
+// on the node word); a node whose probe window is full overflows to nodekey[] -- occupancy only
+// grows within a frame, so every candidate of a node resolves to the same place.
+struct Cells {
+  unsigned long long *gkey;      // nodekey[] of this utterance (overflow, and everything when nslot == 0)
+  int2 *touched;
+  unsigned long long *lkey;      // [nslot] LDS cells (0 = empty)
+  int *lnode;                    // [nslot] owning node (-1 = free)
+  int nslot, shift;              // nslot = 1 << (32 - shift)
+};
+constexpr int kCellProbes = 24;
+
+__device__ __forceinline__ unsigned long long push(Shared &sh, const Cells &cl, int node, float score, unsigned id) {
   if (score <= JAMD_LOG_ZERO) return 0ull;                    // propagate_token() :1951
   const unsigned long long key = ((unsigned long long)ord(score) << 32) | id;
-  const unsigned long long old = atomicMax(&nodekey[node], key);
-  const int s = wave_alloc(&sh.n_new, old == 0ull);
-  if (old == 0ull) {
-    touched[s] = node;
-    return 0ull;
+  unsigned long long old;
+  bool first;
+  int slot = -1;
+  if (cl.nslot > 0) {
+    unsigned h = ((unsigned)node * 2654435761u) >> cl.shift;
+    for (int pr = 0; pr < kCellProbes; pr++) {
+      const int o = atomicCAS(&cl.lnode[h], -1, node);
+      if (o == -1 || o == node) { slot = (int)h; first = (o == -1); break; }
+      h = (h + 1) & (unsigned)(cl.nslot - 1);
+    }
   }
-  return ((unsigned)(old >> 32) == (unsigned)(key >> 32) && old != key) ? old : 0ull;
+  if (slot >= 0) {
+    old = atomicMax(&cl.lkey[slot], key);
+  } else {
+    old = atomicMax(&cl.gkey[node], key);
+    first = (old == 0ull);
+  }
+  const int s = wave_alloc(&sh.n_new, first);
+  if (first) cl.touched[s] = make_int2(node, slot);
+  // old == 0: nothing stored in the cell yet (the slot's claimer may still be on its way; it will
+  // then see this key as its `old`, so no tie goes unnoticed)
+  return (old != 0ull && (unsigned)(old >> 32) == (unsigned)(key >> 32) && old != key) ? old : 0ull;
 }
 
-__global__ void __launch_bounds__(NT)
+// TIMED adds per-phase wall clocks (jamd_pass1_result.phase_us, thread 0; development aid selected
+// with JAMD_BEAM_TIMING=1 when the work area is created) -- they cost some 20 VGPRs, so the
+// production instantiation carries none.
+#ifndef JAMD_BEAM_WPE
+#define JAMD_BEAM_WPE 4                 // waves per SIMD the register allocation targets (4 = one workgroup per CU)
+#endif
+template <bool TIMED>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(JAMD_BEAM_WPE, JAMD_BEAM_WPE)))
 beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
                   const int *__restrict__ utt_off, int smode) {
   __shared__ Shared sh;
@@ -265,7 +303,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   unsigned long long *nodekey = wk.nodekey + (size_t)u * wk.nnode;
   Tok *cur = wk.cur + (size_t)u * wk.tok_cap;
   unsigned *cur_key = wk.cur_key + (size_t)u * wk.tok_cap;
-  int *touched = wk.touched + (size_t)u * wk.tok_cap;
+  int2 *touched = wk.touched + (size_t)u * wk.tok_cap;
   int2 *arcq = wk.arcq + (size_t)u * wk.tok_cap;       // extra arcs of this frame's survivors: (survivor, arc)
   jamd_trellis_atom *atoms = wk.atoms + (size_t)u * wk.atom_cap;
   jamd_pass1_result *res = wk.res + u;
@@ -278,6 +316,13 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   int *hkey = welist + wk.beam;
   int *hval = hkey + wk.hsize;
   const int hmask = wk.hsize - 1;
+  // the frame's Viterbi cells: LDS table behind the survivor image (16-byte aligned), see Cells
+  Cells cl;
+  cl.gkey = nodekey; cl.touched = touched; cl.nslot = wk.use_lds ? wk.cell_slots : 0;
+  cl.lkey = (unsigned long long *)(dyn_lds + wk.sv_bytes);
+  cl.lnode = (int *)(cl.lkey + cl.nslot);
+  cl.shift = cl.nslot > 0 ? 32 - (31 - __clz(cl.nslot)) : 0;
+  for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; }
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
   const bool dfa = lx.lm_type != JAMD_LM_NGRAM;          // grammar or word list: initial-token frame, no factoring
   const bool wordmode = lx.lm_type == JAMD_LM_WORD;      // isolated words: no cross-word transition at all
@@ -328,7 +373,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   }
   float thr = resume ? ss->thr : JAMD_LOG_ZERO;        // d->score_pruning_threshold (beam.c:1935)
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tq = 0;   // phase clocks (100 MHz), thread 0 only
-#define PHASE(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
+#define PHASE(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
   int max_tokens = resume ? ss->max_tokens : 1;
   bool stopped = false;
   __syncthreads();
@@ -354,7 +399,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         tmpsum -= tk.last_lscore;
         tmpsum += ng;
       }
-      const unsigned long long tie = push(sh, nodekey, touched, next_node, tmpsum, (unsigned)node);
+      const unsigned long long tie = push(sh, cl, next_node, tmpsum, (unsigned)node);
       if (tie != 0ull) {
         // two different sources reach next_node with exactly the same score.
         // Harmless when both carry the same history (same predecessor atom, context
@@ -448,12 +493,12 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         float ng = lx.penalty1;
         ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
         tmpsum += ng;
-        if (push(sh, nodekey, touched, lx.startnode[r], tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+        if (push(sh, cl, lx.startnode[r], tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
           atomicAdd(&sh.ties, 1);
       }
       if (t == 0)          // pseudo frame 0: the initial tokens (init_nodescore(), beam.c:1669-1757)
         for (int e = tid; e < lx.ninit; e += NT)
-          push(sh, nodekey, touched, lx.init_node[e], lx.init_lscore[e], 0xC0000000u | (unsigned)e);
+          push(sh, cl, lx.init_node[e], lx.init_lscore[e], 0xC0000000u | (unsigned)e);
     } else {
       const int n_we = sh.n_we, niso = lx.isolatenum;
       const int total = n_we * niso;
@@ -472,7 +517,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const float ng = p * lmw + pen;
         tmpsum += ng;
         if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
-        if (push(sh, nodekey, touched, ir.x, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+        if (push(sh, cl, ir.x, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
           atomicAdd(&sh.ties, 1);
       }
     }
@@ -491,7 +536,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         tmpsum += ng;
         if (trans2) tmpsum += lx.lm_penalty_trans;
         if (tmpsum < thr) continue;                               // :2580
-        if (push(sh, nodekey, touched, __float_as_int(sr.x), tmpsum, 0xC0000000u) != 0ull) atomicAdd(&sh.ties, 1);
+        if (push(sh, cl, __float_as_int(sr.x), tmpsum, 0xC0000000u) != 0ull) atomicAdd(&sh.ties, 1);
       }
     }
     __syncthreads();
@@ -505,15 +550,18 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const float *__restrict__ row = scores + (size_t)(t_begin + t - base) * S;
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
       for (int s = tid; s < n_new; s += NT) {
-        if (tid == 0) tq = wall_clock64();
-        const int node = touched[s];
-        const unsigned long long key = atomicExch(&nodekey[node], 0ull);
+        if (TIMED && tid == 0) tq = wall_clock64();
+        const int2 tc2 = touched[s];                   // {node, LDS slot or -1}
+        const int node = tc2.x;
+        unsigned long long key;
+        if (tc2.y >= 0) { key = cl.lkey[tc2.y]; cl.lkey[tc2.y] = 0ull; cl.lnode[tc2.y] = -1; }   // back to empty
+        else key = atomicExch(&nodekey[node], 0ull);
         const int4 nr = lx.node_b[node];             // {stend, scid, out_id, out_kind}
         const unsigned id = (unsigned)key;
         const float score = unord((unsigned)(key >> 32));
         Tok nw;
         nw.node = node; nw.pad0 = nw.pad1 = 0;
-        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[4] += n_ - tq + (nr.x & 0); tq = n_; }
+        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[4] += n_ - tq + (nr.x & 0); tq = n_; }
         if ((id >> 31) == 0u) {                      // intra-word, id = source node
           const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
           nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
@@ -544,11 +592,11 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             nw.last_lscore = lx.fscore[-nr.y] * lmw + pen;
           }
         }
-        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[5] += n_ - tq + (__float_as_int(nw.last_lscore) & 0); tq = n_; }
+        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[5] += n_ - tq + (__float_as_int(nw.last_lscore) & 0); tq = n_; }
         // outprob_style(), outprob_style.c:354-486: a plain state score is added here; a
         // state-set reduction (tens of gathers) is deferred to the cooperative drain below
         const int ent = outprob_entry(lx, nr.w, nr.z, nw.last_wid);
-        if (tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (ent & 0); tq = n_; }
+        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (ent & 0); tq = n_; }
         if (ent >= 0) {
           nw.score = score + row[ent];
           const unsigned b = ord(nw.score);
@@ -759,7 +807,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       ss->max_tokens = max_tokens;
       res->natom = min(sh.n_atom, wk.atom_cap); res->frames = T; res->max_tokens = max_tokens;
       res->ties = sh.ties + sh.ties_we + sh.ties_cut;
-      for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+      if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
     }
     return;
   }
@@ -798,7 +846,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   if (tid == 0) {
     res->natom = natom; res->ties = sh.ties + sh.ties_we + sh.ties_cut; res->max_tokens = max_tokens;
     res->ties_node = sh.ties; res->ties_wordend = sh.ties_we; res->ties_cut = sh.ties_cut;
-    for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
     res->frames = T;
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
@@ -1119,6 +1167,7 @@ struct jamd_beam {
   int max_utts = 0;
   int *d_utt_off = nullptr;
   bool strict = false;
+  bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
   int stream_pushes = 0;
   StrictWork sw{};
@@ -1259,6 +1308,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   JAMD_HIP(hipSetDevice(e->device));
   jamd_beam *b = new jamd_beam();
   b->eng = e; b->lex = l; b->max_utts = max_utts;
+  { const char *tm = getenv("JAMD_BEAM_TIMING"); b->timed = tm != nullptr && atoi(tm) != 0; }
   Work &w = b->w;
   w.beam = beam_width; w.width = score_pruning_width; w.nnode = l->d.nnode; w.nword = l->d.nword;
   w.atom_cap = atoms_per_utt;
@@ -1277,10 +1327,20 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   w.sv_bytes = (int)(beam_width * (sizeof(Tok) + 2 * sizeof(int)) + (size_t)w.hsize * 2 * sizeof(int));
   w.sv_bytes = (w.sv_bytes + 15) & ~15;
   w.use_lds = w.sv_bytes <= kMaxDynLds ? 1 : 0;
+  // what is left of the LDS budget holds the frame's Viterbi cells (12 bytes per slot), if that is
+  // at least 4096 slots; a frame that outgrows the table overflows into nodekey[]
+  w.cell_slots = 0;
+  if (w.use_lds) {
+    int slots = 4096;
+    while ((size_t)w.sv_bytes + (size_t)slots * 2 * 12 <= (size_t)kMaxDynLds && slots < 65536) slots *= 2;
+    if ((size_t)w.sv_bytes + (size_t)slots * 12 <= (size_t)kMaxDynLds) w.cell_slots = slots;
+    if (getenv("JAMD_BEAM_NO_LDS_CELLS") != nullptr) w.cell_slots = 0;      // development switch (timing comparison)
+  }
+  w.lds_bytes = w.use_lds ? w.sv_bytes + 12 * w.cell_slots : 0;
   if (rc == JAMD_OK) rc = alloc((void **)&w.nodekey, U * w.nnode * sizeof(unsigned long long), true);
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur, U * w.tok_cap * sizeof(Tok), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur_key, U * w.tok_cap * sizeof(unsigned), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int), false);
+  if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int2), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.arcq, U * w.tok_cap * sizeof(int2), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.atoms, U * w.atom_cap * sizeof(jamd_trellis_atom), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
@@ -1288,8 +1348,11 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   w.nscword = l->nscword > 0 ? l->nscword : 1;
   if (rc == JAMD_OK) rc = alloc((void **)&w.lmcache, U * (size_t)w.nscword * sizeof(unsigned long long), false);
   if (rc == JAMD_OK && w.use_lds) {
-    hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        w.sv_bytes);
+    // the attribute is per kernel, not per work area: always ask for the whole budget
+    hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        kMaxDynLds);
+    if (ae == hipSuccess)
+      ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     if (ae != hipSuccess) { jamd_set_error("jamd_beam_create: cannot reserve %d bytes of LDS: %s", w.sv_bytes,
                                            hipGetErrorString(ae)); rc = JAMD_ENODEV; }
   }
@@ -1327,9 +1390,12 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   if (b->strict)
     hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
+  else if (b->timed)
+    hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
+                       b->w, dev_scores, nstate, b->d_utt_off, 0);
   else
-    hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w,
-                       dev_scores, nstate, b->d_utt_off, 0);
+    hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
+                       b->w, dev_scores, nstate, b->d_utt_off, 0);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   return JAMD_OK;
@@ -1374,8 +1440,12 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, chunk_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(beam_pass1_kernel, dim3(nutt), dim3(NT), b->w.use_lds ? b->w.sv_bytes : 0, st, b->lex->d, b->w,
-                     dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
+  if (b->timed)
+    hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
+                       b->w, dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
+  else
+    hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
+                       b->w, dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_stream_push_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   if (final) b->streaming = 0;

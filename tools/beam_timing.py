@@ -7,6 +7,9 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from julius_amd import lib, synth
+import os
+if os.environ.get("JAMD_LIB"):
+    lib.LIB_PATH = Path(os.environ["JAMD_LIB"]).resolve()
 
 nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 beam = int(sys.argv[2]) if len(sys.argv) > 2 else 800
