@@ -188,6 +188,7 @@ struct Shared {
   int n_new, n_we, n_arc, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
+  unsigned wsum[NT / 64];            // per-wave histogram totals of the rank select
   int eq_n, eq_node[128];           // tokens exactly on the rank cut (tie handling)
 };
 
@@ -281,6 +282,9 @@ __device__ __forceinline__ unsigned long long push(Shared &sh, const Cells &cl, 
 // TIMED adds per-phase wall clocks (jamd_pass1_result.phase_us, thread 0; development aid selected
 // with JAMD_BEAM_TIMING=1 when the work area is created) -- they cost some 20 VGPRs, so the
 // production instantiation carries none.
+#ifndef JAMD_BEAM_CB
+#define JAMD_BEAM_CB 4                  // tokens per thread carried together through the finalize step
+#endif
 #ifndef JAMD_BEAM_WPE
 #define JAMD_BEAM_WPE 4                 // waves per SIMD the register allocation targets (4 = one workgroup per CU)
 #endif
@@ -549,67 +553,131 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     {
       const float *__restrict__ row = scores + (size_t)(t_begin + t - base) * S;
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
-      for (int s = tid; s < n_new; s += NT) {
-        if (TIMED && tid == 0) tq = wall_clock64();
-        const int2 tc2 = touched[s];                   // {node, LDS slot or -1}
-        const int node = tc2.x;
-        unsigned long long key;
-        if (tc2.y >= 0) { key = cl.lkey[tc2.y]; cl.lkey[tc2.y] = 0ull; cl.lnode[tc2.y] = -1; }   // back to empty
-        else key = atomicExch(&nodekey[node], 0ull);
-        const int4 nr = lx.node_b[node];             // {stend, scid, out_id, out_kind}
-        const unsigned id = (unsigned)key;
-        const float score = unord((unsigned)(key >> 32));
-        Tok nw;
-        nw.node = node; nw.pad0 = nw.pad1 = 0;
-        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[4] += n_ - tq + (nr.x & 0); tq = n_; }
-        if ((id >> 31) == 0u) {                      // intra-word, id = source node
-          const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
-          nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
-          if (node != tk.node && nr.y != 0)               // beam_intra_word_core() :2069-2082
-            nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y, memo) * lmw + pen;
-          else
-            nw.last_lscore = tk.last_lscore;
-        } else if (dfa && (id >> 30) == 3u) {        // an initial token of the grammar
-          nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1;
-          nw.last_lscore = lx.init_lscore[id & 0x3fffffffu];
-        } else {
-          const bool iso = (id >> 30) == 2u;
-          const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
-          const int j = hash_get(hkey, hval, hmask, lx.word_end[sword]);
-          const Tok tk = sv[j];
-          const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
-          nw.last_tre = sv_atom[j]; nw.last_cword = last_word; nw.last_wid = sword;
-          if (dfa) {                                       // beam_inter_word() :2452-2461
-            float ng = lx.penalty1;
-            ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
-            nw.last_lscore = ng;
-          } else if (iso) {                                // beam_inter_word() :2430-2438
-            const int wn = lx.scword[nr.y];
-            const float p = (last_word < 0) ? 0.0f
-                            : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
-            nw.last_lscore = p * lmw + pen;
-          } else {                                         // beam_inter_word_factoring() :2572-2573
-            nw.last_lscore = lx.fscore[-nr.y] * lmw + pen;
+      // CB tokens per thread are carried through the steps together: every step's loads (node
+      // record, LM memo, context table, score row) are issued for all of them before any is used, so
+      // one thread has up to CB independent gathers in flight instead of one dependent chain per token.
+      constexpr int CB = JAMD_BEAM_CB;
+      for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
+        bool ok[CB]; int node[CB], slot[CB]; int4 nr[CB]; unsigned long long key[CB];
+        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB];
+        float l_ls[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const int s = s0 + k * NT;
+          ok[k] = s < n_new;
+          const int2 t2 = ok[k] ? touched[s] : make_int2(0, -1);     // {node, LDS slot or -1}
+          node[k] = t2.x; slot[k] = t2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < CB; k++) nr[k] = lx.node_b[node[k]];     // {stend, scid, out_id, out_kind}
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          key[k] = 0ull;
+          if (ok[k]) {
+            if (slot[k] >= 0) { key[k] = cl.lkey[slot[k]]; cl.lkey[slot[k]] = 0ull; cl.lnode[slot[k]] = -1; }   // back to empty
+            else key[k] = atomicExch(&nodekey[node[k]], 0ull);
           }
         }
-        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[5] += n_ - tq + (__float_as_int(nw.last_lscore) & 0); tq = n_; }
+        // winner's payload.  lmreq != 0: the LM factoring value has to be looked up (next step)
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const unsigned id = (unsigned)key[k];
+          lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f;
+          if (!ok[k]) continue;
+          if ((id >> 31) == 0u) {                      // intra-word, id = source node
+            const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
+            l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
+            if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
+            else l_ls[k] = tk.last_lscore;
+          } else if (dfa && (id >> 30) == 3u) {        // an initial token of the grammar
+            l_ls[k] = lx.init_lscore[id & 0x3fffffffu];
+          } else {
+            const bool iso = (id >> 30) == 2u;
+            const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
+            const int j = hash_get(hkey, hval, hmask, lx.word_end[sword]);
+            const Tok tk = sv[j];
+            const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+            l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
+            if (dfa) {                                       // beam_inter_word() :2452-2461
+              float ng = lx.penalty1;
+              ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+              l_ls[k] = ng;
+            } else if (iso) {                                // beam_inter_word() :2430-2438
+              const int wn = lx.scword[nr[k].y];
+              const float p = (last_word < 0) ? 0.0f
+                              : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+              l_ls[k] = p * lmw + pen;
+            } else {                                         // beam_inter_word_factoring() :2572-2573
+              l_ls[k] = lx.fscore[-nr[k].y] * lmw + pen;
+            }
+          }
+        }
+        // LM factoring value on entering a branch node: max_successor_prob(), its memo read issued
+        // for all CB tokens first (factoring_sub.c:942-1008)
+        {
+          int ctx[CB]; unsigned long long mm[CB]; float fs[CB];
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            ctx[k] = -1; mm[k] = 0ull; fs[k] = 0.0f;
+            if (lmreq[k] != 0 && l_cword[k] >= 0) {
+              if (lmreq[k] < 0) fs[k] = lx.fscore[-lmreq[k]];
+              else { ctx[k] = lx.wton[l_cword[k]]; mm[k] = memo[lmreq[k]]; }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (lmreq[k] == 0) continue;
+            float p = 0.0f;                                   // lastword < 0: no LM context yet
+            if (l_cword[k] >= 0) {
+              if (lmreq[k] < 0) p = fs[k];
+              else if ((int)(unsigned)(mm[k] >> 32) == ctx[k]) p = __uint_as_float((unsigned)mm[k]);
+              else p = max_successor_prob(lx, l_cword[k], lmreq[k], memo);     // memo miss: 2-gram search, refill
+            }
+            l_ls[k] = p * lmw + pen;
+          }
+        }
         // outprob_style(), outprob_style.c:354-486: a plain state score is added here; a
         // state-set reduction (tens of gathers) is deferred to the cooperative drain below
-        const int ent = outprob_entry(lx, nr.w, nr.z, nw.last_wid);
-        if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[6] += n_ - tq + (ent & 0); tq = n_; }
-        if (ent >= 0) {
-          nw.score = score + row[ent];
-          const unsigned b = ord(nw.score);
-          cur_key[s] = b;
-          if (b > mymax) mymax = b;
-          if (b < mymin) mymin = b;
-        } else {
-          nw.score = score;
-          arcq[atomicAdd(&sh.n_arc, 1)] = make_int2(s, ~ent);     // (token, state set); arcq is free again
+        {
+          int col[CB];
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            col[k] = lx.nlc;
+            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc[l_wid[k]];
+          }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (nr[k].w == JAMD_AS_STATE) ent[k] = nr[k].z;
+            else if (nr[k].w == JAMD_AS_LSET) ent[k] = ~nr[k].z;
+            else ent[k] = ok[k] ? lx.lc_tab[(size_t)nr[k].z * (lx.nlc + 1) + col[k]] : 0;
+          }
         }
-        cur[s] = nw;
+        float ac[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) ac[k] = (ok[k] && ent[k] >= 0) ? row[ent[k]] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          if (!ok[k]) continue;
+          const int s = s0 + k * NT;
+          const float score = unord((unsigned)(key[k] >> 32));
+          Tok nw;
+          nw.node = node[k]; nw.pad0 = nw.pad1 = 0;
+          nw.last_tre = l_tre[k]; nw.last_cword = l_cword[k]; nw.last_wid = l_wid[k]; nw.last_lscore = l_ls[k];
+          if (ent[k] >= 0) {
+            nw.score = score + ac[k];
+            const unsigned b = ord(nw.score);
+            cur_key[s] = b;
+            if (b > mymax) mymax = b;
+            if (b < mymin) mymin = b;
+          } else {
+            nw.score = score;
+            arcq[atomicAdd(&sh.n_arc, 1)] = make_int2(s, ~ent[k]);     // (token, state set); arcq is free again
+          }
+          cur[s] = nw;
+        }
       }
       __syncthreads();
+      if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[4] += n_ - tc; tq = n_; }   // token loop
       // drain: four lanes per (token, set) item, each reduces every fourth member, then the
       // partial results are merged through shuffles (outprob_cd(), outprob.c:287-400)
       const int n_set = sh.n_arc;
@@ -630,9 +698,14 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             if (p > b2) { t_ = b2; b2 = p; p = t_; }
             if (p > b3) { b3 = p; }
           };
-          for (int m = a + sub; m < bnd; m += 4) {
-            const float p = row[lx.set_states[m]];
-            if (p > JAMD_LOG_ZERO) { n++; ins(p); }
+          for (int m = a + sub; m < bnd; m += 16) {          // four members per lane in flight
+            int ix[4]; float pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states[m + 4 * j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pv[j] = (ix[j] >= 0) ? row[ix[j]] : JAMD_LOG_ZERO;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (pv[j] > JAMD_LOG_ZERO) { n++; ins(pv[j]); }
           }
           // merge the four partial top lists into the group's first lane (values <= LOG_ZERO are
           // padding and never displace anything)
@@ -653,7 +726,15 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           r = sum / (float)n;
         } else if (lx.cdset_method == JAMD_IWCD_MAX) {
           float m_ = JAMD_LOG_ZERO;
-          for (int m = a + sub; m < bnd; m += 4) { const float p = row[lx.set_states[m]]; if (m_ < p) m_ = p; }
+          for (int m = a + sub; m < bnd; m += 16) {
+            int ix[4]; float pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states[m + 4 * j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pv[j] = (ix[j] >= 0) ? row[ix[j]] : JAMD_LOG_ZERO;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (m_ < pv[j]) m_ = pv[j];
+          }
 #pragma unroll
           for (int src = 1; src < 4; src++) { const float c = __shfl(m_, (lane & ~3) + src, 64); if (m_ < c) m_ = c; }
           r = m_;
@@ -670,6 +751,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           if (b < mymin) mymin = b;
         }
       }
+      if (TIMED && tid == 0) { ph[5] += wall_clock64() - tq; ph[6] += sh.n_arc; }     // set drain; number of set reductions
       atomicMax(&sh.maxbits, mymax);
       atomicMin(&sh.minbits, mymin);
     }
@@ -719,26 +801,26 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           if (hi == prefix) atomicAdd(&sh.hist[(b >> shift) & dmask], 1u);
         }
         __syncthreads();
-        if (tid < 64) {
-          // lane l owns digits 32l..32l+31; `above` = tokens with a larger digit
-          unsigned mine = 0;
-          for (int q = 0; q < 32; q++) mine += sh.hist[32 * tid + q];
-          unsigned incl = mine;                         // inclusive suffix sum over lanes >= tid
+        {
+          // suffix scan over the 2048 digits with the whole workgroup: thread i owns digits 2i, 2i+1;
+          // `above` = tokens with a larger digit
+          const unsigned h0 = sh.hist[2 * tid], h1 = sh.hist[2 * tid + 1];
+          const unsigned pair = h0 + h1;
+          unsigned incl = pair;                          // inclusive suffix sum over the lanes >= this one
+          const int ln = tid & 63;
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) {
             const unsigned o = __shfl_down(incl, off, 64);
-            if (tid + off < 64) incl += o;
+            if (ln + off < 64) incl += o;
           }
-          unsigned above = incl - mine;
-          if (above < need && need <= above + mine) {   // the digit is in this lane's range
-            for (int q = 31; q >= 0; q--) {
-              const unsigned c = sh.hist[32 * tid + q];
-              if (above < need && need <= above + c) {
-                sh.sel_digit = 32u * tid + q; sh.sel_need = need - above; sh.sel_count = c;
-              }
-              above += c;
-            }
-          }
+          if (ln == 0) sh.wsum[tid >> 6] = incl;         // this wave's total
+          __syncthreads();
+          unsigned above = incl - pair;                  // larger digits inside the wave ...
+          for (int wv = (tid >> 6) + 1; wv < NT / 64; wv++) above += sh.wsum[wv];   // ... and in the waves above
+          // digit 2i+1 first (the larger one)
+          if (above < need && need <= above + h1) { sh.sel_digit = 2u * tid + 1u; sh.sel_need = need - above; sh.sel_count = h1; }
+          above += h1;
+          if (above < need && need <= above + h0) { sh.sel_digit = 2u * tid; sh.sel_need = need - above; sh.sel_count = h0; }
         }
         __syncthreads();
         prefix = (prefix << w) | sh.sel_digit;
