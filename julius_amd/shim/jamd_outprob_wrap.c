@@ -48,14 +48,18 @@ typedef struct {
 } wrap_ctx;
 
 static jamd_engine *g_eng = NULL;
-static wrap_ctx g_ctx[16];
-static int g_nctx = 0;
+static wrap_ctx *g_ctx = NULL;       /* one per acoustic model work area, grown on demand */
+static int g_nctx = 0, g_capctx = 0;
 
 static wrap_ctx *ctx_get(HMMWork *wrk)
 {
   int i;
   for (i = 0; i < g_nctx; i++) if (g_ctx[i].wrk == wrk) return &g_ctx[i];
-  if (g_nctx >= 16) return NULL;
+  if (g_nctx == g_capctx) {
+    wrap_ctx *n = (wrap_ctx *)realloc(g_ctx, sizeof(wrap_ctx) * (g_capctx ? 2 * g_capctx : 8));
+    if (n == NULL) return NULL;
+    g_ctx = n; g_capctx = g_capctx ? 2 * g_capctx : 8;
+  }
   memset(&g_ctx[g_nctx], 0, sizeof(wrap_ctx));
   g_ctx[g_nctx].wrk = wrk;
   return &g_ctx[g_nctx++];

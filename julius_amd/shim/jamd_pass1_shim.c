@@ -60,8 +60,8 @@ typedef struct pre_entry {
 } pre_entry;
 
 static jamd_engine *g_eng = NULL;
-static pass1_ctx g_ctx[16];
-static int g_nctx = 0;
+static pass1_ctx *g_ctx = NULL;      /* one per recognition process instance, grown on demand */
+static int g_nctx = 0, g_capctx = 0;
 
 static void pre_clear(pass1_ctx *c)
 {
@@ -85,7 +85,11 @@ static pass1_ctx *ctx_get(RecogProcess *r)
 {
   int i;
   for (i = 0; i < g_nctx; i++) if (g_ctx[i].r == r) return &g_ctx[i];
-  if (g_nctx >= 16) return NULL;
+  if (g_nctx == g_capctx) {
+    pass1_ctx *n = (pass1_ctx *)realloc(g_ctx, sizeof(pass1_ctx) * (g_capctx ? 2 * g_capctx : 8));
+    if (n == NULL) return NULL;
+    g_ctx = n; g_capctx = g_capctx ? 2 * g_capctx : 8;
+  }
   memset(&g_ctx[g_nctx], 0, sizeof(pass1_ctx));
   g_ctx[g_nctx].r = r;
   return &g_ctx[g_nctx++];
