@@ -105,6 +105,11 @@ typedef struct {
  * layout (DESIGN.md "HBM layout"). */
 int  jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gprune_num,
                      jamd_gmm **out);
+/* The same from a "JAMDGMM1" file: the flattened model as jamd_gmm_save()
+ * (julius_amd/shim/jamd_flatten.c) wrote it from the HTK_HMM_INFO that Julius' own
+ * hmmdefs / binhmm reader (libsent/src/hmminfo/rdhmmdef.c, read_binhmm.c) built.
+ * For workers that never link Julius. */
+int  jamd_gmm_load(jamd_engine *e, const char *path, int gprune, int gprune_num, jamd_gmm **out);
 void jamd_gmm_destroy(jamd_gmm *g);
 int  jamd_gmm_nstate(const jamd_gmm *g);
 int  jamd_gmm_veclen(const jamd_gmm *g);
@@ -159,6 +164,12 @@ typedef struct {
 } jamd_dnn_desc;
 
 int  jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out);
+/* The same from Julius' own on-disk DNN definition: the -dnnconf text file, the NumPy
+ * .npy weight / bias files and the state prior list it names, read as the reference does
+ * (dnn_config_file_parse(), libjulius/src/m_jconf.c:577-735; load_npy() / dnn_layer_load()
+ * / prior file, libsent/src/phmm/calc_dnn.c:225-335, :390-434, :678-707).  Relative
+ * paths are relative to the dnnconf file. */
+int  jamd_dnn_load(jamd_engine *e, const char *dnnconf_path, jamd_dnn **out);
 void jamd_dnn_destroy(jamd_dnn *n);
 int  jamd_dnn_nstate(const jamd_dnn *n);   /* dims[nlayer] */
 int  jamd_dnn_veclen(const jamd_dnn *n);   /* dims[0]      */
@@ -281,6 +292,10 @@ typedef struct jamd_beam    jamd_beam;
  * get_back_trellis_init() reads from r->wchmm (libjulius/src/beam.c:1825).
  * JAMD_EINVAL for inconsistent tables (a root without factoring value / successor word). */
 int  jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *d, jamd_lexicon **out);
+/* The same from a "JAMDLEX1" file written by jamd_lexicon_save()
+ * (julius_amd/shim/jamd_flatten_lex.c) in a process that loaded the dictionary and LM
+ * with Julius' own readers. */
+int  jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out);
 void jamd_lexicon_destroy(jamd_lexicon *l);
 
 /* First-pass status of one utterance */

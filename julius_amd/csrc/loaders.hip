@@ -1,0 +1,261 @@
+// loaders.hip -- on-disk formats -> device models, without a Julius process.
+//
+//   jamd_gmm_load()      "JAMDGMM1" blob  (written by jamd_gmm_save(), julius_amd/shim/jamd_flatten.c,
+//                                          from the HTK_HMM_INFO Julius' own hmmdefs / binhmm reader built)
+//   jamd_lexicon_load()  "JAMDLEX1" blob  (written by jamd_lexicon_save(), julius_amd/shim/jamd_flatten_lex.c,
+//                                          from the tree lexicon + LM tables of a RecogProcess)
+//   jamd_dnn_load()      Julius' own DNN definition: the -dnnconf text file, the NumPy .npy weight and
+//                        bias files it names and the state prior list -- read as the reference does
+//                        (libjulius/src/m_jconf.c:577-735 dnn_config_file_parse(),
+//                         libsent/src/phmm/calc_dnn.c:225-335 load_npy(), :390-434 dnn_layer_load(),
+//                         :678-707 prior file), so the model equals DNNData after dnn_setup().
+// Blob layout: magic[8], int32 nrec, then per record char name[24], int32 dtype (0 int32, 1 float32,
+// 2 uint8), int32 count, payload padded to 4 bytes; scalars travel in the records "ints"/"floats".
+// Host-only code; the kernels are in the other translation units.
+#include "jamd_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Rec { int dtype = 0, count = 0; std::vector<unsigned char> data; };
+using Blob = std::map<std::string, Rec>;
+
+bool read_blob(const char *path, const char *magic, Blob &out) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { jamd_set_error("cannot open %s", path); return false; }
+  char m[8]; int nrec = 0;
+  bool ok = fread(m, 1, 8, f) == 8 && memcmp(m, magic, 8) == 0 && fread(&nrec, 4, 1, f) == 1 && nrec > 0 && nrec < 4096;
+  if (!ok) jamd_set_error("%s: not a %.8s file", path, magic);
+  for (int i = 0; ok && i < nrec; i++) {
+    char name[25]; Rec r;
+    name[24] = 0;
+    ok = fread(name, 1, 24, f) == 24 && fread(&r.dtype, 4, 1, f) == 1 && fread(&r.count, 4, 1, f) == 1 &&
+         r.dtype >= 0 && r.dtype <= 2 && r.count >= 0;
+    if (!ok) break;
+    const size_t bytes = (size_t)r.count * (r.dtype == 2 ? 1 : 4), padded = (bytes + 3) & ~(size_t)3;
+    r.data.resize(padded ? padded : 4);
+    ok = padded == 0 || fread(r.data.data(), 1, padded, f) == padded;
+    if (ok) out[name] = std::move(r);
+  }
+  if (!ok && nrec > 0) jamd_set_error("%s: truncated or corrupt record table", path);
+  fclose(f);
+  return ok;
+}
+
+// typed view of a record; count < 0 accepts any length
+template <typename T>
+const T *view(const Blob &b, const char *name, int dtype, long long count, bool &ok) {
+  auto it = b.find(name);
+  if (it == b.end() || it->second.dtype != dtype || (count >= 0 && it->second.count != count)) {
+    if (ok) jamd_set_error("blob record \"%s\" missing or of unexpected type/size", name);
+    ok = false;
+    return nullptr;
+  }
+  return reinterpret_cast<const T *>(it->second.data.data());
+}
+
+// ---- NumPy .npy, as load_npy() reads it (calc_dnn.c:225-335): magic, version 1.0, little-endian
+// float32 ('<f4'), two-dimensional (or (n,) / (n,1) for a bias), C order; the payload is taken raw
+bool read_npy(const std::string &path, long long want, std::vector<float> &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) { jamd_set_error("cannot open %s", path.c_str()); return false; }
+  unsigned char h[10];
+  bool ok = fread(h, 1, 10, f) == 10 && memcmp(h, "\x93NUMPY", 6) == 0 && h[6] == 1;
+  if (!ok) { jamd_set_error("%s: not a version-1 .npy file", path.c_str()); fclose(f); return false; }
+  const int hlen = h[8] | (h[9] << 8);
+  std::string hdr(hlen, '\0');
+  ok = fread(&hdr[0], 1, hlen, f) == (size_t)hlen;
+  if (ok && hdr.find("'<f4'") == std::string::npos) { jamd_set_error("%s: dtype is not '<f4'", path.c_str()); ok = false; }
+  long long n = 1;
+  if (ok) {                                           // 'shape': (a, b) -- product must match
+    const size_t p = hdr.find("'shape'"), l = hdr.find('(', p), r = hdr.find(')', l);
+    if (p == std::string::npos || l == std::string::npos || r == std::string::npos) ok = false;
+    else {
+      const char *c = hdr.c_str() + l + 1;
+      while (c < hdr.c_str() + r) {
+        char *e = nullptr;
+        const long long v = strtoll(c, &e, 10);
+        if (e == c) { c++; continue; }
+        n *= v; c = e;
+      }
+    }
+    if (!ok || n != want) { jamd_set_error("%s: %lld values, expected %lld", path.c_str(), n, want); ok = false; }
+  }
+  if (ok) { out.resize((size_t)want); ok = fread(out.data(), 4, (size_t)want, f) == (size_t)want; if (!ok) jamd_set_error("%s: short read", path.c_str()); }
+  fclose(f);
+  return ok;
+}
+
+std::string dir_of(const std::string &p) { const size_t s = p.rfind('/'); return s == std::string::npos ? "" : p.substr(0, s + 1); }
+std::string rel(const std::string &dir, const std::string &v) { return (!v.empty() && v[0] == '/') ? v : dir + v; }   // filepath(), m_jconf.c
+
+}  // namespace
+
+extern "C" {
+
+int jamd_gmm_load(jamd_engine *e, const char *path, int gprune, int gprune_num, jamd_gmm **out) {
+  if (!e || !path || !out) { jamd_set_error("jamd_gmm_load: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  Blob b;
+  if (!read_blob(path, "JAMDGMM1", b)) return JAMD_EINVAL;
+  bool ok = true;
+  const int *ints = view<int>(b, "ints", 0, 6, ok);
+  if (!ok) return JAMD_EINVAL;
+  jamd_gmm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.nstate = ints[0]; d.veclen = ints[1]; d.ndens = ints[2]; d.nentry = ints[3]; d.nbook = ints[4]; d.nstream = ints[5];
+  if (d.nstate <= 0 || d.veclen <= 0 || d.ndens <= 0 || d.nentry <= 0) { jamd_set_error("%s: bad sizes", path); return JAMD_EINVAL; }
+  d.mean = view<float>(b, "mean", 1, (long long)d.ndens * d.veclen, ok);
+  d.ivar = view<float>(b, "ivar", 1, (long long)d.ndens * d.veclen, ok);
+  d.gconst = view<float>(b, "gconst", 1, d.ndens, ok);
+  d.st_off = view<int>(b, "st_off", 0, d.nstate + 1, ok);
+  d.ent_dens = view<int>(b, "ent_dens", 0, d.nentry, ok);
+  d.ent_logw = view<float>(b, "ent_logw", 1, d.nentry, ok);
+  if (b.count("st_book")) d.st_book = view<int>(b, "st_book", 0, d.nstate, ok);
+  if (!ok) return JAMD_EINVAL;
+  return jamd_gmm_create(e, &d, gprune, gprune_num, out);
+}
+
+int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
+  if (!e || !path || !out) { jamd_set_error("jamd_lexicon_load: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  Blob b;
+  if (!read_blob(path, "JAMDLEX1", b)) return JAMD_EINVAL;
+  bool ok = true;
+  auto ir = b.find("ints"); auto fr = b.find("floats");
+  if (ir == b.end() || fr == b.end() || ir->second.dtype != 0 || fr->second.dtype != 1 || ir->second.count < 18 || fr->second.count < 4) {
+    jamd_set_error("%s: scalar records missing", path); return JAMD_EINVAL;
+  }
+  const int *I = reinterpret_cast<const int *>(ir->second.data.data());
+  const float *F = reinterpret_cast<const float *>(fr->second.data.data());
+  jamd_lexicon_desc d;
+  memset(&d, 0, sizeof(d));
+  d.nnode = I[0]; d.nword = I[1]; d.startnum = I[2]; d.isolatenum = I[3]; d.nlc = I[4]; d.nlcrow = I[5]; d.nset = I[6];
+  d.cdset_method = I[7]; d.cdmax_num = I[8]; d.head_silwid = I[9]; d.tail_silwid = I[10]; d.nfscore = I[11]; d.nscword = I[12];
+  d.ng_mode = I[13]; d.ng_nword = I[14]; d.ng_nbigram = I[15]; d.ng_unk_id = I[16];
+  if (ir->second.count >= 21) { d.lm_type = I[18]; d.ncat = I[19]; d.ninit = I[20]; }      // files written before grammar support stop at 18
+  d.ng_unk_num_log = F[0]; d.lm_weight = F[1]; d.lm_penalty = F[2]; d.lm_penalty_trans = F[3];
+  if (fr->second.count >= 5) d.penalty1 = F[4];
+  if (d.nnode <= 0 || d.nword <= 0 || d.startnum < 0 || d.nset < 0 || d.nlc < 0 || d.nlcrow < 0) { jamd_set_error("%s: bad sizes", path); return JAMD_EINVAL; }
+  d.self_a = view<float>(b, "self_a", 1, d.nnode, ok); d.next_a = view<float>(b, "next_a", 1, d.nnode, ok);
+  d.ac_off = view<int>(b, "ac_off", 0, d.nnode + 1, ok);
+  const long long nac = ok ? d.ac_off[d.nnode] : 0;
+  d.ac_to = view<int>(b, "ac_to", 0, nac, ok); d.ac_a = view<float>(b, "ac_a", 1, nac, ok);
+  d.stend = view<int>(b, "stend", 0, d.nnode, ok); d.scid = view<int>(b, "scid", 0, d.nnode, ok);
+  d.out_kind = view<unsigned char>(b, "out_kind", 2, d.nnode, ok); d.out_id = view<int>(b, "out_id", 0, d.nnode, ok);
+  d.lc_tab = view<int>(b, "lc_tab", 0, (long long)d.nlcrow * (d.nlc + 1), ok); d.word_lc = view<int>(b, "word_lc", 0, d.nword, ok);
+  d.set_off = view<int>(b, "set_off", 0, d.nset + 1, ok);
+  d.set_states = view<int>(b, "set_states", 0, ok ? d.set_off[d.nset] : 0, ok);
+  d.startnode = view<int>(b, "startnode", 0, d.startnum, ok); d.start2isolate = view<int>(b, "start2isolate", 0, d.startnum, ok);
+  d.wordend_a = view<float>(b, "wordend_a", 1, d.nword, ok); d.wton = view<int>(b, "wton", 0, d.nword, ok);
+  d.cprob = view<float>(b, "cprob", 1, d.nword, ok);
+  d.is_transparent = view<unsigned char>(b, "is_transparent", 2, d.nword, ok); d.word_head = view<int>(b, "word_head", 0, d.nword, ok);
+  d.fscore = view<float>(b, "fscore", 1, d.nfscore, ok); d.scword = view<int>(b, "scword", 0, d.nscword, ok);
+  d.ng_uni_prob = view<float>(b, "ng_uni_prob", 1, d.ng_nword, ok); d.ng_uni_bo = view<float>(b, "ng_uni_bo", 1, d.ng_nword, ok);
+  d.ng_bi_bgn = view<int>(b, "ng_bi_bgn", 0, d.ng_nword, ok); d.ng_bi_num = view<int>(b, "ng_bi_num", 0, d.ng_nword, ok);
+  d.ng_bi_wid = view<int>(b, "ng_bi_wid", 0, d.ng_nbigram, ok); d.ng_bi_prob = view<float>(b, "ng_bi_prob", 1, d.ng_nbigram, ok);
+  if (d.lm_type != JAMD_LM_NGRAM) {
+    d.cat_pair = view<unsigned char>(b, "cat_pair", 2, (long long)d.ncat * d.ncat, ok);
+    d.start2wid = view<int>(b, "start2wid", 0, d.startnum, ok);
+    d.init_node = view<int>(b, "init_node", 0, d.ninit, ok); d.init_lscore = view<float>(b, "init_lscore", 1, d.ninit, ok);
+  }
+  if (!ok) return JAMD_EINVAL;
+  return jamd_lexicon_create(e, &d, out);
+}
+
+int jamd_dnn_load(jamd_engine *e, const char *dnnconf, jamd_dnn **out) {
+  if (!e || !dnnconf || !out) { jamd_set_error("jamd_dnn_load: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  FILE *f = fopen(dnnconf, "r");
+  if (!f) { jamd_set_error("cannot open %s", dnnconf); return JAMD_EINVAL; }
+  const std::string dir = dir_of(dnnconf);
+  int veclen = 0, contextlen = 0, in = 0, outn = 0, hid = 0, nh = 0, log10nize = 1;
+  float prior_factor = 1.0f;                              // jconf default (libjulius/src/default.c)
+  std::vector<std::string> wf, bf;
+  std::string ow, ob, prior;
+  char line[4096];
+  bool ok = true;
+  while (ok && fgets(line, sizeof(line), f)) {            // dnn_config_file_parse(), m_jconf.c:601-690
+    if (char *h = strchr(line, '#')) *h = 0;
+    size_t n = strlen(line);
+    while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r' || line[n - 1] == ' ' || line[n - 1] == '\t')) line[--n] = 0;
+    char *k = line;
+    while (*k == ' ' || *k == '\t') k++;
+    if (*k == 0) continue;
+    char *sp = strchr(k, ' ');
+    if (!sp) { jamd_set_error("%s: wrong line: %s", dnnconf, k); ok = false; break; }
+    char *v = sp;
+    while (*v == ' ') v++;
+    *sp = 0;
+    const std::string key(k);
+    if (key == "feature_len") veclen = atoi(v);
+    else if (key == "context_len") contextlen = atoi(v);
+    else if (key == "input_nodes") in = atoi(v);
+    else if (key == "output_nodes") outn = atoi(v);
+    else if (key == "hidden_nodes") hid = atoi(v);
+    else if (key == "hidden_layers") { nh = atoi(v); if (nh < 0 || nh > 64) { ok = false; break; } wf.assign(nh, ""); bf.assign(nh, ""); }
+    else if (key == "output_W") ow = rel(dir, v);
+    else if (key == "output_B") ob = rel(dir, v);
+    else if (key == "state_prior") prior = rel(dir, v);
+    else if (key == "state_prior_factor") prior_factor = (float)atof(v);
+    else if (key == "state_prior_log10nize") {
+      if (!strcmp(v, "yes") || !strcmp(v, "true")) log10nize = 1;
+      else if (!strcmp(v, "no") || !strcmp(v, "false")) log10nize = 0;
+      else { jamd_set_error("%s: state_prior_log10nize must be true or false", dnnconf); ok = false; }
+    } else if (key[0] == 'W' || key[0] == 'B') {
+      const int l = atoi(k + 1);
+      if (l <= 0 || l > nh) { jamd_set_error("%s: layer id %d outside 1..%d", dnnconf, l, nh); ok = false; }
+      else (key[0] == 'W' ? wf : bf)[l - 1] = rel(dir, v);
+    } else if (key == "feature_type" || key == "feature_options" || key == "batch_size" || key == "num_threads" || key == "cuda_mode") {
+      // front-end / host threading / CUDA settings: not part of the model
+    } else { jamd_set_error("%s: unknown spec: %s", dnnconf, k); ok = false; }
+  }
+  fclose(f);
+  if (ok && (nh <= 0 || in <= 0 || outn <= 0 || hid <= 0 || ow.empty() || ob.empty() || prior.empty())) {
+    jamd_set_error("%s: incomplete DNN definition", dnnconf); ok = false;
+  }
+  if (ok && veclen > 0 && contextlen > 0 && veclen * contextlen != in) {     // calc_dnn.c:640-643
+    jamd_set_error("%s: veclen(%d) * contextlen(%d) != inputnodes(%d)", dnnconf, veclen, contextlen, in); ok = false;
+  }
+  for (int l = 0; ok && l < nh; l++) if (wf[l].empty() || bf[l].empty()) { jamd_set_error("%s: no W/B file for hidden layer #%d", dnnconf, l + 1); ok = false; }
+  if (!ok) return JAMD_EINVAL;
+  const int nlayer = nh + 1;
+  std::vector<int> dims(nlayer + 1);
+  dims[0] = in;
+  for (int l = 1; l <= nh; l++) dims[l] = hid;
+  dims[nlayer] = outn;
+  std::vector<std::vector<float>> W(nlayer), B(nlayer);
+  for (int l = 0; ok && l < nlayer; l++) {                // dnn_layer_load(), calc_dnn.c:390-412
+    ok = read_npy(l < nh ? wf[l] : ow, (long long)dims[l] * dims[l + 1], W[l]) &&
+         read_npy(l < nh ? bf[l] : ob, dims[l + 1], B[l]);
+  }
+  std::vector<float> pr(outn, 0.0f);
+  if (ok) {                                               // calc_dnn.c:678-707
+    FILE *pf = fopen(prior.c_str(), "r");
+    if (!pf) { jamd_set_error("cannot open %s", prior.c_str()); ok = false; }
+    else {
+      int id; float val;
+      while (ok && fscanf(pf, "%d %e", &id, &val) == 2) {
+        if (id < 0 || id >= outn) { jamd_set_error("%s: wrong state id %d", prior.c_str(), id); ok = false; break; }
+        pr[id] = val * prior_factor;
+        if (log10nize) pr[id] = (float)log10(pr[id]);
+      }
+      fclose(pf);
+    }
+  }
+  if (!ok) return JAMD_EINVAL;
+  std::vector<const float *> wp(nlayer), bp(nlayer);
+  for (int l = 0; l < nlayer; l++) { wp[l] = W[l].data(); bp[l] = B[l].data(); }
+  jamd_dnn_desc d;
+  d.nlayer = nlayer; d.dims = dims.data(); d.w = wp.data(); d.b = bp.data(); d.state_prior = pr.data();
+  return jamd_dnn_create(e, &d, out);
+}
+
+}  // extern "C"

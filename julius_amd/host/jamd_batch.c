@@ -1,0 +1,138 @@
+/*
+ * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
+ *
+ *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict]
+ *              (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
+ *
+ * model.blob / lexicon.blob are written once by a Julius process through the shim
+ * (jamd_gmm_save / jamd_lexicon_save); a DNN is read from Julius' own dnnconf + .npy files.
+ * Every line of the file list names an HTK parameter file (what Julius reads with
+ * `-input htkparam`: 12-byte big-endian header nSamples, sampPeriod, sampSize, parmKind, then
+ * big-endian float vectors -- libsent/src/anlz/rdparam.c).  All utterances are scored and
+ * decoded in device launches of up to 256 utterances; one result line per utterance:
+ *   <file> status=<0 ok|1 no result|2 beam died|3 trellis overflow> score=<pass-1 score> words=<id id ...>
+ * which is what get_back_trellis_end() leaves in r->pass1_wseq / pass1_score.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "julius_amd.h"
+
+static void die(const char *what)
+{
+  fprintf(stderr, "jamd_batch: %s: %s\n", what, jamd_last_error());
+  exit(1);
+}
+
+static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+/* one HTK parameter file -> frames appended to *buf; returns the frame count or -1 */
+static int read_htk(const char *path, int veclen, float **buf, size_t *used, size_t *cap)
+{
+  FILE *f = fopen(path, "rb");
+  unsigned char h[12], *raw;
+  int n, size, i;
+  if (f == NULL) return -1;
+  if (fread(h, 1, 12, f) != 12) { fclose(f); return -1; }
+  n = (int)be32(h); size = (h[8] << 8) | h[9];
+  if (n <= 0 || size != 4 * veclen) { fclose(f); return -1; }
+  raw = (unsigned char *)malloc((size_t)n * size);
+  if (raw == NULL || fread(raw, (size_t)size, (size_t)n, f) != (size_t)n) { free(raw); fclose(f); return -1; }
+  fclose(f);
+  if (*used + (size_t)n * veclen > *cap) {
+    *cap = 2 * (*used + (size_t)n * veclen);
+    *buf = (float *)realloc(*buf, sizeof(float) * *cap);
+  }
+  for (i = 0; i < n * veclen; i++) {
+    uint32_t v = be32(raw + 4 * (size_t)i);
+    memcpy(*buf + *used + i, &v, 4);
+  }
+  *used += (size_t)n * veclen;
+  free(raw);
+  return n;
+}
+
+int main(int argc, char **argv)
+{
+  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL;
+  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, i;
+  float bs = -1.0f;
+  jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_lexicon *lx; jamd_beam *bm;
+  char **files = NULL; int nfile = 0, capfile = 0, veclen, nstate, first;
+  char line[4096];
+  FILE *fl;
+
+  for (i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-d") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-b") && i + 1 < argc) beam = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-bs") && i + 1 < argc) bs = (float)atof(argv[++i]);
+    else if (!strcmp(argv[i], "-gprune") && i + 1 < argc) {
+      if (!strcmp(argv[++i], "safe") && i + 1 < argc) { gprune = JAMD_GPRUNE_SAFE; gnum = atoi(argv[++i]); }
+    } else if (!strcmp(argv[i], "-strict")) strict = 1;
+    else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
+    else if (!strcmp(argv[i], "-dnnconf") && i + 1 < argc) dnnconf = argv[++i];
+    else if (!strcmp(argv[i], "-lex") && i + 1 < argc) lexp = argv[++i];
+    else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
+    else { fprintf(stderr, "jamd_batch: unknown option %s\n", argv[i]); return 2; }
+  }
+  if ((am == NULL) == (dnnconf == NULL) || lexp == NULL || list == NULL) {
+    fprintf(stderr, "usage: jamd_batch (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
+                    "[-d dev] [-b beam] [-bs width] [-gprune safe N] [-strict]\n");
+    return 2;
+  }
+  if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
+  if (jamd_engine_create(device, &e) != JAMD_OK) die("engine");
+  if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }
+  else if (jamd_dnn_load(e, dnnconf, &dn) != JAMD_OK) die("DNN");
+  veclen = gm ? jamd_gmm_veclen(gm) : jamd_dnn_veclen(dn);
+  nstate = gm ? jamd_gmm_nstate(gm) : jamd_dnn_nstate(dn);
+  if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
+  if (jamd_beam_create(e, lx, beam, bs, 256, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
+  if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
+
+  if ((fl = fopen(list, "r")) == NULL) { fprintf(stderr, "jamd_batch: cannot open %s\n", list); return 1; }
+  while (fgets(line, sizeof(line), fl)) {
+    size_t n = strlen(line);
+    while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r' || line[n - 1] == ' ')) line[--n] = 0;
+    if (n == 0) continue;
+    if (nfile == capfile) { capfile = capfile ? 2 * capfile : 64; files = (char **)realloc(files, sizeof(char *) * capfile); }
+    files[nfile++] = strdup(line);
+  }
+  fclose(fl);
+
+  for (first = 0; first < nfile; first += 256) {                 /* launches of up to 256 utterances */
+    const int n = nfile - first < 256 ? nfile - first : 256;
+    float *frames = NULL, *d_frames = NULL, *d_scores = NULL; size_t used = 0, cap = 0;
+    int off[257], u;
+    jamd_pass1_result res[256];
+    off[0] = 0;
+    for (u = 0; u < n; u++) {
+      const int t = read_htk(files[first + u], veclen, &frames, &used, &cap);
+      if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first + u], veclen); return 1; }
+      off[u + 1] = off[u] + t;
+    }
+    if (jamd_malloc(e, sizeof(float) * used, (void **)&d_frames) != JAMD_OK ||
+        jamd_malloc(e, sizeof(float) * (size_t)off[n] * nstate, (void **)&d_scores) != JAMD_OK ||
+        jamd_memcpy_h2d(e, d_frames, frames, sizeof(float) * used) != JAMD_OK) die("device buffers");
+    if ((gm ? jamd_gmm_outprob_dev(gm, d_frames, off[n], d_scores, NULL)
+            : jamd_dnn_outprob_dev(dn, d_frames, off[n], d_scores, NULL)) != JAMD_OK) die("scoring");
+    if (jamd_beam_pass1_dev(bm, d_scores, nstate, off, n, NULL) != JAMD_OK || jamd_engine_sync(e) != JAMD_OK ||
+        jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+    for (u = 0; u < n; u++) {
+      int k;
+      printf("%s status=%d score=%.9g words=", files[first + u], res[u].status, (double)res[u].score);
+      for (k = 0; k < res[u].wnum; k++) printf("%s%d", k ? " " : "", res[u].wseq[k]);
+      printf("\n");
+    }
+    jamd_free(e, d_frames); jamd_free(e, d_scores); free(frames);
+  }
+  jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
+  if (gm) jamd_gmm_destroy(gm);
+  if (dn) jamd_dnn_destroy(dn);
+  jamd_engine_destroy(e);
+  for (i = 0; i < nfile; i++) free(files[i]);
+  free(files);
+  return 0;
+}

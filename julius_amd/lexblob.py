@@ -63,6 +63,24 @@ def load_gmm(path) -> dict:
                 st_book=rec.get("st_book") if nbook > 0 else None, nbook=nbook, nstream=nstream)
 
 
+def save_gmm(model: dict, path) -> None:
+    """Same format as jamd_gmm_save() (julius_amd/shim/jamd_flatten.c)."""
+    mean = np.ascontiguousarray(model["mean"], np.float32)
+    st_book = model.get("st_book")
+    recs = [("ints", np.array([len(model["st_off"]) - 1, mean.shape[1], mean.shape[0], len(model["ent_dens"]),
+                               int(model.get("nbook", 0)), int(model.get("nstream", 1))], np.int32)),
+            ("mean", mean), ("ivar", np.asarray(model["ivar"], np.float32)), ("gconst", np.asarray(model["gconst"], np.float32)),
+            ("st_off", np.asarray(model["st_off"], np.int32)), ("ent_dens", np.asarray(model["ent_dens"], np.int32)),
+            ("ent_logw", np.asarray(model["ent_logw"], np.float32))]
+    if st_book is not None:
+        recs.append(("st_book", np.asarray(st_book, np.int32)))
+    out = [b"JAMDGMM1", struct.pack("<i", len(recs))]
+    for name, arr in recs:
+        arr = np.ascontiguousarray(arr)
+        out.append(name.encode().ljust(24, b"\0") + struct.pack("<ii", 0 if arr.dtype == np.int32 else 1, arr.size) + arr.tobytes())
+    Path(path).write_bytes(b"".join(out))
+
+
 def save(lex: dict, path) -> None:
     """Same format as jamd_lexicon_save() (used to commit small golden fixtures)."""
     out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if lex.get("lm_type", 0) != 0 else 0))]

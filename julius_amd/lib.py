@@ -69,6 +69,9 @@ def load():
         "jamd_memcpy_h2d": (ci, [vp, vp, vp, C.c_size_t]),
         "jamd_memcpy_d2h": (ci, [vp, vp, vp, C.c_size_t]),
         "jamd_gmm_create": (ci, [vp, P(GmmDesc), ci, ci, P(vp)]),
+        "jamd_gmm_load": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
+        "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
+        "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),
         "jamd_gmm_veclen": (ci, [vp]),
@@ -215,6 +218,19 @@ class Gmm:
         self.S, self.D = d.nstate, d.veclen
         self.nbook, self.gprune_num = nbook, gprune_num
 
+    @classmethod
+    def from_file(cls, eng: Engine, path, gprune: int = GPRUNE_NONE, gprune_num: int = 0):
+        """jamd_gmm_load(): a JAMDGMM1 blob read by the library itself."""
+        lib = load()
+        self = cls.__new__(cls)
+        self.eng, self._keep = eng, {}
+        h = C.c_void_p()
+        _check(lib.jamd_gmm_load(eng.h, str(path).encode(), gprune, gprune_num, C.byref(h)), "jamd_gmm_load")
+        self.h = h
+        self.S, self.D = lib.jamd_gmm_nstate(h), lib.jamd_gmm_veclen(h)
+        self.nbook, self.gprune_num = lib.jamd_gmm_nbook(h), gprune_num
+        return self
+
     def outprob_host(self, frames: np.ndarray) -> np.ndarray:
         fr = _f32(frames)
         T = fr.shape[0]
@@ -321,6 +337,18 @@ class Dnn:
         self.h = h
         self.S, self.D = int(self.dims[-1]), int(self.dims[0])
 
+    @classmethod
+    def from_dnnconf(cls, eng: Engine, path):
+        """jamd_dnn_load(): Julius' dnnconf + .npy + prior files read by the library itself."""
+        lib = load()
+        self = cls.__new__(cls)
+        self.eng = eng
+        h = C.c_void_p()
+        _check(lib.jamd_dnn_load(eng.h, str(path).encode(), C.byref(h)), "jamd_dnn_load")
+        self.h = h
+        self.S, self.D = lib.jamd_dnn_nstate(h), lib.jamd_dnn_veclen(h)
+        return self
+
     def outprob_host(self, frames: np.ndarray) -> np.ndarray:
         fr = _f32(frames)
         T = fr.shape[0]
@@ -365,6 +393,16 @@ class Lexicon:
         h = C.c_void_p()
         _check(load().jamd_lexicon_create(eng.h, C.byref(d), C.byref(h)), "jamd_lexicon_create")
         self.h = h
+
+    @classmethod
+    def from_file(cls, eng: Engine, path):
+        """jamd_lexicon_load(): a JAMDLEX1 blob read by the library itself."""
+        self = cls.__new__(cls)
+        self.eng, self.lex, self._keep = eng, None, None
+        h = C.c_void_p()
+        _check(load().jamd_lexicon_load(eng.h, str(path).encode(), C.byref(h)), "jamd_lexicon_load")
+        self.h = h
+        return self
 
     def close(self):
         if getattr(self, "h", None):

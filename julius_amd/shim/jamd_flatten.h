@@ -86,7 +86,7 @@ typedef struct {
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
 void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
 /* Write the descriptor as a self-describing blob of named arrays (the format
- * julius_amd/lexblob.py and jamd_lexicon_load() read). */
+ * julius_amd/lexblob.py and jamd_lexicon_load() (include/julius_amd.h) read). */
 int  jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path);
 
 /* ---- batch of buffered inputs through the first-pass shim (jamd_pass1_shim.c) ----------------

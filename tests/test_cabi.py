@@ -42,3 +42,10 @@ def test_product_does_not_import_oracle():
         if re.search(r"(from|import)\s+oracle|liboracle|libjref|jamd_oracle", txt):
             bad.append(str(p))
     assert not bad, bad
+
+
+def test_standalone_driver_is_plain_c(tmp_path):
+    """julius_amd/host/jamd_batch.c compiles as C99 against the public header alone."""
+    src = lib._PKG / "host" / "jamd_batch.c"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", str(lib._PKG.parent / "include"),
+                    "-c", str(src), "-o", str(tmp_path / "b.o")], check=True)

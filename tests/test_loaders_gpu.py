@@ -1,0 +1,99 @@
+"""GPU: the library's own readers of on-disk models (jamd_gmm_load / jamd_lexicon_load /
+jamd_dnn_load) give the same device models as the descriptor path: the golden
+outputs of the compiled reference are reproduced bit for bit from files alone."""
+import numpy as np
+import pytest
+
+from beamutil import assert_trellis_equal, load_beam_golden
+from conftest import GOLDEN
+from julius_amd import lexblob, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(z):
+    return dict(mean=z["mean"], ivar=z["ivar"], gconst=z["gconst"], st_off=z["st_off"], ent_dens=z["ent_dens"],
+                ent_logw=z["ent_logw"], st_book=z["st_book"] if "st_book" in z.files else None,
+                nbook=int(z["nbook"]) if "nbook" in z.files else 0, nstream=1)
+
+
+def test_gmm_blob(engine, tmp_path):
+    z = np.load(GOLDEN / "gmm_plain_none.npz")
+    lexblob.save_gmm(_model(z), tmp_path / "am.blob")
+    gm = lib.Gmm.from_file(engine, tmp_path / "am.blob")
+    assert (gm.S, gm.D) == (len(z["st_off"]) - 1, z["mean"].shape[1])
+    assert np.array_equal(gm.outprob_host(z["frames"]), z["out"])
+
+
+def test_tied_mixture_blob(engine, tmp_path):
+    z = np.load(GOLDEN / "gmm_tied.npz")
+    lexblob.save_gmm(_model(z), tmp_path / "am.blob")
+    assert lexblob.load_gmm(tmp_path / "am.blob")["nbook"] == int(z["nbook"])      # python reader agrees on the format
+    gm = lib.Gmm.from_file(engine, tmp_path / "am.blob", lib.GPRUNE_SAFE, 2)
+    assert np.array_equal(gm.outprob_host(z["frames"]), z["out_safe2"])
+
+
+@pytest.mark.parametrize("name", ["beam_rank.npz", "beam_grammar.npz"])
+def test_lexicon_blob(engine, oracle, tmp_path, name):
+    g = load_beam_golden(name)
+    lexblob.save(g["lex"], tmp_path / "lex.blob")
+    lx = lib.Lexicon.from_file(engine, tmp_path / "lex.blob")
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    bm.set_strict_order(True)                                  # exact, no tie caveat
+    res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0 and r.score == u["score"] and np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"])
+        assert_trellis_equal(atoms, u["trellis"])
+
+
+def test_dnn_from_dnnconf(engine, tmp_path):
+    """The reference's own on-disk DNN format: dnnconf + .npy + prior list."""
+    z = np.load(GOLDEN / "dnn_small.npz")
+    dnn = synth.make_dnn(dims=(48, 64, 64, 64, 40), seed=51)   # the network tools/make_golden.py wrote for the reference
+    assert all(np.array_equal(dnn["w"][l], z[f"w{l}"]) for l in range(4))
+    for l in range(4):
+        synth.write_npy(tmp_path / f"W{l}.npy", dnn["w"][l])
+        synth.write_npy(tmp_path / f"b{l}.npy", np.asarray(dnn["b"][l]).reshape(-1, 1))
+    with open(tmp_path / "prior", "w") as f:
+        for i, v in enumerate(dnn["prior_lin"]):
+            f.write(f"{i} {float(v):.9e}\n")
+    (tmp_path / "dnn.conf").write_text(
+        "feature_type USER\nfeature_len 48\ncontext_len 1\ninput_nodes 48\noutput_nodes 40\nhidden_nodes 64\n"
+        "hidden_layers 3\nW1 W0.npy\nW2 W1.npy\nW3 W2.npy\nB1 b0.npy\nB2 b1.npy\nB3 b2.npy\noutput_W W3.npy\n"
+        "output_B b3.npy\nstate_prior prior   # relative to this file\nstate_prior_factor 1.0\nstate_prior_log10nize yes\nnum_threads 1\n")
+    net = lib.Dnn.from_dnnconf(engine, tmp_path / "dnn.conf")
+    assert (net.D, net.S) == (48, 40)
+    assert np.array_equal(net.outprob_host(z["frames"]), z["out"])
+
+
+def test_loaders_report_bad_files(engine, tmp_path):
+    (tmp_path / "junk").write_bytes(b"not a blob at all")
+    for call in (lambda: lib.Gmm.from_file(engine, tmp_path / "junk"), lambda: lib.Lexicon.from_file(engine, tmp_path / "junk"),
+                 lambda: lib.Dnn.from_dnnconf(engine, tmp_path / "missing.conf")):
+        with pytest.raises(lib.JamdError):
+            call()
+
+
+def test_standalone_c_driver(oracle, tmp_path):
+    """julius_amd/jamd_batch (C, links only libjulius_amd.so): model blob + lexicon blob + a list of
+    HTK parameter files in, the reference's pass-1 sentences and scores out."""
+    import subprocess
+    exe = lib._PKG / "jamd_batch"
+    assert exe.exists(), "build it with make -C julius_amd/csrc"
+    g = load_beam_golden("beam_rank.npz")
+    lexblob.save_gmm(g["am"], tmp_path / "am.blob")
+    lexblob.save(g["lex"], tmp_path / "lex.blob")
+    names = []
+    for u, utt in enumerate(g["utts"]):
+        names.append(str(tmp_path / f"u{u}.mfc"))
+        synth.write_htk_param(names[-1], utt["frames"])
+    (tmp_path / "list").write_text("\n".join(names) + "\n")
+    out = subprocess.run([str(exe), "-am", str(tmp_path / "am.blob"), "-lex", str(tmp_path / "lex.blob"), "-filelist",
+                          str(tmp_path / "list"), "-b", str(g["beam_width"]), "-strict"],
+                         check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(g["utts"])
+    for line, name, utt in zip(out, names, g["utts"]):
+        f = line.split(" ", 3)
+        assert f[0] == name and f[1] == "status=0"
+        assert np.float32(float(f[2].split("=")[1])) == np.float32(utt["score"])
+        assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(utt["wseq"])
