@@ -1416,6 +1416,9 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     int slots = 4096;
     while ((size_t)w.sv_bytes + (size_t)slots * 2 * 12 <= (size_t)kMaxDynLds && slots < 65536) slots *= 2;
     if ((size_t)w.sv_bytes + (size_t)slots * 12 <= (size_t)kMaxDynLds) w.cell_slots = slots;
+    // a frame creates about five tokens per survivor; a table that would run above ~2/3 load
+    // costs more in failed probes than it saves, so narrower-than-needed tables are not used
+    if (w.cell_slots < 8 * beam_width) w.cell_slots = 0;
     if (getenv("JAMD_BEAM_NO_LDS_CELLS") != nullptr) w.cell_slots = 0;      // development switch (timing comparison)
   }
   w.lds_bytes = w.use_lds ? w.sv_bytes + 12 * w.cell_slots : 0;
