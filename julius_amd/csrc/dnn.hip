@@ -182,10 +182,27 @@ dnn_lse_kernel(const float *__restrict__ x, const float *__restrict__ tbl, float
 __global__ void __launch_bounds__(256)
 dnn_norm_kernel(float *__restrict__ x, const float *__restrict__ lse, const float *__restrict__ prior,
                 int T, int S) {
-  const size_t n = (size_t)T * S;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i / S), s = (int)(i - (size_t)t * S);
-    x[i] = (float)(JAMD_INV_LOG_TEN * (double)(x[i] - lse[t]) - (double)prior[s]);
+  // blockIdx.y walks frames, the block's threads walk the states of a frame four at a time
+  // (S is a multiple of 4 whenever the rows are 16-byte aligned; a scalar tail covers the rest)
+  const int s4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (s4 >= S) return;
+  const bool vec = (S & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(prior) & 15) == 0;
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    float *row = x + (size_t)t * S;
+    if (vec) {
+      float4 v = *reinterpret_cast<const float4 *>(row + s4);
+      const float4 p = *reinterpret_cast<const float4 *>(prior + s4);
+      const float lf = lse[t];
+      v.x = (float)(JAMD_INV_LOG_TEN * (double)(v.x - lf) - (double)p.x);
+      v.y = (float)(JAMD_INV_LOG_TEN * (double)(v.y - lf) - (double)p.y);
+      v.z = (float)(JAMD_INV_LOG_TEN * (double)(v.z - lf) - (double)p.z);
+      v.w = (float)(JAMD_INV_LOG_TEN * (double)(v.w - lf) - (double)p.w);
+      *reinterpret_cast<float4 *>(row + s4) = v;
+    } else {
+      const float lf = lse[t];
+      for (int s = s4; s < S && s < s4 + 4; s++)
+        row[s] = (float)(JAMD_INV_LOG_TEN * (double)(row[s] - lf) - (double)prior[s]);
+    }
   }
 }
 
@@ -326,7 +343,8 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
     float *oc = dev_out + (size_t)t0 * S;
     hipLaunchKernelGGL(dnn_lse_kernel, dim3((Tc + 63) / 64), dim3(64), 0, ts, oc, n->eng->d_addlog,
                        n->d_lse + t0, Tc, S, n->eng->addmin_f);
-    hipLaunchKernelGGL(dnn_norm_kernel, dim3(512), dim3(256), 0, ts, oc, n->d_lse + t0, n->d_prior, Tc, S);
+    hipLaunchKernelGGL(dnn_norm_kernel, dim3((S + 1023) / 1024, Tc < 4096 ? Tc : 4096), dim3(256), 0, ts, oc,
+                       n->d_lse + t0, n->d_prior, Tc, S);
   }
   if (nchunk > 1) {     // join: the caller's stream continues only after the last tail
     JAMD_HIP(hipEventRecord(n->ev_tail, n->side));
