@@ -24,12 +24,16 @@
 //   C  one thread per touched node takes the winner, rebuilds its payload from
 //      the winning candidate id, adds the acoustic score, tracks the frame max;
 //   D  rank pruning: radix select of the beam_width-th score + compaction.
-// "push" is a 64-bit atomicMax on nodekey[node] = (order-preserving score bits,
+// "push" is a 64-bit atomicMax on the node's Viterbi cell = (order-preserving score bits,
 // candidate id): the Viterbi max of propagate_token() (beam.c:1945) without any
-// ordering between candidates.  The first candidate that finds the key empty
-// registers the node in the frame's touched list, step C swaps the key back to
-// 0, so the node table is clean again without a clearing sweep (what
-// clear_tokens(), beam.c:1122, does on the CPU).
+// ordering between candidates.  The cells of the frame being built live in an LDS hash
+// table keyed by node (struct Cells; nodekey[] in global memory is its overflow).  The
+// thread that claims a cell registers the node in the frame's touched list, step C
+// empties the cell again, so both tables are clean after every frame without a clearing
+// sweep (what clear_tokens(), beam.c:1122, does on the CPU).
+// Grammar (per-category trees) and isolated-word recognition run through the same kernel
+// (lx.lm_type): initial tokens enter through steps C and D of a pseudo frame 0, step B
+// becomes word ends x all roots with the category-pair test, or nothing at all.
 //
 // Determinism / parity: every float is produced by the same sequence of fp32
 // operations as the reference (this file is compiled with -ffp-contract=off).
