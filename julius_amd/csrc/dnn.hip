@@ -59,14 +59,16 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
                  float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb) {
   __shared__ __align__(16) float Xs[2][BM][PITCH];
   __shared__ __align__(16) float Ws[2][BN][PITCH];
-  // XCD-aware order: the dispatcher puts block b on XCD b % 8; consecutive
-  // blocks of one XCD walk the N tiles of the same 64-frame strip so the strip
-  // of X stays in that XCD's L2 while W streams.
   const int nnb = (N + BN - 1) / BN;
   const int b = blockIdx.x;
   const int xcd = b & 7, q = b >> 3;
-  const int mb = xcd + 8 * (q / nnb), nb = q % nnb;
-  if (mb >= nmb) return;
+  // The dispatcher puts block b on XCD b % 8.  Each XCD owns every eighth 64-output tile for ALL
+  // frame strips: its share of W (1/8 of the layer, 2 MB at 2048 x 2048) stays in its 4 MB L2
+  // while the strips of X stream through -- instead of all of W streaming through every L2
+  // once per strip (17 GB -> 5 GB of L2 fills per hidden layer at 64 000 frames).
+  const int tpx = (nnb + 7) / 8;
+  const int nb = xcd + 8 * (q % tpx), mb = q / tpx;
+  if (mb >= nmb || nb >= nnb) return;
   const int t0 = mb * BM, o0 = nb * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -325,7 +327,7 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
       const bool last = (l == n->nlayer - 1);
       float *dst = last ? dev_out + (size_t)t0 * S : n->d_act[l & 1];
       const int nnb = (N + BN - 1) / BN;
-      const int grid = 8 * ((nmb + 7) / 8) * nnb;
+      const int grid = 8 * ((nnb + 7) / 8) * nmb;
       if (last)
         hipLaunchKernelGGL((dnn_layer_kernel<0>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
                            n->eng->d_logistic, dst, Tc, K, N, K, N, nmb);

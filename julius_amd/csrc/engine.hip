@@ -57,13 +57,15 @@ int jamd_engine_create(int device, jamd_engine **out) {
   JAMD_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 
   // addlog.c:42-57
-  std::vector<float> tbl(JAMD_TBLSIZE);
+  std::vector<float> tbl(JAMD_TBLSIZE + 1);
+  tbl[JAMD_TBLSIZE] = 0.0f;     // one entry past the reference's table: "no table term" for the pipelined
+                                // gathers of the GMM kernels (adding +0.0f changes nothing)
   for (int i = 0; i < JAMD_TBLSIZE; i++) {
     float f = -((float)15 * (float)i / (float)JAMD_TBLSIZE);
     tbl[i] = (float)log(1 + exp(f));
   }
-  JAMD_HIP(hipMalloc(&e->d_addlog, sizeof(float) * JAMD_TBLSIZE));
-  JAMD_HIP(hipMemcpy(e->d_addlog, tbl.data(), sizeof(float) * JAMD_TBLSIZE, hipMemcpyHostToDevice));
+  JAMD_HIP(hipMalloc(&e->d_addlog, sizeof(float) * (JAMD_TBLSIZE + 1)));
+  JAMD_HIP(hipMemcpy(e->d_addlog, tbl.data(), sizeof(float) * (JAMD_TBLSIZE + 1), hipMemcpyHostToDevice));
   // calc_dnn.c:349-361
   std::vector<float> sig(JAMD_LOGISTIC_MAX + 1);
   for (int i = 0; i <= JAMD_LOGISTIC_MAX; i++) {

@@ -89,10 +89,12 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
     const int ns = min(NS, s_end - sg);
     for (int si = 0; si < ns; si++) {
       const int e0 = st_off[sg + si], e1 = st_off[sg + si + 1];
-      float y[FPL], tv[FPL];
-      bool need[FPL];
+      float y[FPL];
+      f2 y2[NP], tv2[NP];            // ABL == 0: running log-sum and pending table term, packed per frame pair
 #pragma unroll
-      for (int k = 0; k < FPL; k++) { y[k] = JAMD_LOG_ZERO; tv[k] = 0.0f; need[k] = false; }
+      for (int k = 0; k < FPL; k++) y[k] = JAMD_LOG_ZERO;
+#pragma unroll
+      for (int p = 0; p < NP; p++) { y2[p] = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO}; tv2[p] = f2{0.0f, 0.0f}; }
       for (int e = e1 - 1; e >= e0; e--) {
         const float *__restrict__ r = rec + (size_t)e * REC;
         const float gc = r[2 * D], lw = r[2 * D + 1];
@@ -114,6 +116,25 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
         const bool nulld = (gc != gc);  // NULL density marker (gprune_none.c:67)
 #pragma unroll
         for (int p = 0; p < NP; p++) {
+          if (ABL == 0) {
+            // Packed form of the step below for the two frames of a lane.  The table term of the
+            // previous entry arrives in tv2 (0.0f from the extra table entry when none was due), so
+            // finishing that step (addlog.c:119: y += tbl[idx]) is one packed add without a select.
+            f2 s2 = acc[p] * f2{-0.5f, -0.5f};
+            if (nulld) s2 = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO};
+            s2 = s2 + f2{lw, lw};
+            __builtin_amdgcn_sched_barrier(0);     // keep the wait for the gathered term behind the D-loop
+            const f2 yy = y2[p] + tv2[p];
+            const bool g0 = s2.x > yy.x, g1 = s2.y > yy.y;
+            const f2 hi = {g0 ? s2.x : yy.x, g1 ? s2.y : yy.y};
+            const f2 lo = {g0 ? yy.x : s2.x, g1 ? yy.y : s2.y};
+            const f2 dd = lo - hi;
+            const unsigned i0 = !(dd.x < addmin_f) ? (unsigned)((double)(-dd.x) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
+            const unsigned i1 = !(dd.y < addmin_f) ? (unsigned)((double)(-dd.y) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
+            tv2[p] = f2{tbl[i0], tbl[i1]};
+            y2[p] = hi;
+            continue;
+          }
           float s0 = acc[p].x * -0.5f, s1 = acc[p].y * -0.5f;
           if (nulld) { s0 = JAMD_LOG_ZERO; s1 = JAMD_LOG_ZERO; }
           s0 = s0 + lw; s1 = s1 + lw;
@@ -121,18 +142,7 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
 #pragma unroll
           for (int h = 0; h < 2; h++) {
             const int k = 2 * p + h;
-            if (ABL == 0) {
-              // finish the previous step (addlog.c:119: y += tbl[idx]) with the value
-              // whose gather was issued one entry ago
-              const float yy = y[k] + (need[k] ? tv[k] : 0.0f);
-              const bool gt = sc2[h] > yy;
-              const float hi = gt ? sc2[h] : yy, lo = gt ? yy : sc2[h];
-              const float dd = lo - hi;
-              need[k] = !(dd < addmin_f);
-              const unsigned idx = need[k] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
-              tv[k] = tbl[idx];
-              y[k] = hi;
-            } else if (ABL == 1) {
+            if (ABL == 1) {
               y[k] = addlog_step(y[k], sc2[h], tbl, addmin_f);
             } else if (ABL == 2) {  // timing only: index math but no gather
               const bool gt = sc2[h] > y[k];
@@ -149,7 +159,7 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
       }
 #pragma unroll
       for (int k = 0; k < FPL; k++) {
-        if (ABL == 0) y[k] = y[k] + (need[k] ? tv[k] : 0.0f);
+        if (ABL == 0) { const f2 fin = y2[k / 2] + tv2[k / 2]; y[k] = (k & 1) ? fin.y : fin.x; }
         tile[wave][k * 64 + lane][si] = finish_state(y[k]);
       }
     }

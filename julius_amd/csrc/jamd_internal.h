@@ -34,7 +34,7 @@ void jamd_set_error(const char *fmt, ...);
 struct jamd_engine {
   int device = 0;
   hipStream_t stream = nullptr;   // engine-owned stream
-  float *d_addlog = nullptr;      // [JAMD_TBLSIZE]
+  float *d_addlog = nullptr;      // [JAMD_TBLSIZE + 1]; the extra last entry is 0.0f
   float *d_logistic = nullptr;    // [JAMD_LOGISTIC_MAX + 1]
   float addmin_f = 0.f;           // smallest float >= LOG_ADDMIN (exact float form of the double compare)
   int num_cu = 256;
