@@ -21,11 +21,12 @@
 //
 // GEMM shape: C[t][o] = sum_k X[t][k] * W[o][k]  (both operands K-contiguous).
 // Block = 4 waves = 64 frames x 64 outputs, K slab 64 staged through a DOUBLE-
-// BUFFERED LDS tile (one barrier per slab: the next slab is prefetched into
-// registers before the MFMAs of the current one and stored into the other
-// buffer after them); LDS rows are pitched 68 floats so the ds_read_b128
-// fragment reads (one 16-byte quad of k per lane) are conflict free for the
-// instruction's 16-lane groups (MI355X_MICROARCH.md, LDS).
+// BUFFERED LDS tile filled by LDS-DMA (global_load_lds_dwordx4, one barrier per
+// slab: the DMA of the next slab is issued before the MFMAs of the current one
+// and lands in the other buffer); rows are unpadded and quad-swizzled (quad c of
+// row r at position c ^ (r & 15)) so that the ds_read_b128 fragment reads (one
+// 16-byte quad of k per lane) are conflict free for the instruction's 16-lane
+// groups (MI355X_MICROARCH.md, LDS).
 #include "jamd_device.h"
 
 struct jamd_dnn {
@@ -34,6 +35,7 @@ struct jamd_dnn {
   std::vector<int> dims;
   std::vector<float *> d_w, d_b;   // W[l]: [dims[l+1]][dims[l]] as given
   float *d_prior = nullptr;
+  float *d_zero = nullptr;           // 64 zero bytes: DMA source of out-of-range quads
   int maxdim = 0;
   float *d_act[2] = {nullptr, nullptr}; size_t act_cap = 0;
   float *d_lse = nullptr; size_t lse_cap = 0;
@@ -49,16 +51,27 @@ using namespace jamd;
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, KS = 64, PITCH = KS + 4;
+constexpr int BM = 64, BN = 64, KS = 64;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 // ACT: 1 = table logistic (hidden layer), 0 = raw (output layer).
+// zero16: 16 bytes of zeros in global memory, the source of every out-of-range quad (zero
+// padding keeps every chain exact: fma(0,0,acc) == acc).
 template <int ACT>
 __global__ void __launch_bounds__(256, 2)
 dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
                  const float *__restrict__ bias, const float *__restrict__ sig,
-                 float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb) {
-  __shared__ __align__(16) float Xs[2][BM][PITCH];
-  __shared__ __align__(16) float Ws[2][BN][PITCH];
+                 float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb,
+                 const float *__restrict__ zero16) {
+  // K slab of the X tile and of the W tile, two buffers each, UNPADDED rows of 16 quads: the
+  // tiles arrive by LDS-DMA (global_load_lds_dwordx4: a wave writes 1 KB = 4 rows lane-linearly,
+  // no VGPR round trip, no ds_write), so padding is impossible; instead quad c of row r is kept
+  // at position c ^ (r & 15) -- the permutation is applied to the per-lane SOURCE address --
+  // which makes the ds_read_b128 fragment reads of 16 consecutive rows conflict free.
+  __shared__ __align__(16) float Xs[2][BM][KS];
+  __shared__ __align__(16) float Ws[2][BN][KS];
   const int nnb = (N + BN - 1) / BN;
   const int b = blockIdx.x;
   const int xcd = b & 7, q = b >> 3;
@@ -73,39 +86,35 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 
-  // staging: per slab a thread loads 4 float4 of X and 4 of W: row = tid/16 (+16h), quad = tid%16
-  constexpr int NH = 4;
-  const int lr = tid >> 4, lq = (tid & 15) * 4;
-  const float *xrow[NH], *wrow[NH];
-  bool wvalid[NH];
+  // staging: 32 DMA instructions per slab (16 for X, 16 for W), eight per wave.  Instruction
+  // id = 8 * wave + j moves rows 4 * (id & 15) .. + 3 of X (id < 16) or W; lane = 16 * (row in
+  // group) + position, and fetches the quad that belongs at that position.
+  constexpr int NI = 8;
+  const float *src[NI];     // row base + 4 * quad, K offset added per slab
+  int cq[NI];               // 4 * logical quad (k offset inside the slab) of this lane
+  bool rowok[NI];
 #pragma unroll
-  for (int h = 0; h < NH; h++) {
-    int tr = t0 + lr + 16 * h; if (tr > T - 1) tr = T - 1;
-    xrow[h] = X + (size_t)tr * ldx;
-    int orow = o0 + lr + 16 * h; wvalid[h] = orow < N; if (orow > N - 1) orow = N - 1;
-    wrow[h] = W + (size_t)orow * K;
-  }
-  // K is a multiple of 8 (jamd_dnn_create), so a float4 is either fully inside a row or
-  // fully past its end; past-the-end quads are loaded from the last valid quad and zeroed
-  // with a select (zero padding keeps every chain exact: fma(0,0,acc) == acc) -- no
-  // branches, so the prefetch really overlaps the MFMAs.
-  auto gload = [&](int k0, f4v (&xa)[NH], f4v (&wa)[NH]) {
-    const int k = k0 + lq;
-    const int kk = (k < K) ? k : K - 4;
-#pragma unroll
-    for (int h = 0; h < NH; h++) {
-      xa[h] = *(const f4v *)(xrow[h] + kk);
-      wa[h] = *(const f4v *)(wrow[h] + kk);
+  for (int j = 0; j < NI; j++) {
+    const int id = 8 * wave + j, r = 4 * (id & 15) + (lane >> 4);
+    const int c = (lane & 15) ^ (r & 15);
+    cq[j] = 4 * c;
+    if (id < 16) {
+      int tr = t0 + r; if (tr > T - 1) tr = T - 1;
+      src[j] = X + (size_t)tr * ldx + 4 * c; rowok[j] = true;
+    } else {
+      int orow = o0 + r; rowok[j] = orow < N; if (orow > N - 1) orow = N - 1;
+      src[j] = W + (size_t)orow * K + 4 * c;
     }
-  };
-  // the zeroing select is applied here, AFTER the MFMAs of the current slab, so that the
-  // loads stay in flight behind them
-  auto lstore = [&](int buf, int k0, const f4v (&xa)[NH], const f4v (&wa)[NH]) {
-    const bool inside = k0 + lq < K;
+  }
+  // K is a multiple of 8 (jamd_dnn_create), so a quad is either fully inside a row or fully
+  // past its end
+  auto stage = [&](int buf, int k0) {
 #pragma unroll
-    for (int h = 0; h < NH; h++) {
-      *(f4v *)&Xs[buf][lr + 16 * h][lq] = inside ? xa[h] : f4v{0, 0, 0, 0};
-      *(f4v *)&Ws[buf][lr + 16 * h][lq] = (inside && wvalid[h]) ? wa[h] : f4v{0, 0, 0, 0};
+    for (int j = 0; j < NI; j++) {
+      const int id = 8 * wave + j;
+      const float *g = (rowok[j] && k0 + cq[j] < K) ? src[j] + k0 : zero16;
+      float *dst = (id < 16) ? &Xs[buf][4 * (id & 15)][0] : &Ws[buf][4 * (id & 15)][0];
+      __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)dst, 16, 0, 0);
     }
   };
 
@@ -115,30 +124,28 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[l][r] = 0.0f;
 
-  f4v xa[NH], wa[NH];
-  gload(0, xa, wa);
-  lstore(0, 0, xa, wa);
-  __syncthreads();
+  stage(0, 0);
+  __syncthreads();          // carries the vmcnt(0) that lands the DMA
   const int arow = wm + (lane & 31), brow = wn + (lane & 31), half = lane >> 5;
+  const int asw = arow & 15, bsw = brow & 15;
   int cur = 0;
   for (int k0 = 0; k0 < K; k0 += KS) {
-    const bool more = k0 + KS < K;
-    if (more) gload(k0 + KS, xa, wa);   // prefetch next slab into registers
+    if (k0 + KS < K) stage(cur ^ 1, k0 + KS);   // the other buffer was last read before the previous barrier
 #pragma unroll
     for (int g = 0; g < KS; g += 16) {
       // lanes 0-31 take k = g+0..7, lanes 32-63 k = g+8..15: accumulator l sees
       // k = g+l then g+8+l -- ascending within its residue class mod 8
-      const f4v a0 = *(const f4v *)&Xs[cur][arow][g + 8 * half];
-      const f4v a1 = *(const f4v *)&Xs[cur][arow][g + 8 * half + 4];
-      const f4v b0 = *(const f4v *)&Ws[cur][brow][g + 8 * half];
-      const f4v b1 = *(const f4v *)&Ws[cur][brow][g + 8 * half + 4];
+      const int q0 = g / 4 + 2 * half;
+      const f4v a0 = *(const f4v *)&Xs[cur][arow][4 * (q0 ^ asw)];
+      const f4v a1 = *(const f4v *)&Xs[cur][arow][4 * ((q0 + 1) ^ asw)];
+      const f4v b0 = *(const f4v *)&Ws[cur][brow][4 * (q0 ^ bsw)];
+      const f4v b1 = *(const f4v *)&Ws[cur][brow][4 * ((q0 + 1) ^ bsw)];
 #pragma unroll
       for (int l = 0; l < 4; l++) {
         acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[l], b0[l], acc[l], 0, 0, 0);
         acc[l + 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[l], b1[l], acc[l + 4], 0, 0, 0);
       }
     }
-    if (more) lstore(cur ^ 1, k0 + KS, xa, wa);  // the other buffer was last read one iteration ago
     __syncthreads();
     cur ^= 1;
   }
@@ -254,6 +261,8 @@ int jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out) {
   const int S = n->dims[d->nlayer];
   JAMD_HIP(hipMalloc(&n->d_prior, sizeof(float) * S));
   JAMD_HIP(hipMemcpy(n->d_prior, d->state_prior, sizeof(float) * S, hipMemcpyHostToDevice));
+  JAMD_HIP(hipMalloc(&n->d_zero, 64));
+  JAMD_HIP(hipMemset(n->d_zero, 0, 64));
   *out = n;
   return JAMD_OK;
 }
@@ -269,7 +278,7 @@ void jamd_dnn_destroy(jamd_dnn *n) {
     (void)hipEventDestroy(n->ev_tail); (void)hipEventDestroy(n->ev_start);
     (void)hipStreamDestroy(n->side);
   }
-  float *ptrs[] = { n->d_prior, n->d_act[0], n->d_act[1], n->d_lse, n->d_frames, n->d_out };
+  float *ptrs[] = { n->d_prior, n->d_zero, n->d_act[0], n->d_act[1], n->d_lse, n->d_frames, n->d_out };
   for (float *p : ptrs) if (p) (void)hipFree(p);
   delete n;
 }
@@ -330,10 +339,10 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
       const int grid = 8 * ((nnb + 7) / 8) * nmb;
       if (last)
         hipLaunchKernelGGL((dnn_layer_kernel<0>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
-                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb);
+                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb, n->d_zero);
       else
         hipLaunchKernelGGL((dnn_layer_kernel<1>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
-                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb);
+                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb, n->d_zero);
       src = dst;
     }
     hipStream_t ts = st;
