@@ -90,9 +90,9 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
   // id = 8 * wave + j moves rows 4 * (id & 15) .. + 3 of X (id < 16) or W; lane = 16 * (row in
   // group) + position, and fetches the quad that belongs at that position.
   constexpr int NI = 8;
-  const float *src[NI];     // row base + 4 * quad, K offset added per slab
+  const float *src[NI];     // row base + 4 * quad (or the zero block), K offset added per slab
   int cq[NI];               // 4 * logical quad (k offset inside the slab) of this lane
-  bool rowok[NI];
+  int kmask[NI];            // ~0, or 0 for a W row past N: the source stays on the zero block
 #pragma unroll
   for (int j = 0; j < NI; j++) {
     const int id = 8 * wave + j, r = 4 * (id & 15) + (lane >> 4);
@@ -100,19 +100,24 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
     cq[j] = 4 * c;
     if (id < 16) {
       int tr = t0 + r; if (tr > T - 1) tr = T - 1;
-      src[j] = X + (size_t)tr * ldx + 4 * c; rowok[j] = true;
+      src[j] = X + (size_t)tr * ldx + 4 * c; kmask[j] = ~0;
     } else {
-      int orow = o0 + r; rowok[j] = orow < N; if (orow > N - 1) orow = N - 1;
-      src[j] = W + (size_t)orow * K + 4 * c;
+      const int orow = o0 + r;
+      kmask[j] = orow < N ? ~0 : 0;
+      src[j] = orow < N ? W + (size_t)orow * K + 4 * c : zero16;
     }
   }
   // K is a multiple of 8 (jamd_dnn_create), so a quad is either fully inside a row or fully
   // past its end
+  // a slab that lies completely inside K needs no per-quad test (all but the last slab of a
+  // layer whose K is not a multiple of 64)
   auto stage = [&](int buf, int k0) {
+    const bool full = k0 + KS <= K;
 #pragma unroll
     for (int j = 0; j < NI; j++) {
       const int id = 8 * wave + j;
-      const float *g = (rowok[j] && k0 + cq[j] < K) ? src[j] + k0 : zero16;
+      const float *g = src[j] + (k0 & kmask[j]);
+      if (!full && !(k0 + cq[j] < K)) g = zero16;
       float *dst = (id < 16) ? &Xs[buf][4 * (id & 15)][0] : &Ws[buf][4 * (id & 15)][0];
       __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)dst, 16, 0, 0);
     }
