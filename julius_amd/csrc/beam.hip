@@ -49,7 +49,8 @@ using namespace jamd;
 
 constexpr int NT = 1024;                // threads per utterance workgroup
 constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
-constexpr int kMaxDynLds = 144 * 1024;  // survivor state above this stays in global memory (160 KB LDS per CU, ~10 KB static)
+constexpr int kMaxDynLds = 159 * 1024;  // dynamic LDS budget of the one workgroup a CU holds (160 KB LDS per CU, < 1 KB static)
+constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its space with the first cells (free during step D)
 
 struct LexDev {
   int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
@@ -102,7 +103,9 @@ struct Work {            // per-utterance slices are addressed with the strides 
   int nscword;
   int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
   int cell_slots;                // LDS Viterbi cells of the current frame (power of two, 0 = all cells in nodekey[])
-  int lds_bytes;                 // dynamic LDS per workgroup: sv_bytes + 12 * cell_slots
+  int lds_bytes;                 // dynamic LDS per workgroup without the score-row cache
+  int cell_off, node_off, row_off;  // byte offsets in dynamic LDS: cells / histogram, cell owners, score row
+  int row_cache;                 // set per launch: the frame's [nstate] score row is copied to LDS
   int tok_cap, atom_cap, beam, nnode, nword;
   float width;
 };
@@ -186,9 +189,16 @@ __device__ __forceinline__ int outprob_entry(const LexDev &lx, int kind, int id,
   return lx.lc_tab[(size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc[last_wid])];
 }
 
+// the acoustic scores of the frame being finalized: the [nstate] row in global memory, or its copy
+// in LDS (a frame makes some 15 000 gathers from it: one per new token plus the members of every
+// state set -- a third of all the divergent loads of the frame)
+struct RowRef {
+  const float *g; const float *l; bool lds;
+  __device__ __forceinline__ float operator[](int i) const { return lds ? l[i] : g[i]; }
+};
+
 struct Shared {
   unsigned long long we_best;       // (ord(score + wordend_a), word that ended)
-  unsigned hist[2048];
   int n_new, n_we, n_arc, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
@@ -327,8 +337,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   // the frame's Viterbi cells: LDS table behind the survivor image (16-byte aligned), see Cells
   Cells cl;
   cl.gkey = nodekey; cl.touched = touched; cl.nslot = wk.use_lds ? wk.cell_slots : 0;
-  cl.lkey = (unsigned long long *)(dyn_lds + wk.sv_bytes);
-  cl.lnode = (int *)(cl.lkey + cl.nslot);
+  cl.lkey = (unsigned long long *)(dyn_lds + wk.cell_off);
+  cl.lnode = (int *)(dyn_lds + wk.node_off);
+  unsigned *hist = (unsigned *)(dyn_lds + wk.cell_off);    // step D only: the cells are all empty then
+  float *rowc = (float *)(dyn_lds + wk.row_off);           // this frame's score row when wk.row_cache
   cl.shift = cl.nslot > 0 ? 32 - (31 - __clz(cl.nslot)) : 0;
   for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; }
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
@@ -395,6 +407,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
     __syncthreads();
     const bool last = (t == T);     // get_back_trellis_end(): word ends only, no pruning test
+    if (wk.row_cache && !last) {    // readers: step C of this frame, two barriers from here
+      const float *__restrict__ rg = scores + (size_t)(t_begin + t - base) * S;
+      for (int i = tid; i < S; i += NT) rowc[i] = rg[i];
+    }
 
     // one intra-word candidate of token tk: score, LM factoring update, push, tie accounting
     auto intra_candidate = [&](const Tok &tk, int next_node, float a) {
@@ -555,7 +571,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     const int n_new = sh.n_new;
     if (n_new > max_tokens) max_tokens = n_new;
     {
-      const float *__restrict__ row = scores + (size_t)(t_begin + t - base) * S;
+      const RowRef row{scores + (size_t)(t_begin + t - base) * S, rowc, wk.row_cache != 0};
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
       // CB tokens per thread are carried through the steps together: every step's loads (node
       // record, LM memo, context table, score row) are issued for all of them before any is used, so
@@ -797,18 +813,18 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const int w = remaining < 11 ? remaining : 11;
         const int shift = remaining - w;
         const unsigned dmask = (1u << w) - 1u;
-        for (int i = tid; i < 2048; i += NT) sh.hist[i] = 0;
+        for (int i = tid; i < 2048; i += NT) hist[i] = 0;
         __syncthreads();
         for (int s = tid; s < n_new; s += NT) {
           const unsigned b = cur_key[s];
           const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
-          if (hi == prefix) atomicAdd(&sh.hist[(b >> shift) & dmask], 1u);
+          if (hi == prefix) atomicAdd(&hist[(b >> shift) & dmask], 1u);
         }
         __syncthreads();
         {
           // suffix scan over the 2048 digits with the whole workgroup: thread i owns digits 2i, 2i+1;
           // `above` = tokens with a larger digit
-          const unsigned h0 = sh.hist[2 * tid], h1 = sh.hist[2 * tid + 1];
+          const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
           const unsigned pair = h0 + h1;
           unsigned incl = pair;                          // inclusive suffix sum over the lanes >= this one
           const int ln = tid & 63;
@@ -834,6 +850,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       }
       // prefix = score bits of the beam_width-th token; keep everything above it and
       // `need` of the count_eq tokens equal to it
+      for (int i = tid; i < 2048; i += NT) hist[i] = 0;   // the histogram sat on the first cells: empty them again
     }
     for (int i = tid; i < wk.hsize; i += NT) hkey[i] = -1;
     const bool cut_tie = prune && count_eq > need;
@@ -1412,7 +1429,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   w.hsize = 64; while (w.hsize < 2 * beam_width) w.hsize <<= 1;
   w.sv_bytes = (int)(beam_width * (sizeof(Tok) + 2 * sizeof(int)) + (size_t)w.hsize * 2 * sizeof(int));
   w.sv_bytes = (w.sv_bytes + 15) & ~15;
-  w.use_lds = w.sv_bytes <= kMaxDynLds ? 1 : 0;
+  w.use_lds = w.sv_bytes + kHistBytes <= kMaxDynLds ? 1 : 0;
   // what is left of the LDS budget holds the frame's Viterbi cells (12 bytes per slot), if that is
   // at least 4096 slots; a frame that outgrows the table overflows into nodekey[]
   w.cell_slots = 0;
@@ -1425,7 +1442,11 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     if (w.cell_slots < 8 * beam_width) w.cell_slots = 0;
     if (getenv("JAMD_BEAM_NO_LDS_CELLS") != nullptr) w.cell_slots = 0;      // development switch (timing comparison)
   }
-  w.lds_bytes = w.use_lds ? w.sv_bytes + 12 * w.cell_slots : 0;
+  w.cell_off = w.use_lds ? w.sv_bytes : 0;
+  w.node_off = w.cell_off + (8 * w.cell_slots > kHistBytes ? 8 * w.cell_slots : kHistBytes);
+  w.row_off = w.node_off + 4 * w.cell_slots;
+  w.lds_bytes = w.row_off;
+  w.row_cache = 0;
   if (rc == JAMD_OK) rc = alloc((void **)&w.nodekey, U * w.nnode * sizeof(unsigned long long), true);
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur, U * w.tok_cap * sizeof(Tok), false);
   if (rc == JAMD_OK) rc = alloc((void **)&w.cur_key, U * w.tok_cap * sizeof(unsigned), false);
@@ -1436,7 +1457,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   if (rc == JAMD_OK && !w.use_lds) rc = alloc((void **)&w.sv_global, U * (size_t)w.sv_bytes, false);
   w.nscword = l->nscword > 0 ? l->nscword : 1;
   if (rc == JAMD_OK) rc = alloc((void **)&w.lmcache, U * (size_t)w.nscword * sizeof(unsigned long long), false);
-  if (rc == JAMD_OK && w.use_lds) {
+  if (rc == JAMD_OK) {
     // the attribute is per kernel, not per work area: always ask for the whole budget
     hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         kMaxDynLds);
@@ -1479,12 +1500,17 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   if (b->strict)
     hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
-  else if (b->timed)
-    hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
-                       b->w, dev_scores, nstate, b->d_utt_off, 0);
-  else
-    hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
-                       b->w, dev_scores, nstate, b->d_utt_off, 0);
+  else {
+    Work w = b->w;                                     // the score row joins the LDS image when it still fits
+    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds && getenv("JAMD_BEAM_NO_ROW_CACHE") == nullptr;
+    const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
+    if (b->timed)
+      hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
+                         b->d_utt_off, 0);
+    else
+      hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
+                         b->d_utt_off, 0);
+  }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   return JAMD_OK;
@@ -1529,12 +1555,17 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, chunk_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  if (b->timed)
-    hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
-                       b->w, dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
-  else
-    hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), b->w.lds_bytes, st, b->lex->d,
-                       b->w, dev_scores, nstate, b->d_utt_off, final ? 2 : 1);
+  {
+    Work w = b->w;
+    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds && getenv("JAMD_BEAM_NO_ROW_CACHE") == nullptr;
+    const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
+    if (b->timed)
+      hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
+                         b->d_utt_off, final ? 2 : 1);
+    else
+      hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
+                         b->d_utt_off, final ? 2 : 1);
+  }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_stream_push_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   if (final) b->streaming = 0;

@@ -96,7 +96,9 @@ __device__ __forceinline__ void topn_push(float (&sc)[NMAX], int (&id)[NMAX], in
 // (libsent/src/phmm/outprob.c:287-400); shared by the cdset kernel and the
 // first-pass kernel.  `states[a..b)` are the member state ids.
 constexpr int kNbestMax = 16;
-__device__ __forceinline__ float cd_reduce(const float *__restrict__ row, const int *__restrict__ states,
+// `row` is anything indexable by state id (a global pointer, or the first-pass kernel's RowRef).
+template <typename Row>
+__device__ __forceinline__ float cd_reduce(const Row &row, const int *__restrict__ states,
                                            int a, int b, int method, int nbest) {
   if (method == JAMD_IWCD_MAX) {                       // outprob_cd_max :332-344
     float m = JAMD_LOG_ZERO;
