@@ -1273,6 +1273,7 @@ struct jamd_beam {
   bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
   int stream_pushes = 0;
+  std::vector<int> stream_frames;  // frames pushed so far per utterance of the session (limit 32767 each)
   StrictWork sw{};
   std::vector<void *> owned;
 };
@@ -1529,6 +1530,7 @@ int jamd_beam_stream_begin(jamd_beam *b, int nutt) {
   JAMD_HIP(hipMemsetAsync(b->w.stream, 0, sizeof(StreamState) * (size_t)nutt, b->eng->stream));
   JAMD_HIP(hipStreamSynchronize(b->eng->stream));
   b->streaming = nutt; b->stream_pushes = 0;
+  b->stream_frames.assign((size_t)nutt, 0);
   return JAMD_OK;
 }
 
@@ -1540,8 +1542,13 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   if (b->streaming <= 0 || nutt != b->streaming) {
     jamd_set_error("jamd_beam_stream_push_dev: call jamd_beam_stream_begin(b, %d) first", nutt); return JAMD_ESTATE;
   }
-  for (int u = 0; u < nutt; u++)
+  for (int u = 0; u < nutt; u++) {
     if (chunk_off[u + 1] < chunk_off[u]) { jamd_set_error("jamd_beam_stream_push_dev: chunk_off must be non-decreasing"); return JAMD_EINVAL; }
+    if ((long)b->stream_frames[u] + (chunk_off[u + 1] - chunk_off[u]) > 32767) {   // TRELLIS_ATOM times are short
+      jamd_set_error("jamd_beam_stream_push_dev: utterance %d would exceed 32767 frames", u); return JAMD_EINVAL;
+    }
+  }
+  for (int u = 0; u < nutt; u++) b->stream_frames[u] += chunk_off[u + 1] - chunk_off[u];
   if (b->strict) {
     // the strict-order kernel keeps no state between launches: one push carrying everything
     if (!final || b->stream_pushes != 0) {
