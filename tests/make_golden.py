@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libjref.so).
 
 Run in the dev container (where /root/reference exists):
-    python tools/make_golden.py
+    python tests/make_golden.py
 Each fixture holds a seeded synthetic model *as the reference's own loader left
 it in memory* (exported through the product-side flattening code), the input
 frames, and the reference's outputs.  The fixtures are small (<200 kB each) and

@@ -1,6 +1,6 @@
 """CPU: the first-pass oracle (oracle/jamd_oracle_beam.c) against
   (1) the committed golden fixtures the compiled reference produced
-      (tools/make_golden.py beam), and
+      (tests/make_golden.py beam), and
   (2) the compiled reference itself on fresh seeded tasks (when oracle/_ref is built).
 Bit-exact: word ids, frame indices, predecessor links, float scores."""
 import numpy as np

@@ -49,7 +49,7 @@ def test_lexicon_blob(engine, oracle, tmp_path, name):
 def test_dnn_from_dnnconf(engine, tmp_path):
     """The reference's own on-disk DNN format: dnnconf + .npy + prior list."""
     z = np.load(GOLDEN / "dnn_small.npz")
-    dnn = synth.make_dnn(dims=(48, 64, 64, 64, 40), seed=51)   # the network tools/make_golden.py wrote for the reference
+    dnn = synth.make_dnn(dims=(48, 64, 64, 64, 40), seed=51)   # the network tests/make_golden.py wrote for the reference
     assert all(np.array_equal(dnn["w"][l], z[f"w{l}"]) for l in range(4))
     for l in range(4):
         synth.write_npy(tmp_path / f"W{l}.npy", dnn["w"][l])

@@ -1,6 +1,6 @@
 """CPU: the oracle restatement (oracle/jamd_oracle_am.c) against the committed
 golden fixtures, which were produced by the COMPILED REFERENCE
-(tools/make_golden.py -> oracle/_ref/libjref.so).  Bit-exact."""
+(tests/make_golden.py -> oracle/_ref/libjref.so).  Bit-exact."""
 import numpy as np
 import pytest
 
