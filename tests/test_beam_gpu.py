@@ -91,6 +91,8 @@ def test_work_area_is_reusable(engine, oracle):
     (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),          # transparent words
     (27, 150, ["-sepnum", "4"], dict(nunk=10)),                                     # words outside the LM -> <unk>
     (28, 150, ["-sepnum", "4"], dict(with_rl3=True)),                               # LR 2-gram + RL 3-gram (additional area)
+    (29, 5000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),          # survivor image too large for LDS: global path
+    (30, 1200, ["-sepnum", "10", "-bs", "90"], dict(nword=500, nphone=12, S=200)),  # LDS survivors, but no room for the cell table
 ])
 def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
@@ -98,7 +100,7 @@ def test_vs_oracle_and_reference_live(engine, oracle, ref, tmp_path, seed, beam,
     utts = [synth.make_utterance(task, nwords=2 + 3 * u, seed=100 * seed + u)[0] for u in range(4)]
     scores = [oracle.gmm_outprob(am, fr) for fr in utts]
     lx = lib.Lexicon(engine, lex)
-    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts))
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 19)
     res, tre = bm.pass1_host(scores)
     for fr, sc, r, atoms in zip(utts, scores, res, tre):
         oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, bs)
