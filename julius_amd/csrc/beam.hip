@@ -52,28 +52,47 @@ constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speec
 constexpr int kMaxDynLds = 159 * 1024;  // dynamic LDS budget of the one workgroup a CU holds (160 KB LDS per CU, < 1 KB static)
 constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its space with the first cells (free during step D)
 
+// All lexicon / LM arrays live in ONE device allocation and are addressed as base + 32-bit byte
+// offset: a kernel that carries some forty 64-bit array pointers next to its per-utterance work
+// pointers needs twice the scalar registers the hardware has, and the spilled ones come back
+// through v_readlane -- a third of the first-pass kernel's instructions before this layout.  With a
+// uniform base the loads also take the `global_load v, voffset32, s[base]` form (no 64-bit address
+// arithmetic per access).
+#define JAMD_LEX_ARRAYS(X)                                                                       \
+  X(int4, node_a)          /* [nnode] {self_a bits, next_a bits, ac_off, ac_end} (wchmm->self_a/next_a/ac) */ \
+  X(int4, node_b)          /* [nnode] {stend, scid, out_id, out_kind} (stend, state[].scid, outstyle)      */ \
+  X(int, scid)             /* [nnode] again, for the destination of a transition                           */ \
+  X(int, ac_to) X(float, ac_a)                                                                               \
+  X(int2, iso_root)        /* [isolatenum] {root node, successor word scword[scid[root]]}                  */ \
+  X(float2, shared_root)   /* [nshared]    {root node bits, fscore[-scid[root]]}                           */ \
+  X(int, word_end)         /* [nword] node whose stend is the word                                         */ \
+  X(int, startnode) X(int, start2isolate)   /* [startnum] as in wchmm (the strict-order kernel walks them like beam.c) */ \
+  X(int, lc_tab) X(int, word_lc) X(int, set_off) X(int, set_states)                                          \
+  X(float, wordend_a) X(int, wton) X(float, cprob) X(unsigned char, is_transparent)                          \
+  X(int, word_head) X(float, fscore) X(int, scword)                                                          \
+  X(float, ng_uni_prob) X(float, ng_uni_bo) X(int, ng_bi_bgn) X(int, ng_bi_num) X(int, ng_bi_wid) X(float, ng_bi_prob) \
+  /* grammar (per-category trees): category-pair matrix [ncat][ncat] (dfa_cp()), each root's category         \
+     wton[start2wid[root]], the initial tokens [ninit] */                                                      \
+  X(unsigned char, cat_pair) X(int, root_cat) X(int, init_node) X(float, init_lscore)
+
 struct LexDev {
   int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
   int head_silwid, tail_silwid, ng_mode, ng_unk_id;
   float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
-  // packed per-node records: one 16-byte load each
-  const int4 *node_a;         // [nnode] {self_a bits, next_a bits, ac_off, ac_end}   (wchmm->self_a/next_a/ac)
-  const int4 *node_b;         // [nnode] {stend, scid, out_id, out_kind}               (stend, state[].scid, outstyle)
-  const int *scid;            // [nnode] again, for the destination of a transition
-  const int *ac_to; const float *ac_a;
-  const int2 *iso_root;       // [isolatenum] {root node, successor word scword[scid[root]]}
-  const float2 *shared_root;  // [nshared]    {root node bits, fscore[-scid[root]]}
-  const int *word_end;        // [nword] node whose stend is the word
-  const int *startnode, *start2isolate;   // [startnum] as in wchmm (strict-order kernel walks them like beam.c)
-  const int *lc_tab, *word_lc, *set_off, *set_states;
-  const float *wordend_a; const int *wton; const float *cprob; const unsigned char *is_transparent;
-  const int *word_head; const float *fscore; const int *scword;
-  const float *ng_uni_prob, *ng_uni_bo; const int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; const float *ng_bi_prob;
-  // grammar (per-category trees): category-pair matrix, each root's category, the initial tokens
   int lm_type, ncat, ninit; float penalty1;
-  const unsigned char *cat_pair;   // [ncat][ncat]  dfa_cp()
-  const int *root_cat;             // [startnum]    wton[start2wid[root]]
-  const int *init_node; const float *init_lscore;   // [ninit]
+  const unsigned char *base;          // the arena
+#define X(T, name) unsigned o_##name;
+  JAMD_LEX_ARRAYS(X)
+#undef X
+  template <typename T>
+  __device__ __forceinline__ T at(unsigned off, int i) const {
+    return *reinterpret_cast<const T *>(base + (unsigned)(off + (unsigned)i * (unsigned)sizeof(T)));
+  }
+#define X(T, name)                                                                   \
+  __device__ __forceinline__ T name(int i) const { return at<T>(o_##name, i); }      \
+  __device__ __forceinline__ const T *name##_ptr() const { return reinterpret_cast<const T *>(base + o_##name); }
+  JAMD_LEX_ARRAYS(X)
+#undef X
 };
 
 struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/beam.h:35-45
@@ -121,29 +140,29 @@ __device__ __forceinline__ float unord(unsigned u) {
 
 // search_bigram(), ngram_access.c:225-247
 __device__ __forceinline__ int search_bigram(const LexDev &lx, int w_context, int w) {
-  int left = lx.ng_bi_bgn[w_context];
+  int left = lx.ng_bi_bgn(w_context);
   if (left < 0) return -1;
-  int right = left + lx.ng_bi_num[w_context] - 1;
+  int right = left + lx.ng_bi_num(w_context) - 1;
   while (left < right) {
     const int mid = (left + right) / 2;
-    if (lx.ng_bi_wid[mid] < w) left = mid + 1; else right = mid;
+    if (lx.ng_bi_wid(mid) < w) left = mid + 1; else right = mid;
   }
-  return (lx.ng_bi_wid[left] == w) ? left : -1;
+  return (lx.ng_bi_wid(left) == w) ? left : -1;
 }
 
 // ngram->bigram_prob as chosen by bi_prob_func_set(), ngram_access.c:288-466
 __device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
   int n2; float prob;
   if (lx.ng_mode == JAMD_NG_NORMAL || lx.ng_mode == JAMD_NG_ADDITIONAL_OLD) {
-    if ((n2 = search_bigram(lx, w1, w2)) >= 0) prob = lx.ng_bi_prob[n2];
-    else prob = lx.ng_uni_bo[w1] + lx.ng_uni_prob[w2];
+    if ((n2 = search_bigram(lx, w1, w2)) >= 0) prob = lx.ng_bi_prob(n2);
+    else prob = lx.ng_uni_bo(w1) + lx.ng_uni_prob(w2);
   } else if (lx.ng_mode == JAMD_NG_ADDITIONAL) {
-    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob[n2];
-    else prob = lx.ng_uni_bo[w1] + lx.ng_uni_prob[w2];
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob(n2);
+    else prob = lx.ng_uni_bo(w1) + lx.ng_uni_prob(w2);
   } else {
-    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob[n2];
-    else prob = lx.ng_uni_bo[w2] + lx.ng_uni_prob[w1];
-    prob = prob + lx.ng_uni_prob[w2] - lx.ng_uni_prob[w1];
+    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob(n2);
+    else prob = lx.ng_uni_bo(w2) + lx.ng_uni_prob(w1);
+    prob = prob + lx.ng_uni_prob(w2) - lx.ng_uni_prob(w1);
   }
   if (w2 != lx.ng_unk_id) return prob;
   return prob - lx.ng_unk_num_log;
@@ -158,14 +177,14 @@ __device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
 __device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int scid,
                                                     unsigned long long *memo = nullptr) {
   if (lastword < 0) return 0.0f;
-  if (scid < 0) return lx.fscore[-scid];
-  const int ctx = lx.wton[lastword];
+  if (scid < 0) return lx.fscore(-scid);
+  const int ctx = lx.wton(lastword);
   if (memo) {
     const unsigned long long m = memo[scid];
     if ((int)(unsigned)(m >> 32) == ctx) return __uint_as_float((unsigned)m);
   }
-  const int w = lx.scword[scid];
-  const float p = bigram_prob(lx, ctx, lx.wton[w]) + lx.cprob[w];
+  const int w = lx.scword(scid);
+  const float p = bigram_prob(lx, ctx, lx.wton(w)) + lx.cprob(w);
   if (memo) memo[scid] = ((unsigned long long)(unsigned)ctx << 32) | __float_as_uint(p);
   return p;
 }
@@ -176,17 +195,17 @@ __device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, i
   int ent;
   if (kind == JAMD_AS_STATE) return row[id];
   if (kind == JAMD_AS_LSET) ent = ~id;
-  else ent = lx.lc_tab[(size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc[last_wid])];
+  else ent = lx.lc_tab((size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc(last_wid)));
   if (ent >= 0) return row[ent];
   ent = ~ent;
-  return cd_reduce(row, lx.set_states, lx.set_off[ent], lx.set_off[ent + 1], lx.cdset_method, lx.cdmax_num);
+  return cd_reduce(row, lx.set_states_ptr(), lx.set_off(ent), lx.set_off(ent + 1), lx.cdset_method, lx.cdmax_num);
 }
 
 // the state (>= 0) or ~state-set (< 0) that outprob_style() scores for a node
 __device__ __forceinline__ int outprob_entry(const LexDev &lx, int kind, int id, int last_wid) {
   if (kind == JAMD_AS_STATE) return id;
   if (kind == JAMD_AS_LSET) return ~id;
-  return lx.lc_tab[(size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc[last_wid])];
+  return lx.lc_tab((size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc(last_wid)));
 }
 
 // the acoustic scores of the frame being finalized: the [nstate] row in global memory, or its copy
@@ -378,8 +397,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     // With a grammar the initial tokens (one per word that may start a sentence, :1669-1757)
     // enter through the finalize and rank-pruning steps of a pseudo frame 0 below.
     if (tid == 0 && !dfa) {
-      const int node = lx.word_head[lx.head_silwid];
-      const int4 nr = lx.node_b[node];                 // {stend, scid, out_id, out_kind}
+      const int node = lx.word_head(lx.head_silwid);
+      const int4 nr = lx.node_b(node);                 // {stend, scid, out_id, out_kind}
       Tok nw;
       float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
       ls = ls * lmw + pen;
@@ -416,7 +435,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     auto intra_candidate = [&](const Tok &tk, int next_node, float a) {
       const int node = tk.node;
       float tmpsum = tk.score + a;
-      const int nscid = (next_node != node) ? lx.scid[next_node] : 0;
+      const int nscid = (next_node != node) ? lx.scid(next_node) : 0;
       const bool fac = nscid != 0;
       if (fac) {
         const float ng = max_successor_prob(lx, tk.last_cword, nscid, memo) * lmw + pen;
@@ -434,7 +453,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           const Tok o = sv[hash_get(hkey, hval, hmask, (int)(unsigned)tie)];
           // the LM score is recomputed from last_cword on entering a factoring
           // node from another node (see step C); otherwise it is inherited
-          const bool re_o = next_node != o.node && lx.scid[next_node] != 0;
+          const bool re_o = next_node != o.node && lx.scid(next_node) != 0;
           same = o.last_tre == tk.last_tre && o.last_cword == tk.last_cword &&
                  (fac == re_o) && (fac || o.last_lscore == tk.last_lscore);
         }
@@ -445,8 +464,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     for (int j = tid; j < n_surv; j += NT) {
       const Tok tk = sv[j];
       const int node = tk.node;
-      const int4 na = lx.node_a[node];               // {self_a, next_a, ac_off, ac_end}
-      const int sword = lx.node_b[node].x;           // stend
+      const int4 na = lx.node_a(node);               // {self_a, next_a, ac_off, ac_end}
+      const int sword = lx.node_b(node).x;           // stend
       if (!last) {
         if (tk.score <= JAMD_LOG_ZERO) continue;
         if (tk.score < thr) continue;
@@ -478,7 +497,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         sv_atom[j] = ai;
         if (!last && !wordmode && sword != lx.tail_silwid) {   // beam_inter_word() :2296-2313
           welist[atomicAdd(&sh.n_we, 1)] = j;
-          const float tmpprob = tk.score + lx.wordend_a[sword];
+          const float tmpprob = tk.score + lx.wordend_a(sword);
           if (!dfa && tmpprob > JAMD_LOG_ZERO) {
             const unsigned long long key = ((unsigned long long)ord(tmpprob) << 32) | (unsigned)sword;
             const unsigned long long old = atomicMax(&sh.we_best, key);
@@ -492,7 +511,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const int n_arc = sh.n_arc;
       for (int q = tid; q < n_arc; q += NT) {
         const int2 it = arcq[q];
-        intra_candidate(sv[it.x], lx.ac_to[it.y], lx.ac_a[it.y]);
+        intra_candidate(sv[it.x], lx.ac_to(it.y), lx.ac_a(it.y));
       }
       __syncthreads();
     }
@@ -509,38 +528,38 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       for (int x = tid; x < total; x += NT) {
         const int w = x / nroot, r = x - w * nroot;
         const Tok tk = sv[welist[w]];
-        const int sword = lx.node_b[tk.node].x;
-        if (!lx.cat_pair[lx.wton[sword] * lx.ncat + lx.root_cat[r]]) continue;
-        const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+        const int sword = lx.node_b(tk.node).x;
+        if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
+        const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
         float tmpsum = tk.score;
-        tmpsum += lx.wordend_a[sword];
+        tmpsum += lx.wordend_a(sword);
         float ng = lx.penalty1;
-        ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+        ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
         tmpsum += ng;
-        if (push(sh, cl, lx.startnode[r], tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
+        if (push(sh, cl, lx.startnode(r), tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
           atomicAdd(&sh.ties, 1);
       }
       if (t == 0)          // pseudo frame 0: the initial tokens (init_nodescore(), beam.c:1669-1757)
         for (int e = tid; e < lx.ninit; e += NT)
-          push(sh, cl, lx.init_node[e], lx.init_lscore[e], 0xC0000000u | (unsigned)e);
+          push(sh, cl, lx.init_node(e), lx.init_lscore(e), 0xC0000000u | (unsigned)e);
     } else {
       const int n_we = sh.n_we, niso = lx.isolatenum;
       const int total = n_we * niso;
       for (int x = tid; x < total; x += NT) {
         const int w = x / niso, i = x - w * niso;
         const Tok tk = sv[welist[w]];
-        const int sword = lx.node_b[tk.node].x;
-        const bool tr = lx.is_transparent[sword] != 0;
+        const int sword = lx.node_b(tk.node).x;
+        const bool tr = lx.is_transparent(sword) != 0;
         const int last_word = tr ? tk.last_cword : sword;
-        const int2 ir = lx.iso_root[i];                    // {root node, successor word}
+        const int2 ir = lx.iso_root(i);                    // {root node, successor word}
         // one entry of max_successor_prob_iw()'s array (factoring_sub.c:1119-1143)
         const float p = (last_word < 0) ? 0.0f
-                        : bigram_prob(lx, lx.wton[last_word], lx.wton[ir.y]) + lx.cprob[ir.y];
+                        : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
         float tmpsum = tk.score;
-        tmpsum += lx.wordend_a[sword];
+        tmpsum += lx.wordend_a(sword);
         const float ng = p * lmw + pen;
         tmpsum += ng;
-        if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
+        if (tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword)) tmpsum += lx.lm_penalty_trans;
         if (push(sh, cl, ir.x, tmpsum, 0x80000000u | (unsigned)sword) != 0ull)
           atomicAdd(&sh.ties, 1);
       }
@@ -551,10 +570,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const unsigned long long kb = sh.we_best;
       const float best_score = unord((unsigned)(kb >> 32));
       const int sword = (int)(unsigned)kb;
-      const Tok tk = sv[hash_get(hkey, hval, hmask, lx.word_end[sword])];
-      const bool trans2 = lx.is_transparent[sword] && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword];
+      const Tok tk = sv[hash_get(hkey, hval, hmask, lx.word_end(sword))];
+      const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
       for (int r = tid; r < lx.nshared; r += NT) {
-        const float2 sr = lx.shared_root[r];               // {root node (bits), fscore}
+        const float2 sr = lx.shared_root(r);               // {root node (bits), fscore}
         const float ng = sr.y * lmw + pen;
         float tmpsum = best_score;
         tmpsum += ng;
@@ -589,7 +608,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           node[k] = t2.x; slot[k] = t2.y;
         }
 #pragma unroll
-        for (int k = 0; k < CB; k++) nr[k] = lx.node_b[node[k]];     // {stend, scid, out_id, out_kind}
+        for (int k = 0; k < CB; k++) nr[k] = lx.node_b(node[k]);     // {stend, scid, out_id, out_kind}
 #pragma unroll
         for (int k = 0; k < CB; k++) {
           key[k] = 0ull;
@@ -610,25 +629,25 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
             else l_ls[k] = tk.last_lscore;
           } else if (dfa && (id >> 30) == 3u) {        // an initial token of the grammar
-            l_ls[k] = lx.init_lscore[id & 0x3fffffffu];
+            l_ls[k] = lx.init_lscore(id & 0x3fffffffu);
           } else {
             const bool iso = (id >> 30) == 2u;
             const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
-            const int j = hash_get(hkey, hval, hmask, lx.word_end[sword]);
+            const int j = hash_get(hkey, hval, hmask, lx.word_end(sword));
             const Tok tk = sv[j];
-            const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+            const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
             l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
             if (dfa) {                                       // beam_inter_word() :2452-2461
               float ng = lx.penalty1;
-              ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+              ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
               l_ls[k] = ng;
             } else if (iso) {                                // beam_inter_word() :2430-2438
-              const int wn = lx.scword[nr[k].y];
+              const int wn = lx.scword(nr[k].y);
               const float p = (last_word < 0) ? 0.0f
-                              : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+                              : bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn);
               l_ls[k] = p * lmw + pen;
             } else {                                         // beam_inter_word_factoring() :2572-2573
-              l_ls[k] = lx.fscore[-nr[k].y] * lmw + pen;
+              l_ls[k] = lx.fscore(-nr[k].y) * lmw + pen;
             }
           }
         }
@@ -640,8 +659,8 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           for (int k = 0; k < CB; k++) {
             ctx[k] = -1; mm[k] = 0ull; fs[k] = 0.0f;
             if (lmreq[k] != 0 && l_cword[k] >= 0) {
-              if (lmreq[k] < 0) fs[k] = lx.fscore[-lmreq[k]];
-              else { ctx[k] = lx.wton[l_cword[k]]; mm[k] = memo[lmreq[k]]; }
+              if (lmreq[k] < 0) fs[k] = lx.fscore(-lmreq[k]);
+              else { ctx[k] = lx.wton(l_cword[k]); mm[k] = memo[lmreq[k]]; }
             }
           }
 #pragma unroll
@@ -663,13 +682,13 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 #pragma unroll
           for (int k = 0; k < CB; k++) {
             col[k] = lx.nlc;
-            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc[l_wid[k]];
+            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc(l_wid[k]);
           }
 #pragma unroll
           for (int k = 0; k < CB; k++) {
             if (nr[k].w == JAMD_AS_STATE) ent[k] = nr[k].z;
             else if (nr[k].w == JAMD_AS_LSET) ent[k] = ~nr[k].z;
-            else ent[k] = ok[k] ? lx.lc_tab[(size_t)nr[k].z * (lx.nlc + 1) + col[k]] : 0;
+            else ent[k] = ok[k] ? lx.lc_tab((size_t)nr[k].z * (lx.nlc + 1) + col[k]) : 0;
           }
         }
         float ac[CB];
@@ -706,7 +725,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const int q = q0 + (tid >> 2);
         const bool act = q < n_set;
         const int2 it = act ? arcq[q] : make_int2(0, 0);
-        const int a = act ? lx.set_off[it.y] : 0, bnd = act ? lx.set_off[it.y + 1] : 0;
+        const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
         float r;
         if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
           float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
@@ -721,7 +740,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           for (int m = a + sub; m < bnd; m += 16) {          // four members per lane in flight
             int ix[4]; float pv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states[m + 4 * j] : -1;
+            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states(m + 4 * j) : -1;
 #pragma unroll
             for (int j = 0; j < 4; j++) pv[j] = (ix[j] >= 0) ? row[ix[j]] : JAMD_LOG_ZERO;
 #pragma unroll
@@ -749,7 +768,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           for (int m = a + sub; m < bnd; m += 16) {
             int ix[4]; float pv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states[m + 4 * j] : -1;
+            for (int j = 0; j < 4; j++) ix[j] = (m + 4 * j < bnd) ? lx.set_states(m + 4 * j) : -1;
 #pragma unroll
             for (int j = 0; j < 4; j++) pv[j] = (ix[j] >= 0) ? row[ix[j]] : JAMD_LOG_ZERO;
 #pragma unroll
@@ -760,7 +779,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           r = m_;
         } else {
           // average (member-order float sum) and long N-best lists: one lane, reference order
-          r = (act && sub == 0) ? cd_reduce(row, lx.set_states, a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
+          r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
         }
         if (act && sub == 0) {
           const float sc = cur[it.x].score + r;
@@ -1061,7 +1080,7 @@ __device__ void s_propagate(SBeam &b, int next_node, float next_score, int last_
 __device__ void s_intra_core(SBeam &b, const STok &tk, int next_node, float next_a) {   // :2004
   const LexDev &lx = *b.lx;
   float tmpsum = tk.score + next_a, ng = JAMD_LOG_ZERO;
-  const int nscid = (next_node != tk.node) ? lx.scid[next_node] : 0;
+  const int nscid = (next_node != tk.node) ? lx.scid(next_node) : 0;
   if (nscid != 0) {
     ng = max_successor_prob(lx, tk.last_cword, nscid) * lx.lm_weight + lx.lm_penalty;
     tmpsum -= tk.last_lscore;
@@ -1108,17 +1127,17 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
     for (int e = 0; e < lx.ninit; e++) {
       const int id = s_create_token(b);
       STok &nw = b.tl[b.tn][id];
-      const int node = lx.init_node[e];
-      const int4 nr = lx.node_b[node];
-      nw.last_lscore = lx.init_lscore[e]; nw.last_tre = -1; nw.last_cword = -1;
+      const int node = lx.init_node(e);
+      const int4 nr = lx.node_b(node);
+      nw.last_lscore = lx.init_lscore(e); nw.last_tre = -1; nw.last_cword = -1;
       nw.score = node_outprob(lx, b.sc, nr.w, nr.z, -1) + nw.last_lscore;
       nw.node = node; b.token[node] = id;
     }
   } else {                                                           // init_nodescore() :1622-1665
     const int id = s_create_token(b);
     STok &nw = b.tl[b.tn][id];
-    const int node = lx.word_head[lx.head_silwid];
-    const int4 nr = lx.node_b[node];
+    const int node = lx.word_head(lx.head_silwid);
+    const int4 nr = lx.node_b(node);
     float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
     ls = ls * lmw + pen;
     nw.last_lscore = ls; nw.last_tre = -1; nw.last_cword = -1;
@@ -1138,59 +1157,59 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
       if (tk.score <= JAMD_LOG_ZERO) continue;
       if (tk.score < b.thr) continue;
       const int node = tk.node;
-      const int4 na = lx.node_a[node];
+      const int4 na = lx.node_a(node);
       const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
       if (a_self != JAMD_LOG_ZERO) s_intra_core(b, tk, node, a_self);           // beam_intra_word() :2154
       if (a_next != JAMD_LOG_ZERO) s_intra_core(b, tk, node + 1, a_next);
-      for (int e = na.z; e < na.w; e++) s_intra_core(b, tk, lx.ac_to[e], lx.ac_a[e]);
-      const int sword = lx.node_b[node].x;
+      for (int e = na.z; e < na.w; e++) s_intra_core(b, tk, lx.ac_to(e), lx.ac_a(e));
+      const int sword = lx.node_b(node).x;
       if (sword >= 0) {
         const int tre = s_save_trellis(b, tk, sword, t);
         if (wordmode) {                                                         // :2875: isolated words stop here
         } else if (dfa) {                                                       // beam_inter_word(), grammar branch
-          const int last_word = lx.is_transparent[sword] ? tk.last_cword : sword;
+          const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
           for (int stid = lx.startnum - 1; stid >= 0; stid--) {
-            if (!lx.cat_pair[lx.wton[sword] * lx.ncat + lx.root_cat[stid]]) continue;      // :2404-2412
+            if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(stid))) continue;      // :2404-2412
             float tmpsum = tk.score;
-            tmpsum += lx.wordend_a[sword];
+            tmpsum += lx.wordend_a(sword);
             float ng = lx.penalty1;                                             // :2452-2461
-            ng += (last_word >= 0) ? lx.cprob[last_word] : 0.0f;
+            ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
             tmpsum += ng;
-            s_propagate(b, lx.startnode[stid], tmpsum, tre, last_word, ng);
+            s_propagate(b, lx.startnode(stid), tmpsum, tre, last_word, ng);
           }
         } else if (sword != lx.tail_silwid) {                                   // beam_inter_word() :2271
-          const bool tr = lx.is_transparent[sword] != 0;
+          const bool tr = lx.is_transparent(sword) != 0;
           const int last_word = tr ? tk.last_cword : sword;
-          float tmpprob = tk.score + lx.wordend_a[sword];
+          float tmpprob = tk.score + lx.wordend_a(sword);
           if (b.we_best_score < tmpprob) {
             b.we_best_score = tmpprob; b.we_best_node = node; b.we_best_tre = tre; b.we_best_cword = tk.last_cword;
           }
           for (int stid = lx.startnum - 1; stid >= 0; stid--) {
-            if (lx.start2isolate[stid] == -1) continue;
-            const int next_node = lx.startnode[stid];
-            const int wn = lx.scword[lx.scid[next_node]];
+            if (lx.start2isolate(stid) == -1) continue;
+            const int next_node = lx.startnode(stid);
+            const int wn = lx.scword(lx.scid(next_node));
             const float p = (last_word < 0) ? 0.0f
-                            : bigram_prob(lx, lx.wton[last_word], lx.wton[wn]) + lx.cprob[wn];
+                            : bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn);
             float tmpsum = tk.score;
-            tmpsum += lx.wordend_a[sword];
+            tmpsum += lx.wordend_a(sword);
             const float ng = p * lmw + pen;
             tmpsum += ng;
-            if (tr && tk.last_cword >= 0 && lx.is_transparent[tk.last_cword]) tmpsum += lx.lm_penalty_trans;
+            if (tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword)) tmpsum += lx.lm_penalty_trans;
             s_propagate(b, next_node, tmpsum, tre, last_word, ng);
           }
         }
       }
     }
     if (!dfa && b.we_best_score > JAMD_LOG_ZERO) {                               // beam_inter_word_factoring() :2549
-      const int sword = lx.node_b[b.we_best_node].x;
-      const int last_word = lx.is_transparent[sword] ? b.we_best_cword : sword;
+      const int sword = lx.node_b(b.we_best_node).x;
+      const int last_word = lx.is_transparent(sword) ? b.we_best_cword : sword;
       for (int stid = lx.startnum - 1; stid >= 0; stid--) {
-        if (lx.start2isolate[stid] != -1) continue;
-        const int next_node = lx.startnode[stid];
-        const float ng = lx.fscore[-lx.scid[next_node]] * lmw + pen;
+        if (lx.start2isolate(stid) != -1) continue;
+        const int next_node = lx.startnode(stid);
+        const float ng = lx.fscore(-lx.scid(next_node)) * lmw + pen;
         float tmpsum = b.we_best_score;
         tmpsum += ng;
-        if (lx.is_transparent[sword] && b.we_best_cword >= 0 && lx.is_transparent[b.we_best_cword]) tmpsum += lx.lm_penalty_trans;
+        if (lx.is_transparent(sword) && b.we_best_cword >= 0 && lx.is_transparent(b.we_best_cword)) tmpsum += lx.lm_penalty_trans;
         if (tmpsum < b.thr) continue;
         s_propagate(b, next_node, tmpsum, b.we_best_tre, last_word, ng);
       }
@@ -1199,7 +1218,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
     const float *row = b.sc + (size_t)t * S;
     for (int j = 0; j < b.tnum[tn]; j++) {                                       // :2944-2951
       STok &tk = b.tl[tn][b.ti[tn][j]];
-      const int4 nr = lx.node_b[tk.node];
+      const int4 nr = lx.node_b(tk.node);
       const int lw = tk.last_tre < 0 ? -1 : b.atoms[tk.last_tre].wid;
       tk.score += node_outprob(lx, row, nr.w, nr.z, lw);
       if (pmax < tk.score) pmax = tk.score;
@@ -1215,7 +1234,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
     b.tlx = b.tn; b.tn = b.tn ? 0 : 1;
     for (int j = b.n_start; j <= b.n_end; j++) {
       const STok tk = b.tl[b.tlx][b.ti[b.tlx][j]];
-      const int sword = lx.node_b[tk.node].x;
+      const int sword = lx.node_b(tk.node).x;
       if (sword >= 0) s_save_trellis(b, tk, sword, T);
     }
     int best = -1;                                                               // find_1pass_result() :399
@@ -1331,11 +1350,15 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   d.lm_penalty_trans = h->lm_penalty_trans;
   const int nac = h->ac_off[h->nnode], nset_states = h->nset ? h->set_off[h->nset] : 0;
   int rc = JAMD_OK;
+  // every array is appended (16-byte aligned) to one host image that is uploaded once; the kernel
+  // sees the base pointer and 32-bit byte offsets (see LexDev)
+  std::vector<unsigned char> arena;
 #define UP(field, src, n)                                                              \
   do {                                                                                 \
-    std::remove_const_t<std::remove_pointer_t<decltype(d.field)>> *p_ = nullptr;        \
-    if (rc == JAMD_OK) rc = upload(&p_, src, (size_t)(n));                              \
-    d.field = p_; if (p_) l->owned.push_back((void *)p_);                               \
+    const size_t bytes_ = sizeof(*(src)) * (size_t)(n), at_ = (arena.size() + 15) & ~(size_t)15;   \
+    arena.resize(at_ + (bytes_ ? bytes_ : 16));                                        \
+    if (bytes_) memcpy(arena.data() + at_, (src), bytes_);                             \
+    d.o_##field = (unsigned)at_;                                                       \
   } while (0)
   std::vector<int4> na(h->nnode), nb(h->nnode);
   std::vector<int> word_end(h->nword, -1);
@@ -1388,6 +1411,13 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     UP(init_node, h->init_node, h->ninit); UP(init_lscore, h->init_lscore, h->ninit);
   }
 #undef UP
+  if (rc == JAMD_OK && arena.size() >= ((size_t)1 << 32)) { jamd_set_error("jamd_lexicon_create: lexicon image exceeds 4 GB"); rc = JAMD_EINVAL; }
+  if (rc == JAMD_OK) {
+    unsigned char *dev = nullptr;
+    rc = upload(&dev, arena.data(), arena.size());
+    d.base = dev;
+    if (dev) l->owned.push_back((void *)dev);
+  }
   if (rc != JAMD_OK) { jamd_lexicon_destroy(l); return rc; }
   *out = l;
   return JAMD_OK;
