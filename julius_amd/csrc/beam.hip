@@ -107,18 +107,21 @@ struct StreamState {     // what a streaming utterance carries from one launch t
 
 struct Work {            // per-utterance slices are addressed with the strides below
   StreamState *stream;           // [utt] (allocated by jamd_beam_stream_begin)
-  unsigned long long *nodekey;   // [utt][nnode]    Viterbi cells (0 = empty)
-  Tok *cur;                      // [utt][tok_cap]  tokens created this frame
-  unsigned *cur_key;             // [utt][tok_cap]  their order-preserving score bits (compact, for the rank select)
-  int2 *touched;                 // [utt][tok_cap]  nodes touched this frame: {node, LDS cell slot or -1 = nodekey[]}
-  int2 *arcq;                    // [utt][tok_cap]  work queue of (survivor, extra arc) pairs
-  jamd_trellis_atom *atoms;      // [utt][atom_cap]
+  // Per-utterance arrays live in ONE slice per utterance (slices + utt * utt_stride) and are
+  // addressed as slice base + 32-bit offset, for the same reason as the lexicon arena (LexDev):
+  unsigned char *slices; unsigned long long utt_stride;
+  unsigned o_nodekey;            // u64  [nnode]    Viterbi cells (0 = empty)
+  unsigned o_cur;                // Tok  [tok_cap]  tokens created this frame
+  unsigned o_cur_key;            // u32  [tok_cap]  their order-preserving score bits (compact, for the rank select)
+  unsigned o_touched;            // int2 [tok_cap]  nodes touched this frame: {node, LDS cell slot or -1 = nodekey[]}
+  unsigned o_arcq;               // int2 [tok_cap]  work queue of (survivor, extra arc) pairs
+  unsigned o_atoms;              // jamd_trellis_atom [atom_cap]
+  unsigned o_lmcache;            // u64  [nscword]  LM memo, see below
+  unsigned o_sv;                 // survivor image (sv_bytes) when it does not live in LDS / between streaming launches
   jamd_pass1_result *res;        // [utt]
-  // survivor state: lives in LDS when it fits (sv_bytes of dynamic shared memory),
-  // else in these per-utterance global arrays of the same layout
-  unsigned char *sv_global;      // [utt][sv_bytes]
-  unsigned long long *lmcache;   // [utt][nscword] (context N-gram id << 32 | prob bits): the reference's
-                                 // per-successor-id memo LM_PROB_CACHE (wchmm.h:117-149, factoring_sub.c:965-986)
+  // the survivor state lives in LDS when it fits (sv_bytes of dynamic shared memory), else at o_sv;
+  // the LM memo holds (context N-gram id << 32 | prob bits) per successor id: the reference's
+  // LM_PROB_CACHE (wchmm.h:117-149, factoring_sub.c:965-986)
   int nscword;
   int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
   int cell_slots;                // LDS Viterbi cells of the current frame (power of two, 0 = all cells in nodekey[])
@@ -277,8 +280,8 @@ __device__ __forceinline__ int wave_alloc(int *counter, bool want) {
 // on the node word); a node whose probe window is full overflows to nodekey[] -- occupancy only
 // grows within a frame, so every candidate of a node resolves to the same place.
 struct Cells {
-  unsigned long long *gkey;      // nodekey[] of this utterance (overflow, and everything when nslot == 0)
-  int2 *touched;
+  unsigned char *ub;             // this utterance's slice: nodekey[] (overflow, and everything when nslot == 0), touched[]
+  unsigned o_nodekey, o_touched;
   unsigned long long *lkey;      // [nslot] LDS cells (0 = empty)
   int *lnode;                    // [nslot] owning node (-1 = free)
   int nslot, shift;              // nslot = 1 << (32 - shift)
@@ -302,11 +305,11 @@ __device__ __forceinline__ unsigned long long push(Shared &sh, const Cells &cl, 
   if (slot >= 0) {
     old = atomicMax(&cl.lkey[slot], key);
   } else {
-    old = atomicMax(&cl.gkey[node], key);
+    old = atomicMax(reinterpret_cast<unsigned long long *>(cl.ub + (unsigned)(cl.o_nodekey + 8u * (unsigned)node)), key);
     first = (old == 0ull);
   }
   const int s = wave_alloc(&sh.n_new, first);
-  if (first) cl.touched[s] = make_int2(node, slot);
+  if (first) *reinterpret_cast<int2 *>(cl.ub + (unsigned)(cl.o_touched + 8u * (unsigned)s)) = make_int2(node, slot);
   // old == 0: nothing stored in the cell yet (the slot's claimer may still be on its way; it will
   // then see this key as its `old`, so no tie goes unnoticed)
   return (old != 0ull && (unsigned)(old >> 32) == (unsigned)(key >> 32) && old != key) ? old : 0ull;
@@ -330,23 +333,25 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   const int u = blockIdx.x, tid = threadIdx.x;
   // smode 0: whole utterances.  smode 1 / 2: streaming -- this launch advances every utterance
   // by the rows utt_off[u]..utt_off[u+1]) of `scores`; 2 = also run get_back_trellis_end() and
-  // the traceback.  The state between launches lives in wk.stream[u] and wk.sv_global.
+  // the traceback.  The state between launches lives in wk.stream[u] and in the slice at o_sv.
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
   StreamState *ss = smode ? wk.stream + u : nullptr;
   const bool resume = smode && ss->started;
   const int base = resume ? ss->frames_done : 0;            // absolute index of this launch's first row
   const int T = base + nrows;                                // frames seen so far
   const bool finish = smode != 1;                            // run the end phase after the last row
-  unsigned long long *nodekey = wk.nodekey + (size_t)u * wk.nnode;
-  Tok *cur = wk.cur + (size_t)u * wk.tok_cap;
-  unsigned *cur_key = wk.cur_key + (size_t)u * wk.tok_cap;
-  int2 *touched = wk.touched + (size_t)u * wk.tok_cap;
-  int2 *arcq = wk.arcq + (size_t)u * wk.tok_cap;       // extra arcs of this frame's survivors: (survivor, arc)
-  jamd_trellis_atom *atoms = wk.atoms + (size_t)u * wk.atom_cap;
+  unsigned char *const ub = wk.slices + (size_t)u * wk.utt_stride;     // this utterance's slice
+#define SLICE(T, off, i) (*reinterpret_cast<T *>(ub + (unsigned)((off) + (unsigned)sizeof(T) * (unsigned)(i))))
+#define NODEKEY(i) SLICE(unsigned long long, wk.o_nodekey, i)
+#define CUR(i) SLICE(Tok, wk.o_cur, i)
+#define CURKEY(i) SLICE(unsigned, wk.o_cur_key, i)
+#define TOUCHED(i) SLICE(int2, wk.o_touched, i)
+#define ARCQ(i) SLICE(int2, wk.o_arcq, i)            /* extra arcs of this frame's survivors: (survivor, arc) */
+#define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
   jamd_pass1_result *res = wk.res + u;
   // survivor state of the previous frame (tokens, the atom each word end emitted, the
   // frame's word-end list, node -> survivor hash)
-  unsigned char *svb = wk.use_lds ? dyn_lds : wk.sv_global + (size_t)u * wk.sv_bytes;
+  unsigned char *svb = wk.use_lds ? dyn_lds : ub + wk.o_sv;
   Tok *sv = (Tok *)svb;
   int *sv_atom = (int *)(svb + (size_t)wk.beam * sizeof(Tok));
   int *welist = sv_atom + wk.beam;
@@ -355,7 +360,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   const int hmask = wk.hsize - 1;
   // the frame's Viterbi cells: LDS table behind the survivor image (16-byte aligned), see Cells
   Cells cl;
-  cl.gkey = nodekey; cl.touched = touched; cl.nslot = wk.use_lds ? wk.cell_slots : 0;
+  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_touched = wk.o_touched; cl.nslot = wk.use_lds ? wk.cell_slots : 0;
   cl.lkey = (unsigned long long *)(dyn_lds + wk.cell_off);
   cl.lnode = (int *)(dyn_lds + wk.node_off);
   unsigned *hist = (unsigned *)(dyn_lds + wk.cell_off);    // step D only: the cells are all empty then
@@ -365,12 +370,12 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
   const bool dfa = lx.lm_type != JAMD_LM_NGRAM;          // grammar or word list: initial-token frame, no factoring
   const bool wordmode = lx.lm_type == JAMD_LM_WORD;      // isolated words: no cross-word transition at all
-  unsigned long long *memo = wk.lmcache + (size_t)u * wk.nscword;
+  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);
 
   if (resume) {
     if (!ss->active) return;                                 // died / overflowed / finished earlier
     if (wk.use_lds) {                                        // survivor image back into LDS
-      const uint4 *src = (const uint4 *)(wk.sv_global + (size_t)u * wk.sv_bytes);
+      const uint4 *src = (const uint4 *)(ub + wk.o_sv);
       uint4 *dst = (uint4 *)dyn_lds;
       for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
     }
@@ -475,7 +480,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const int e0 = na.z, e1 = na.w;
         if (e1 > e0) {
           const int base = atomicAdd(&sh.n_arc, e1 - e0);
-          for (int e = e0; e < e1; e++) arcq[base + e - e0] = make_int2(j, e);
+          for (int e = e0; e < e1; e++) ARCQ(base + e - e0) = make_int2(j, e);
         }
         for (int k = 0; k < 2; k++) {
           int next_node; float a;
@@ -490,9 +495,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         if (ai < wk.atom_cap) {
           jamd_trellis_atom a;
           a.wid = sword; a.last_tre = tk.last_tre; a.backscore = tk.score; a.lscore = tk.last_lscore;
-          a.begintime = (short)((tk.last_tre < 0 ? -1 : atoms[tk.last_tre].endtime) + 1);
+          a.begintime = (short)((tk.last_tre < 0 ? -1 : ATOM(tk.last_tre).endtime) + 1);
           a.endtime = (short)(t - 1);
-          atoms[ai] = a;
+          ATOM(ai) = a;
         }
         sv_atom[j] = ai;
         if (!last && !wordmode && sword != lx.tail_silwid) {   // beam_inter_word() :2296-2313
@@ -510,7 +515,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     if (!last) {                                   // drain the extra-arc queue, one arc per thread
       const int n_arc = sh.n_arc;
       for (int q = tid; q < n_arc; q += NT) {
-        const int2 it = arcq[q];
+        const int2 it = ARCQ(q);
         intra_candidate(sv[it.x], lx.ac_to(it.y), lx.ac_a(it.y));
       }
       __syncthreads();
@@ -604,7 +609,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         for (int k = 0; k < CB; k++) {
           const int s = s0 + k * NT;
           ok[k] = s < n_new;
-          const int2 t2 = ok[k] ? touched[s] : make_int2(0, -1);     // {node, LDS slot or -1}
+          const int2 t2 = ok[k] ? TOUCHED(s) : make_int2(0, -1);     // {node, LDS slot or -1}
           node[k] = t2.x; slot[k] = t2.y;
         }
 #pragma unroll
@@ -614,7 +619,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           key[k] = 0ull;
           if (ok[k]) {
             if (slot[k] >= 0) { key[k] = cl.lkey[slot[k]]; cl.lkey[slot[k]] = 0ull; cl.lnode[slot[k]] = -1; }   // back to empty
-            else key[k] = atomicExch(&nodekey[node[k]], 0ull);
+            else key[k] = atomicExch(&NODEKEY(node[k]), 0ull);
           }
         }
         // winner's payload.  lmreq != 0: the LM factoring value has to be looked up (next step)
@@ -705,14 +710,14 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           if (ent[k] >= 0) {
             nw.score = score + ac[k];
             const unsigned b = ord(nw.score);
-            cur_key[s] = b;
+            CURKEY(s) = b;
             if (b > mymax) mymax = b;
             if (b < mymin) mymin = b;
           } else {
             nw.score = score;
-            arcq[atomicAdd(&sh.n_arc, 1)] = make_int2(s, ~ent[k]);     // (token, state set); arcq is free again
+            ARCQ(atomicAdd(&sh.n_arc, 1)) = make_int2(s, ~ent[k]);     // (token, state set); arcq is free again
           }
-          cur[s] = nw;
+          CUR(s) = nw;
         }
       }
       __syncthreads();
@@ -724,7 +729,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       for (int q0 = 0; q0 < n_set; q0 += NT / 4) {
         const int q = q0 + (tid >> 2);
         const bool act = q < n_set;
-        const int2 it = act ? arcq[q] : make_int2(0, 0);
+        const int2 it = act ? ARCQ(q) : make_int2(0, 0);
         const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
         float r;
         if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
@@ -782,10 +787,10 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
         }
         if (act && sub == 0) {
-          const float sc = cur[it.x].score + r;
-          cur[it.x].score = sc;
+          const float sc = CUR(it.x).score + r;
+          CUR(it.x).score = sc;
           const unsigned b = ord(sc);
-          cur_key[it.x] = b;
+          CURKEY(it.x) = b;
           if (b > mymax) mymax = b;
           if (b < mymin) mymin = b;
         }
@@ -835,7 +840,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         for (int i = tid; i < 2048; i += NT) hist[i] = 0;
         __syncthreads();
         for (int s = tid; s < n_new; s += NT) {
-          const unsigned b = cur_key[s];
+          const unsigned b = CURKEY(s);
           const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
           if (hi == prefix) atomicAdd(&hist[(b >> shift) & dmask], 1u);
         }
@@ -880,33 +885,33 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       // those on the smallest nodes (canonical; the reference keeps whichever its heap
       // order left inside)
       for (int s = tid; s < n_new; s += NT)
-        if (cur_key[s] == prefix) {
+        if (CURKEY(s) == prefix) {
           const int q = atomicAdd(&sh.eq_n, 1);
-          if (q < 128) sh.eq_node[q] = cur[s].node;
+          if (q < 128) sh.eq_node[q] = CUR(s).node;
         }
       __syncthreads();
     }
     for (int s = tid; s < n_new; s += NT) {
       bool keep = true;
       if (prune) {
-        const unsigned b = cur_key[s];
+        const unsigned b = CURKEY(s);
         keep = b > prefix;
         if (b == prefix) {
           if (!cut_tie) keep = true;
           else {
-            const int mynode = cur[s].node;
+            const int mynode = CUR(s).node;
             unsigned rank = 0;
             if (sh.eq_n <= 128) {
               for (int q = 0; q < sh.eq_n; q++) rank += (sh.eq_node[q] < mynode) ? 1u : 0u;
             } else {
-              for (int q = 0; q < n_new; q++) rank += (cur_key[q] == prefix && cur[q].node < mynode) ? 1u : 0u;
+              for (int q = 0; q < n_new; q++) rank += (CURKEY(q) == prefix && CUR(q).node < mynode) ? 1u : 0u;
             }
             keep = rank < need;
           }
         }
       }
       if (keep) {
-        const Tok me = cur[s];
+        const Tok me = CUR(s);
         const int j = wave_alloc(&sh.n_surv, true);
         sv[j] = me;
         hash_put(hkey, hval, hmask, me.node, j);
@@ -919,7 +924,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 
   if (smode == 1) {            // not finished: park the state for the next launch
     if (wk.use_lds && !stopped) {
-      uint4 *dst = (uint4 *)(wk.sv_global + (size_t)u * wk.sv_bytes);
+      uint4 *dst = (uint4 *)(ub + wk.o_sv);
       const uint4 *src = (const uint4 *)dyn_lds;
       for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
     }
@@ -946,22 +951,22 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     __syncthreads();
     int lt = -1;
     for (int i = tid; i < natom; i += NT)
-      if (atoms[i].backscore > JAMD_LOG_ZERO && atoms[i].endtime > lt) lt = atoms[i].endtime;
+      if (ATOM(i).backscore > JAMD_LOG_ZERO && ATOM(i).endtime > lt) lt = ATOM(i).endtime;
     if (lt >= 0) atomicMax(&sh.n_arc, lt);
     __syncthreads();
     lt = sh.n_arc;
     for (int i = tid; i < natom; i += NT)
-      if (atoms[i].endtime == lt && atoms[i].backscore > JAMD_LOG_ZERO)
-        atomicMax(&sh.we_best, ((unsigned long long)ord(atoms[i].backscore) << 32) | (0xffffffffu - (unsigned)atoms[i].wid));
+      if (ATOM(i).endtime == lt && ATOM(i).backscore > JAMD_LOG_ZERO)
+        atomicMax(&sh.we_best, ((unsigned long long)ord(ATOM(i).backscore) << 32) | (0xffffffffu - (unsigned)ATOM(i).wid));
     __syncthreads();
     const unsigned long long kb = sh.we_best;
     for (int i = tid; i < natom; i += NT)      // (frame, word) names one atom: a word has one end node
-      if (kb != 0ull && atoms[i].endtime == lt && (unsigned)atoms[i].wid == 0xffffffffu - (unsigned)kb &&
-          ord(atoms[i].backscore) == (unsigned)(kb >> 32)) sh.best_atom = i;
+      if (kb != 0ull && ATOM(i).endtime == lt && (unsigned)ATOM(i).wid == 0xffffffffu - (unsigned)kb &&
+          ord(ATOM(i).backscore) == (unsigned)(kb >> 32)) sh.best_atom = i;
   } else if (res->status == JAMD_PASS1_OK) {
     int best = -1;
     for (int i = tid; i < natom; i += NT)
-      if (atoms[i].wid == lx.tail_silwid && atoms[i].backscore > JAMD_LOG_ZERO) best = i;  // ascending i
+      if (ATOM(i).wid == lx.tail_silwid && ATOM(i).backscore > JAMD_LOG_ZERO) best = i;  // ascending i
     if (best >= 0) atomicMax(&sh.best_atom, best);
   }
   __syncthreads();
@@ -977,15 +982,23 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       else {
         int n = 0, a = best;
         int rev[MAXSEQ];
-        rev[n++] = atoms[a].wid;
-        while (atoms[a].begintime > 0 && n < MAXSEQ) { a = atoms[a].last_tre; rev[n++] = atoms[a].wid; }
+        rev[n++] = ATOM(a).wid;
+        while (ATOM(a).begintime > 0 && n < MAXSEQ) { a = ATOM(a).last_tre; rev[n++] = ATOM(a).wid; }
         for (int k = 0; k < n; k++) res->wseq[k] = rev[n - 1 - k];
-        res->wnum = n; res->score = atoms[best].backscore;
+        res->wnum = n; res->score = ATOM(best).backscore;
       }
     }
   }
 }
 
+
+#undef SLICE
+#undef NODEKEY
+#undef CUR
+#undef CURKEY
+#undef TOUCHED
+#undef ARCQ
+#undef ATOM
 
 // ---------------------------------------------------------------------------------------
 // STRICT-ORDER first pass (verification mode, jamd_beam_set_strict_order()).
@@ -1111,7 +1124,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
   b.lx = &lx; b.sc = scores + (size_t)t_begin * S; b.S = S;
   for (int i = 0; i < 2; i++) { b.tl[i] = sw.tl[i] + (size_t)u * sw.cap; b.ti[i] = sw.ti[i] + (size_t)u * sw.cap; b.tnum[i] = 0; }
   b.token = sw.token + (size_t)u * wk.nnode; b.cap = sw.cap;
-  b.atoms = wk.atoms + (size_t)u * wk.atom_cap; b.natom = 0; b.atom_cap = wk.atom_cap; b.overflow = false;
+  b.atoms = reinterpret_cast<jamd_trellis_atom *>(wk.slices + (size_t)u * wk.utt_stride + wk.o_atoms); b.natom = 0; b.atom_cap = wk.atom_cap; b.overflow = false;
   res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO; res->died_at = -1;
   res->ties = res->ties_node = res->ties_wordend = res->ties_cut = 0; res->frames = T; res->max_tokens = 0;
   for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
@@ -1478,16 +1491,24 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   w.row_off = w.node_off + 4 * w.cell_slots;
   w.lds_bytes = w.row_off;
   w.row_cache = 0;
-  if (rc == JAMD_OK) rc = alloc((void **)&w.nodekey, U * w.nnode * sizeof(unsigned long long), true);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.cur, U * w.tok_cap * sizeof(Tok), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.cur_key, U * w.tok_cap * sizeof(unsigned), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.touched, U * w.tok_cap * sizeof(int2), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.arcq, U * w.tok_cap * sizeof(int2), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.atoms, U * w.atom_cap * sizeof(jamd_trellis_atom), false);
-  if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
-  if (rc == JAMD_OK && !w.use_lds) rc = alloc((void **)&w.sv_global, U * (size_t)w.sv_bytes, false);
+  // one slice per utterance: every array at a 256-byte aligned 32-bit offset
   w.nscword = l->nscword > 0 ? l->nscword : 1;
-  if (rc == JAMD_OK) rc = alloc((void **)&w.lmcache, U * (size_t)w.nscword * sizeof(unsigned long long), false);
+  {
+    size_t at = 0;
+    auto place = [&](unsigned *off, size_t bytes) { *off = (unsigned)at; at = (at + bytes + 255) & ~(size_t)255; };
+    place(&w.o_nodekey, (size_t)w.nnode * sizeof(unsigned long long));
+    place(&w.o_cur, (size_t)w.tok_cap * sizeof(Tok));
+    place(&w.o_cur_key, (size_t)w.tok_cap * sizeof(unsigned));
+    place(&w.o_touched, (size_t)w.tok_cap * sizeof(int2));
+    place(&w.o_arcq, (size_t)w.tok_cap * sizeof(int2));
+    place(&w.o_atoms, (size_t)w.atom_cap * sizeof(jamd_trellis_atom));
+    place(&w.o_lmcache, (size_t)w.nscword * sizeof(unsigned long long));
+    place(&w.o_sv, (size_t)w.sv_bytes);
+    if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
+    w.utt_stride = at;
+  }
+  if (rc == JAMD_OK) rc = alloc((void **)&w.slices, U * (size_t)w.utt_stride, true);    // zero: empty Viterbi cells
+  if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
   if (rc == JAMD_OK) {
     // the attribute is per kernel, not per work area: always ask for the whole budget
     hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1553,9 +1574,6 @@ int jamd_beam_stream_begin(jamd_beam *b, int nutt) {
   void *p = nullptr;
   if (b->w.stream == nullptr) {
     JAMD_HIP(hipMalloc(&p, sizeof(StreamState) * (size_t)b->max_utts)); b->owned.push_back(p); b->w.stream = (StreamState *)p;
-  }
-  if (b->w.sv_global == nullptr) {     // parking space for the LDS-resident survivor state between launches
-    JAMD_HIP(hipMalloc(&p, (size_t)b->max_utts * b->w.sv_bytes)); b->owned.push_back(p); b->w.sv_global = (unsigned char *)p;
   }
   JAMD_HIP(hipMemsetAsync(b->w.stream, 0, sizeof(StreamState) * (size_t)nutt, b->eng->stream));
   JAMD_HIP(hipStreamSynchronize(b->eng->stream));
@@ -1643,7 +1661,7 @@ int jamd_beam_trellis(jamd_beam *b, int utt, jamd_trellis_atom *atoms, int cap, 
   *natom = r.natom;
   if (atoms) {
     const int n = r.natom < cap ? r.natom : cap;
-    if (n > 0) JAMD_HIP(hipMemcpy(atoms, b->w.atoms + (size_t)utt * b->w.atom_cap, sizeof(jamd_trellis_atom) * n,
+    if (n > 0) JAMD_HIP(hipMemcpy(atoms, b->w.slices + (size_t)utt * b->w.utt_stride + b->w.o_atoms, sizeof(jamd_trellis_atom) * n,
                                   hipMemcpyDeviceToHost));
   }
   return JAMD_OK;
