@@ -160,6 +160,55 @@ def test_full_size_lexicon_vs_oracle(engine, oracle):
     assert_trellis_equal_modulo_ties(tre[0], lexblob.canonical_trellis(oatoms), res[0].ties_node + res[0].ties_cut + res[0].ties_wordend)
 
 
+def test_full_size_batch_properties(engine):
+    """Size-independent properties at BASELINE size (20 000-word lexicon, beam 800, a batch of 24
+    utterances scored by the HIP GMM kernel on the device): the result of an utterance does not
+    depend on the batch it is in, on its position, or on the run (no race in the LDS cell table,
+    the atomics or the slot allocation); streaming in chunks equals the one-shot call."""
+    from julius_amd import lexblob
+    S = 3000
+    lex = synth.make_lexicon(nword=20000, nphone=40, S=S, seed=0)
+    model = synth.make_gmm(S=S, M=2, D=39, seed=0)
+    utts = [synth.make_lexicon_utterance(lex, model, nwords=3 + u % 6, seed=40 + u)[0] for u in range(24)]
+    gm = lib.Gmm(engine, model)
+    scores = [gm.outprob_host(fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, 800, -1.0, max_utts=len(utts))
+    res1, tre1 = bm.pass1_host(scores)
+    assert all(r.status == 0 for r in res1)
+    canon1 = [lexblob.canonical_trellis(t) for t in tre1]
+    perm = list(np.random.default_rng(1).permutation(len(utts)))
+    res2, tre2 = bm.pass1_host([scores[i] for i in perm])          # other order, same work area
+    for k, i in enumerate(perm):
+        a, b = res1[i], res2[k]
+        # (the tie COUNTERS may differ between runs: a tie between two losing candidates is only seen
+        # when they meet before the winner arrives; a tie between the two best is always seen)
+        assert (a.status, a.natom, a.wnum, a.score) == (b.status, b.natom, b.wnum, b.score)
+        c2 = lexblob.canonical_trellis(tre2[k])
+        assert all(np.array_equal(canon1[i][key], c2[key]) for key in canon1[i])
+    solo = lib.Beam(engine, lx, 800, -1.0, max_utts=1)             # alone in its own work area
+    r3, t3 = solo.pass1_host([scores[5]])
+    assert (r3[0].natom, r3[0].score) == (res1[5].natom, res1[5].score)
+    c3 = lexblob.canonical_trellis(t3[0])
+    assert all(np.array_equal(canon1[5][key], c3[key]) for key in c3)
+    # streaming, 37 frames at a time
+    bm.stream_begin(len(scores))
+    done = [0] * len(scores)
+    while any(d < len(sc) for d, sc in zip(done, scores)):
+        take = [min(37, len(sc) - d) for d, sc in zip(done, scores)]
+        rows = np.concatenate([sc[d:d + k] for sc, d, k in zip(scores, done, take)])
+        off = np.zeros(len(scores) + 1, np.int32)
+        off[1:] = np.cumsum(take)
+        done = [d + k for d, k in zip(done, take)]
+        buf = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(buf.ptr, S, off, final=all(d >= len(sc) for d, sc in zip(done, scores)))
+        buf.free()
+    for i, r in enumerate(bm.results(len(scores))):
+        assert (r.status, r.natom, r.wnum, r.score) == (res1[i].status, res1[i].natom, res1[i].wnum, res1[i].score)
+        c4 = lexblob.canonical_trellis(bm.trellis(i))
+        assert all(np.array_equal(canon1[i][key], c4[key]) for key in c4)
+
+
 @pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz",
                                   "beam_grammar.npz", "beam_grammar_free.npz"])
 def test_strict_order_golden(engine, oracle, name):
