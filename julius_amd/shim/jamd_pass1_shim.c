@@ -119,6 +119,10 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
     return FALSE;
   }
+  if (r->am->hmmwrk.OP_gshmm != NULL) {
+    jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) changes the scores it skips; run without it (the device scores every state)\n");
+    return FALSE;
+  }
   if (r->am->dnn != NULL) {                    /* DNN-HMM: dnn_calc_outprob() for the whole utterance */
     jamd_flat_dnn fd;
     if (jamd_flatten_dnn(r->am->dnn, &fd) != JAMD_OK) { jlog("ERROR: jamd: cannot flatten the DNN\n"); return FALSE; }
@@ -183,7 +187,7 @@ int jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param)
 {
   pass1_ctx *c = ctx_get(r);
   pre_entry *e;
-  if (c == NULL || param == NULL || param->samplenum <= 0 || !ctx_prepare(c, r)) return JAMD_EINVAL;
+  if (c == NULL || param == NULL || param->samplenum <= 0 || param->is_outprob || !ctx_prepare(c, r)) return JAMD_EINVAL;
   if (c->npre == c->pre_cap) {
     c->pre_cap = c->pre_cap ? 2 * c->pre_cap : 64;
     c->pre = (pre_entry *)realloc(c->pre, sizeof(pre_entry) * c->pre_cap);
@@ -322,7 +326,16 @@ static boolean push_frames(pass1_ctx *c, RecogProcess *r, HTK_Param *param, int 
   boolean ok = FALSE;
   const boolean keep = !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL;
   off[0] = 0; off[1] = n;
-  if (n > 0) {
+  if (n > 0 && param->is_outprob) {
+    /* -input outprob: the vectors ARE the state scores (outprob_state() returns parvec[t][id],
+     * libsent/src/phmm/outprob.c:209-216); they go to the device search as they are, and the 2nd
+     * pass reads them from the parameter itself */
+    if (param->veclen != c->nstate) { jlog("ERROR: jamd: outprob vector size %d != %d states\n", param->veclen, c->nstate); goto out; }
+    frames = jamd_pack_param(param, c->pushed, upto);
+    if (frames == NULL ||
+        jamd_malloc(g_eng, sizeof(float) * (size_t)n * c->nstate, (void **)&d_scores) != JAMD_OK ||
+        jamd_memcpy_h2d(g_eng, d_scores, frames, sizeof(float) * (size_t)n * c->nstate) != JAMD_OK) goto out;
+  } else if (n > 0) {
     frames = jamd_pack_param(param, c->pushed, upto);
     if (frames == NULL ||
         jamd_malloc(g_eng, sizeof(float) * (size_t)n * param->veclen, (void **)&d_frames) != JAMD_OK ||

@@ -287,3 +287,30 @@ def test_batch_driver_equals_per_utterance(ref, tmp_path, monkeypatch, lm):
         if lm == "ngram":
             assert np.array_equal(fw, fin1[1])
     assert amd.prefetch_served() == 7                 # the queued inputs really came from the batch launch
+
+
+def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monkeypatch):
+    """`-input outprob`: the input file already holds the [T][S] state scores (what -outprobout
+    writes); the shim hands them to the device search unscored and Julius' 2nd pass reads them from
+    the parameter itself.  Same trellis (strict order) and results as the plain reference."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    task = synth.make_triphone_task(tmp_path, seed=81, nword=100, nphone=10, S=160)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "outprob", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5"]
+    am = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + u, seed=8100 + u)
+        synth.write_htk_param(tmp_path / "u.prob", oracle.gmm_outprob(am, fr), parmkind=synth.PARM_USER)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.prob")
+        st0, f0, fs0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(tmp_path / "u.prob")
+        st1, f1, fs1 = amd.final_result()
+        assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0
+        assert np.array_equal(f1, f0) and fs1 == fs0
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k
