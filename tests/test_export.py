@@ -1,0 +1,40 @@
+"""CPU: julius_amd/shim/jamd_export.c -- the exporter a Julius maintainer runs once per
+configuration: Julius' own loaders -> "JAMDGMM1" / "JAMDLEX1" files for workers that never link
+Julius.  Built against the unmodified reference by oracle/Makefile (oracle/_ref/jamd_export);
+its files must equal what the tap driver's in-process flattening produces."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from julius_amd import lexblob, synth
+from oracle import pyoracle
+
+EXPORT = pyoracle.REF_SO.parent / "jamd_export"
+
+
+@pytest.mark.parametrize("lm", ["ngram", "grammar"])
+def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
+    if not EXPORT.exists():
+        pytest.skip("oracle/_ref/jamd_export not built")
+    task = synth.make_triphone_task(tmp_path, seed=91, nword=60)
+    if lm == "ngram":
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                "-input", "htkparam", "-gprune", "none", "-b", "120", "-sepnum", "4"]
+    else:
+        task = synth.make_triphone_grammar(task, ncat=3, seed=91)
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+                "-input", "htkparam", "-gprune", "none", "-b", "120", "-penalty1", "-2.0"]
+    args = [str(a) for a in args]
+    out = subprocess.run([str(EXPORT)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True, text=True)
+    assert "wrote" in out.stdout
+    eng = pyoracle.RefEngine(ref, args)
+    eng.save_lexicon(tmp_path / "ref.lex")
+    a, b = lexblob.load(tmp_path / "m.lex"), lexblob.load(tmp_path / "ref.lex")
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    am = ref.am_load(task["hmmdefs"], task["hmmlist"])
+    want, got = am.export(), lexblob.load_gmm(tmp_path / "m.am")
+    for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+        assert np.array_equal(got[k], want[k]), k
