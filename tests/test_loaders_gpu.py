@@ -97,3 +97,35 @@ def test_standalone_c_driver(oracle, tmp_path):
         assert f[0] == name and f[1] == "status=0"
         assert np.float32(float(f[2].split("=")[1])) == np.float32(utt["score"])
         assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(utt["wseq"])
+
+
+def test_export_then_standalone_batch(ref, tmp_path):
+    """The whole no-Julius-at-run-time flow: jamd_export (Julius' loaders -> files), then jamd_batch
+    (C, C ABI only) over a file list; pass-1 sentences and scores equal the plain reference's."""
+    import subprocess
+    from oracle import pyoracle
+    export = pyoracle.REF_SO.parent / "jamd_export"
+    exe = lib._PKG / "jamd_batch"
+    if not export.exists():
+        pytest.skip("oracle/_ref/jamd_export not built")
+    task = synth.make_triphone_task(tmp_path, seed=93, nword=120, nphone=10, S=160)
+    args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                             "-input", "htkparam", "-gprune", "safe", "-tmix", "3", "-b", "150", "-sepnum", "5", "-1pass"]]
+    subprocess.run([str(export)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True)
+    eng = pyoracle.RefEngine(ref, args)
+    names, want = [], []
+    for u in range(5):
+        fr, _ = synth.make_utterance(task, nwords=2 + u, seed=9300 + u)
+        names.append(str(tmp_path / f"u{u}.mfc"))
+        synth.write_htk_param(names[-1], fr)
+        _, p1 = eng.recognize(names[-1])
+        want.append(p1)
+    (tmp_path / "list").write_text("\n".join(names) + "\n")
+    out = subprocess.run([str(exe), "-am", str(tmp_path / "m.am"), "-lex", str(tmp_path / "m.lex"), "-filelist",
+                          str(tmp_path / "list"), "-b", "150", "-gprune", "safe", "3", "-strict"],
+                         check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(names)
+    for line, (wseq, score) in zip(out, want):
+        f = line.split(" ", 3)
+        assert f[1] == "status=0" and np.float32(float(f[2].split("=")[1])) == np.float32(score)
+        assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(wseq)
