@@ -1,8 +1,12 @@
 /*
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
- *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict]
+ *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict] [-shard R N]
  *              (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
+ *
+ * -shard R N: this process takes the utterances u with u % N == R (one process per GPU, e.g.
+ * `for r in 0..7: jamd_batch -d $r -shard $r 8 ...`): utterances are independent, the model is
+ * replicated, nothing is exchanged.
  *
  * model.blob / lexicon.blob are written once by a Julius process through the shim
  * (jamd_gmm_save / jamd_lexicon_save); a DNN is read from Julius' own dnnconf + .npy files.
@@ -57,10 +61,10 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
 int main(int argc, char **argv)
 {
   const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL;
-  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, i;
+  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, shard_r = 0, shard_n = 1, i;
   float bs = -1.0f;
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_lexicon *lx; jamd_beam *bm;
-  char **files = NULL; int nfile = 0, capfile = 0, veclen, nstate, first;
+  char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first;
   char line[4096];
   FILE *fl;
 
@@ -71,15 +75,16 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-gprune") && i + 1 < argc) {
       if (!strcmp(argv[++i], "safe") && i + 1 < argc) { gprune = JAMD_GPRUNE_SAFE; gnum = atoi(argv[++i]); }
     } else if (!strcmp(argv[i], "-strict")) strict = 1;
+    else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
     else if (!strcmp(argv[i], "-dnnconf") && i + 1 < argc) dnnconf = argv[++i];
     else if (!strcmp(argv[i], "-lex") && i + 1 < argc) lexp = argv[++i];
     else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
     else { fprintf(stderr, "jamd_batch: unknown option %s\n", argv[i]); return 2; }
   }
-  if ((am == NULL) == (dnnconf == NULL) || lexp == NULL || list == NULL) {
+  if ((am == NULL) == (dnnconf == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) {
     fprintf(stderr, "usage: jamd_batch (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
-                    "[-d dev] [-b beam] [-bs width] [-gprune safe N] [-strict]\n");
+                    "[-d dev] [-b beam] [-bs width] [-gprune safe N] [-strict] [-shard R N]\n");
     return 2;
   }
   if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
@@ -97,6 +102,7 @@ int main(int argc, char **argv)
     size_t n = strlen(line);
     while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r' || line[n - 1] == ' ')) line[--n] = 0;
     if (n == 0) continue;
+    if (shard_n > 1 && (i = nline++) % shard_n != shard_r) continue;     /* another process's utterance */
     if (nfile == capfile) { capfile = capfile ? 2 * capfile : 64; files = (char **)realloc(files, sizeof(char *) * capfile); }
     files[nfile++] = strdup(line);
   }
