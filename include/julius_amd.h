@@ -136,6 +136,15 @@ int  jamd_gmm_tmix_cap(const jamd_gmm *g);
 int  jamd_gmm_nbook(const jamd_gmm *g);
 /* Name of the kernel variant the last outprob call used ("tile<39,2>", ...). */
 const char *jamd_gmm_last_kernel(const jamd_gmm *g);
+/* Per-Gaussian scores for Julius' official plugin slot (compute_gaussset: calcmix(),
+ * plugin/calcmix.c:86-323): out[t][e] = (gconst_e + sum_d (o_td - mean_ed)^2 * ivar_ed) * -0.5
+ * for every mixture entry e (state order, e = st_off[s] + i for component i of state s), LOG_ZERO
+ * for a NULL density -- what the sample plugin's calcmix() stores in OP_calced_score[i]; calc_mix()
+ * then adds the weights and takes the log-sum itself.  out is [T][jamd_gmm_nentry()] row-major.
+ * Plain (not tied-mixture) single-stream models only. */
+int  jamd_gmm_nentry(const jamd_gmm *g);
+int  jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream);
+int  jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
 
 /* ------------------------------------------------- pseudo-phone state sets */
 /* CD_State_Set table (htk_hmm.h:249-253): set i = states[set_off[i]..set_off[i+1]).

@@ -475,6 +475,59 @@ int launch_tile_generic(jamd_gmm *g, const float *frames, int T, float *out, hip
   return JAMD_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Per-Gaussian scores for the reference's plugin slot (compute_gaussset / calcmix,
+// plugin/calcmix.c:86-323): dens[t][e] = compute_g_base() of mixture entry e at frame t,
+// (gconst + sum_d (o_d - mu_d)^2 * ivar_d) * -0.5, the same four fp32 operations per dimension as
+// K1 and no weight, no log-sum (calc_mix() applies those to what the plugin returns).  One wave =
+// 64 frames (their vectors transposed in LDS so any D fits), a block walks a chunk of entries,
+// 16 at a time through a wave-private tile so that [T][E] is written in 64-byte row segments.
+constexpr int kDensChunk = 1024;
+__global__ void __launch_bounds__(64)
+gmm_dens_kernel(const float *__restrict__ rec, const float *__restrict__ frames, float *__restrict__ out,
+                int T, int E, int D, int REC) {
+  extern __shared__ float xs[];                  // [D][64] then tile [64][17]
+  float (*tile)[17] = reinterpret_cast<float (*)[17]>(xs + (size_t)D * 64);
+  const int lane = threadIdx.x;
+  const int t0 = blockIdx.x * 64, e_begin = blockIdx.y * kDensChunk;
+  const int e_end = min(E, e_begin + kDensChunk);
+  {
+    int t = t0 + lane; if (t > T - 1) t = T - 1;
+    const float *f = frames + (size_t)t * D;
+    for (int d = 0; d < D; d++) xs[d * 64 + lane] = f[d];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int e0 = e_begin; e0 < e_end; e0 += 16) {
+    const int ne = min(16, e_end - e0);
+    for (int g = 0; g < ne; g++) {
+      const float *__restrict__ r = rec + (size_t)(e0 + g) * REC;
+      const float gc = r[2 * D];
+      float acc = gc;
+      for (int d = 0; d < D; d++) {
+        float x = xs[d * 64 + lane] - r[d];
+        x = x * x;
+        x = x * r[D + d];
+        acc = acc + x;
+      }
+      float sc = acc * -0.5f;
+      if (gc != gc) sc = JAMD_LOG_ZERO;            // NULL density (gprune_none.c:67, plugin/calcmix.c:104)
+      tile[lane][g] = sc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int col = lane & 15, rsub = lane >> 4;
+    for (int it = 0; it < 16; it++) {
+      const int rr = it * 4 + rsub, t = t0 + rr;
+      if (t < T && col < ne) out[(size_t)t * E + e0 + col] = tile[rr][col];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int ensure(float **p, size_t *cap, size_t need) {
   if (*cap >= need) return JAMD_OK;
   if (*p) JAMD_HIP(hipFree(*p));
@@ -646,6 +699,46 @@ void jamd_gmm_destroy(jamd_gmm *g) {
 int jamd_gmm_nstate(const jamd_gmm *g) { return g ? g->S : -1; }
 int jamd_gmm_veclen(const jamd_gmm *g) { return g ? g->D : -1; }
 const char *jamd_gmm_last_kernel(const jamd_gmm *g) { return g ? g->last_kernel : ""; }
+
+int jamd_gmm_nentry(const jamd_gmm *g) { return g ? g->E : 0; }
+
+int jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream) {
+  if (!g || !dev_frames || !dev_out || T < 0) { jamd_set_error("jamd_gmm_dens_dev: bad argument"); return JAMD_EINVAL; }
+  if (g->ntied != 0 || g->E_plain != g->E) {
+    jamd_set_error("jamd_gmm_dens_dev: tied-mixture models are scored per codebook, not per state entry");
+    return JAMD_EINVAL;
+  }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(g->eng->device));
+  hipStream_t st = jamd_stream(g->eng, stream);
+  const size_t lds = sizeof(float) * ((size_t)g->D * 64 + 64 * 17);
+  if (lds > 64 * 1024) { jamd_set_error("jamd_gmm_dens_dev: vector length %d too large", g->D); return JAMD_EINVAL; }
+  hipLaunchKernelGGL(gmm_dens_kernel, dim3((T + 63) / 64, (g->E + kDensChunk - 1) / kDensChunk), dim3(64), lds, st,
+                     g->d_rec, dev_frames, dev_out, T, g->E, g->D, g->rec);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { jamd_set_error("jamd_gmm_dens_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  return JAMD_OK;
+}
+
+int jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host_out) {
+  if (!g || !host_frames || !host_out || T < 0) { jamd_set_error("jamd_gmm_dens_host: bad argument"); return JAMD_EINVAL; }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(g->eng->device));
+  float *d_fr = nullptr, *d_out = nullptr;
+  int rc = JAMD_OK;
+  hipStream_t st = g->eng->stream;
+  if (hipMalloc(&d_fr, sizeof(float) * (size_t)T * g->D) != hipSuccess ||
+      hipMalloc(&d_out, sizeof(float) * (size_t)T * g->E) != hipSuccess) {
+    jamd_set_error("jamd_gmm_dens_host: out of device memory"); rc = JAMD_ENOMEM;
+  }
+  if (rc == JAMD_OK && hipMemcpyAsync(d_fr, host_frames, sizeof(float) * (size_t)T * g->D, hipMemcpyHostToDevice, st) != hipSuccess) rc = JAMD_ENODEV;
+  if (rc == JAMD_OK) rc = jamd_gmm_dens_dev(g, d_fr, T, d_out, st);
+  if (rc == JAMD_OK && (hipMemcpyAsync(host_out, d_out, sizeof(float) * (size_t)T * g->E, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess)) { jamd_set_error("jamd_gmm_dens_host: copy failed"); rc = JAMD_ELAUNCH; }
+  if (d_fr) (void)hipFree(d_fr);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
 
 int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream) {
   if (!g || !dev_frames || !dev_out || T < 0) {

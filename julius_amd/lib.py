@@ -70,6 +70,9 @@ def load():
         "jamd_memcpy_d2h": (ci, [vp, vp, vp, C.c_size_t]),
         "jamd_gmm_create": (ci, [vp, P(GmmDesc), ci, ci, P(vp)]),
         "jamd_gmm_load": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
+        "jamd_gmm_nentry": (ci, [vp]),
+        "jamd_gmm_dens_dev": (ci, [vp, vp, ci, vp, vp]),
+        "jamd_gmm_dens_host": (ci, [vp, vp, ci, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
@@ -243,6 +246,14 @@ class Gmm:
     def outprob_dev(self, dev_frames: int, T: int, dev_out: int, stream: int = 0):
         _check(load().jamd_gmm_outprob_dev(self.h, dev_frames, T, dev_out, stream or None),
                "jamd_gmm_outprob_dev")
+
+    def dens_host(self, frames: np.ndarray) -> np.ndarray:
+        """Per-Gaussian scores [T][nentry] (the plugin slot's compute_gaussset values)."""
+        fr = _f32(frames)
+        E = load().jamd_gmm_nentry(self.h)
+        out = np.empty((fr.shape[0], E), dtype=np.float32)
+        _check(load().jamd_gmm_dens_host(self.h, fr.ctypes.data, fr.shape[0], out.ctypes.data), "jamd_gmm_dens_host")
+        return out
 
     def last_kernel(self) -> str:
         return load().jamd_gmm_last_kernel(self.h).decode()

@@ -18,6 +18,7 @@ HERE = Path(__file__).resolve().parent
 ORACLE_SO = HERE / "liboracle.so"
 REF_SO = HERE / "_ref" / "libjref.so"
 REF_AMD_SO = HERE / "_ref" / "libjref_amd.so"   # same reference, first pass served by julius_amd/shim
+PLUGIN_DIR = HERE / "_ref" / "plugin"
 REF_O_SO = HERE / "_ref" / "libjref_o.so"       # same reference (own beam), scoring entry points wrapped (boundary O)
 
 GPRUNE_NONE, GPRUNE_SAFE = 0, 1
@@ -169,12 +170,15 @@ class Oracle:
 class Ref:
     """The compiled reference (oracle/_ref/libjref.so)."""
 
-    def __init__(self, quiet=True, so=None):
+    def __init__(self, quiet=True, so=None, global_symbols=False):
+        """global_symbols: load with RTLD_GLOBAL, as an executable's symbols are visible -- needed
+        when the reference is to dlopen() a plugin that calls back into libsent (jlog, mymalloc).
+        Use it in a process that loads no other variant of the reference."""
         so = so or REF_SO
         if not so.exists():
             raise FileNotFoundError(
                 f"{so} missing: run `make -C oracle ref` where /root/reference is available")
-        self.lib = lib = C.CDLL(str(so))
+        self.lib = lib = C.CDLL(str(so), mode=C.RTLD_GLOBAL) if global_symbols else C.CDLL(str(so))
         vp, ci, cd = C.c_void_p, C.c_int, C.c_double
         lib.jref_quiet.argtypes = [ci]
         lib.jref_am_load.restype = vp

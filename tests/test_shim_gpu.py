@@ -314,3 +314,61 @@ def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monk
         assert np.array_equal(f1, f0) and fs1 == fs0
         for k in tr0:
             assert np.array_equal(tr1[k], tr0[k]), k
+
+
+def test_official_plugin_slot(tmp_path):
+    """Boundary P: the UNMODIFIED reference (libjref.so, nothing relinked) dlopen()s
+    oracle/_ref/plugin/jamd_calcmix.jpi through `-plugindir ... -gprune jamd`; its Gaussian
+    computation slot is then served from device-computed per-Gaussian scores.  Same word trellis,
+    pass-1 and final results as the reference's own gprune_none; the counters prove the slot ran.
+    Runs in a subprocess because the reference must be loaded with its symbols visible to the plugin."""
+    import subprocess, sys, textwrap
+    if not (pyoracle.PLUGIN_DIR / "jamd_calcmix.jpi").exists():
+        pytest.skip("oracle/_ref/plugin/jamd_calcmix.jpi not built")
+    code = textwrap.dedent(f"""
+        import sys, ctypes, numpy as np
+        sys.path.insert(0, {str(pyoracle.HERE.parent)!r}); sys.path.insert(0, {str(pyoracle.HERE.parent / 'tests')!r})
+        from pathlib import Path
+        from julius_amd import synth
+        from oracle import pyoracle
+        tmp = Path({str(tmp_path)!r})
+        ref = pyoracle.Ref(global_symbols=True)
+        task = synth.make_triphone_task(tmp, seed=95, nword=100, nphone=10, S=160)
+        base = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                "-input", "htkparam", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5"]
+        plain = pyoracle.RefEngine(ref, base + ["-gprune", "none"])
+        plug = pyoracle.RefEngine(ref, ["-plugindir", {str(pyoracle.PLUGIN_DIR)!r}] + base + ["-gprune", "jamd"])
+        jpi = ctypes.CDLL({str(pyoracle.PLUGIN_DIR / 'jamd_calcmix.jpi')!r})
+        jpi.jamd_calcmix_calls.restype = ctypes.c_long; jpi.jamd_calcmix_fills.restype = ctypes.c_long
+        for u in range(3):
+            fr, _ = synth.make_utterance(task, nwords=3 + u, seed=9500 + u)
+            synth.write_htk_param(tmp / "u.mfc", fr)
+            tr0, (w0, s0) = plain.recognize(tmp / "u.mfc"); st0, f0, fs0 = plain.final_result()
+            tr1, (w1, s1) = plug.recognize(tmp / "u.mfc"); st1, f1, fs1 = plug.final_result()
+            assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0 and np.array_equal(f1, f0) and fs1 == fs0
+            for k in tr0:
+                assert np.array_equal(tr1[k], tr0[k]), k
+        assert jpi.jamd_calcmix_fills() == 3 and jpi.jamd_calcmix_calls() > 1000, (jpi.jamd_calcmix_fills(), jpi.jamd_calcmix_calls())
+        print("PLUGIN_OK", jpi.jamd_calcmix_calls(), jpi.jamd_calcmix_fills())
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "PLUGIN_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_per_gaussian_scores(engine):
+    """jamd_gmm_dens_*: the values the plugin slot hands to calc_mix(), against an fp32 restatement
+    of compute_g_base() (gprune_none.c:59-82) in numpy, bit for bit."""
+    from julius_amd import lib
+    model = synth.make_gmm(S=40, M=5, D=39, seed=7, ragged=True, null_frac=0.1)
+    fr = synth.make_frames(model, T=70, seed=2)
+    got = lib.Gmm(engine, model).dens_host(fr)
+    dens = model["ent_dens"]
+    acc = np.where(dens >= 0, model["gconst"][np.maximum(dens, 0)], np.float32(0))[None, :].repeat(len(fr), 0).astype(np.float32)
+    for d in range(fr.shape[1]):
+        x = (fr[:, None, d] - model["mean"][np.maximum(dens, 0), d][None, :]).astype(np.float32)
+        x = (x * x).astype(np.float32)
+        x = (x * model["ivar"][np.maximum(dens, 0), d][None, :]).astype(np.float32)
+        acc = (acc + x).astype(np.float32)
+    want = (acc * np.float32(-0.5)).astype(np.float32)
+    want[:, dens < 0] = np.float32(-1000000.0)
+    assert np.array_equal(got, want)
