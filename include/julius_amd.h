@@ -141,8 +141,12 @@ const char *jamd_gmm_last_kernel(const jamd_gmm *g);
  * for every mixture entry e (state order, e = st_off[s] + i for component i of state s), LOG_ZERO
  * for a NULL density -- what the sample plugin's calcmix() stores in OP_calced_score[i]; calc_mix()
  * then adds the weights and takes the log-sum itself.  out is [T][jamd_gmm_nentry()] row-major.
- * Plain (not tied-mixture) single-stream models only. */
+ * Single-stream models whose states are all plain or all tied-mixture. */
 int  jamd_gmm_nentry(const jamd_gmm *g);
+/* For a model whose states are all tied-mixture the columns are the codebook Gaussians instead
+ * (what calc_tied_mix() sends through the slot: book->d, libsent/src/phmm/calc_tied_mix.c:189-227):
+ * column jamd_gmm_book_offsets()[b] + k is Gaussian k of codebook b; off receives nbook + 1 ints. */
+int  jamd_gmm_book_offsets(const jamd_gmm *g, int *off, int cap);
 int  jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream);
 int  jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
 

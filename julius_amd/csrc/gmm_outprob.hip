@@ -674,6 +674,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
     g->tm_cap = (gprune == JAMD_GPRUNE_NONE) ? g->maxbook : (gprune_num < g->maxbook ? gprune_num : g->maxbook);
     JAMD_HIP(hipMalloc(&g->d_book_rec, sizeof(float) * (brec.size() ? brec.size() : 4)));
     JAMD_HIP(hipMemcpy(g->d_book_rec, brec.data(), sizeof(float) * brec.size(), hipMemcpyHostToDevice));
+    g->h_book_off = book_off;
     JAMD_HIP(hipMalloc(&g->d_book_off, sizeof(int) * (g->nbook + 1)));
     JAMD_HIP(hipMemcpy(g->d_book_off, book_off.data(), sizeof(int) * (g->nbook + 1), hipMemcpyHostToDevice));
     JAMD_HIP(hipMalloc(&g->d_st_book, sizeof(int) * g->S));
@@ -700,12 +701,28 @@ int jamd_gmm_nstate(const jamd_gmm *g) { return g ? g->S : -1; }
 int jamd_gmm_veclen(const jamd_gmm *g) { return g ? g->D : -1; }
 const char *jamd_gmm_last_kernel(const jamd_gmm *g) { return g ? g->last_kernel : ""; }
 
-int jamd_gmm_nentry(const jamd_gmm *g) { return g ? g->E : 0; }
+// number of per-Gaussian score columns: the mixture entries of a plain model in state order, the
+// codebook Gaussians of a tied-mixture model in codebook order; 0 for a model that mixes both
+int jamd_gmm_nentry(const jamd_gmm *g) {
+  if (!g) return 0;
+  if (g->ntied == 0) return g->E;
+  if (g->ntied == g->S && !g->h_book_off.empty()) return g->h_book_off[g->nbook];
+  return 0;
+}
+
+int jamd_gmm_book_offsets(const jamd_gmm *g, int *off, int cap) {
+  if (!g || !off || g->ntied != g->S || (int)g->h_book_off.size() != g->nbook + 1 || cap < g->nbook + 1) {
+    jamd_set_error("jamd_gmm_book_offsets: not an all-tied-mixture model, or buffer too small"); return JAMD_EINVAL;
+  }
+  memcpy(off, g->h_book_off.data(), sizeof(int) * (size_t)(g->nbook + 1));
+  return JAMD_OK;
+}
 
 int jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream) {
   if (!g || !dev_frames || !dev_out || T < 0) { jamd_set_error("jamd_gmm_dens_dev: bad argument"); return JAMD_EINVAL; }
-  if (g->ntied != 0 || g->E_plain != g->E) {
-    jamd_set_error("jamd_gmm_dens_dev: tied-mixture models are scored per codebook, not per state entry");
+  const int E = jamd_gmm_nentry(g);
+  if (E <= 0) {
+    jamd_set_error("jamd_gmm_dens_dev: models mixing plain and tied-mixture states have no single column order");
     return JAMD_EINVAL;
   }
   if (T == 0) return JAMD_OK;
@@ -713,8 +730,8 @@ int jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_ou
   hipStream_t st = jamd_stream(g->eng, stream);
   const size_t lds = sizeof(float) * ((size_t)g->D * 64 + 64 * 17);
   if (lds > 64 * 1024) { jamd_set_error("jamd_gmm_dens_dev: vector length %d too large", g->D); return JAMD_EINVAL; }
-  hipLaunchKernelGGL(gmm_dens_kernel, dim3((T + 63) / 64, (g->E + kDensChunk - 1) / kDensChunk), dim3(64), lds, st,
-                     g->d_rec, dev_frames, dev_out, T, g->E, g->D, g->rec);
+  hipLaunchKernelGGL(gmm_dens_kernel, dim3((T + 63) / 64, (E + kDensChunk - 1) / kDensChunk), dim3(64), lds, st,
+                     g->ntied ? g->d_book_rec : g->d_rec, dev_frames, dev_out, T, E, g->D, g->rec);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_gmm_dens_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   return JAMD_OK;
@@ -727,13 +744,15 @@ int jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host
   float *d_fr = nullptr, *d_out = nullptr;
   int rc = JAMD_OK;
   hipStream_t st = g->eng->stream;
+  const int E = jamd_gmm_nentry(g);
+  if (E <= 0) { jamd_set_error("jamd_gmm_dens_host: no single column order for this model"); return JAMD_EINVAL; }
   if (hipMalloc(&d_fr, sizeof(float) * (size_t)T * g->D) != hipSuccess ||
-      hipMalloc(&d_out, sizeof(float) * (size_t)T * g->E) != hipSuccess) {
+      hipMalloc(&d_out, sizeof(float) * (size_t)T * E) != hipSuccess) {
     jamd_set_error("jamd_gmm_dens_host: out of device memory"); rc = JAMD_ENOMEM;
   }
   if (rc == JAMD_OK && hipMemcpyAsync(d_fr, host_frames, sizeof(float) * (size_t)T * g->D, hipMemcpyHostToDevice, st) != hipSuccess) rc = JAMD_ENODEV;
   if (rc == JAMD_OK) rc = jamd_gmm_dens_dev(g, d_fr, T, d_out, st);
-  if (rc == JAMD_OK && (hipMemcpyAsync(host_out, d_out, sizeof(float) * (size_t)T * g->E, hipMemcpyDeviceToHost, st) != hipSuccess ||
+  if (rc == JAMD_OK && (hipMemcpyAsync(host_out, d_out, sizeof(float) * (size_t)T * E, hipMemcpyDeviceToHost, st) != hipSuccess ||
                         hipStreamSynchronize(st) != hipSuccess)) { jamd_set_error("jamd_gmm_dens_host: copy failed"); rc = JAMD_ELAUNCH; }
   if (d_fr) (void)hipFree(d_fr);
   if (d_out) (void)hipFree(d_out);

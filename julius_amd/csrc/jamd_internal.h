@@ -57,6 +57,7 @@ struct jamd_gmm {
   // tied-mixture
   int *d_st_book = nullptr;       // [S]
   int *d_book_off = nullptr;      // [nbook+1] into book records
+  std::vector<int> h_book_off;    // host copy of the same
   float *d_book_rec = nullptr;    // [sum book sizes][rec] (logw unused)
   float *d_ent_logw = nullptr;    // [E] entry weights (tied states index by codebook position)
   int *d_tied_states = nullptr;   // [ntied] ids of tied-mixture states

@@ -71,6 +71,7 @@ def load():
         "jamd_gmm_create": (ci, [vp, P(GmmDesc), ci, ci, P(vp)]),
         "jamd_gmm_load": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
         "jamd_gmm_nentry": (ci, [vp]),
+        "jamd_gmm_book_offsets": (ci, [vp, vp, ci]),
         "jamd_gmm_dens_dev": (ci, [vp, vp, ci, vp, vp]),
         "jamd_gmm_dens_host": (ci, [vp, vp, ci, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),

@@ -17,9 +17,10 @@
  * sample plugin) and every later call is a row lookup.  The values are bit-identical to what the
  * sample plugin's loop computes, so Julius' result does not change.
  *
- * Scope: plain (not tied-mixture), single-stream GMM-HMMs -- for tied-mixture models the slot is
- * entered per codebook, which this lookup does not key on; such models are refused in
- * calcmix_init() (use the link-time bindings of INTEGRATION.md sections 2 and 3 instead).
+ * Scope: single-stream GMM-HMMs whose states are all plain or all tied-mixture.  For a tied-mixture
+ * model calc_tied_mix() (libsent/src/phmm/calc_tied_mix.c:162-227) sends the Gaussians of a
+ * CODEBOOK through the slot (book->d, book->num) and caches what comes back per (frame, codebook);
+ * the device rows then hold the codebook Gaussians in codebook order.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,7 +38,8 @@ typedef struct {
   HMMWork *wrk;
   jamd_gmm *gmm;
   int nentry, nstate, veclen;
-  int *st_off;                 /* [nstate + 1] first mixture entry of each state */
+  int *st_off;                 /* [nstate + 1] first mixture entry of each state (plain model) */
+  int tied, nbook; int *book_off;   /* tied-mixture model: first column of each codebook */
   float *dens;                 /* [cap][nentry] per-Gaussian scores of the current input */
   int cap, filled;             /* frames allocated / computed */
   unsigned long long key;      /* content hash of the input the rows belong to */
@@ -81,8 +83,8 @@ boolean calcmix_init(HMMWork *wrk)
   jamd_flat_gmm fg;
   plug_ctx *c;
   const char *dev = getenv("JAMD_DEVICE");
-  if (hmm->is_tied_mixture || wrk->OP_nstream != 1) {
-    jlog("Error: jamd plugin: tied-mixture / multi-stream models are not served through the plugin slot\n");
+  if (wrk->OP_nstream != 1) {
+    jlog("Error: jamd plugin: multi-stream models are not served through the plugin slot\n");
     return FALSE;
   }
   if (jamd_abi_version() != JAMD_ABI_VERSION) { jlog("Error: jamd plugin: ABI mismatch with libjulius_amd.so\n"); return FALSE; }
@@ -106,10 +108,16 @@ boolean calcmix_init(HMMWork *wrk)
     jamd_flat_gmm_free(&fg);
     return FALSE;
   }
-  c->nentry = fg.desc.nentry; c->nstate = fg.desc.nstate; c->veclen = fg.desc.veclen;
+  c->nentry = jamd_gmm_nentry(c->gmm); c->nstate = fg.desc.nstate; c->veclen = fg.desc.veclen;
+  c->tied = hmm->is_tied_mixture ? 1 : 0; c->nbook = jamd_gmm_nbook(c->gmm);
   c->st_off = (int *)malloc(sizeof(int) * (size_t)(c->nstate + 1));
   memcpy(c->st_off, fg.desc.st_off, sizeof(int) * (size_t)(c->nstate + 1));
   jamd_flat_gmm_free(&fg);
+  if (c->nentry <= 0) { jlog("Error: jamd plugin: models mixing plain and tied-mixture states are not served through the slot\n"); return FALSE; }
+  if (c->tied) {
+    c->book_off = (int *)malloc(sizeof(int) * (size_t)(c->nbook + 1));
+    if (jamd_gmm_book_offsets(c->gmm, c->book_off, c->nbook + 1) != JAMD_OK) { jlog("Error: jamd plugin: %s\n", jamd_last_error()); return FALSE; }
+  }
   g_nctx++;
   jlog("Stat: jamd plugin: Gaussian scores on HIP device %d (%d states, %d mixture components)\n",
        jamd_engine_device(g_eng), c->nstate, c->nentry);
@@ -150,22 +158,33 @@ void calcmix(HMMWork *wrk, HTK_HMM_Dens **g, int num, int *last_id, int lnum)
   const HTK_Param *param = wrk->OP_param;
   const int t = wrk->OP_time;
   const float *row;
-  int i;
+  int i, col0;
   (void)last_id; (void)lnum;
   if (c == NULL || param == NULL || t < 0 || t >= param->samplenum || param->veclen != c->veclen) {
     fprintf(stderr, "jamd calcmix plugin: called outside an input it can serve\n");
     exit(1);
   }
-  if (g != wrk->OP_state->pdf[0]->b || num != wrk->OP_state->pdf[0]->mix_num) {
-    fprintf(stderr, "jamd calcmix plugin: called for a Gaussian set that is not the current state's mixture\n");
-    exit(1);
+  if (c->tied) {                /* calc_tied_mix(): the current state's codebook */
+    const GCODEBOOK *book = (const GCODEBOOK *)(wrk->OP_state->pdf[0]->b);
+    if (!wrk->OP_state->pdf[0]->tmix || g != book->d || num != book->num || book->id < 0 || book->id >= c->nbook ||
+        c->book_off[book->id + 1] - c->book_off[book->id] != num) {
+      fprintf(stderr, "jamd calcmix plugin: called for a Gaussian set that is not the current state's codebook\n");
+      exit(1);
+    }
+    col0 = c->book_off[book->id];
+  } else {
+    if (g != wrk->OP_state->pdf[0]->b || num != wrk->OP_state->pdf[0]->mix_num) {
+      fprintf(stderr, "jamd calcmix plugin: called for a Gaussian set that is not the current state's mixture\n");
+      exit(1);
+    }
+    col0 = c->st_off[wrk->OP_state_id];
   }
   /* every input is entered at frame 0 (init_nodescore(), libjulius/src/beam.c:1552): there the
    * rows kept from the previous input are checked against the frames they were computed from */
   if (t == 0 && c->filled > 0 &&
       (param->samplenum < c->filled || hash_frames(param, 0, c->filled, FNV_INIT) != c->key)) c->filled = 0;
   if (t >= c->filled) fill(c, param, c->filled, param->samplenum);      /* a new input, or one that grew (live) */
-  row = c->dens + (size_t)t * c->nentry + c->st_off[wrk->OP_state_id];
+  row = c->dens + (size_t)t * c->nentry + col0;
   for (i = 0; i < num; i++) { wrk->OP_calced_id[i] = i; wrk->OP_calced_score[i] = row[i]; }
   wrk->OP_calced_num = num;
   g_calls++;
@@ -178,7 +197,7 @@ void calcmix_free(HMMWork *wrk)
   free(wrk->OP_calced_id);
   if (c != NULL) {
     if (c->gmm) jamd_gmm_destroy(c->gmm);
-    free(c->st_off); free(c->dens);
+    free(c->st_off); free(c->book_off); free(c->dens);
     *c = g_ctx[--g_nctx];
   }
 }

@@ -316,7 +316,8 @@ def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monk
             assert np.array_equal(tr1[k], tr0[k]), k
 
 
-def test_official_plugin_slot(tmp_path):
+@pytest.mark.parametrize("kind", ["triphone", "c1"])
+def test_official_plugin_slot(tmp_path, kind):
     """Boundary P: the UNMODIFIED reference (libjref.so, nothing relinked) dlopen()s
     oracle/_ref/plugin/jamd_calcmix.jpi through `-plugindir ... -gprune jamd`; its Gaussian
     computation slot is then served from device-computed per-Gaussian scores.  Same word trellis,
@@ -333,22 +334,27 @@ def test_official_plugin_slot(tmp_path):
         from oracle import pyoracle
         tmp = Path({str(tmp_path)!r})
         ref = pyoracle.Ref(global_symbols=True)
-        task = synth.make_triphone_task(tmp, seed=95, nword=100, nphone=10, S=160)
-        base = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
-                "-input", "htkparam", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5"]
+        if {kind!r} == "triphone":
+            task = synth.make_triphone_task(tmp, seed=95, nword=100, nphone=10, S=160)
+            base = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                    "-input", "htkparam", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5"]
+            mk = lambda u: synth.make_utterance(task, nwords=3 + u, seed=9500 + u)[0]
+        else:       # BASELINE configs[0] shape: tied-mixture monophones + 100-word grammar (the slot is entered per codebook)
+            task = synth.make_grammar_task(tmp, seed=96)
+            base = ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam", "-b", "200"]
+            mk = lambda u: synth.make_grammar_utterance(task, nwords=3 + u, seed=9600 + u)[0]
         plain = pyoracle.RefEngine(ref, base + ["-gprune", "none"])
         plug = pyoracle.RefEngine(ref, ["-plugindir", {str(pyoracle.PLUGIN_DIR)!r}] + base + ["-gprune", "jamd"])
         jpi = ctypes.CDLL({str(pyoracle.PLUGIN_DIR / 'jamd_calcmix.jpi')!r})
         jpi.jamd_calcmix_calls.restype = ctypes.c_long; jpi.jamd_calcmix_fills.restype = ctypes.c_long
         for u in range(3):
-            fr, _ = synth.make_utterance(task, nwords=3 + u, seed=9500 + u)
-            synth.write_htk_param(tmp / "u.mfc", fr)
+            synth.write_htk_param(tmp / "u.mfc", mk(u))
             tr0, (w0, s0) = plain.recognize(tmp / "u.mfc"); st0, f0, fs0 = plain.final_result()
             tr1, (w1, s1) = plug.recognize(tmp / "u.mfc"); st1, f1, fs1 = plug.final_result()
             assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0 and np.array_equal(f1, f0) and fs1 == fs0
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
-        assert jpi.jamd_calcmix_fills() == 3 and jpi.jamd_calcmix_calls() > 1000, (jpi.jamd_calcmix_fills(), jpi.jamd_calcmix_calls())
+        assert jpi.jamd_calcmix_fills() == 3 and jpi.jamd_calcmix_calls() > 500, (jpi.jamd_calcmix_fills(), jpi.jamd_calcmix_calls())
         print("PLUGIN_OK", jpi.jamd_calcmix_calls(), jpi.jamd_calcmix_fills())
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
