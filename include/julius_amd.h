@@ -150,6 +150,23 @@ int  jamd_gmm_book_offsets(const jamd_gmm *g, int *off, int cap);
 int  jamd_gmm_dens_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream);
 int  jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
 
+/* ---- Gaussian mixture selection (-gshmm FILE -gsnum N) --------------------------------------
+ * Replaces gms_state() (libsent/src/phmm/gms.c:394-412, with compute_gs_scores()/do_gms(),
+ * gms.c:189-264, and compute_g_max(), gms_gprune.c:80-150).  gs is the flattened selection model
+ * (plain single-stream GMM states, one per GS HMM state in gms.c:106-117's order), state2gs[s] the
+ * selection state of state s of the real model (state2gs in gms.c:119-145; -1 = state not mapped,
+ * left alone), nbest the -gsnum value.  jamd_gms_apply_dev() turns a [T][nstate] matrix of real
+ * scores into what outprob_state() returns under GMS: where the selection state of s is not among
+ * the frame's nbest, scores[t][s] becomes the selection state's own score.  utt_off[nutt+1] (host)
+ * gives the first frame of every utterance in the T concatenated frames (the reference resets the
+ * last-best Gaussian at every utterance, gms_gprune.c:190-207); NULL = one utterance. */
+typedef struct jamd_gms jamd_gms;
+int  jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2gs, int nstate, int nbest,
+                     jamd_gms **out);
+void jamd_gms_destroy(jamd_gms *m);
+int  jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *utt_off, int nutt,
+                        float *dev_scores, void *stream);
+
 /* ------------------------------------------------- pseudo-phone state sets */
 /* CD_State_Set table (htk_hmm.h:249-253): set i = states[set_off[i]..set_off[i+1]).
  * Replaces outprob_cd() (outprob.c:383): cd[t][i] from one [T][nstate] score

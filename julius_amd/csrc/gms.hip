@@ -1,0 +1,200 @@
+// gms.hip -- Gaussian mixture selection (-gshmm / -gsnum) on gfx950.
+//
+// Replaces gms_state() and its helpers (libsent/src/phmm/gms.c:189-412, gms_gprune.c:80-257):
+// with a selection model loaded, Julius scores a small monophone GMM set ("GS HMM") every frame,
+// keeps the nbest highest states and, for every state of the real model whose selection state is
+// NOT among them, returns the selection state's score instead of the real one.  On a CPU that saves
+// most of the Gaussian work; here every real score exists anyway and this stage REPLACES the ones
+// Julius would not have computed, so that a configuration with -gshmm gives the reference's
+// numbers.  Two sequential dependencies are kept exactly:
+//   * compute_g_max() evaluates last frame's best Gaussian of the state first and then the others
+//     from the highest index down with a strict >, so an exact tie is broken by history;
+//   * the nbest states are taken from a partial heap sort over an index array that is not reset
+//     between frames (sort_gsindex_upward()), so a tie on the selection boundary is, too.
+// Hence one wave per utterance walks its frames in order: the lanes share the states of a frame
+// (per-Gaussian scores come from gmm_dens, the kernel behind the plugin slot), lane 0 runs the heap
+// in LDS.  The index array is reset at every utterance (the reference never resets it); that can
+// only matter for an exact tie between two selection states on the boundary.
+#include "jamd_device.h"
+
+struct jamd_gms {
+  jamd_engine *eng = nullptr;
+  jamd_gmm *gs = nullptr;          // the selection model (per-Gaussian scores)
+  int Sgs = 0, Egs = 0, S = 0, nbest = 0;
+  int *d_st_off = nullptr;         // [Sgs + 1]
+  float *d_logw = nullptr;         // [Egs]
+  int *d_state2gs = nullptr;       // [S]
+  int *d_utt_off = nullptr; int utt_cap = 0;
+  float *d_dens = nullptr; size_t dens_cap = 0;
+  float *d_fs = nullptr; size_t fs_cap = 0;
+};
+
+namespace {
+using namespace jamd;
+
+__global__ void __launch_bounds__(64)
+gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ st_off, const float *__restrict__ logw,
+                  const int *__restrict__ utt_off, float *__restrict__ fs_out, int Sgs, int Egs, int nbest) {
+  extern __shared__ float lds[];
+  float *fs = lds;                              // [Sgs]
+  int *idx = (int *)(lds + Sgs);                // [Sgs]
+  int *last = idx + Sgs;                        // [Sgs]
+  const int lane = threadIdx.x, u = blockIdx.x;
+  const int t0 = utt_off[u], t1 = utt_off[u + 1];
+  for (int i = lane; i < Sgs; i += 64) { idx[i] = i; last[i] = -1; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int t = t0; t < t1; t++) {
+    const float *__restrict__ row = dens + (size_t)t * Egs;
+    for (int i = lane; i < Sgs; i += 64) {                         // compute_g_max(), LAST_BEST
+      const int e0 = st_off[i], n = st_off[i + 1] - e0;
+      const int first = (last[i] != -1) ? last[i] : n - 1;
+      // calc_contprob_with_safe_pruning(): a score below the running maximum (LOG_ZERO for the first
+      // one) comes back as LOG_ZERO
+      float maxprob = row[e0 + first];
+      if (maxprob < JAMD_LOG_ZERO) maxprob = JAMD_LOG_ZERO;
+      int maxi = first;
+      for (int k = n - 1; k >= 0; k--) {
+        if (k == first) continue;
+        const float p = row[e0 + k];
+        if (p > maxprob) { maxprob = p; maxi = k; }
+      }
+      last[i] = maxi;
+      float sum = 0.0f;
+      sum += (maxprob + logw[e0 + maxi]) * 1.0f;
+      fs[i] = (float)((double)sum * JAMD_INV_LOG_TEN);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {                                                // sort_gsindex_upward() + do_gms()
+      const int totalnum = Sgs, neednum = nbest < Sgs ? nbest : Sgs;
+#define SD_(A) idx[(A) - 1]
+#define SV_(A) (fs[idx[(A) - 1]])
+      for (int root = totalnum / 2; root >= 1; root--) {
+        const int sd = SD_(root);
+        int parent = root, child;
+        while ((child = parent * 2) <= totalnum) {
+          if (child < totalnum && SV_(child) < SV_(child + 1)) child++;
+          if (fs[sd] >= SV_(child)) break;
+          SD_(parent) = SD_(child); parent = child;
+        }
+        SD_(parent) = sd;
+      }
+      int n = totalnum;
+      while (n > totalnum - neednum) {
+        const int sd = SD_(n);
+        SD_(n) = SD_(1); n--;
+        int parent = 1, child;
+        while ((child = parent * 2) <= n) {
+          if (child < n && SV_(child) < SV_(child + 1)) child++;
+          if (fs[sd] >= SV_(child)) break;
+          SD_(parent) = SD_(child); parent = child;
+        }
+        SD_(parent) = sd;
+      }
+#undef SD_
+#undef SV_
+      for (int i = totalnum - neednum; i < totalnum; i++) fs[idx[i]] = JAMD_LOG_ZERO;   // selected
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < Sgs; i += 64) fs_out[(size_t)t * Sgs + i] = fs[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// gms_state(): fallback value unless the selection state was selected (marked LOG_ZERO)
+__global__ void __launch_bounds__(256)
+gms_combine_kernel(const float *__restrict__ fs, const int *__restrict__ state2gs, float *__restrict__ scores,
+                   int T, int S, int Sgs) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int g = state2gs[s];
+  if (g < 0) return;
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    const float f = fs[(size_t)t * Sgs + g];
+    if (f != JAMD_LOG_ZERO) scores[(size_t)t * S + s] = f;
+  }
+}
+
+int grow(float **p, size_t *cap, size_t need) {
+  if (*cap >= need) return JAMD_OK;
+  if (*p) JAMD_HIP(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  JAMD_HIP(hipMalloc(p, need));
+  *cap = need;
+  return JAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2gs, int nstate, int nbest,
+                    jamd_gms **out) {
+  if (!e || !gs || !state2gs || !out || nstate <= 0 || nbest < 1) { jamd_set_error("jamd_gms_create: bad argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  if (gs->nbook > 0 || gs->nstream != 1) { jamd_set_error("jamd_gms_create: the selection model must be a plain single-stream GMM"); return JAMD_EINVAL; }
+  for (int s = 0; s < nstate; s++)
+    if (state2gs[s] >= gs->nstate) { jamd_set_error("jamd_gms_create: state2gs[%d] out of range", s); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  jamd_gms *m = new jamd_gms();
+  m->eng = e; m->Sgs = gs->nstate; m->Egs = gs->nentry; m->S = nstate; m->nbest = nbest;
+  int rc = jamd_gmm_create(e, gs, JAMD_GPRUNE_NONE, 0, &m->gs);
+  if (rc == JAMD_OK && hipMalloc(&m->d_st_off, sizeof(int) * (gs->nstate + 1)) != hipSuccess) rc = JAMD_ENOMEM;
+  if (rc == JAMD_OK && hipMalloc(&m->d_logw, sizeof(float) * (gs->nentry > 0 ? gs->nentry : 1)) != hipSuccess) rc = JAMD_ENOMEM;
+  if (rc == JAMD_OK && hipMalloc(&m->d_state2gs, sizeof(int) * nstate) != hipSuccess) rc = JAMD_ENOMEM;
+  if (rc == JAMD_OK &&
+      (hipMemcpy(m->d_st_off, gs->st_off, sizeof(int) * (gs->nstate + 1), hipMemcpyHostToDevice) != hipSuccess ||
+       hipMemcpy(m->d_logw, gs->ent_logw, sizeof(float) * gs->nentry, hipMemcpyHostToDevice) != hipSuccess ||
+       hipMemcpy(m->d_state2gs, state2gs, sizeof(int) * nstate, hipMemcpyHostToDevice) != hipSuccess)) rc = JAMD_ENODEV;
+  if (rc != JAMD_OK) { if (rc == JAMD_ENOMEM) jamd_set_error("jamd_gms_create: out of device memory"); jamd_gms_destroy(m); return rc; }
+  *out = m;
+  return JAMD_OK;
+}
+
+void jamd_gms_destroy(jamd_gms *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->eng->device);
+  if (m->gs) jamd_gmm_destroy(m->gs);
+  void *ptrs[] = { m->d_st_off, m->d_logw, m->d_state2gs, m->d_utt_off, m->d_dens, m->d_fs };
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete m;
+}
+
+int jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *utt_off, int nutt,
+                       float *dev_scores, void *stream) {
+  if (!m || !dev_frames || !dev_scores || T < 0 || (utt_off && nutt < 1)) { jamd_set_error("jamd_gms_apply_dev: bad argument"); return JAMD_EINVAL; }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(m->eng->device));
+  hipStream_t st = jamd_stream(m->eng, stream);
+  const int one[2] = {0, T};
+  if (!utt_off) { utt_off = one; nutt = 1; }
+  if (utt_off[0] != 0 || utt_off[nutt] != T) { jamd_set_error("jamd_gms_apply_dev: utt_off must run from 0 to T"); return JAMD_EINVAL; }
+  int rc;
+  if (nutt + 1 > m->utt_cap) {
+    if (m->d_utt_off) JAMD_HIP(hipFree(m->d_utt_off));
+    m->d_utt_off = nullptr;
+    JAMD_HIP(hipMalloc(&m->d_utt_off, sizeof(int) * (nutt + 1)));
+    m->utt_cap = nutt + 1;
+  }
+  if ((rc = grow(&m->d_dens, &m->dens_cap, sizeof(float) * (size_t)T * m->Egs)) != JAMD_OK) return rc;
+  if ((rc = grow(&m->d_fs, &m->fs_cap, sizeof(float) * (size_t)T * m->Sgs)) != JAMD_OK) return rc;
+  JAMD_HIP(hipMemcpyAsync(m->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
+  if ((rc = jamd_gmm_dens_dev(m->gs, dev_frames, T, m->d_dens, st)) != JAMD_OK) return rc;
+  const size_t lds = sizeof(float) * 3 * (size_t)m->Sgs;
+  if (lds > 60 * 1024) { jamd_set_error("jamd_gms_apply_dev: %d selection states do not fit in LDS", m->Sgs); return JAMD_EINVAL; }
+  hipLaunchKernelGGL(gms_select_kernel, dim3(nutt), dim3(64), lds, st, m->d_dens, m->d_st_off, m->d_logw, m->d_utt_off,
+                     m->d_fs, m->Sgs, m->Egs, m->nbest);
+  hipLaunchKernelGGL(gms_combine_kernel, dim3((m->S + 255) / 256, T < 1024 ? T : 1024), dim3(256), 0, st, m->d_fs,
+                     m->d_state2gs, dev_scores, T, m->S, m->Sgs);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { jamd_set_error("jamd_gms_apply_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  return JAMD_OK;
+}
+
+}  // extern "C"

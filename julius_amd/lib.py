@@ -34,6 +34,7 @@ class GmmDesc(C.Structure):
     ]
 
 
+
 class DnnDesc(C.Structure):
     _fields_ = [
         ("nlayer", C.c_int), ("dims", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p),
@@ -74,6 +75,9 @@ def load():
         "jamd_gmm_book_offsets": (ci, [vp, vp, ci]),
         "jamd_gmm_dens_dev": (ci, [vp, vp, ci, vp, vp]),
         "jamd_gmm_dens_host": (ci, [vp, vp, ci, vp]),
+        "jamd_gms_create": (ci, [vp, P(GmmDesc), vp, ci, ci, P(vp)]),
+        "jamd_gms_destroy": (None, [vp]),
+        "jamd_gms_apply_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
@@ -206,7 +210,7 @@ class Gmm:
         nbook = int(model.get("nbook", 0))
         if st_book is not None:
             self._keep["st_book"] = _i32(st_book)
-        d = GmmDesc()
+        d = self._desc = GmmDesc()
         d.nstate = len(self._keep["st_off"]) - 1
         d.veclen = self._keep["mean"].shape[1]
         d.ndens = self._keep["mean"].shape[0]
@@ -278,6 +282,59 @@ class Gmm:
     def close(self):
         if getattr(self, "h", None):
             load().jamd_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+class Gms:
+    """Gaussian mixture selection stage (jamd_gms): gms_state() of libsent/src/phmm/gms.c."""
+
+    def __init__(self, eng: Engine, gs_model: dict, state2gs, nbest: int):
+        lib = load()
+        self.eng = eng
+        self._keep = {k: (_i32 if k in ("st_off", "ent_dens") else _f32)(gs_model[k])
+                      for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw")}
+        d = GmmDesc()
+        d.nstate = len(self._keep["st_off"]) - 1
+        d.veclen = self._keep["mean"].shape[1]
+        d.ndens = self._keep["mean"].shape[0]
+        d.nentry = len(self._keep["ent_dens"])
+        d.nbook, d.nstream, d.st_book = 0, 1, None
+        for k in self._keep:
+            setattr(d, k, self._keep[k].ctypes.data)
+        self.state2gs = _i32(state2gs)
+        self.S, self.D, self.nbest = len(self.state2gs), d.veclen, int(nbest)
+        h = C.c_void_p()
+        _check(lib.jamd_gms_create(eng.h, C.byref(d), self.state2gs.ctypes.data, self.S, self.nbest, C.byref(h)),
+               "jamd_gms_create")
+        self.h = h
+
+    def apply_dev(self, dev_frames: int, T: int, dev_scores: int, utt_off=None, stream: int = 0):
+        if utt_off is not None:
+            utt_off = _i32(utt_off)
+            _check(load().jamd_gms_apply_dev(self.h, dev_frames, T, utt_off.ctypes.data, len(utt_off) - 1,
+                                             dev_scores, stream or None), "jamd_gms_apply_dev")
+        else:
+            _check(load().jamd_gms_apply_dev(self.h, dev_frames, T, None, 0, dev_scores, stream or None),
+                   "jamd_gms_apply_dev")
+
+    def apply_host(self, frames: np.ndarray, scores: np.ndarray, utt_off=None) -> np.ndarray:
+        fr, sc = _f32(frames), _f32(scores)
+        T = fr.shape[0]
+        assert sc.shape == (T, self.S) and fr.shape[1] == self.D
+        d_fr = DevBuf(self.eng, max(fr.nbytes, 4)).upload(fr)
+        d_sc = DevBuf(self.eng, max(sc.nbytes, 4)).upload(sc)
+        self.apply_dev(d_fr.ptr, T, d_sc.ptr, utt_off)
+        self.eng.sync()
+        return d_sc.download((T, self.S), np.float32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_gms_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -826,3 +826,25 @@ def make_wordlist_utterance(task, seed=0, frames_per_state=3, noise=0.7):
     st = np.repeat(np.array(seq), frames_per_state)
     fr = centre[st] + rng.normal(0, noise, size=(len(st), centre.shape[1]))
     return fr.astype(np.float32), i
+
+
+def make_gs_model(task, M=3, seed=0):
+    """A Gaussian-mixture-selection model (-gshmm) for a triphone task: one 3-state GMM-HMM per
+    PHYSICAL model of the task, its states named "<model><i+1>m" as build_state2gs() looks them up
+    (libsent/src/phmm/gms.c:104-160: center name of the model + state index).  Written next to the
+    task's files; returns the path and the flat model."""
+    names = [f"{c}_v{v}" for c in task["phones"] for v in range(3)] + ["silB", "silE"]
+    S = 3 * len(names)
+    model = make_gmm(S=S, M=M, D=task["model"]["mean"].shape[1], seed=seed + 500)
+    # centre the selection model on the task's acoustic space so that selections are non-trivial
+    rng = np.random.default_rng(seed + 501)
+    cen = task["model"]["centre"]
+    for s in range(S):
+        e0, e1 = int(model["st_off"][s]), int(model["st_off"][s + 1])
+        model["mean"][model["ent_dens"][e0:e1]] = (cen[rng.integers(0, len(cen), e1 - e0)] +
+                                                   rng.normal(0, 0.5, (e1 - e0, cen.shape[1]))).astype(np.float32)
+    state_names = [f"{names[s // 3]}{s % 3 + 2}m" for s in range(S)]
+    phones = [(names[h], (3 * h, 3 * h + 1, 3 * h + 2)) for h in range(len(names))]
+    path = Path(task["dir"]) / "gshmm"
+    write_hmmdefs(path, model, phones=phones, state_names=state_names)
+    return path, model

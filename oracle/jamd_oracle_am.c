@@ -440,3 +440,95 @@ int jo_dnn_outprob(int nlayer, const int *dims, const float *const *w, const flo
   free(buf0); free(buf1);
   return 0;
 }
+
+/* ---- Gaussian mixture selection (-gshmm), libsent/src/phmm/gms.c + gms_gprune.c ------------
+ * Per frame: every selection-model state gets max over its Gaussians of the UNWEIGHTED score, plus
+ * the weight of that Gaussian, times INV_LOG_TEN (compute_g_max(), gms_gprune.c:119-170, GS_MAX_PROB
+ * + LAST_BEST: last frame's best Gaussian first, then from the highest index down, strict >, with
+ * the safe partial-sum cut-off of calc_contprob_with_safe_pruning() :80-110 -- which never changes
+ * the maximum); the nbest highest states are "selected" (sort_gsindex_upward(), gms.c:189-243: a
+ * partial heap sort over an index array that persists from frame to frame); a state of the real
+ * model keeps its real score when its selection state is selected and gets that state's score
+ * otherwise (gms_state(), gms.c:394-412).  scores is [T][S]: real scores in, GMS scores out;
+ * states with state2gs < 0 are left alone (the reference reads out of bounds for them). */
+int jo_gms_apply(int Sgs, int D, const float *mean, const float *ivar, const float *gconst,
+                 const int *st_off, const int *ent_dens, const float *ent_logw,
+                 const int *state2gs, int S, int nbest, const float *frames, int T, float *scores)
+{
+  float *fs = (float *)malloc(sizeof(float) * (size_t)Sgs);
+  int *idx = (int *)malloc(sizeof(int) * (size_t)Sgs);
+  int *last = (int *)malloc(sizeof(int) * (size_t)Sgs);
+  int t, i, s;
+  if (!fs || !idx || !last) return -1;
+  for (i = 0; i < Sgs; i++) { idx[i] = i; last[i] = -1; }
+  for (t = 0; t < T; t++) {
+    const float *vec = frames + (size_t)t * D;
+    for (i = 0; i < Sgs; i++) {                                     /* compute_gs_scores() */
+      const int e0 = st_off[i], n = st_off[i + 1] - st_off[i];
+      float maxprob = JO_LOG_ZERO; int maxi, k, pass;
+      /* order: last best first (if any), then n-1 .. 0 skipping it */
+      maxi = (last[i] != -1) ? last[i] : n - 1;
+      for (pass = 0; pass < 2; pass++) {
+        const int k0 = pass == 0 ? maxi : n - 1, k1 = pass == 0 ? maxi : 0;
+        for (k = k0; k >= k1; k--) {
+          float tmp, thr, prob; int d, g, cut = 0;
+          if (pass == 1 && k == ((last[i] != -1) ? last[i] : n - 1)) continue;
+          g = ent_dens[e0 + k];
+          if (g < 0) prob = JO_LOG_ZERO;
+          else {
+            thr = (pass == 0 ? JO_LOG_ZERO : maxprob) * (-2.0f);
+            tmp = gconst[g];
+            for (d = 0; d < D; d++) {
+              float x = vec[d] - mean[(size_t)g * D + d];
+              tmp += x * x * ivar[(size_t)g * D + d];
+              if (tmp > thr) { cut = 1; break; }
+            }
+            prob = cut ? JO_LOG_ZERO : tmp * -0.5f;
+          }
+          if (pass == 0) { maxprob = prob; }
+          else if (prob > maxprob) { maxprob = prob; maxi = k; }
+        }
+      }
+      last[i] = maxi;
+      {
+        float logprobsum = 0.0f;
+        logprobsum += (maxprob + ent_logw[e0 + maxi]) * 1.0f;
+        fs[i] = (float)(logprobsum * JO_INV_LOG_TEN);
+      }
+    }
+    {                                                               /* sort_gsindex_upward() */
+      const int totalnum = Sgs, neednum = nbest < Sgs ? nbest : Sgs;
+      int n, root, child, parent, sd;
+#define SD_(A) idx[(A) - 1]
+#define SV_(A) (fs[idx[(A) - 1]])
+      for (root = totalnum / 2; root >= 1; root--) {
+        sd = SD_(root); parent = root;
+        while ((child = parent * 2) <= totalnum) {
+          if (child < totalnum && SV_(child) < SV_(child + 1)) child++;
+          if (fs[sd] >= SV_(child)) break;
+          SD_(parent) = SD_(child); parent = child;
+        }
+        SD_(parent) = sd;
+      }
+      n = totalnum;
+      while (n > totalnum - neednum) {
+        sd = SD_(n); SD_(n) = SD_(1); n--; parent = 1;
+        while ((child = parent * 2) <= n) {
+          if (child < n && SV_(child) < SV_(child + 1)) child++;
+          if (fs[sd] >= SV_(child)) break;
+          SD_(parent) = SD_(child); parent = child;
+        }
+        SD_(parent) = sd;
+      }
+#undef SD_
+#undef SV_
+      for (i = totalnum - neednum; i < totalnum; i++) fs[idx[i]] = JO_LOG_ZERO;    /* do_gms(): selected */
+    }
+    for (s = 0; s < S; s++) {                                       /* gms_state() */
+      const int gsid = state2gs[s];
+      if (gsid >= 0 && fs[gsid] != JO_LOG_ZERO) scores[(size_t)t * S + s] = fs[gsid];
+    }
+  }
+  free(fs); free(idx); free(last);
+  return 0;
+}

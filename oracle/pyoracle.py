@@ -101,6 +101,20 @@ class Oracle:
         assert rc == 0
         return out
 
+    def gms_apply(self, gs, frames, scores):
+        """Gaussian mixture selection: gs = dict(model=flat selection model, state2gs, nbest) as
+        RefAM.gms() returns it; scores [T][S] real state scores -> the scores gms_state() returns."""
+        m = gs["model"]
+        mean, ivar, gconst = _f32(m["mean"]), _f32(m["ivar"]), _f32(m["gconst"])
+        st_off, ent_dens, ent_logw = _i32(m["st_off"]), _i32(m["ent_dens"]), _f32(m["ent_logw"])
+        s2g = _i32(gs["state2gs"])
+        fr = _f32(frames)
+        out = np.array(scores, dtype=np.float32, order="C", copy=True)
+        rc = self.lib.jo_gms_apply(len(st_off) - 1, fr.shape[1], _p(mean), _p(ivar), _p(gconst), _p(st_off), _p(ent_dens),
+                                   _p(ent_logw), _p(s2g), out.shape[1], int(gs["nbest"]), _p(fr), fr.shape[0], _p(out))
+        assert rc == 0
+        return out
+
     def tmix_topn(self, model, book, frames, gprune, gprune_num):
         mean, ivar, gconst = _f32(model["mean"]), _f32(model["ivar"]), _f32(model["gconst"])
         # a codebook's densities, in codebook order, are the entries of any state tied to it
@@ -204,9 +218,16 @@ class Ref:
         lib.jref_simd_avail.restype = ci
         lib.jref_quiet(1 if quiet else 0)
 
-    def am_load(self, hmmdefs, hmmlist=None, gprune="none", gprune_num=2, cdset="max", cdmax=3):
-        h = self.lib.jref_am_load(str(hmmdefs).encode(), str(hmmlist).encode() if hmmlist else None,
-                                  REF_GPRUNE[gprune], gprune_num, REF_IWCD[cdset], cdmax)
+    def am_load(self, hmmdefs, hmmlist=None, gprune="none", gprune_num=2, cdset="max", cdmax=3, gshmm=None, gms_num=24):
+        """gshmm: Gaussian mixture selection model (-gshmm), gms_num = -gsnum."""
+        if gshmm is not None:
+            self.lib.jref_am_load_gms.restype = C.c_void_p
+            self.lib.jref_am_load_gms.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+            h = self.lib.jref_am_load_gms(str(hmmdefs).encode(), str(hmmlist).encode() if hmmlist else None,
+                                          REF_GPRUNE[gprune], gprune_num, REF_IWCD[cdset], cdmax, str(gshmm).encode(), gms_num)
+        else:
+            h = self.lib.jref_am_load(str(hmmdefs).encode(), str(hmmlist).encode() if hmmlist else None,
+                                      REF_GPRUNE[gprune], gprune_num, REF_IWCD[cdset], cdmax)
         if not h:
             raise RuntimeError(f"reference failed to load {hmmdefs}")
         return RefAM(self, h)
@@ -285,6 +306,23 @@ class RefAM:
         else:
             m["st_book"] = None
         return m
+
+    def gms(self):
+        """Gaussian mixture selection data of a model loaded with gshmm=...: the flattened selection
+        model, state2gs[S] and the number of selected states (gms.c)."""
+        lib = self.ref.lib
+        lib.jref_am_gms_model.restype = C.c_void_p
+        lib.jref_am_gms_model.argtypes = [C.c_void_p]
+        lib.jref_am_gms_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        v = lib.jref_am_gms_model(self.h)
+        if not v:
+            raise RuntimeError("model was loaded without a selection model")
+        gs = RefAM(self.ref, v).export()
+        s2g = np.zeros(self.S, np.int32)
+        nb = C.c_int()
+        n = lib.jref_am_gms_map(self.h, _p(s2g), C.byref(nb))
+        assert n == len(gs["st_off"]) - 1
+        return dict(model=gs, state2gs=s2g, nbest=int(nb.value))
 
     def save_blob(self, path):
         self.ref.lib.jref_am_save.argtypes = [C.c_void_p, C.c_char_p]

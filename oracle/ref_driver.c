@@ -33,6 +33,8 @@ typedef struct {
   jamd_flat_gmm flat;
   int have_flat;
   HTK_HMM_State **by_id;   /* state pointer by id */
+  HTK_HMM_INFO *gshmm;     /* Gaussian mixture selection model (-gshmm), or NULL */
+  int view_only;           /* wrapper around another model's gshmm: nothing to free but the flat copy */
 } jref_am;
 
 static double now_sec(void) {
@@ -60,11 +62,52 @@ void *jref_am_load(const char *hmmdefs, const char *hmmlist, int gprune, int gpr
   return a;
 }
 
+/* The same with Gaussian mixture selection (-gshmm file, -gsnum n): outprob_init() wires
+ * gms_state() in front of the state computation (outprob_init.c:150-180). */
+void *jref_am_load_gms(const char *hmmdefs, const char *hmmlist, int gprune, int gprune_num,
+                       int cdset_method, int cdmax_num, const char *gshmm, int gms_num)
+{
+  jref_am *a = (jref_am *)calloc(1, sizeof(jref_am));
+  HTK_HMM_State *st;
+  a->hmminfo = hmminfo_new();
+  if (!init_hmminfo(a->hmminfo, (char *)hmmdefs, (char *)hmmlist, NULL)) { free(a); return NULL; }
+  a->hmminfo->cdset_method = cdset_method;
+  a->hmminfo->cdmax_num = cdmax_num;
+  a->gshmm = hmminfo_new();
+  if (!init_hmminfo(a->gshmm, (char *)gshmm, NULL, NULL)) { free(a); return NULL; }
+  memset(&a->wrk, 0, sizeof(a->wrk));
+  if (!outprob_init(&a->wrk, a->hmminfo, a->gshmm, gms_num, gprune, gprune_num, NULL)) { free(a); return NULL; }
+  a->by_id = (HTK_HMM_State **)calloc(a->hmminfo->totalstatenum, sizeof(HTK_HMM_State *));
+  for (st = a->hmminfo->ststart; st; st = st->next) a->by_id[st->id] = st;
+  return a;
+}
+
+/* A read-only view of the selection model for jref_am_dims() / jref_am_export(). */
+void *jref_am_gms_model(void *h)
+{
+  jref_am *a = (jref_am *)h, *v;
+  if (!a || !a->gshmm) return NULL;
+  v = (jref_am *)calloc(1, sizeof(jref_am));
+  v->hmminfo = a->gshmm; v->view_only = 1;
+  return v;
+}
+
+/* state2gs[S] (gms.c:104-160) and the number of selected states; returns the GS state count. */
+int jref_am_gms_map(void *h, int *state2gs, int *nbest)
+{
+  jref_am *a = (jref_am *)h;
+  if (!a || !a->gshmm) return -1;
+  memcpy(state2gs, a->wrk.state2gs, sizeof(int) * (size_t)a->hmminfo->totalstatenum);
+  *nbest = a->wrk.my_nbest;
+  return a->wrk.gsset_num;
+}
+
 void jref_am_free(void *h)
 {
   jref_am *a = (jref_am *)h;
   if (!a) return;
   if (a->have_flat) jamd_flat_gmm_free(&a->flat);
+  if (a->view_only) { free(a); return; }
   outprob_free(&a->wrk);
   hmminfo_free(a->hmminfo);
   free(a->by_id);

@@ -189,9 +189,32 @@ def main_beam():
                     nword=70, wrap=False)
 
 
+def main_gms():
+    """S1: Gaussian mixture selection (-gshmm, -gsnum 4 / 24): what outprob_state() returns for every
+    state of the triphone model once gms_state() stands in front of it."""
+    ref = pyoracle.Ref()
+    tmp = Path(tempfile.mkdtemp())
+    task = synth.make_triphone_task(tmp, seed=5, nword=60)
+    gpath, _ = synth.make_gs_model(task, seed=5)
+    frs = [synth.make_utterance(task, nwords=2 + u, seed=50 + u)[0] for u in range(3)]
+    full = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
+    out = {"full_" + k: v for k, v in model_arrays(full).items()}
+    out["frames"] = np.concatenate(frs)
+    out["utt_off"] = np.cumsum([0] + [len(f) for f in frs]).astype(np.int32)
+    for nbest in (4, 24):
+        am = ref.am_load(task["hmmdefs"], task["hmmlist"], gshmm=gpath, gms_num=nbest)
+        gs = am.gms()
+        out.update({"gs_" + k: v for k, v in model_arrays(gs["model"]).items()})
+        out["state2gs"] = gs["state2gs"]
+        out["out_%d" % nbest] = np.concatenate([am.outprob(f) for f in frs])
+    save("gms.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "beam":
-        main_beam()
-    else:
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("am", "all"):
         main()
+    if what in ("beam", "all"):
         main_beam()
+    if what in ("gms", "all"):
+        main_gms()

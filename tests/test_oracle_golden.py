@@ -82,3 +82,17 @@ def test_dnn_fma_path(oracle):
     for mode in (po.DNN_AVX, po.DNN_SSE, po.DNN_SCALAR):
         got = oracle.dnn_outprob(dnn, fr, mode)
         assert np.all(np.abs(got - want) <= 1e-4 * np.maximum(1.0, np.abs(want)))
+
+
+@pytest.mark.parametrize("nbest", [4, 24])
+def test_gaussian_mixture_selection(oracle, nbest):
+    """gms_state() (gms.c:394-412) on the committed reference outputs, utterance by utterance."""
+    z = np.load(GOLDEN / "gms.npz")
+    sub = lambda p: {k[len(p):]: z[k] for k in z.files if k.startswith(p)}
+    full, gs = sub("full_"), dict(model=sub("gs_"), state2gs=z["state2gs"], nbest=nbest)
+    full.update(nbook=0, st_book=None)
+    used = z["state2gs"] >= 0
+    for a, b in zip(z["utt_off"][:-1], z["utt_off"][1:]):
+        fr = z["frames"][a:b]
+        got = oracle.gms_apply(gs, fr, oracle.gmm_outprob(full, fr, po.GPRUNE_NONE))
+        assert np.array_equal(got[:, used], z["out_%d" % nbest][a:b][:, used])

@@ -82,3 +82,22 @@ def test_gmm_blob_roundtrip(ref, tmp_path):
         assert (a["st_book"] is None) == (b["st_book"] is None) and a["nbook"] == b["nbook"]
         if a["st_book"] is not None:
             assert np.array_equal(a["st_book"], b["st_book"])
+
+
+@pytest.mark.parametrize("nbest", [4, 8, 24])
+def test_gaussian_mixture_selection(oracle, ref, tmp_path, nbest):
+    """-gshmm / -gsnum: gms_state() (gms.c:394) returns the real score for states whose selection
+    state is among the nbest of the frame and the selection state's score otherwise."""
+    task = synth.make_triphone_task(tmp_path, seed=5, nword=60)
+    gpath, _ = synth.make_gs_model(task, seed=5)
+    am = ref.am_load(task["hmmdefs"], task["hmmlist"], gshmm=gpath, gms_num=nbest)
+    gs = am.gms()
+    assert gs["nbest"] == nbest and len(gs["model"]["st_off"]) - 1 == 78
+    full_model = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=2 + u, seed=50 + u)
+        want = am.outprob(fr)
+        got = oracle.gms_apply(gs, fr, oracle.gmm_outprob(full_model, fr))
+        used = gs["state2gs"] >= 0              # states outside every model: the reference reads out of bounds
+        assert np.array_equal(got[:, used], want[:, used])
+        assert 0.0 < (got[:, used] != oracle.gmm_outprob(full_model, fr)[:, used]).mean() < 1.0
