@@ -37,7 +37,7 @@ typedef struct {
   WCHMM_INFO *wchmm;           /* lexicon the handles were built from */
   HTK_HMM_INFO *hmminfo;
   int beam_width; float bs_width;
-  jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam;
+  jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam; jamd_gms *gms;
   int nstate;
   int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
   /* streaming state of the current utterance */
@@ -75,10 +75,11 @@ static void ctx_release(pass1_ctx *c)
   pre_clear(c);
   if (c->beam) jamd_beam_destroy(c->beam);
   if (c->lex) jamd_lexicon_destroy(c->lex);
+  if (c->gms) jamd_gms_destroy(c->gms);
   if (c->gmm) jamd_gmm_destroy(c->gmm);
   if (c->dnn) jamd_dnn_destroy(c->dnn);
   free(c->host_scores); c->host_scores = NULL; c->host_cap = 0;
-  c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL;
+  c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL; c->gms = NULL;
 }
 
 static pass1_ctx *ctx_get(RecogProcess *r)
@@ -119,8 +120,8 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
     return FALSE;
   }
-  if (r->am->hmmwrk.OP_gshmm != NULL) {
-    jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) changes the scores it skips; run without it (the device scores every state)\n");
+  if (r->am->hmmwrk.OP_gshmm != NULL && r->am->dnn != NULL) {
+    jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) with a DNN-HMM is not supported\n");
     return FALSE;
   }
   if (r->am->dnn != NULL) {                    /* DNN-HMM: dnn_calc_outprob() for the whole utterance */
@@ -145,6 +146,22 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       c->nstate = fg.desc.nstate;
       jamd_flat_gmm_free(&fg);
       if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+    }
+    if (r->am->hmmwrk.OP_gshmm != NULL) {
+      /* Gaussian mixture selection (gms_init(), libsent/src/phmm/gms.c:275-317): the device scores
+       * every state anyway; the stage below REPLACES the scores the reference would not have
+       * computed by the selection state's, so the search sees the reference's numbers */
+      HMMWork *wrk = &(r->am->hmmwrk);
+      jamd_flat_gmm fs;
+      int *map = (int *)malloc(sizeof(int) * (size_t)c->nstate), s;
+      if (map == NULL || jamd_flatten_hmminfo(wrk->OP_gshmm, &fs) != 0) { free(map); jlog("ERROR: jamd: cannot flatten the selection model\n"); return FALSE; }
+      for (s = 0; s < c->nstate; s++)                  /* selection state ids are the flattened order */
+        map[s] = (wrk->state2gs[s] >= 0 && wrk->state2gs[s] < wrk->gsset_num) ? wrk->gsset[wrk->state2gs[s]].state->id : -1;
+      rc = jamd_gms_create(g_eng, &fs.desc, map, c->nstate, wrk->my_nbest, &c->gms);
+      jamd_flat_gmm_free(&fs); free(map);
+      if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+      jlog("STAT: jamd: Gaussian mixture selection on the device (%d selection states, %d selected per frame)\n",
+           wrk->gsset_num, wrk->my_nbest);
     }
   }
   {
@@ -225,6 +242,7 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
       jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||
       (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, (int)total, d_scores, NULL)
               : jamd_gmm_outprob_dev(c->gmm, d_frames, (int)total, d_scores, NULL)) != JAMD_OK ||
+      (c->gms && jamd_gms_apply_dev(c->gms, d_frames, (int)total, off, n, d_scores, NULL) != JAMD_OK) ||
       jamd_beam_pass1_dev(bb, d_scores, c->nstate, off, n, NULL) != JAMD_OK ||
       jamd_engine_sync(g_eng) != JAMD_OK || jamd_beam_results(bb, res, n) != JAMD_OK) goto out;
   for (u = 0; u < n; u++) {
@@ -300,6 +318,7 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   r->have_interim = FALSE;
   c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
   if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) c->chunk = 0;   /* one final push */
+  if (c->gms != NULL) c->chunk = 0;                   /* the selection carries state from frame to frame */
   c->pushed = 0; c->failed = 0; c->hit = -1;
   if (c->npre > 0 && param->samplenum > 0) {          /* decoded ahead in a batch? */
     float *fr = jamd_pack_param(param, 0, param->samplenum);
@@ -342,7 +361,8 @@ static boolean push_frames(pass1_ctx *c, RecogProcess *r, HTK_Param *param, int 
         jamd_malloc(g_eng, sizeof(float) * (size_t)n * c->nstate, (void **)&d_scores) != JAMD_OK ||
         jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * (size_t)n * param->veclen) != JAMD_OK ||
         (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, n, d_scores, NULL)
-                : jamd_gmm_outprob_dev(c->gmm, d_frames, n, d_scores, NULL)) != JAMD_OK) goto out;
+                : jamd_gmm_outprob_dev(c->gmm, d_frames, n, d_scores, NULL)) != JAMD_OK ||
+        (c->gms && jamd_gms_apply_dev(c->gms, d_frames, n, NULL, 0, d_scores, NULL) != JAMD_OK)) goto out;
     if (keep) {                                      /* rows for the reference's outprob cache (2nd pass) */
       if (upto > c->host_cap) {
         c->host_cap = upto + 1024;

@@ -289,6 +289,51 @@ def test_batch_driver_equals_per_utterance(ref, tmp_path, monkeypatch, lm):
     assert amd.prefetch_served() == 7                 # the queued inputs really came from the batch launch
 
 
+@pytest.mark.parametrize("mode", ["strict", "fast", "batch"])
+def test_gaussian_mixture_selection_two_pass(ref, tmp_path, monkeypatch, mode):
+    """-gshmm / -gsnum.  The plain reference scores the selection model, keeps the
+    nbest states per frame and answers every other state with its selection state's score
+    (gms_state(), gms.c:394-412); the shim runs that stage on the device after the full scoring, so
+    the search and the 2nd pass see the same numbers: same trellis, same pass-1 and final results."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "25")     # ignored under GMS: the selection carries state across frames
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    task = synth.make_triphone_task(tmp_path, seed=81, nword=120, nphone=10, S=160)
+    gpath, _ = synth.make_gs_model(task, seed=81)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-gprune", "none", "-b", "200", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5",
+            "-gshmm", str(gpath), "-gsnum", "6"]
+    nogms = pyoracle.RefEngine(ref, args[:-4])
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    files = []
+    for u in range(4):
+        fr, _ = synth.make_utterance(task, nwords=3 + u, seed=8100 + u)
+        files.append(tmp_path / f"u{u}.mfc")
+        synth.write_htk_param(files[-1], fr)
+    if mode == "batch":
+        amd.prefetch(files)
+    changed = 0
+    for f in files:
+        tr0, (w0, s0) = plain.recognize(f)
+        fin0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(f)
+        fin1 = amd.final_result()
+        assert np.array_equal(w1, w0) and s1 == s0
+        assert fin1[0] == fin0[0] and np.array_equal(fin1[1], fin0[1]) and fin1[2] == fin0[2]
+        if mode == "strict":
+            for k in tr0:
+                assert np.array_equal(tr1[k], tr0[k]), k
+        else:
+            assert_canonical_close(tr1, tr0, max_diff=8)
+        _, (_, s2) = nogms.recognize(f)
+        changed += s2 != s0
+    assert changed > 0                                # the selection really changed what the search saw
+    if mode == "batch":
+        assert amd.prefetch_served() == len(files)
+
+
 def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monkeypatch):
     """`-input outprob`: the input file already holds the [T][S] state scores (what -outprobout
     writes); the shim hands them to the device search unscored and Julius' 2nd pass reads them from
