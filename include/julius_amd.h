@@ -163,9 +163,16 @@ int  jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *hos
 typedef struct jamd_gms jamd_gms;
 int  jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2gs, int nstate, int nbest,
                      jamd_gms **out);
+/* A selection model file written by jamd_export (-gshmm given): jamd_gms_save(),
+ * julius_amd/shim/jamd_flatten.c. */
+int  jamd_gms_load(jamd_engine *e, const char *path, jamd_gms **out);
+int  jamd_gms_nstate(const jamd_gms *m);     /* states of the REAL model (columns of the score matrix) */
 void jamd_gms_destroy(jamd_gms *m);
 int  jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *utt_off, int nutt,
                         float *dev_scores, void *stream);
+/* The same over host buffers (frames in, scores in and out), on the engine's own stream. */
+int  jamd_gms_apply_host(jamd_gms *m, const float *host_frames, int T, const int *utt_off, int nutt,
+                         float *host_scores);
 
 /* ------------------------------------------------- pseudo-phone state sets */
 /* CD_State_Set table (htk_hmm.h:249-253): set i = states[set_off[i]..set_off[i+1]).

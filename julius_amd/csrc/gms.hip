@@ -157,6 +157,8 @@ int jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2gs
   return JAMD_OK;
 }
 
+int jamd_gms_nstate(const jamd_gms *m) { return m ? m->S : 0; }
+
 void jamd_gms_destroy(jamd_gms *m) {
   if (!m) return;
   (void)hipSetDevice(m->eng->device);
@@ -195,6 +197,31 @@ int jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *u
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_gms_apply_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   return JAMD_OK;
+}
+
+int jamd_gms_apply_host(jamd_gms *m, const float *host_frames, int T, const int *utt_off, int nutt,
+                        float *host_scores) {
+  if (!m || !host_frames || !host_scores || T < 0) { jamd_set_error("jamd_gms_apply_host: bad argument"); return JAMD_EINVAL; }
+  if (T == 0) return JAMD_OK;
+  JAMD_HIP(hipSetDevice(m->eng->device));
+  hipStream_t st = m->eng->stream;
+  const int D = jamd_gmm_veclen(m->gs);
+  float *d_fr = nullptr, *d_sc = nullptr;
+  int rc = JAMD_OK;
+  if (hipMalloc(&d_fr, sizeof(float) * (size_t)T * D) != hipSuccess ||
+      hipMalloc(&d_sc, sizeof(float) * (size_t)T * m->S) != hipSuccess) {
+    jamd_set_error("jamd_gms_apply_host: out of device memory"); rc = JAMD_ENOMEM;
+  }
+  if (rc == JAMD_OK && (hipMemcpyAsync(d_fr, host_frames, sizeof(float) * (size_t)T * D, hipMemcpyHostToDevice, st) != hipSuccess ||
+                        hipMemcpyAsync(d_sc, host_scores, sizeof(float) * (size_t)T * m->S, hipMemcpyHostToDevice, st) != hipSuccess)) {
+    jamd_set_error("jamd_gms_apply_host: copy failed"); rc = JAMD_ENODEV;
+  }
+  if (rc == JAMD_OK) rc = jamd_gms_apply_dev(m, d_fr, T, utt_off, nutt, d_sc, st);
+  if (rc == JAMD_OK && (hipMemcpyAsync(host_scores, d_sc, sizeof(float) * (size_t)T * m->S, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess)) { jamd_set_error("jamd_gms_apply_host: copy failed"); rc = JAMD_ELAUNCH; }
+  if (d_fr) (void)hipFree(d_fr);
+  if (d_sc) (void)hipFree(d_sc);
+  return rc;
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 //
 //   jamd_gmm_load()      "JAMDGMM1" blob  (written by jamd_gmm_save(), julius_amd/shim/jamd_flatten.c,
 //                                          from the HTK_HMM_INFO Julius' own hmmdefs / binhmm reader built)
+//   jamd_gms_load()      "JAMDGMM1" blob with the records "state2gs" and "gms" (jamd_gms_save(): the
+//                                          selection model of -gshmm and its state map)
 //   jamd_lexicon_load()  "JAMDLEX1" blob  (written by jamd_lexicon_save(), julius_amd/shim/jamd_flatten_lex.c,
 //                                          from the tree lexicon + LM tables of a RecogProcess)
 //   jamd_dnn_load()      Julius' own DNN definition: the -dnnconf text file, the NumPy .npy weight and
@@ -121,6 +123,30 @@ int jamd_gmm_load(jamd_engine *e, const char *path, int gprune, int gprune_num, 
   if (b.count("st_book")) d.st_book = view<int>(b, "st_book", 0, d.nstate, ok);
   if (!ok) return JAMD_EINVAL;
   return jamd_gmm_create(e, &d, gprune, gprune_num, out);
+}
+
+int jamd_gms_load(jamd_engine *e, const char *path, jamd_gms **out) {
+  if (!e || !path || !out) { jamd_set_error("jamd_gms_load: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  Blob b;
+  if (!read_blob(path, "JAMDGMM1", b)) return JAMD_EINVAL;
+  bool ok = true;
+  const int *ints = view<int>(b, "ints", 0, 6, ok);
+  const int *gms = view<int>(b, "gms", 0, 1, ok);
+  if (!ok) { jamd_set_error("%s: not a selection model (no \"gms\" record)", path); return JAMD_EINVAL; }
+  jamd_gmm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.nstate = ints[0]; d.veclen = ints[1]; d.ndens = ints[2]; d.nentry = ints[3]; d.nbook = ints[4]; d.nstream = ints[5];
+  if (d.nstate <= 0 || d.veclen <= 0 || d.ndens <= 0 || d.nentry <= 0) { jamd_set_error("%s: bad sizes", path); return JAMD_EINVAL; }
+  d.mean = view<float>(b, "mean", 1, (long long)d.ndens * d.veclen, ok);
+  d.ivar = view<float>(b, "ivar", 1, (long long)d.ndens * d.veclen, ok);
+  d.gconst = view<float>(b, "gconst", 1, d.ndens, ok);
+  d.st_off = view<int>(b, "st_off", 0, d.nstate + 1, ok);
+  d.ent_dens = view<int>(b, "ent_dens", 0, d.nentry, ok);
+  d.ent_logw = view<float>(b, "ent_logw", 1, d.nentry, ok);
+  const int *map = view<int>(b, "state2gs", 0, -1, ok);
+  if (!ok) return JAMD_EINVAL;
+  return jamd_gms_create(e, &d, map, b["state2gs"].count, gms[0], out);
 }
 
 int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {

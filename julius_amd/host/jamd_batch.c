@@ -2,7 +2,7 @@
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
  *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict] [-shard R N]
- *              (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
+ *              (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
  *
  * -shard R N: this process takes the utterances u with u % N == R (one process per GPU, e.g.
  * `for r in 0..7: jamd_batch -d $r -shard $r 8 ...`): utterances are independent, the model is
@@ -60,10 +60,10 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
 
 int main(int argc, char **argv)
 {
-  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL;
+  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL;
   int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, shard_r = 0, shard_n = 1, i;
   float bs = -1.0f;
-  jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_lexicon *lx; jamd_beam *bm;
+  jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_lexicon *lx; jamd_beam *bm;
   char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first;
   char line[4096];
   FILE *fl;
@@ -77,13 +77,14 @@ int main(int argc, char **argv)
     } else if (!strcmp(argv[i], "-strict")) strict = 1;
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
+    else if (!strcmp(argv[i], "-gms") && i + 1 < argc) gmsp = argv[++i];
     else if (!strcmp(argv[i], "-dnnconf") && i + 1 < argc) dnnconf = argv[++i];
     else if (!strcmp(argv[i], "-lex") && i + 1 < argc) lexp = argv[++i];
     else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
     else { fprintf(stderr, "jamd_batch: unknown option %s\n", argv[i]); return 2; }
   }
-  if ((am == NULL) == (dnnconf == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) {
-    fprintf(stderr, "usage: jamd_batch (-am model.blob | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
+  if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) {
+    fprintf(stderr, "usage: jamd_batch (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
                     "[-d dev] [-b beam] [-bs width] [-gprune safe N] [-strict] [-shard R N]\n");
     return 2;
   }
@@ -93,6 +94,10 @@ int main(int argc, char **argv)
   else if (jamd_dnn_load(e, dnnconf, &dn) != JAMD_OK) die("DNN");
   veclen = gm ? jamd_gmm_veclen(gm) : jamd_dnn_veclen(dn);
   nstate = gm ? jamd_gmm_nstate(gm) : jamd_dnn_nstate(dn);
+  if (gmsp != NULL) {                                 /* -gshmm of the exported configuration */
+    if (jamd_gms_load(e, gmsp, &gs) != JAMD_OK) die("selection model");
+    if (jamd_gms_nstate(gs) != nstate) { fprintf(stderr, "jamd_batch: %s belongs to another acoustic model\n", gmsp); return 1; }
+  }
   if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
   if (jamd_beam_create(e, lx, beam, bs, 256, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
   if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
@@ -124,6 +129,7 @@ int main(int argc, char **argv)
         jamd_memcpy_h2d(e, d_frames, frames, sizeof(float) * used) != JAMD_OK) die("device buffers");
     if ((gm ? jamd_gmm_outprob_dev(gm, d_frames, off[n], d_scores, NULL)
             : jamd_dnn_outprob_dev(dn, d_frames, off[n], d_scores, NULL)) != JAMD_OK) die("scoring");
+    if (gs != NULL && jamd_gms_apply_dev(gs, d_frames, off[n], off, n, d_scores, NULL) != JAMD_OK) die("Gaussian mixture selection");
     if (jamd_beam_pass1_dev(bm, d_scores, nstate, off, n, NULL) != JAMD_OK || jamd_engine_sync(e) != JAMD_OK ||
         jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
     for (u = 0; u < n; u++) {
@@ -135,6 +141,7 @@ int main(int argc, char **argv)
     jamd_free(e, d_frames); jamd_free(e, d_scores); free(frames);
   }
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
+  if (gs) jamd_gms_destroy(gs);
   if (gm) jamd_gmm_destroy(gm);
   if (dn) jamd_dnn_destroy(dn);
   jamd_engine_destroy(e);

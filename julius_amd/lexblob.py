@@ -58,13 +58,15 @@ def load_gmm(path) -> dict:
         rec[name] = np.frombuffer(raw, dtype=_DT[dtype], count=count, offset=pos).copy()
         pos += 4 * count
     S, D, G, E, nbook, nstream = (int(x) for x in rec.pop("ints"))
-    return dict(mean=rec["mean"].reshape(G, D), ivar=rec["ivar"].reshape(G, D), gconst=rec["gconst"],
+    extra = dict(state2gs=rec["state2gs"], nbest=int(rec["gms"][0])) if "gms" in rec else {}
+    return dict(**extra, mean=rec["mean"].reshape(G, D), ivar=rec["ivar"].reshape(G, D), gconst=rec["gconst"],
                 st_off=rec["st_off"], ent_dens=rec["ent_dens"], ent_logw=rec["ent_logw"],
                 st_book=rec.get("st_book") if nbook > 0 else None, nbook=nbook, nstream=nstream)
 
 
-def save_gmm(model: dict, path) -> None:
-    """Same format as jamd_gmm_save() (julius_amd/shim/jamd_flatten.c)."""
+def save_gmm(model: dict, path, state2gs=None, nbest: int = 0) -> None:
+    """Same format as jamd_gmm_save() (julius_amd/shim/jamd_flatten.c); with state2gs and nbest the
+    selection-model file of jamd_gms_save()."""
     mean = np.ascontiguousarray(model["mean"], np.float32)
     st_book = model.get("st_book")
     recs = [("ints", np.array([len(model["st_off"]) - 1, mean.shape[1], mean.shape[0], len(model["ent_dens"]),
@@ -74,6 +76,8 @@ def save_gmm(model: dict, path) -> None:
             ("ent_logw", np.asarray(model["ent_logw"], np.float32))]
     if st_book is not None:
         recs.append(("st_book", np.asarray(st_book, np.int32)))
+    if state2gs is not None:
+        recs += [("state2gs", np.asarray(state2gs, np.int32)), ("gms", np.array([nbest], np.int32))]
     out = [b"JAMDGMM1", struct.pack("<i", len(recs))]
     for name, arr in recs:
         arr = np.ascontiguousarray(arr)

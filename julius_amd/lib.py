@@ -77,7 +77,10 @@ def load():
         "jamd_gmm_dens_host": (ci, [vp, vp, ci, vp]),
         "jamd_gms_create": (ci, [vp, P(GmmDesc), vp, ci, ci, P(vp)]),
         "jamd_gms_destroy": (None, [vp]),
+        "jamd_gms_load": (ci, [vp, C.c_char_p, P(vp)]),
+        "jamd_gms_nstate": (ci, [vp]),
         "jamd_gms_apply_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
+        "jamd_gms_apply_host": (ci, [vp, vp, ci, vp, ci, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
@@ -313,6 +316,17 @@ class Gms:
                "jamd_gms_create")
         self.h = h
 
+    @classmethod
+    def from_file(cls, eng: Engine, path, veclen: int):
+        """jamd_gms_load(): the selection model file jamd_export writes next to PREFIX.am."""
+        self = cls.__new__(cls)
+        self.eng, self._keep = eng, {}
+        h = C.c_void_p()
+        _check(load().jamd_gms_load(eng.h, str(path).encode(), C.byref(h)), "jamd_gms_load")
+        self.h = h
+        self.S, self.D = load().jamd_gms_nstate(h), int(veclen)
+        return self
+
     def apply_dev(self, dev_frames: int, T: int, dev_scores: int, utt_off=None, stream: int = 0):
         if utt_off is not None:
             utt_off = _i32(utt_off)
@@ -326,11 +340,11 @@ class Gms:
         fr, sc = _f32(frames), _f32(scores)
         T = fr.shape[0]
         assert sc.shape == (T, self.S) and fr.shape[1] == self.D
-        d_fr = DevBuf(self.eng, max(fr.nbytes, 4)).upload(fr)
-        d_sc = DevBuf(self.eng, max(sc.nbytes, 4)).upload(sc)
-        self.apply_dev(d_fr.ptr, T, d_sc.ptr, utt_off)
-        self.eng.sync()
-        return d_sc.download((T, self.S), np.float32)
+        out = sc.copy()
+        off = _i32(utt_off) if utt_off is not None else None
+        _check(load().jamd_gms_apply_host(self.h, fr.ctypes.data, T, off.ctypes.data if off is not None else None,
+                                          len(off) - 1 if off is not None else 0, out.ctypes.data), "jamd_gms_apply_host")
+        return out
 
     def close(self):
         if getattr(self, "h", None):

@@ -9,6 +9,7 @@
  * the recogniser would (j_final_fusion() inside j_create_instance_from_jconf()), and writes
  *   PREFIX.am    "JAMDGMM1"  flattened GMM-HMM         (jamd_gmm_save; absent for a DNN-HMM, whose
  *                                                       -dnnconf files the engine reads directly)
+ *   PREFIX.gms   "JAMDGMM1"  selection model of -gshmm  (jamd_gms_save; only with -gshmm)
  *   PREFIX.lex   "JAMDLEX1"  tree lexicon + LM tables   (jamd_lexicon_save)
  * for workers that never link Julius (jamd_gmm_load / jamd_lexicon_load / jamd_dnn_load,
  * julius_amd/host/jamd_batch.c).  Compiled inside the Julius tree like the other shim files.
@@ -53,6 +54,20 @@ int main(int argc, char **argv)
     jamd_flat_gmm_free(&fg);
     if (rc != JAMD_OK) { fprintf(stderr, "jamd_export: cannot write %s\n", path); return 1; }
     printf("wrote %s\n", path);
+    if (r->am->hmmwrk.OP_gshmm != NULL) {           /* gms_init() has run inside j_final_fusion() */
+      HMMWork *wrk = &(r->am->hmmwrk);
+      jamd_flat_gmm fs;
+      const int S = r->am->hmminfo->totalstatenum;
+      int *map = (int *)malloc(sizeof(int) * (size_t)S), s;
+      if (map == NULL || jamd_flatten_hmminfo(wrk->OP_gshmm, &fs) != 0) { fprintf(stderr, "jamd_export: the selection model cannot be flattened\n"); return 1; }
+      for (s = 0; s < S; s++)
+        map[s] = (wrk->state2gs[s] >= 0 && wrk->state2gs[s] < wrk->gsset_num) ? wrk->gsset[wrk->state2gs[s]].state->id : -1;
+      snprintf(path, sizeof(path), "%s.gms", prefix);
+      rc = jamd_gms_save(&fs.desc, map, S, wrk->my_nbest, path);
+      jamd_flat_gmm_free(&fs); free(map);
+      if (rc != JAMD_OK) { fprintf(stderr, "jamd_export: cannot write %s\n", path); return 1; }
+      printf("wrote %s (%d selection states, %d selected per frame)\n", path, wrk->gsset_num, wrk->my_nbest);
+    }
   } else printf("DNN-HMM: give the -dnnconf file to jamd_dnn_load() / jamd_batch -dnnconf\n");
   {
     jamd_flat_lexicon fl;

@@ -193,10 +193,25 @@ static int gmm_put(FILE *f, const char *name, int dtype, int count, const void *
   return 0;
 }
 
+static int gmm_save_with(const jamd_gmm_desc *d, const char *path, const int *state2gs, int nstate, int nbest);
+
 int jamd_gmm_save(const jamd_gmm_desc *d, const char *path)
 {
+  return gmm_save_with(d, path, NULL, 0, 0);
+}
+
+/* The selection model of -gshmm: the same blob plus the records "state2gs" (selection state of every
+ * state of the real model, -1 = none) and "gms" {nbest}; jamd_gms_load() reads it. */
+int jamd_gms_save(const jamd_gmm_desc *gs, const int *state2gs, int nstate, int nbest, const char *path)
+{
+  if (state2gs == NULL || nstate <= 0 || nbest < 1 || gs->nbook > 0) return JAMD_EINVAL;
+  return gmm_save_with(gs, path, state2gs, nstate, nbest);
+}
+
+static int gmm_save_with(const jamd_gmm_desc *d, const char *path, const int *state2gs, int nstate, int nbest)
+{
   FILE *f = fopen(path, "wb");
-  int nrec = d->st_book ? 8 : 7, rc = 0, ints[6];
+  int nrec = (d->st_book ? 8 : 7) + (state2gs ? 2 : 0), rc = 0, ints[6];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nstate; ints[1] = d->veclen; ints[2] = d->ndens; ints[3] = d->nentry; ints[4] = d->nbook; ints[5] = d->nstream;
   fwrite("JAMDGMM1", 1, 8, f); fwrite(&nrec, 4, 1, f);
@@ -208,6 +223,7 @@ int jamd_gmm_save(const jamd_gmm_desc *d, const char *path)
   rc |= gmm_put(f, "ent_dens", 0, d->nentry, d->ent_dens);
   rc |= gmm_put(f, "ent_logw", 1, d->nentry, d->ent_logw);
   if (d->st_book) rc |= gmm_put(f, "st_book", 0, d->nstate, d->st_book);
+  if (state2gs) { rc |= gmm_put(f, "state2gs", 0, nstate, state2gs); rc |= gmm_put(f, "gms", 0, 1, &nbest); }
   if (fclose(f) != 0) rc = -1;
   return rc ? JAMD_EINVAL : JAMD_OK;
 }

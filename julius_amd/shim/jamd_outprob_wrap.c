@@ -19,7 +19,9 @@
  * calc_tied_mix().
  *
  * Supported: GMM acoustic models (plain or tied-mixture), single stream, -gprune none
- * or -gprune safe; DNN acoustic models (-dnnconf).  Anything else (heu/beam pruning, GMS,
+ * or -gprune safe, with or without Gaussian mixture selection (-gshmm: the selection stage of
+ * gms.c runs on the device after the scoring, jamd_gms_apply_host); DNN acoustic models
+ * (-dnnconf).  Anything else (heu/beam pruning,
  * multi-stream, -input outprob) is left to libsent's CPU code with one log line -- those paths are outside
  * the engine's scope.  A supported configuration without a usable
  * gfx950 device is a hard error (exit), as in the reference's own CUDA path
@@ -42,6 +44,7 @@ typedef struct {
   int state;                 /* 0 = not examined, 1 = device, 2 = left to libsent */
   jamd_gmm *gmm;
   jamd_dnn *dnn;
+  jamd_gms *gms;             /* -gshmm: selection stage applied to the device scores */
   int nstate;
   const HTK_Param *param;    /* utterance the cache was filled for */
   int filled;                /* frames [0, filled) are in the cache */
@@ -78,8 +81,8 @@ static void examine(wrap_ctx *c)
   int gprune;
   jamd_flat_gmm fg;
   c->state = 2;
-  if (wrk->OP_gshmm != NULL || (wrk->OP_dnn == NULL && wrk->OP_nstream != 1)) {
-    jlog("Stat: jamd: GMS / multi-stream scoring stays on libsent's CPU code\n");
+  if ((wrk->OP_gshmm != NULL && wrk->OP_dnn != NULL) || (wrk->OP_dnn == NULL && wrk->OP_nstream != 1)) {
+    jlog("Stat: jamd: multi-stream scoring stays on libsent's CPU code\n");
     return;
   }
   if (jamd_abi_version() != JAMD_ABI_VERSION) die("ABI mismatch between shim and libjulius_amd.so");
@@ -107,6 +110,17 @@ static void examine(wrap_ctx *c)
   if (jamd_gmm_create(g_eng, &fg.desc, gprune, wrk->OP_gprune_num, &c->gmm) != JAMD_OK) die("jamd_gmm_create");
   c->nstate = fg.desc.nstate;
   jamd_flat_gmm_free(&fg);
+  if (wrk->OP_gshmm != NULL) {              /* gms_init(), gms.c:275-317: gsset[] is indexed by selection state id */
+    jamd_flat_gmm fs;
+    int *map = (int *)malloc(sizeof(int) * (size_t)c->nstate), s;
+    if (map == NULL || jamd_flatten_hmminfo(wrk->OP_gshmm, &fs) != 0) die("cannot flatten the selection model");
+    for (s = 0; s < c->nstate; s++)
+      map[s] = (wrk->state2gs[s] >= 0 && wrk->state2gs[s] < wrk->gsset_num) ? wrk->gsset[wrk->state2gs[s]].state->id : -1;
+    if (jamd_gms_create(g_eng, &fs.desc, map, c->nstate, wrk->my_nbest, &c->gms) != JAMD_OK) die("jamd_gms_create");
+    jamd_flat_gmm_free(&fs); free(map);
+    jlog("Stat: jamd: Gaussian mixture selection on the device (%d selection states, %d selected per frame)\n",
+         wrk->gsset_num, wrk->my_nbest);
+  }
   c->state = 1;
   jlog("Stat: jamd: acoustic scoring on HIP device %d (%d states)\n", jamd_engine_device(g_eng), c->nstate);
 }
@@ -123,6 +137,7 @@ static void ensure(HMMWork *wrk, HTK_Param *param)
   T = param->samplenum;
   if (c->param != param) { c->param = param; c->filled = 0; }
   if (c->filled >= T) return;
+  if (c->gms != NULL) c->filled = 0;        /* the selection carries state from frame to frame: always from frame 0 */
   n = T - c->filled;
   fr = jamd_pack_param(param, c->filled, T);
   sc = (float *)malloc(sizeof(float) * (size_t)n * c->nstate);
@@ -131,6 +146,7 @@ static void ensure(HMMWork *wrk, HTK_Param *param)
     if (param->veclen != jamd_dnn_veclen(c->dnn)) die("feature vectors are not spliced to the DNN input length");
     if (jamd_dnn_outprob_host(c->dnn, fr, n, sc) != JAMD_OK) die("jamd_dnn_outprob_host");
   } else if (jamd_gmm_outprob_host(c->gmm, fr, n, sc) != JAMD_OK) die("jamd_gmm_outprob_host");
+  if (c->gms != NULL && jamd_gms_apply_host(c->gms, fr, n, NULL, 0, sc) != JAMD_OK) die("jamd_gms_apply_host");
   if (jamd_fill_outprob_cache(wrk, sc, c->filled, n, c->nstate) != JAMD_OK) die("cache layout mismatch");
   c->filled = T;
   free(fr); free(sc);
@@ -166,6 +182,7 @@ void __wrap_outprob_free(HMMWork *wrk)
   int i;
   for (i = 0; i < g_nctx; i++)
     if (g_ctx[i].wrk == wrk) {
+      if (g_ctx[i].gms) jamd_gms_destroy(g_ctx[i].gms);
       if (g_ctx[i].gmm) jamd_gmm_destroy(g_ctx[i].gmm);
       if (g_ctx[i].dnn) jamd_dnn_destroy(g_ctx[i].dnn);
       g_ctx[i] = g_ctx[--g_nctx];

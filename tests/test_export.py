@@ -38,3 +38,22 @@ def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
     want, got = am.export(), lexblob.load_gmm(tmp_path / "m.am")
     for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_export_selection_model(ref, tmp_path):
+    """-gshmm: PREFIX.gms holds the flattened selection model, the state map and -gsnum, equal to what
+    gms_init() (gms.c:275-317) built inside the reference."""
+    if not EXPORT.exists():
+        pytest.skip("oracle/_ref/jamd_export not built")
+    task = synth.make_triphone_task(tmp_path, seed=92, nword=60)
+    gpath, _ = synth.make_gs_model(task, seed=92)
+    args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                             "-input", "htkparam", "-gprune", "none", "-b", "120", "-gshmm", gpath, "-gsnum", "9"]]
+    out = subprocess.run([str(EXPORT)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True, text=True)
+    assert "m.gms" in out.stdout
+    got = lexblob.load_gmm(tmp_path / "m.gms")
+    want = ref.am_load(task["hmmdefs"], task["hmmlist"], gshmm=gpath, gms_num=9).gms()
+    assert got["nbest"] == want["nbest"] == 9
+    assert np.array_equal(got["state2gs"], want["state2gs"])
+    for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+        assert np.array_equal(got[k], want["model"][k]), k

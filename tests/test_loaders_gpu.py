@@ -66,6 +66,24 @@ def test_dnn_from_dnnconf(engine, tmp_path):
     assert np.array_equal(net.outprob_host(z["frames"]), z["out"])
 
 
+def test_selection_model_blob(engine, tmp_path):
+    """jamd_gms_load(): the selection model and its state map from a file; same outputs as the
+    committed reference fixture."""
+    z = np.load(GOLDEN / "gms.npz")
+    sub = lambda p: {k[len(p):]: z[k] for k in z.files if k.startswith(p)}
+    lexblob.save_gmm(sub("gs_"), tmp_path / "m.gms", state2gs=z["state2gs"], nbest=4)
+    back = lexblob.load_gmm(tmp_path / "m.gms")
+    assert back["nbest"] == 4 and np.array_equal(back["state2gs"], z["state2gs"])
+    stage = lib.Gms.from_file(engine, tmp_path / "m.gms", veclen=z["frames"].shape[1])
+    assert stage.S == len(z["state2gs"])
+    real = lib.Gmm(engine, sub("full_")).outprob_host(z["frames"])
+    used = z["state2gs"] >= 0
+    assert np.array_equal(stage.apply_host(z["frames"], real, z["utt_off"])[:, used], z["out_4"][:, used])
+    lexblob.save_gmm(sub("gs_"), tmp_path / "plain.am")
+    with pytest.raises(lib.JamdError):                 # an acoustic-model blob is not a selection model
+        lib.Gms.from_file(engine, tmp_path / "plain.am", veclen=39)
+
+
 def test_loaders_report_bad_files(engine, tmp_path):
     (tmp_path / "junk").write_bytes(b"not a blob at all")
     for call in (lambda: lib.Gmm.from_file(engine, tmp_path / "junk"), lambda: lib.Lexicon.from_file(engine, tmp_path / "junk"),
@@ -99,9 +117,11 @@ def test_standalone_c_driver(oracle, tmp_path):
         assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(utt["wseq"])
 
 
-def test_export_then_standalone_batch(ref, tmp_path):
+@pytest.mark.parametrize("gms", [False, True])
+def test_export_then_standalone_batch(ref, tmp_path, gms):
     """The whole no-Julius-at-run-time flow: jamd_export (Julius' loaders -> files), then jamd_batch
-    (C, C ABI only) over a file list; pass-1 sentences and scores equal the plain reference's."""
+    (C, C ABI only) over a file list; pass-1 sentences and scores equal the plain reference's --
+    also with Gaussian mixture selection (-gshmm -> PREFIX.gms -> jamd_batch -gms)."""
     import subprocess
     from oracle import pyoracle
     export = pyoracle.REF_SO.parent / "jamd_export"
@@ -111,7 +131,10 @@ def test_export_then_standalone_batch(ref, tmp_path):
     task = synth.make_triphone_task(tmp_path, seed=93, nword=120, nphone=10, S=160)
     args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
                              "-input", "htkparam", "-gprune", "safe", "-tmix", "3", "-b", "150", "-sepnum", "5", "-1pass"]]
+    if gms:
+        args += ["-gshmm", str(synth.make_gs_model(task, seed=93)[0]), "-gsnum", "7"]
     subprocess.run([str(export)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True)
+    assert (tmp_path / "m.gms").exists() == gms
     eng = pyoracle.RefEngine(ref, args)
     names, want = [], []
     for u in range(5):
@@ -122,7 +145,8 @@ def test_export_then_standalone_batch(ref, tmp_path):
         want.append(p1)
     (tmp_path / "list").write_text("\n".join(names) + "\n")
     out = subprocess.run([str(exe), "-am", str(tmp_path / "m.am"), "-lex", str(tmp_path / "m.lex"), "-filelist",
-                          str(tmp_path / "list"), "-b", "150", "-gprune", "safe", "3", "-strict"],
+                          str(tmp_path / "list"), "-b", "150", "-gprune", "safe", "3", "-strict"] +
+                         (["-gms", str(tmp_path / "m.gms")] if gms else []),
                          check=True, capture_output=True, text=True).stdout.strip().splitlines()
     assert len(out) == len(names)
     for line, (wseq, score) in zip(out, want):

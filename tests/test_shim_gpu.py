@@ -103,6 +103,26 @@ def test_reference_search_over_device_scores(ref, tmp_path, seed, beam, extra):
         _compare_exact(plain, wrapped, tmp_path / "u.mfc")
 
 
+@pytest.mark.parametrize("gprune", [["-gprune", "none"], ["-gprune", "safe", "-tmix", "3"]])
+def test_reference_search_over_selected_device_scores(ref, tmp_path, gprune):
+    """Boundary O with -gshmm: the wrapper applies the selection stage to the device scores before
+    they go into the reference's cache, so the CPU beam and the 2nd pass read exactly what
+    gms_state() would have returned."""
+    if not pyoracle.REF_O_SO.exists():
+        pytest.skip("oracle/_ref/libjref_o.so not built")
+    task = synth.make_triphone_task(tmp_path, seed=43, nword=120, nphone=10, S=160)
+    gpath, _ = synth.make_gs_model(task, seed=43)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5",
+            "-gshmm", str(gpath), "-gsnum", "5"] + gprune
+    plain = pyoracle.RefEngine(ref, args)
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_O_SO), args)
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=4300 + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        _compare_exact(plain, wrapped, tmp_path / "u.mfc")
+
+
 def test_c1_tied_mixture_grammar_over_device_scores(ref, tmp_path):
     """BASELINE configs[0] shape on the GPU: tied-mixture monophone GMM-HMM + a 100-word DFA
     grammar.  The grammar search is the reference's; the tied-mixture scoring (codebook
