@@ -166,6 +166,10 @@ int  jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2g
 /* A selection model file written by jamd_export (-gshmm given): jamd_gms_save(),
  * julius_amd/shim/jamd_flatten.c. */
 int  jamd_gms_load(jamd_engine *e, const char *path, jamd_gms **out);
+/* on != 0: select with the reference's heap (sort_gsindex_upward(), gms.c:189-230) on one lane, so
+ * that an exact tie between two selection states on the nbest boundary falls as in the reference;
+ * default is the wave-parallel ranking, where the lower state id wins such a tie. */
+int  jamd_gms_set_strict_order(jamd_gms *m, int on);
 int  jamd_gms_nstate(const jamd_gms *m);     /* states of the REAL model (columns of the score matrix) */
 void jamd_gms_destroy(jamd_gms *m);
 int  jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *utt_off, int nutt,

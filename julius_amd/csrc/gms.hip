@@ -12,15 +12,18 @@
 //   * the nbest states are taken from a partial heap sort over an index array that is not reset
 //     between frames (sort_gsindex_upward()), so a tie on the selection boundary is, too.
 // Hence one wave per utterance walks its frames in order: the lanes share the states of a frame
-// (per-Gaussian scores come from gmm_dens, the kernel behind the plugin slot), lane 0 runs the heap
-// in LDS.  The index array is reset at every utterance (the reference never resets it); that can
-// only matter for an exact tie between two selection states on the boundary.
+// (per-Gaussian scores come from gmm_dens, the kernel behind the plugin slot; rows reach LDS by DMA
+// one frame ahead).  The selection itself has two forms, like the first pass: by default every lane
+// ranks its states against all others -- the reference's set unless two selection states tie exactly
+// on the boundary -- and in strict order (jamd_gms_set_strict_order) lane 0 runs the reference's
+// heap in LDS.  Even then the index array is reset at every utterance (the reference never resets
+// it), which again can only matter for an exact tie on the boundary.
 #include "jamd_device.h"
 
 struct jamd_gms {
   jamd_engine *eng = nullptr;
   jamd_gmm *gs = nullptr;          // the selection model (per-Gaussian scores)
-  int Sgs = 0, Egs = 0, S = 0, nbest = 0;
+  int Sgs = 0, Egs = 0, S = 0, nbest = 0, strict = 0;
   int *d_st_off = nullptr;         // [Sgs + 1]
   float *d_logw = nullptr;         // [Egs]
   int *d_state2gs = nullptr;       // [S]
@@ -32,21 +35,51 @@ struct jamd_gms {
 namespace {
 using namespace jamd;
 
-__global__ void __launch_bounds__(64)
-gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ st_off, const float *__restrict__ logw,
-                  const int *__restrict__ utt_off, float *__restrict__ fs_out, int Sgs, int Egs, int nbest) {
-  extern __shared__ float lds[];
-  float *fs = lds;                              // [Sgs]
-  int *idx = (int *)(lds + Sgs);                // [Sgs]
-  int *last = idx + Sgs;                        // [Sgs]
-  const int lane = threadIdx.x, u = blockIdx.x;
-  const int t0 = utt_off[u], t1 = utt_off[u + 1];
-  for (int i = lane; i < Sgs; i += 64) { idx[i] = i; last[i] = -1; }
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int t = t0; t < t1; t++) {
-    const float *__restrict__ row = dens + (size_t)t * Egs;
+}
+
+// One wave per utterance.  LDS: fs[Sgs] | idx[Sgs] | last[Sgs] | st_off[Sgs+1] | logw[Egs] | row[2][EgsPad].
+// The frame's per-Gaussian scores (one row of dens) arrive by LDS-DMA, the next frame's row while
+// this one is processed, so the serial walk over the frames never waits for HBM.
+// STRICT: lane 0 runs the reference's heap.  Otherwise every lane ranks its own states against all
+// (broadcast reads), which selects the same set unless two states tie exactly on the boundary; then
+// the lower state id wins where the reference's answer depends on the heap's history.
+template <bool STRICT>
+__global__ void __launch_bounds__(64)
+gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ g_st_off, const float *__restrict__ g_logw,
+                  const int *__restrict__ utt_off, float *__restrict__ fs_out, int Sgs, int Egs, int EgsPad, int nbest) {
+  extern __shared__ float lds[];
+  float *fs = lds;                              // [Sgs]
+  int *idx = (int *)(fs + Sgs);                 // [Sgs]   heap order (STRICT) / selected flag
+  int *last = idx + Sgs;                        // [Sgs]
+  int *st_off = last + Sgs;                     // [Sgs + 1]
+  float *logw = (float *)(st_off + Sgs + 1);    // [Egs]
+  float *rowbuf = logw + Egs;                   // [2][EgsPad], 256-byte aligned by the launcher's padding
+  const int lane = threadIdx.x, u = blockIdx.x;
+  const int t0 = utt_off[u], t1 = utt_off[u + 1];
+  rowbuf += (64 - ((3 * Sgs + Sgs + 1 + Egs) & 63)) & 63;
+  for (int i = lane; i < Sgs; i += 64) { idx[i] = i; last[i] = -1; }
+  for (int i = lane; i <= Sgs; i += 64) st_off[i] = g_st_off[i];
+  for (int i = lane; i < Egs; i += 64) logw[i] = g_logw[i];
+  auto stage = [&](int buf, int t) {
+    const float *g = dens + (size_t)t * Egs + lane;
+    float *dst = rowbuf + buf * EgsPad;
+    for (int e0 = 0; e0 < EgsPad; e0 += 64)
+      __builtin_amdgcn_global_load_lds((glb_void *)(g + e0), (lds_void *)(dst + e0), 4, 0, 0);
+  };
+  if (t0 < t1) stage(0, t0);
+  int cur = 0;
+  for (int t = t0; t < t1; t++, cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this frame's row has landed
+    wave_sync();
+    if (t + 1 < t1) stage(cur ^ 1, t + 1);
+    const float *row = rowbuf + cur * EgsPad;
     for (int i = lane; i < Sgs; i += 64) {                         // compute_g_max(), LAST_BEST
       const int e0 = st_off[i], n = st_off[i + 1] - e0;
       const int first = (last[i] != -1) ? last[i] : n - 1;
@@ -56,54 +89,59 @@ gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ st_off
       if (maxprob < JAMD_LOG_ZERO) maxprob = JAMD_LOG_ZERO;
       int maxi = first;
       for (int k = n - 1; k >= 0; k--) {
-        if (k == first) continue;
         const float p = row[e0 + k];
-        if (p > maxprob) { maxprob = p; maxi = k; }
+        if (k != first && p > maxprob) { maxprob = p; maxi = k; }
       }
       last[i] = maxi;
       float sum = 0.0f;
       sum += (maxprob + logw[e0 + maxi]) * 1.0f;
       fs[i] = (float)((double)sum * JAMD_INV_LOG_TEN);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {                                                // sort_gsindex_upward() + do_gms()
-      const int totalnum = Sgs, neednum = nbest < Sgs ? nbest : Sgs;
+    wave_sync();
+    if (STRICT) {
+      if (lane == 0) {                                              // sort_gsindex_upward() + do_gms()
+        const int totalnum = Sgs, neednum = nbest < Sgs ? nbest : Sgs;
 #define SD_(A) idx[(A) - 1]
 #define SV_(A) (fs[idx[(A) - 1]])
-      for (int root = totalnum / 2; root >= 1; root--) {
-        const int sd = SD_(root);
-        int parent = root, child;
-        while ((child = parent * 2) <= totalnum) {
-          if (child < totalnum && SV_(child) < SV_(child + 1)) child++;
-          if (fs[sd] >= SV_(child)) break;
-          SD_(parent) = SD_(child); parent = child;
+        for (int root = totalnum / 2; root >= 1; root--) {
+          const int sd = SD_(root);
+          int parent = root, child;
+          while ((child = parent * 2) <= totalnum) {
+            if (child < totalnum && SV_(child) < SV_(child + 1)) child++;
+            if (fs[sd] >= SV_(child)) break;
+            SD_(parent) = SD_(child); parent = child;
+          }
+          SD_(parent) = sd;
         }
-        SD_(parent) = sd;
-      }
-      int n = totalnum;
-      while (n > totalnum - neednum) {
-        const int sd = SD_(n);
-        SD_(n) = SD_(1); n--;
-        int parent = 1, child;
-        while ((child = parent * 2) <= n) {
-          if (child < n && SV_(child) < SV_(child + 1)) child++;
-          if (fs[sd] >= SV_(child)) break;
-          SD_(parent) = SD_(child); parent = child;
+        int n = totalnum;
+        while (n > totalnum - neednum) {
+          const int sd = SD_(n);
+          SD_(n) = SD_(1); n--;
+          int parent = 1, child;
+          while ((child = parent * 2) <= n) {
+            if (child < n && SV_(child) < SV_(child + 1)) child++;
+            if (fs[sd] >= SV_(child)) break;
+            SD_(parent) = SD_(child); parent = child;
+          }
+          SD_(parent) = sd;
         }
-        SD_(parent) = sd;
-      }
 #undef SD_
 #undef SV_
-      for (int i = totalnum - neednum; i < totalnum; i++) fs[idx[i]] = JAMD_LOG_ZERO;   // selected
+        for (int i = totalnum - neednum; i < totalnum; i++) fs[idx[i]] = JAMD_LOG_ZERO;   // selected
+      }
+      wave_sync();
+      for (int i = lane; i < Sgs; i += 64) fs_out[(size_t)t * Sgs + i] = fs[i];
+    } else {
+      for (int i = lane; i < Sgs; i += 64) {                        // rank of state i among all
+        const float v = fs[i];
+        int rank = 0;
+        for (int j = 0; j < Sgs; j++) {
+          const float w = fs[j];
+          rank += (w > v || (w == v && j < i)) ? 1 : 0;
+        }
+        fs_out[(size_t)t * Sgs + i] = rank < nbest ? JAMD_LOG_ZERO : v;
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int i = lane; i < Sgs; i += 64) fs_out[(size_t)t * Sgs + i] = fs[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -159,6 +197,12 @@ int jamd_gms_create(jamd_engine *e, const jamd_gmm_desc *gs, const int *state2gs
 
 int jamd_gms_nstate(const jamd_gms *m) { return m ? m->S : 0; }
 
+int jamd_gms_set_strict_order(jamd_gms *m, int on) {
+  if (!m) { jamd_set_error("jamd_gms_set_strict_order: NULL"); return JAMD_EINVAL; }
+  m->strict = on != 0;
+  return JAMD_OK;
+}
+
 void jamd_gms_destroy(jamd_gms *m) {
   if (!m) return;
   (void)hipSetDevice(m->eng->device);
@@ -184,14 +228,17 @@ int jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *u
     JAMD_HIP(hipMalloc(&m->d_utt_off, sizeof(int) * (nutt + 1)));
     m->utt_cap = nutt + 1;
   }
-  if ((rc = grow(&m->d_dens, &m->dens_cap, sizeof(float) * (size_t)T * m->Egs)) != JAMD_OK) return rc;
+  if ((rc = grow(&m->d_dens, &m->dens_cap, sizeof(float) * ((size_t)T * m->Egs + 64))) != JAMD_OK) return rc;
   if ((rc = grow(&m->d_fs, &m->fs_cap, sizeof(float) * (size_t)T * m->Sgs)) != JAMD_OK) return rc;
   JAMD_HIP(hipMemcpyAsync(m->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
   if ((rc = jamd_gmm_dens_dev(m->gs, dev_frames, T, m->d_dens, st)) != JAMD_OK) return rc;
-  const size_t lds = sizeof(float) * 3 * (size_t)m->Sgs;
-  if (lds > 60 * 1024) { jamd_set_error("jamd_gms_apply_dev: %d selection states do not fit in LDS", m->Sgs); return JAMD_EINVAL; }
-  hipLaunchKernelGGL(gms_select_kernel, dim3(nutt), dim3(64), lds, st, m->d_dens, m->d_st_off, m->d_logw, m->d_utt_off,
-                     m->d_fs, m->Sgs, m->Egs, m->nbest);
+  const int EgsPad = (m->Egs + 63) & ~63;
+  const size_t lds = sizeof(float) * ((size_t)3 * m->Sgs + m->Sgs + 1 + m->Egs + 64 + 2 * (size_t)EgsPad);
+  if (lds > 159 * 1024) { jamd_set_error("jamd_gms_apply_dev: a selection model of %d states / %d Gaussians does not fit in LDS", m->Sgs, m->Egs); return JAMD_EINVAL; }
+  auto kern = m->strict ? gms_select_kernel<true> : gms_select_kernel<false>;
+  if (lds > 48 * 1024) JAMD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(nutt), dim3(64), lds, st, m->d_dens, m->d_st_off, m->d_logw, m->d_utt_off,
+                     m->d_fs, m->Sgs, m->Egs, EgsPad, m->nbest);
   hipLaunchKernelGGL(gms_combine_kernel, dim3((m->S + 255) / 256, T < 1024 ? T : 1024), dim3(256), 0, st, m->d_fs,
                      m->d_state2gs, dev_scores, T, m->S, m->Sgs);
   hipError_t le = hipGetLastError();

@@ -96,6 +96,7 @@ int main(int argc, char **argv)
   nstate = gm ? jamd_gmm_nstate(gm) : jamd_dnn_nstate(dn);
   if (gmsp != NULL) {                                 /* -gshmm of the exported configuration */
     if (jamd_gms_load(e, gmsp, &gs) != JAMD_OK) die("selection model");
+    if (strict && jamd_gms_set_strict_order(gs, 1) != JAMD_OK) die("strict order");
     if (jamd_gms_nstate(gs) != nstate) { fprintf(stderr, "jamd_batch: %s belongs to another acoustic model\n", gmsp); return 1; }
   }
   if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");

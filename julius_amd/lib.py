@@ -79,6 +79,7 @@ def load():
         "jamd_gms_destroy": (None, [vp]),
         "jamd_gms_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gms_nstate": (ci, [vp]),
+        "jamd_gms_set_strict_order": (ci, [vp, ci]),
         "jamd_gms_apply_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_gms_apply_host": (ci, [vp, vp, ci, vp, ci, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
@@ -325,6 +326,10 @@ class Gms:
         _check(load().jamd_gms_load(eng.h, str(path).encode(), C.byref(h)), "jamd_gms_load")
         self.h = h
         self.S, self.D = load().jamd_gms_nstate(h), int(veclen)
+        return self
+
+    def set_strict_order(self, on: bool = True):
+        _check(load().jamd_gms_set_strict_order(self.h, int(on)), "jamd_gms_set_strict_order")
         return self
 
     def apply_dev(self, dev_frames: int, T: int, dev_scores: int, utt_off=None, stream: int = 0):

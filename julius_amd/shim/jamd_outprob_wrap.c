@@ -117,6 +117,7 @@ static void examine(wrap_ctx *c)
     for (s = 0; s < c->nstate; s++)
       map[s] = (wrk->state2gs[s] >= 0 && wrk->state2gs[s] < wrk->gsset_num) ? wrk->gsset[wrk->state2gs[s]].state->id : -1;
     if (jamd_gms_create(g_eng, &fs.desc, map, c->nstate, wrk->my_nbest, &c->gms) != JAMD_OK) die("jamd_gms_create");
+    jamd_gms_set_strict_order(c->gms, 1);   /* this boundary promises the reference's numbers, ties included */
     jamd_flat_gmm_free(&fs); free(map);
     jlog("Stat: jamd: Gaussian mixture selection on the device (%d selection states, %d selected per frame)\n",
          wrk->gsset_num, wrk->my_nbest);

@@ -160,6 +160,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       rc = jamd_gms_create(g_eng, &fs.desc, map, c->nstate, wrk->my_nbest, &c->gms);
       jamd_flat_gmm_free(&fs); free(map);
       if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+      if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) jamd_gms_set_strict_order(c->gms, 1);
       jlog("STAT: jamd: Gaussian mixture selection on the device (%d selection states, %d selected per frame)\n",
            wrk->gsset_num, wrk->my_nbest);
     }
