@@ -178,6 +178,31 @@ int  jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *
 int  jamd_gms_apply_host(jamd_gms *m, const float *host_frames, int T, const int *utt_off, int nutt,
                          float *host_scores);
 
+/* ---- GMM-based input verification / rejection (-gmm FILE -gmmnum N -gmmreject NAMES) ---------
+ * Replaces the scoring inside gmm_proceed() (libjulius/src/gmm.c:574-600; gmm_calc_mix() :335-370,
+ * gmm_gprune_safe() :296-313 with gmm_compute_g_base() :177-194 / gmm_compute_g_safe() :218-240):
+ * per frame, the log10 likelihood of each verification GMM's single output state under gmm.c's own
+ * top-N pruning -- which is not libsent's arithmetic (gconst is added last for the first N
+ * Gaussians), so this is a separate kernel, not jamd_gmm_outprob_*().  gmm is the flattened GMM
+ * definition file (jamd_flatten_hmminfo(recog->gmm)), model_state[k] the state id of model k's
+ * output state (d->s[1]->id in recog->gmm->start order, the order of gc->gmm_score[]),
+ * gprune_num the -gmmnum value (jconf->reject.gmm_gprune_num, default 10).
+ *   frame scores  [T][nmodel]     what one gmm_proceed() adds to gc->gmm_score[k]
+ *   utt scores    [nutt][nmodel]  gc->gmm_score[] at gmm_end(): float sums in frame order
+ * gmm_end()'s winner / confidence / gmm_valid_input() stay with the caller (a few flops). */
+typedef struct jamd_rejgmm jamd_rejgmm;
+int  jamd_rejgmm_create(jamd_engine *e, const jamd_gmm_desc *gmm, const int *model_state, int nmodel,
+                        int gprune_num, jamd_rejgmm **out);
+void jamd_rejgmm_destroy(jamd_rejgmm *m);
+int  jamd_rejgmm_nmodel(const jamd_rejgmm *m);
+int  jamd_rejgmm_veclen(const jamd_rejgmm *m);
+int  jamd_rejgmm_frame_scores_dev(jamd_rejgmm *m, const float *dev_frames, int T, float *dev_out, void *stream);
+int  jamd_rejgmm_utt_scores_dev(jamd_rejgmm *m, const float *dev_frame_scores, int T, const int *utt_off, int nutt,
+                                float *dev_out, void *stream);
+/* Host buffers in and out; either output may be NULL (utt_off/nutt only needed for utt scores). */
+int  jamd_rejgmm_scores_host(jamd_rejgmm *m, const float *host_frames, int T, const int *utt_off, int nutt,
+                             float *host_frame_scores, float *host_utt_scores);
+
 /* ------------------------------------------------- pseudo-phone state sets */
 /* CD_State_Set table (htk_hmm.h:249-253): set i = states[set_off[i]..set_off[i+1]).
  * Replaces outprob_cd() (outprob.c:383): cd[t][i] from one [T][nstate] score

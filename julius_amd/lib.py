@@ -82,6 +82,13 @@ def load():
         "jamd_gms_set_strict_order": (ci, [vp, ci]),
         "jamd_gms_apply_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_gms_apply_host": (ci, [vp, vp, ci, vp, ci, vp]),
+        "jamd_rejgmm_create": (ci, [vp, P(GmmDesc), vp, ci, ci, P(vp)]),
+        "jamd_rejgmm_destroy": (None, [vp]),
+        "jamd_rejgmm_nmodel": (ci, [vp]),
+        "jamd_rejgmm_veclen": (ci, [vp]),
+        "jamd_rejgmm_frame_scores_dev": (ci, [vp, vp, ci, vp, vp]),
+        "jamd_rejgmm_utt_scores_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
+        "jamd_rejgmm_scores_host": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
@@ -361,6 +368,53 @@ class Gms:
             self.close()
         except Exception:
             pass
+
+class RejGmm:
+    """GMM-based input verification scores (jamd_rejgmm): gmm_proceed() of libjulius/src/gmm.c."""
+
+    def __init__(self, eng: Engine, model: dict, model_state, gprune_num: int = 10):
+        lib = load()
+        self.eng = eng
+        self._keep = {k: (_i32 if k in ("st_off", "ent_dens") else _f32)(model[k])
+                      for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw")}
+        d = GmmDesc()
+        d.nstate = len(self._keep["st_off"]) - 1
+        d.veclen = self._keep["mean"].shape[1]
+        d.ndens = self._keep["mean"].shape[0]
+        d.nentry = len(self._keep["ent_dens"])
+        d.nbook, d.nstream, d.st_book = 0, 1, None
+        for k in self._keep:
+            setattr(d, k, self._keep[k].ctypes.data)
+        ms = _i32(model_state)
+        self.nmodel, self.D = len(ms), d.veclen
+        h = C.c_void_p()
+        _check(lib.jamd_rejgmm_create(eng.h, C.byref(d), ms.ctypes.data, self.nmodel, int(gprune_num), C.byref(h)),
+               "jamd_rejgmm_create")
+        self.h = h
+
+    def scores_host(self, frames: np.ndarray, utt_off=None):
+        """(frame scores [T][nmodel], utterance sums [nutt][nmodel]); one utterance by default."""
+        fr = _f32(frames)
+        T = fr.shape[0]
+        assert fr.ndim == 2 and fr.shape[1] == self.D
+        off = _i32(utt_off if utt_off is not None else [0, T])
+        fs = np.empty((T, self.nmodel), np.float32)
+        us = np.empty((len(off) - 1, self.nmodel), np.float32)
+        _check(load().jamd_rejgmm_scores_host(self.h, fr.ctypes.data, T, off.ctypes.data, len(off) - 1,
+                                              fs.ctypes.data, us.ctypes.data), "jamd_rejgmm_scores_host")
+        return fs, us
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().jamd_rejgmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 
 class CdSet:

@@ -848,3 +848,33 @@ def make_gs_model(task, M=3, seed=0):
     path = Path(task["dir"]) / "gshmm"
     write_hmmdefs(path, model, phones=phones, state_names=state_names)
     return path, model
+
+
+def make_rejection_gmm(workdir, centre, names=("speech", "noise", "music", "cough"), M=14, seed=0,
+                       ragged=True, null_frac=0.0, kind="MFCC_E_D_A"):
+    """GMM definitions for input verification / rejection (-gmm FILE, libjulius/src/gmm.c): one HMM
+    per name with a single output state (three states in HTK's count, gmm_init() gmm.c:436-442).
+    The mixtures are spread around `centre` rows (the task's acoustic space) so that the private safe
+    pruning has something to prune.  Returns (path, flat model, names)."""
+    D = centre.shape[1]
+    model = make_gmm(S=len(names), M=M, D=D, seed=seed + 700, ragged=ragged, null_frac=null_frac)
+    rng = np.random.default_rng(seed + 701)
+    for s in range(len(names)):
+        e0, e1 = int(model["st_off"][s]), int(model["st_off"][s + 1])
+        ok = model["ent_dens"][e0:e1] >= 0
+        model["mean"][model["ent_dens"][e0:e1][ok]] = (centre[rng.integers(0, len(centre), int(ok.sum()))] +
+                                                       rng.normal(0, 1.0 + s, (int(ok.sum()), D))).astype(np.float32)
+    L = [f"~o <STREAMINFO> 1 {D} <VECSIZE> {D} <NULLD> <{kind}> <DIAGC>"]
+    for s, name in enumerate(names):
+        e0, e1 = int(model["st_off"][s]), int(model["st_off"][s + 1])
+        L.append(f'~h "{name}"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n<NUMMIXES> {e1 - e0}')
+        for m, e in enumerate(range(e0, e1)):
+            if model["ent_dens"][e] < 0:
+                continue
+            L.append(f"<MIXTURE> {m + 1} {model['weight'][e]:.6e}")
+            L.append(f"<MEAN> {D}\n {_vec(model['mean'][model['ent_dens'][e]])}")
+            L.append(f"<VARIANCE> {D}\n {_vec(model['var'][model['ent_dens'][e]])}")
+        L.append("<TRANSP> 3\n 0.0 1.0 0.0\n 0.0 0.6 0.4\n 0.0 0.0 0.0\n<ENDHMM>")
+    path = Path(workdir) / "rejgmm"
+    path.write_text("\n".join(L) + "\n")
+    return path, model, list(names)

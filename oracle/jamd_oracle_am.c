@@ -532,3 +532,71 @@ int jo_gms_apply(int Sgs, int D, const float *mean, const float *ivar, const flo
   free(fs); free(idx); free(last);
   return 0;
 }
+
+
+/* ---- GMM-based input verification / rejection (-gmm, -gmmnum, -gmmreject) --------------------
+ * libjulius/src/gmm.c keeps a private copy of the safe pruning with one difference from libsent's:
+ * the Gaussians visited while the list is not yet full are scored by gmm_compute_g_base()
+ * (gmm.c:177-194: the squared distances are summed from 0 and gconst is added LAST), the later ones
+ * by gmm_compute_g_safe() (gmm.c:218-240: gconst first, LOG_ZERO as soon as the partial sum passes
+ * -2 * the list's last score).  gmm_gprune_safe() gmm.c:296-313, gmm_calc_mix() gmm.c:335-370 (it
+ * returns the last stream's value times INV_LOG_TEN; one stream here), gmm_proceed() gmm.c:574-600:
+ * out[t][k] = score of model k's single output state at frame t.  model_state[k] indexes the
+ * flattened state pool.  Test infrastructure only. */
+int jo_rejgmm_frame_scores(int D, const float *mean, const float *ivar, const float *gconst,
+                           const int *st_off, const int *ent_dens, const float *ent_logw,
+                           const int *model_state, int nmodel, int gprune_num,
+                           const float *frames, int T, float *out)
+{
+  int t, k, i, d, maxmix = 1;
+  float *sc; int *id;
+  for (k = 0; k < nmodel; k++) {
+    const int n = st_off[model_state[k] + 1] - st_off[model_state[k]];
+    if (n > maxmix) maxmix = n;
+  }
+  sc = (float *)malloc(sizeof(float) * (size_t)maxmix);
+  id = (int *)malloc(sizeof(int) * (size_t)maxmix);
+  if (!sc || !id) return -1;
+  for (t = 0; t < T; t++) {
+    const float *vec = frames + (size_t)t * D;
+    for (k = 0; k < nmodel; k++) {
+      const int e0 = st_off[model_state[k]], n = st_off[model_state[k] + 1] - e0;
+      int num = 0;
+      float thres = JO_LOG_ZERO, logprob, logprobsum = 0.0f;
+      for (i = 0; i < n; i++) {                                   /* gmm_gprune_safe() */
+        const int g = ent_dens[e0 + i];
+        float score;
+        if (num < gprune_num) {
+          if (g < 0) score = JO_LOG_ZERO;
+          else {
+            float tmp = 0.0f;
+            for (d = 0; d < D; d++) { float x = vec[d] - mean[(size_t)g * D + d]; tmp += x * x * ivar[(size_t)g * D + d]; }
+            score = (float)((tmp + gconst[g]) * -0.5);
+          }
+        } else {
+          if (g < 0) score = JO_LOG_ZERO;
+          else {
+            const float fthres = (float)(thres * (-2.0));
+            float tmp = gconst[g]; int cut = 0;
+            for (d = 0; d < D; d++) {
+              float x = vec[d] - mean[(size_t)g * D + d];
+              tmp += x * x * ivar[(size_t)g * D + d];
+              if (tmp > fthres) { cut = 1; break; }
+            }
+            score = cut ? JO_LOG_ZERO : (float)(tmp * -0.5);
+          }
+          if (score <= thres) continue;
+        }
+        num = topn_push(sc, id, gprune_num < maxmix ? gprune_num : maxmix, i, score, num);
+        thres = sc[num - 1];
+      }
+      for (i = 0; i < num; i++) sc[i] += ent_logw[e0 + id[i]];   /* gmm_calc_mix() */
+      logprob = jo_addlog_array(sc, num);
+      if (!(logprob <= JO_LOG_ZERO)) logprobsum += logprob * 1.0f;
+      if (logprobsum == 0.0f || logprobsum <= JO_LOG_ZERO) out[(size_t)t * nmodel + k] = JO_LOG_ZERO;
+      else out[(size_t)t * nmodel + k] = (float)(logprob * JO_INV_LOG_TEN);
+    }
+  }
+  free(sc); free(id);
+  return 0;
+}

@@ -115,6 +115,28 @@ class Oracle:
         assert rc == 0
         return out
 
+    def rejgmm_frame_scores(self, gm, frames):
+        """gmm.c's per-frame model scores; gm = RefEngine.gmm_info()-shaped dict."""
+        m = gm["model"]
+        mean, ivar, gconst = _f32(m["mean"]), _f32(m["ivar"]), _f32(m["gconst"])
+        st_off, ent_dens, ent_logw = _i32(m["st_off"]), _i32(m["ent_dens"]), _f32(m["ent_logw"])
+        ms = _i32(gm["model_state"])
+        fr = _f32(frames)
+        out = np.zeros((fr.shape[0], len(ms)), np.float32)
+        rc = self.lib.jo_rejgmm_frame_scores(fr.shape[1], _p(mean), _p(ivar), _p(gconst), _p(st_off), _p(ent_dens),
+                                             _p(ent_logw), _p(ms), len(ms), int(gm["gprune_num"]), _p(fr),
+                                             fr.shape[0], _p(out))
+        assert rc == 0
+        return out
+
+    @staticmethod
+    def rejgmm_accumulate(frame_scores):
+        """gmm_proceed()'s running sums (gmm.c:599): float adds in frame order."""
+        acc = np.zeros(frame_scores.shape[1], np.float32)
+        for row in np.asarray(frame_scores, np.float32):
+            acc = (acc + row).astype(np.float32)
+        return acc
+
     def tmix_topn(self, model, book, frames, gprune, gprune_num):
         mean, ivar, gconst = _f32(model["mean"]), _f32(model["ivar"]), _f32(model["gconst"])
         # a codebook's densities, in codebook order, are the entries of any state tied to it
@@ -426,6 +448,46 @@ class RefEngine:
         sc = C.c_float()
         k = lib.jref_engine_pass1(self.h, _p(wseq), C.byref(sc))
         return a, (wseq[:k].copy(), float(sc.value))
+
+    def gmm_info(self):
+        """-gmm: dict(nmodel, gprune_num, veclen, model=flat state pool, model_state=[nmodel])."""
+        lib = self.ref.lib
+        info = np.zeros(3, np.int32)
+        if lib.jref_engine_gmm_info(C.c_void_p(self.h), _p(info)) != 0:
+            raise RuntimeError("no -gmm in this configuration")
+        lib.jref_engine_gmm_model.restype = C.c_void_p
+        view = RefAM(self.ref, lib.jref_engine_gmm_model(C.c_void_p(self.h)))
+        states = np.zeros(int(info[0]), np.int32)
+        assert lib.jref_engine_gmm_states(C.c_void_p(self.h), _p(states)) == info[0]
+        return dict(nmodel=int(info[0]), gprune_num=int(info[1]), veclen=int(info[2]), model=view.export(),
+                    model_state=states)
+
+    def gmm_frame_scores(self, frames):
+        """gmm_proceed()'s per-frame scores [T][nmodel] through the reference's own entry points."""
+        fr = _f32(frames)
+        info = np.zeros(3, np.int32)
+        self.ref.lib.jref_engine_gmm_info(C.c_void_p(self.h), _p(info))
+        out = np.zeros((fr.shape[0], int(info[0])), np.float32)
+        rc = self.ref.lib.jref_engine_gmm_frame_scores(C.c_void_p(self.h), _p(fr), fr.shape[0], fr.shape[1], _p(out))
+        if rc != 0:
+            raise RuntimeError("jref_engine_gmm_frame_scores failed")
+        return out
+
+    def gmm_device_frames(self):
+        """Frames the shim's gmm.c wrapper scored on the device (-1: plain reference / not supported)."""
+        self.ref.lib.jref_engine_gmm_device_frames.restype = C.c_long
+        return int(self.ref.lib.jref_engine_gmm_device_frames(C.c_void_p(self.h)))
+
+    def gmm_result(self):
+        """After recognize(): (accumulated scores, winner index, confidence, accepted?, frames)."""
+        info = np.zeros(3, np.int32)
+        self.ref.lib.jref_engine_gmm_info(C.c_void_p(self.h), _p(info))
+        sc = np.zeros(int(info[0]), np.float32)
+        mi, val, fc, cm = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        rc = self.ref.lib.jref_engine_gmm_result(C.c_void_p(self.h), _p(sc), C.byref(mi), C.byref(cm), C.byref(val), C.byref(fc))
+        if rc != 0:
+            raise RuntimeError("no GMM result")
+        return sc, int(mi.value), float(cm.value), bool(val.value), int(fc.value)
 
     def prefetch(self, mfcfiles):
         """Batch driver of the first-pass shim build (libjref_amd.so): decode all inputs in one

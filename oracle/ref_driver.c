@@ -506,6 +506,89 @@ int jref_engine_cache_fill(void *h, int *defined, int *total)
   return 0;
 }
 
+/* ---- GMM-based input verification (-gmm / -gmmnum / -gmmreject, libjulius/src/gmm.c) ----------
+ * info: {number of GMMs, -gmmnum, veclen}; -1 without -gmm. */
+int jref_engine_gmm_info(void *h, int *info)
+{
+  jref_eng *e = (jref_eng *)h;
+  if (e->recog->gmm == NULL) return -1;
+  info[0] = e->recog->gmm->totalhmmnum;
+  info[1] = e->recog->jconf->reject.gmm_gprune_num;
+  info[2] = e->recog->gmm->opt.vec_size;
+  return 0;
+}
+
+/* The GMM definitions as a flat state pool (view for jref_am_dims/_export), and the state id of each
+ * model's output state in gmm->start order (the order of gc->gmm_score[]). */
+void *jref_engine_gmm_model(void *h)
+{
+  jref_eng *e = (jref_eng *)h;
+  jref_am *v;
+  if (e->recog->gmm == NULL) return NULL;
+  v = (jref_am *)calloc(1, sizeof(jref_am));
+  v->hmminfo = e->recog->gmm; v->view_only = 1;
+  return v;
+}
+
+int jref_engine_gmm_states(void *h, int *state_id)
+{
+  jref_eng *e = (jref_eng *)h;
+  HTK_HMM_Data *d;
+  int i = 0;
+  if (e->recog->gmm == NULL) return -1;
+  for (d = e->recog->gmm->start; d; d = d->next) state_id[i++] = d->s[1]->id;
+  return i;
+}
+
+/* Per-frame model scores: gmm_prepare() zeroes gc->gmm_score[], one gmm_proceed() then leaves
+ * 0.0 + score = score in it (gmm.c:520-543, 574-600) -- the reference's own entry points, frame by
+ * frame, on a parameter block of ours. */
+int jref_engine_gmm_frame_scores(void *h, const float *frames, int T, int D, float *out)
+{
+  jref_eng *e = (jref_eng *)h;
+  Recog *recog = e->recog;
+  MFCCCalc *mfcc = recog->gmmmfcc;
+  HTK_Param *keep, *p;
+  boolean keep_valid; int keep_f, t, n;
+  if (recog->gmm == NULL || mfcc == NULL || D != recog->gmm->opt.vec_size) return -1;
+  n = recog->gmm->totalhmmnum;
+  p = make_param(frames, T, D);
+  keep = mfcc->param; keep_valid = mfcc->valid; keep_f = mfcc->f;
+  mfcc->param = p; mfcc->valid = TRUE;
+  for (t = 0; t < T; t++) {
+    mfcc->f = t;
+    gmm_prepare(recog);
+    gmm_proceed(recog);
+    memcpy(out + (size_t)t * n, recog->gc->gmm_score, sizeof(float) * (size_t)n);
+  }
+  mfcc->param = keep; mfcc->valid = keep_valid; mfcc->f = keep_f;
+  free_param(p);
+  return 0;
+}
+
+/* After jref_engine_recognize(): accumulated scores, the winner, its confidence (gmm_end(),
+ * gmm.c:614-660), whether gmm_valid_input() accepts, and the frame count. */
+int jref_engine_gmm_result(void *h, float *scores, int *max_i, float *cm, int *valid, int *framecount)
+{
+  jref_eng *e = (jref_eng *)h;
+  if (e->recog->gmm == NULL || e->recog->gc == NULL) return -1;
+  memcpy(scores, e->recog->gc->gmm_score, sizeof(float) * (size_t)e->recog->gmm->totalhmmnum);
+  *max_i = e->recog->gc->max_i;
+  *cm = e->recog->gc->gmm_max_cm;
+  *valid = gmm_valid_input(e->recog) ? 1 : 0;
+  *framecount = e->recog->gc->framecount;
+  return 0;
+}
+
+/* Only in the shimmed builds (julius_amd/shim/jamd_gmm_wrap.c): frames of this recogniser's
+ * verification GMMs that were scored on the device; -1 in the plain reference. */
+extern long jamd_gmm_wrap_frames(Recog *recog) __attribute__((weak));
+long jref_engine_gmm_device_frames(void *h)
+{
+  jref_eng *e = (jref_eng *)h;
+  return jamd_gmm_wrap_frames ? jamd_gmm_wrap_frames(e->recog) : -1;
+}
+
 /* The loaded acoustic model through the product shim's blob writer (jamd_gmm_save). */
 int jref_am_save(void *h, const char *path)
 {

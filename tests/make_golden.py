@@ -210,6 +210,36 @@ def main_gms():
     save("gms.npz", **out)
 
 
+def main_rejgmm():
+    """V1: GMM-based input verification (-gmm, -gmmnum 5 / 20): gmm_proceed()'s per-frame model scores
+    through the reference's own entry points, and gc->gmm_score[] / the winner after whole inputs."""
+    ref = pyoracle.Ref()
+    tmp = Path(tempfile.mkdtemp())
+    task = synth.make_triphone_task(tmp, seed=11, nword=60)
+    gpath, _, names = synth.make_rejection_gmm(tmp, task["model"]["centre"], seed=11, null_frac=0.1)
+    frs = [synth.make_utterance(task, nwords=2 + u, seed=60 + u)[0] for u in range(3)]
+    out = dict(frames=np.concatenate(frs), utt_off=np.cumsum([0] + [len(f) for f in frs]).astype(np.int32))
+    for num in (5, 20):
+        eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                                       "-input", "htkparam", "-gprune", "none", "-b", "120", "-gmm", str(gpath),
+                                       "-gmmnum", str(num), "-gmmreject", "noise,cough"])
+        info = eng.gmm_info()
+        out.update(model_arrays(info["model"]))
+        out["model_state"] = info["model_state"]
+        out["frame_scores_%d" % num] = np.concatenate([eng.gmm_frame_scores(f) for f in frs])
+        sums, winners = [], []
+        for u, f in enumerate(frs):
+            synth.write_htk_param(tmp / "u.mfc", f)
+            eng.recognize(tmp / "u.mfc")
+            sc, mi, cm, valid, fc = eng.gmm_result()
+            assert fc == len(f)
+            sums.append(sc)
+            winners.append(mi)
+        out["utt_scores_%d" % num] = np.stack(sums)
+        out["winner_%d" % num] = np.array(winners, np.int32)
+    save("rejgmm.npz", **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("am", "all"):
@@ -218,3 +248,5 @@ if __name__ == "__main__":
         main_beam()
     if what in ("gms", "all"):
         main_gms()
+    if what in ("rejgmm", "all"):
+        main_rejgmm()

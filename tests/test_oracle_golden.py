@@ -96,3 +96,19 @@ def test_gaussian_mixture_selection(oracle, nbest):
         fr = z["frames"][a:b]
         got = oracle.gms_apply(gs, fr, oracle.gmm_outprob(full, fr, po.GPRUNE_NONE))
         assert np.array_equal(got[:, used], z["out_%d" % nbest][a:b][:, used])
+
+
+@pytest.mark.parametrize("num", [5, 20])
+def test_verification_gmm(oracle, num):
+    """gmm.c's private safe pruning (gmm.c:177-370) on the committed reference outputs: per-frame model
+    scores, and the running sums gmm_proceed() leaves in gc->gmm_score[] (float adds in frame order)."""
+    z = np.load(GOLDEN / "rejgmm.npz")
+    gm = dict(model={k: z[k] for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw")},
+              model_state=z["model_state"], gprune_num=num)
+    got = oracle.rejgmm_frame_scores(gm, z["frames"])
+    assert np.array_equal(got, z["frame_scores_%d" % num])
+    for u, (a, b) in enumerate(zip(z["utt_off"][:-1], z["utt_off"][1:])):
+        sums = oracle.rejgmm_accumulate(got[a:b])
+        assert np.array_equal(sums, z["utt_scores_%d" % num][u])
+        assert int(np.argmax(sums)) == int(z["winner_%d" % num][u])
+    assert not np.array_equal(z["frame_scores_5"], z["frame_scores_20"])      # -gmmnum 5 really prunes

@@ -101,3 +101,25 @@ def test_gaussian_mixture_selection(oracle, ref, tmp_path, nbest):
         used = gs["state2gs"] >= 0              # states outside every model: the reference reads out of bounds
         assert np.array_equal(got[:, used], want[:, used])
         assert 0.0 < (got[:, used] != oracle.gmm_outprob(full_model, fr)[:, used]).mean() < 1.0
+
+
+@pytest.mark.parametrize("num,null_frac", [(1, 0.0), (3, 0.2), (10, 0.0), (64, 0.1)])
+def test_verification_gmm(oracle, ref, tmp_path, num, null_frac):
+    """-gmm / -gmmnum: gmm_proceed() (libjulius/src/gmm.c:574-600) through the reference's own entry
+    points, frame by frame, and gc->gmm_score[] / the winner after a whole input."""
+    task = synth.make_triphone_task(tmp_path, seed=12, nword=60)
+    gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=12 + num, M=20, null_frac=null_frac)
+    eng = po.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                             "-input", "htkparam", "-gprune", "none", "-b", "120", "-gmm", str(gpath), "-gmmnum", str(num)])
+    info = eng.gmm_info()
+    assert info["nmodel"] == len(names) and info["gprune_num"] == num
+    for u in range(2):
+        fr, _ = synth.make_utterance(task, nwords=2 + u, seed=70 + u)
+        want = eng.gmm_frame_scores(fr)
+        got = oracle.rejgmm_frame_scores(info, fr)
+        assert np.array_equal(got, want)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        eng.recognize(tmp_path / "u.mfc")
+        sums, winner, cm, valid, nframe = eng.gmm_result()
+        assert nframe == len(fr) and valid
+        assert np.array_equal(oracle.rejgmm_accumulate(got), sums) and int(np.argmax(sums)) == winner
