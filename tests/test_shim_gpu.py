@@ -354,6 +354,52 @@ def test_gaussian_mixture_selection_two_pass(ref, tmp_path, monkeypatch, mode):
         assert amd.prefetch_served() == len(files)
 
 
+@pytest.mark.parametrize("so", ["amd", "o"])
+def test_verification_gmm_on_device(ref, tmp_path, monkeypatch, so):
+    """-gmm / -gmmnum / -gmmreject.  Both shimmed builds also wrap gmm.c's entry points
+    (julius_amd/shim/jamd_gmm_wrap.c): the frames gmm_proceed() would score one by one are scored on
+    the device at gmm_end().  gc->gmm_score[], the winner, its confidence, gmm_valid_input() and the
+    final status -- including a rejected input, which never reaches the 2nd pass -- equal the plain
+    reference's."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    lib_so = pyoracle.REF_AMD_SO if so == "amd" else pyoracle.REF_O_SO
+    if not lib_so.exists():
+        pytest.skip(f"{lib_so} not built")
+    task = synth.make_triphone_task(tmp_path, seed=85, nword=120, nphone=10, S=160)
+    gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=85, M=24, null_frac=0.05)
+    base = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+            "-input", "htkparam", "-gprune", "none", "-b", "150", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5",
+            "-gmm", str(gpath), "-gmmnum", "6"]
+    files = []
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + u, seed=8500 + u)
+        files.append((tmp_path / f"u{u}.mfc", len(fr)))
+        synth.write_htk_param(files[-1][0], fr)
+    probe = pyoracle.RefEngine(ref, base)
+    probe.recognize(files[0][0])
+    winner_name = names[::-1][probe.gmm_result()[1]]           # gmm->start lists the models in reverse file order
+    other = [n for n in names if n != winner_name][0]
+    total = 0
+    for reject in (other, winner_name):                        # accepted inputs, then rejected ones
+        args = base + ["-gmmreject", reject]
+        plain = pyoracle.RefEngine(ref, args)
+        dev = pyoracle.RefEngine(pyoracle.Ref(so=lib_so), args)
+        assert plain.gmm_device_frames() == -1
+        total = 0
+        for f, n in files:
+            plain.recognize(f)
+            want, fin0 = plain.gmm_result(), plain.final_result()
+            dev.recognize(f)
+            got, fin1 = dev.gmm_result(), dev.final_result()
+            total += n
+            assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+            assert fin1[0] == fin0[0] and np.array_equal(fin1[1], fin0[1]) and fin1[2] == fin0[2]
+            assert dev.gmm_device_frames() == total            # every frame was scored on the device
+        if reject == winner_name:
+            assert fin0[0] < 0 and not want[3]                 # J_RESULT_STATUS_REJECT_GMM
+
+
 def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monkeypatch):
     """`-input outprob`: the input file already holds the [T][S] state scores (what -outprobout
     writes); the shim hands them to the device search unscored and Julius' 2nd pass reads them from
