@@ -262,6 +262,7 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
 #define JAMD_AS_LSET  1   /* AS_LSET   wchmm.h:106: out_id = state-set id                */
 #define JAMD_AS_RSET  2   /* AS_RSET   wchmm.h:107: out_id = row of lc_tab               */
 #define JAMD_AS_LRSET 3   /* AS_LRSET  wchmm.h:108: out_id = row of lc_tab               */
+#define JAMD_AS_NONE  4   /* multipath only: non-emitting node (state[n].out.state == NULL) */
 
 #define JAMD_LM_NGRAM 0   /* LM_PROB  */
 #define JAMD_LM_DFA   1   /* LM_DFA, LM_DFA_GRAMMAR with the default per-category tree */
@@ -269,6 +270,12 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
                            * with a token (beam.c:1762-1788), no cross-word transition (:2810, :2875), the
                            * result is the best word on the last frame (find_1pass_result_word(), :561).
                            * Uses ninit / init_node / init_lscore (all 0.0); cat_pair is not read. */
+
+/* OR-ed into lm_type by jamd_flatten_lexicon_multipath(): a multipath lexicon (hmminfo->multipath:
+ * non-emitting word-begin / word-end nodes, word_head[] = wchmm->wordbegin[], wordend_a unused,
+ * the frame loop of beam.c:2747-2836).  The oracle decodes these; jamd_lexicon_create() does not
+ * accept them yet. */
+#define JAMD_LM_MULTIPATH 0x100
 
 #define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */
 #define JAMD_NG_ADDITIONAL_OLD 1  /* bi_prob_additional_oldbin() ngram_access.c:320 */

@@ -87,7 +87,7 @@ def save_gmm(model: dict, path, state2gs=None, nbest: int = 0) -> None:
 
 def save(lex: dict, path) -> None:
     """Same format as jamd_lexicon_save() (used to commit small golden fixtures)."""
-    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if lex.get("lm_type", 0) != 0 else 0))]
+    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if lex.get("lm_type", 0) & 0xff != 0 else 0))]
 
     def put(name, arr):
         arr = np.ascontiguousarray(arr)
@@ -99,7 +99,7 @@ def save(lex: dict, path) -> None:
     put("floats", np.array([lex.get(k, 0.0) for k in _FLOATS], dtype=np.float32))
     for k in ARRAYS:
         put(k, lex[k])
-    if lex.get("lm_type", 0) != 0:
+    if lex.get("lm_type", 0) & 0xff != 0:
         for k in DFA_ARRAYS:
             put(k, lex[k])
     Path(path).write_bytes(b"".join(out))

@@ -85,6 +85,9 @@ typedef struct {
  * forward DFA or without per-category trees, multipath models, user LM plugin, 24-bit
  * compacted 2-gram index). */
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
+/* The same for a multipath acoustic model (lm_type | JAMD_LM_MULTIPATH); not yet accepted by
+ * jamd_lexicon_create() -- used by the oracle's checks of the multipath search. */
+int  jamd_flatten_lexicon_multipath(RecogProcess *r, jamd_flat_lexicon *out);
 void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
 /* Write the descriptor as a self-describing blob of named arrays (the format
  * julius_amd/lexblob.py and jamd_lexicon_load() (include/julius_amd.h) read). */

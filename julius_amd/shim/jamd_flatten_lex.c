@@ -77,6 +77,20 @@ static int set_id(setreg *sr, CD_State_Set *cs)
   return id;
 }
 
+/* Multipath lexicons (model-skip transitions; non-emitting word-begin and word-end nodes) flatten to
+ * the same descriptor with lm_type | JAMD_LM_MULTIPATH, JAMD_AS_NONE on the non-emitting nodes and
+ * word_head[] = wchmm->wordbegin[].  The device first pass does not take them yet
+ * (jamd_lexicon_create() refuses the flag), so only the explicit entry below produces them. */
+static int g_allow_multipath = 0;
+int jamd_flatten_lexicon_multipath(RecogProcess *r, jamd_flat_lexicon *out)
+{
+  int rc;
+  g_allow_multipath = 1;
+  rc = jamd_flatten_lexicon(r, out);
+  g_allow_multipath = 0;
+  return rc;
+}
+
 int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
 {
   WCHMM_INFO *wchmm = r->wchmm;
@@ -96,7 +110,8 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   memset(out, 0, sizeof(*out));
   const int dfa_mode = (r->lmtype == LM_DFA);
   const int word_mode = (dfa_mode && r->lmvar == LM_DFA_WORD);      /* isolated word recognition (-w) */
-  if (hmminfo->multipath) return JAMD_EINVAL;
+  const int multipath = hmminfo->multipath ? 1 : 0;
+  if (multipath && !g_allow_multipath) return JAMD_EINVAL;
   if (word_mode) {
     if (!wchmm->category_tree) return JAMD_EINVAL;
   } else if (dfa_mode) {              /* grammar: per-category trees, no forward DFA */
@@ -149,7 +164,11 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   /* ---- acoustic spec of every node (outprob_style.c:376-486) ---------------- */
   for (i = 0; i < n; i++) {
     unsigned char kind = wchmm->ccd_flag ? wchmm->outstyle[i] : AS_STATE;
-    if (wchmm->state[i].out.state == NULL) { free(word_lc); return JAMD_EINVAL; }   /* non-emitting: multipath only */
+    if (wchmm->state[i].out.state == NULL) {                   /* non-emitting: multipath only (beam.c:2935) */
+      if (!multipath) { free(word_lc); return JAMD_EINVAL; }
+      out->out_kind[i] = JAMD_AS_NONE; out->out_id[i] = -1;
+      continue;
+    }
     switch (kind) {
     case AS_STATE:
       out->out_kind[i] = JAMD_AS_STATE; out->out_id[i] = wchmm->state[i].out.state->id; break;
@@ -211,8 +230,9 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   out->wordend_a = NEW(float, W); out->wton = NEW(int, W); out->cprob = NEW(float, W);
   out->is_transparent = NEW(unsigned char, W); out->word_head = NEW(int, W);
   for (w = 0; w < W; w++) {
-    out->wordend_a[w] = wchmm->wordend_a[w]; out->wton[w] = winfo->wton[w]; out->cprob[w] = winfo->cprob[w];
-    out->is_transparent[w] = winfo->is_transparent[w] ? 1 : 0; out->word_head[w] = wchmm->offset[w][0];
+    out->wordend_a[w] = multipath ? 0.0f : wchmm->wordend_a[w]; out->wton[w] = winfo->wton[w]; out->cprob[w] = winfo->cprob[w];
+    out->is_transparent[w] = winfo->is_transparent[w] ? 1 : 0;
+    out->word_head[w] = multipath ? wchmm->wordbegin[w] : wchmm->offset[w][0];     /* beam.c:1635-1639 */
   }
   out->word_lc = word_lc;
 
@@ -264,7 +284,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
       if (!m->active) continue;
       if (word_mode) {                                 /* every word of the active lists, beam.c:1762-1788 */
         for (iw = m->word_begin; iw < m->word_begin + m->winfo->num; iw++) {
-          int node = wchmm->offset[iw][0];
+          int node = multipath ? wchmm->wordbegin[iw] : wchmm->offset[iw][0];
           if (seen[node]) continue;
           seen[node] = 1;
           out->init_node[ninit] = node;
@@ -276,7 +296,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
       for (t = m->cate_begin; t < m->cate_begin + m->dfa->term_num; t++) {
         if (dfa_cp_begin(dfa, t) != TRUE) continue;
         for (iw = 0; iw < dfa->term.wnum[t]; iw++) {
-          int wid = dfa->term.tw[t][iw], node = wchmm->offset[wid][0];
+          int wid = dfa->term.tw[t][iw], node = multipath ? wchmm->wordbegin[wid] : wchmm->offset[wid][0];
           if (seen[node]) continue;                    /* node_exist_token(), beam.c:1717 */
           seen[node] = 1;
           out->init_node[ninit] = node;
@@ -310,6 +330,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   d->nfscore = dfa_mode ? 1 : wchmm->fsnum; d->nscword = dfa_mode ? 1 : wchmm->scnum; d->fscore = out->fscore; d->scword = out->scword;
   d->ng_uni_prob = out->ng_uni_prob; d->ng_uni_bo = out->ng_uni_bo; d->ng_bi_bgn = out->ng_bi_bgn;
   d->ng_bi_num = out->ng_bi_num; d->ng_bi_wid = out->ng_bi_wid; d->ng_bi_prob = out->ng_bi_prob;
+  if (multipath) d->lm_type |= JAMD_LM_MULTIPATH;
   d->lm_weight = r->config->lmp.lm_weight; d->lm_penalty = r->config->lmp.lm_penalty;
   d->lm_penalty_trans = r->config->lmp.lm_penalty_trans;
   for (k = 0; k < nlc; k++) free(lcname[k]);
@@ -347,7 +368,7 @@ static int put_rec(FILE *f, const char *name, int dtype, int count, const void *
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");
-  int nrec = 30 + (d->lm_type != JAMD_LM_NGRAM ? 4 : 0), rc = 0;
+  int nrec = 30 + ((d->lm_type & 0xff) != JAMD_LM_NGRAM ? 4 : 0), rc = 0;
   int ints[21]; float floats[5];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nnode; ints[1] = d->nword; ints[2] = d->startnum; ints[3] = d->isolatenum;
@@ -374,7 +395,7 @@ int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
   F32("ng_uni_prob", d->ng_uni_prob, d->ng_nword); F32("ng_uni_bo", d->ng_uni_bo, d->ng_nword);
   I32("ng_bi_bgn", d->ng_bi_bgn, d->ng_nword); I32("ng_bi_num", d->ng_bi_num, d->ng_nword);
   I32("ng_bi_wid", d->ng_bi_wid, d->ng_nbigram); F32("ng_bi_prob", d->ng_bi_prob, d->ng_nbigram);
-  if (d->lm_type != JAMD_LM_NGRAM) {
+  if ((d->lm_type & 0xff) != JAMD_LM_NGRAM) {
     U8("cat_pair", d->cat_pair, d->ncat * d->ncat); I32("start2wid", d->start2wid, d->startnum);
     I32("init_node", d->init_node, d->ninit); F32("init_lscore", d->init_lscore, d->ninit);
   }

@@ -220,7 +220,7 @@ def write_npy(path, a):
 
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
-                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0):
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None):
     """Write a complete synthetic recognition task the reference can load:
     tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
     forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
@@ -244,7 +244,7 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
             phys.append((f"{c}_v{v}", st))
     phys.append(("silB", (S - 6, S - 5, S - 4)))
     phys.append(("silE", (S - 3, S - 2, S - 1)))
-    write_hmmdefs(workdir / "hmmdefs", model, phones=phys)
+    write_hmmdefs(workdir / "hmmdefs", model, phones=phys, trans=trans)
     # logical triphones -> physical variants; contexts include silB/silE
     ctx = phones + sil
     lines = ["silB silB", "silE silE"]

@@ -37,6 +37,8 @@ typedef struct {
   float score_pruning_threshold, score_pruning_max;
   float wordend_best_score; int wordend_best_node, wordend_best_tre, wordend_best_last_cword;
   jamd_trellis_atom *atoms; int natom, atom_cap, overflow;
+  int lmt;                  /* lx->lm_type without the multipath flag */
+  int mp;                   /* multipath lexicon (hmminfo->multipath): beam.c:2747-2836, :2930-2943, :3066-3073 */
 } beam;
 
 /* ---- LM ------------------------------------------------------------------- */
@@ -218,7 +220,7 @@ static void intra_word_core(beam *b, int j, int next_node, float next_a)
   tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];       /* copy: the list may be realloc'ed */
   float tmpsum = tk.score + next_a, ngram_score_cache = JO_LOG_ZERO;
   /* with per-category trees (grammar) the whole factoring block is skipped: beam.c:2029 */
-  if (lx->lm_type == JAMD_LM_NGRAM && next_node != tk.node && lx->scid[next_node] != 0) {
+  if (b->lmt == JAMD_LM_NGRAM && next_node != tk.node && lx->scid[next_node] != 0) {
     ngram_score_cache = max_successor_prob(lx, tk.last_cword, next_node) * lx->lm_weight + lx->lm_penalty;
     tmpsum -= tk.last_lscore;
     tmpsum += ngram_score_cache;
@@ -252,11 +254,25 @@ static int save_trellis(beam *b, const tok *tk, int t)
   return b->natom++;
 }
 
-/* beam_inter_word(), beam.c:2271-2520 (LM_PROB, UNIGRAM_FACTORING, non-multipath) */
-static void inter_word(beam *b, int j, int tre)
+/* Entering a word at its root: beam.c:2467-2510 / :2585-2613.  A multipath root has no output, so the
+ * token goes one step further along the root's own arcs (self, next, extra) within the same frame. */
+static void enter_word(beam *b, int next_node, float tmpsum, int tre, int last_word, float cache)
 {
   const jamd_lexicon_desc *lx = b->lx;
-  tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+  int k;
+  if (!b->mp) { propagate_token(b, next_node, tmpsum, tre, last_word, cache); return; }
+  if (lx->self_a[next_node] != JO_LOG_ZERO) propagate_token(b, next_node, tmpsum + lx->self_a[next_node], tre, last_word, cache);
+  if (lx->next_a[next_node] != JO_LOG_ZERO) propagate_token(b, next_node + 1, tmpsum + lx->next_a[next_node], tre, last_word, cache);
+  for (k = lx->ac_off[next_node]; k < lx->ac_off[next_node + 1]; k++)
+    propagate_token(b, lx->ac_to[k], tmpsum + lx->ac_a[k], tre, last_word, cache);
+}
+
+/* beam_inter_word(), beam.c:2271-2520 (LM_PROB, UNIGRAM_FACTORING).  `li` is the list the source token
+ * lives in: the previous frame's (normal mode) or this frame's (multipath, :2781). */
+static void inter_word(beam *b, int li, int j, int tre)
+{
+  const jamd_lexicon_desc *lx = b->lx;
+  tok tk = b->tlist[li][b->tindex[li][j]];
   int node = tk.node, sword = lx->stend[node], stid, isoid;
   int last_word = lx->is_transparent[sword] ? tk.last_cword : sword;
   float tmpprob, tmpsum, ngram_score_cache;
@@ -267,6 +283,7 @@ static void inter_word(beam *b, int j, int tre)
     b->wordend_best_tre = tre; b->wordend_best_last_cword = tk.last_cword;
   }
   for (stid = lx->startnum - 1; stid >= 0; stid--) {
+    if (b->mp && lx->startnode[stid] == lx->word_head[lx->head_silwid]) continue;   /* :2336-2341 */
     isoid = lx->start2isolate[stid];
     if (isoid == -1) continue;
     tmpprob = iw_prob(lx, last_word, stid);      /* iwparray[isoid], keyed by the same word :2323-2327 */
@@ -276,17 +293,17 @@ static void inter_word(beam *b, int j, int tre)
     tmpsum += ngram_score_cache;
     if (lx->is_transparent[sword] && tk.last_cword >= 0 && lx->is_transparent[tk.last_cword])
       tmpsum += lx->lm_penalty_trans;
-    propagate_token(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
+    enter_word(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
   }
 }
 
 /* beam_inter_word(), grammar branch (LM_DFA with category tree, no forward DFA):
  * category-pair test per root (beam.c:2404-2412), word insertion penalty + delayed class
  * penalty of the previous word (:2452-2461) */
-static void inter_word_dfa(beam *b, int j, int tre)
+static void inter_word_dfa(beam *b, int li, int j, int tre)
 {
   const jamd_lexicon_desc *lx = b->lx;
-  tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+  tok tk = b->tlist[li][b->tindex[li][j]];
   int sword = lx->stend[tk.node], stid;
   int last_word = lx->is_transparent[sword] ? tk.last_cword : sword;
   float tmpsum, ngram_score_cache;
@@ -297,7 +314,7 @@ static void inter_word_dfa(beam *b, int j, int tre)
     ngram_score_cache = lx->penalty1;
     ngram_score_cache += lx->cprob[last_word];
     tmpsum += ngram_score_cache;
-    propagate_token(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
+    enter_word(b, lx->startnode[stid], tmpsum, tre, last_word, ngram_score_cache);
   }
 }
 
@@ -310,6 +327,7 @@ static void inter_word_factoring(beam *b)
   float tmpsum, ngram_score_cache;
   for (stid = lx->startnum - 1; stid >= 0; stid--) {
     next_node = lx->startnode[stid];
+    if (b->mp && next_node == lx->word_head[lx->head_silwid]) continue;      /* :2566-2571 */
     if (lx->start2isolate[stid] != -1) continue;
     ngram_score_cache = lx->fscore[-lx->scid[next_node]] * lx->lm_weight + lx->lm_penalty;
     tmpsum = b->wordend_best_score;
@@ -317,7 +335,7 @@ static void inter_word_factoring(beam *b)
     if (lx->is_transparent[sword] && b->wordend_best_last_cword >= 0 &&
         lx->is_transparent[b->wordend_best_last_cword]) tmpsum += lx->lm_penalty_trans;
     if (tmpsum < b->score_pruning_threshold) continue;
-    propagate_token(b, next_node, tmpsum, b->wordend_best_tre, last_word, ngram_score_cache);
+    enter_word(b, next_node, tmpsum, b->wordend_best_tre, last_word, ngram_score_cache);
   }
 }
 
@@ -342,6 +360,7 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
   int t, j, i, node, rc = 0;
   memset(b, 0, sizeof(*b));
   b->lx = lx; b->sc = sc; b->S = S; b->atoms = atoms; b->atom_cap = atom_cap;
+  b->lmt = lx->lm_type & 0xff; b->mp = (lx->lm_type & JAMD_LM_MULTIPATH) != 0;
   *natom = 0; *wnum = 0; *pass1_score = JO_LOG_ZERO; *died_at = -1;
   if (T <= 0) return 1;
 
@@ -356,14 +375,14 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
   }
   b->token = (int *)malloc(sizeof(int) * lx->nnode);
   for (i = 0; i < lx->nnode; i++) b->token[i] = -1;
-  if (lx->lm_type != JAMD_LM_NGRAM) {                      /* init_nodescore :1669-1757 (grammar), :1762-1788 (word list) */
+  if (b->lmt != JAMD_LM_NGRAM) {                           /* init_nodescore :1669-1757 (grammar), :1762-1788 (word list) */
     int e;
     for (e = 0; e < lx->ninit; e++) {
       int id = create_token(b);
       tok *nw = &b->tlist[b->tn][id];
       node = lx->init_node[e];
       nw->last_tre = -1; nw->last_cword = -1; nw->last_lscore = lx->init_lscore[e];
-      nw->score = outprob_style(b, node, -1, 0) + nw->last_lscore;
+      nw->score = b->mp ? nw->last_lscore : outprob_style(b, node, -1, 0) + nw->last_lscore;   /* :1733-1737 */
       b->token[node] = id; nw->node = node;
     }
   } else {                                                 /* init_nodescore :1622-1665 */
@@ -373,58 +392,88 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
     nw->last_lscore = (lx->scid[node] != 0) ? max_successor_prob(lx, -1, node) : 0.0f;
     nw->last_lscore = nw->last_lscore * lx->lm_weight + lx->lm_penalty;
     nw->last_tre = -1; nw->last_cword = -1;
-    nw->score = outprob_style(b, node, -1, 0) + nw->last_lscore;
+    nw->score = b->mp ? nw->last_lscore : outprob_style(b, node, -1, 0) + nw->last_lscore;     /* :1657-1663 */
     b->token[node] = id; nw->node = node;
   }
   sort_token_no_order(b, beam_width);
   b->score_pruning_threshold = JO_LOG_ZERO;
 
-  /* get_back_trellis_proceed */
-  for (t = 1; t < T; t++) {
+  /* get_back_trellis_proceed: frames 1..T-1; a multipath model also runs frame 0 through it
+   * (pass1.c:239) and ends with one transition-only call (get_back_trellis_end :3066-3073) */
+  for (t = b->mp ? 0 : 1; t < (b->mp ? T + 1 : T); t++) {
+    const int final = b->mp && t == T;
     int tl, tn;
     b->tl = b->tn; b->tn = b->tn ? 0 : 1;
     tl = b->tl; tn = b->tn;
     b->wordend_best_score = JO_LOG_ZERO;
     for (j = 0; j < b->tnum[tl]; j++) b->token[b->tlist[tl][j].node] = -1;   /* clear_tokens :1122 */
-    for (j = b->n_start; j <= b->n_end; j++) {
-      tok tk = b->tlist[tl][b->tindex[tl][j]];
-      if (tk.score <= JO_LOG_ZERO) continue;
-      if (tk.score < b->score_pruning_threshold) continue;
-      intra_word(b, j);
-      if (lx->stend[tk.node] >= 0) {
-        int tre = save_trellis(b, &tk, t);
-        if (lx->lm_type == JAMD_LM_WORD) continue;          /* isolated words: no cross-word transition :2875 */
-        if (lx->lm_type == JAMD_LM_DFA) inter_word_dfa(b, j, tre);
-        else inter_word(b, j, tre);
+    if (b->mp) {
+      /* :2752-2769 word-internal transitions of every survivor, :2774 beam over the NEW tokens,
+       * :2779-2825 word ends among them: trellis word, then cross-word transition within this frame */
+      for (j = b->n_start; j <= b->n_end; j++) {
+        tok tk = b->tlist[tl][b->tindex[tl][j]];
+        if (tk.score <= JO_LOG_ZERO) continue;
+        if (tk.score < b->score_pruning_threshold) continue;
+        intra_word(b, j);
+      }
+      sort_token_no_order(b, beam_width);
+      for (j = b->n_start; j <= b->n_end; j++) {
+        tok tk = b->tlist[tn][b->tindex[tn][j]];
+        if (tk.score < b->score_pruning_threshold) continue;
+        if (lx->stend[tk.node] >= 0) {
+          int tre = save_trellis(b, &tk, t);
+          if (final) continue;
+          if (b->lmt == JAMD_LM_WORD) continue;
+          if (b->lmt == JAMD_LM_DFA) inter_word_dfa(b, tn, j, tre);
+          else inter_word(b, tn, j, tre);
+        }
+      }
+    } else {
+      for (j = b->n_start; j <= b->n_end; j++) {
+        tok tk = b->tlist[tl][b->tindex[tl][j]];
+        if (tk.score <= JO_LOG_ZERO) continue;
+        if (tk.score < b->score_pruning_threshold) continue;
+        intra_word(b, j);
+        if (lx->stend[tk.node] >= 0) {
+          int tre = save_trellis(b, &tk, t);
+          if (b->lmt == JAMD_LM_WORD) continue;               /* isolated words: no cross-word transition :2875 */
+          if (b->lmt == JAMD_LM_DFA) inter_word_dfa(b, tl, j, tre);
+          else inter_word(b, tl, j, tre);
+        }
       }
     }
-    if (lx->lm_type == JAMD_LM_NGRAM && b->wordend_best_score > JO_LOG_ZERO) inter_word_factoring(b);
+    if (b->lmt == JAMD_LM_NGRAM && b->wordend_best_score > JO_LOG_ZERO) inter_word_factoring(b);
     b->score_pruning_max = JO_LOG_ZERO;
-    for (j = 0; j < b->tnum[tn]; j++) {                                       /* :2944-2951 */
-      tok *tk = &b->tlist[tn][b->tindex[tn][j]];
-      int lw = tk->last_tre < 0 ? -1 : atoms[tk->last_tre].wid;
-      tk->score += outprob_style(b, tk->node, lw, t);
-      if (b->score_pruning_max < tk->score) b->score_pruning_max = tk->score;
+    if (!final) {
+      for (j = 0; j < b->tnum[tn]; j++) {                                     /* :2930-2951 */
+        tok *tk = &b->tlist[tn][b->tindex[tn][j]];
+        int lw = tk->last_tre < 0 ? -1 : atoms[tk->last_tre].wid;
+        if (b->mp && lx->out_kind[tk->node] == JAMD_AS_NONE) continue;        /* non-output node :2935 */
+        tk->score += outprob_style(b, tk->node, lw, t);
+        if (b->score_pruning_max < tk->score) b->score_pruning_max = tk->score;
+      }
     }
     if (score_pruning_width >= 0.0f) b->score_pruning_threshold = b->score_pruning_max - score_pruning_width;
     else b->score_pruning_threshold = JO_LOG_ZERO;
     b->tnum[tl] = 0;                                                           /* clear_tlist */
     sort_token_no_order(b, beam_width);
-    if (b->tnum[tn] == 0) { *died_at = t; rc = 2; break; }
+    if (b->tnum[tn] == 0) { if (!final) { *died_at = t; rc = 2; } break; }
   }
 
   if (rc == 0) {
     /* get_back_trellis_end (non-multipath) :3076-3086 */
-    b->tl = b->tn; b->tn = b->tn ? 0 : 1;
-    for (j = b->n_start; j <= b->n_end; j++) {
-      tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
-      if (lx->stend[tk.node] >= 0) save_trellis(b, &tk, T);
+    if (!b->mp) {
+      b->tl = b->tn; b->tn = b->tn ? 0 : 1;
+      for (j = b->n_start; j <= b->n_end; j++) {
+        tok tk = b->tlist[b->tl][b->tindex[b->tl][j]];
+        if (lx->stend[tk.node] >= 0) save_trellis(b, &tk, T);
+      }
     }
     /* find_1pass_result :399-431: the tail-silence word ending latest */
     {
       int best = -1, last_time;
       for (last_time = T - 1; last_time >= 0 && best < 0; last_time--) {
-        if (lx->lm_type != JAMD_LM_NGRAM) {
+        if (b->lmt != JAMD_LM_NGRAM) {
           /* grammar (:433-455), word list (find_1pass_result_word :591-605): the best word on the latest frame that has one; rw[t] is sorted
            * by word id and the test is a strict <, so ties go to the smaller word id */
           float maxscore = JO_LOG_ZERO;

@@ -471,7 +471,8 @@ int jref_engine_save_lexicon(void *h, const char *path)
 {
   jref_eng *e = (jref_eng *)h;
   jamd_flat_lexicon fl;
-  int rc = jamd_flatten_lexicon(e->recog->process_list, &fl);
+  int rc = e->recog->process_list->am->hmminfo->multipath ? jamd_flatten_lexicon_multipath(e->recog->process_list, &fl)
+                                                          : jamd_flatten_lexicon(e->recog->process_list, &fl);
   if (rc != 0) return rc;
   rc = jamd_lexicon_save(&fl.desc, path);
   jamd_flat_lexicon_free(&fl);

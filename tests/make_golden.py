@@ -240,12 +240,23 @@ def main_rejgmm():
     save("rejgmm.npz", **out)
 
 
+def main_multipath():
+    """B6: a model that needs multipath handling (two entry arcs, state skips, early exits): non-emitting
+    word-begin / word-end nodes, frame 0 through get_back_trellis_proceed()."""
+    ref = pyoracle.Ref()
+    tmp = Path(tempfile.mkdtemp())
+    trans = np.array([[0, .7, .3, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2], [0, 0, 0, .6, .4], [0, 0, 0, 0, 0]])
+    beam_fixture(ref, tmp, "beam_multipath", seed=8, beam=100, extra=["-sepnum", "4", "-bs", "90"], nword=50, trans=trans)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("am", "all"):
         main()
     if what in ("beam", "all"):
         main_beam()
+    if what in ("multipath", "all"):
+        main_multipath()
     if what in ("gms", "all"):
         main_gms()
     if what in ("rejgmm", "all"):

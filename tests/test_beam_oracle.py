@@ -11,7 +11,7 @@ from julius_amd import lexblob, synth
 
 
 @pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz",
-                                  "beam_grammar.npz", "beam_grammar_free.npz"])
+                                  "beam_grammar.npz", "beam_grammar_free.npz", "beam_multipath.npz"])
 def test_oracle_matches_golden(oracle, name):
     g = load_beam_golden(name)
     for u in g["utts"]:
@@ -142,3 +142,61 @@ def test_oracle_matches_reference_wordlist(oracle, ref, tmp_path, triphone):
         assert rc == 0
         assert_trellis_equal(atoms, rtr)
         assert list(wseq) == list(fw) and score == fs
+
+
+SKIP_TRANS = np.array([[0, 1, 0, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2], [0, 0, 0, .6, .4], [0, 0, 0, 0, 0]])
+SPLIT_TRANS = np.array([[0, .7, .3, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2], [0, 0, 0, .6, .4], [0, 0, 0, 0, 0]])
+
+
+@pytest.mark.parametrize("seed,beam,extra", [
+    (41, 200, ["-sepnum", "5"]),
+    (42, 30, ["-sepnum", "2"]),
+    (43, 150, ["-sepnum", "4", "-bs", "40", "-iwcd1", "max"]),
+    (44, 120, ["-sepnum", "0", "-iwcd1", "avg", "-transp", "-1.5"]),
+    (45, 150, ["-sepnum", "4", "skip"]),       # state-skip and early-exit arcs: the model itself needs multipath
+    (46, 150, ["-sepnum", "4", "split"]),      # two entry arcs as well
+])
+def test_oracle_matches_reference_multipath(oracle, ref, tmp_path, seed, beam, extra):
+    """-multipath: non-emitting word-begin / word-end nodes, frame 0 through get_back_trellis_proceed(),
+    the beam applied to the new tokens BEFORE the cross-word step and one transition-only call at the
+    end (beam.c:2747-2836, :2930-2943, :3066-3073; pass1.c:239).  The device first pass does not take
+    these lexicons yet; the oracle is pinned here for it."""
+    kw = dict(ntransparent=12) if "-transp" in extra else {}
+    if extra[-1] in ("skip", "split"):         # need_multipath is found by the loader (rdhmmdef.c:357): no -multipath
+        kw["trans"] = SKIP_TRANS if extra[-1] == "skip" else SPLIT_TRANS
+        extra = extra[:-1]
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra), **kw)
+        assert len(lex["ac_to"]) > 0
+    else:
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], **kw)
+    assert eng.multipath == 1 and lex["lm_type"] == 0x100
+    assert (lex["out_kind"] == 4).sum() >= lex["nword"]           # every word ends in a non-emitting node
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    for u in range(3):
+        fr, _ = synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr, (wseq, score) = eng.recognize(tmp_path / "u.mfc")
+        sc = oracle.gmm_outprob(am, fr)
+        atoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, bs)
+        assert rc in (0, 1)
+        assert_trellis_equal(atoms, tr)
+        if rc == 0:
+            assert np.array_equal(owseq, wseq) and oscore == score
+
+
+@pytest.mark.parametrize("seed,beam,extra,wrap", [
+    (51, 120, ["-penalty1", "-2.0"], True),
+    (52, 40, ["-iwcd1", "avg", "-penalty1", "-1.0"], False),
+])
+def test_oracle_matches_reference_multipath_grammar(oracle, ref, tmp_path, seed, beam, extra, wrap):
+    eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], wrap=wrap, nword=70)
+    assert lex["lm_type"] == 0x101
+    for u in range(3):
+        fr, _ = synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        sc = oracle.gmm_outprob(am, fr)
+        atoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, -1.0)
+        assert rc == 0
+        assert_trellis_equal(atoms, rtr)
+        assert np.array_equal(wseq, rwseq) and score == rscore
