@@ -120,18 +120,18 @@ def test_oracle_matches_reference_c1_grammar(oracle, ref, tmp_path):
         assert np.array_equal(wseq, rwseq) and score == rscore
 
 
-@pytest.mark.parametrize("triphone", [True, False])
-def test_oracle_matches_reference_wordlist(oracle, ref, tmp_path, triphone):
+@pytest.mark.parametrize("triphone,multipath", [(True, False), (False, False), (True, True)])
+def test_oracle_matches_reference_wordlist(oracle, ref, tmp_path, triphone, multipath):
     """Isolated word recognition (-w): every listed word starts with a token, no cross-word
     transition, best word on the last frame (beam.c:1762-1788, :2875, find_1pass_result_word())."""
     from oracle import pyoracle
     task = synth.make_wordlist_task(tmp_path, seed=5, triphone=triphone)
     args = ["-h", task["hmmdefs"]] + (["-hlist", task["hmmlist"]] if triphone else []) + [
         "-w", task["wordlist"], "-wsil", "silB", "silE", "silB", "-input", "htkparam", "-gprune", "none", "-b", "60"]
-    eng = pyoracle.RefEngine(ref, args)
+    eng = pyoracle.RefEngine(ref, args + (["-multipath"] if multipath else []))
     eng.save_lexicon(tmp_path / "lex.blob")
     lex = lexblob.load(tmp_path / "lex.blob")
-    assert lex["lm_type"] == 2
+    assert lex["lm_type"] == (0x102 if multipath else 2)
     am = ref.am_load(task["hmmdefs"], hmmlist=task["hmmlist"] if triphone else None).export()
     for u in range(4):
         fr, _ = synth.make_wordlist_utterance(task, seed=u)
