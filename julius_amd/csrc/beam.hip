@@ -1279,6 +1279,190 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
   res->status = status; res->died_at = died_at; res->natom = b.natom; res->max_tokens = max_tokens;
 }
 
+// ---- multipath lexicons (hmminfo->multipath), strict order only -------------------------------------
+// A multipath model (model-skip / state-skip transitions) builds a lexicon whose word-begin and
+// word-end nodes have no output, and beam.c runs a different frame for it (:2747-2836): word-internal
+// transitions of every survivor, THEN the beam over the new tokens, THEN trellis words and cross-word
+// transitions from the word ends among those (the root has no output, so the token is passed on along
+// the root's own arcs within the frame, :2467-2510), output probabilities only on emitting nodes
+// (:2930-2943); frame 0 already goes through this (pass1.c:239) and one transition-only call ends the
+// input (:3066-3073).  Kept as its own kernel beside beam_strict_kernel: same helpers, same records.
+// EXPERIMENTAL: written when no device time was left to run it; the CPU restatement of the same frame
+// is pinned to the reference on multipath tasks (tests/test_beam_oracle.py).  Lexicons of this kind are
+// accepted only with JAMD_EXPERIMENTAL_MULTIPATH=1 until tests/test_beam_gpu.py has passed on hardware.
+__device__ void s_enter_word_mp(SBeam &b, const LexDev &lx, int root, float tmpsum, int tre, int last_word, float ng) {
+  const int4 na = lx.node_a(root);
+  const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
+  if (a_self != JAMD_LOG_ZERO) s_propagate(b, root, tmpsum + a_self, tre, last_word, ng);
+  if (a_next != JAMD_LOG_ZERO) s_propagate(b, root + 1, tmpsum + a_next, tre, last_word, ng);
+  for (int e = na.z; e < na.w; e++) s_propagate(b, lx.ac_to(e), tmpsum + lx.ac_a(e), tre, last_word, ng);
+}
+
+__global__ void __launch_bounds__(64)
+beam_strict_mp_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ scores, int S,
+                      const int *__restrict__ utt_off, int nutt) {
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  if (u >= nutt) return;
+  const int t_begin = utt_off[u], T = utt_off[u + 1] - t_begin;
+  jamd_pass1_result *res = wk.res + u;
+  SBeam b;
+  b.lx = &lx; b.sc = scores + (size_t)t_begin * S; b.S = S;
+  for (int i = 0; i < 2; i++) { b.tl[i] = sw.tl[i] + (size_t)u * sw.cap; b.ti[i] = sw.ti[i] + (size_t)u * sw.cap; b.tnum[i] = 0; }
+  b.token = sw.token + (size_t)u * wk.nnode; b.cap = sw.cap;
+  b.atoms = reinterpret_cast<jamd_trellis_atom *>(wk.slices + (size_t)u * wk.utt_stride + wk.o_atoms); b.natom = 0; b.atom_cap = wk.atom_cap; b.overflow = false;
+  res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO; res->died_at = -1;
+  res->ties = res->ties_node = res->ties_wordend = res->ties_cut = 0; res->frames = T; res->max_tokens = 0;
+  for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
+  if (T <= 0) { res->status = JAMD_PASS1_FAIL; return; }
+  for (int i = 0; i < wk.nnode; i++) b.token[i] = -1;
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+  int status = JAMD_PASS1_OK, died_at = -1, max_tokens = 1;
+  b.tn = 0; b.tlx = 1;
+  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;
+  const bool wordmode = lx.lm_type == JAMD_LM_WORD;
+  const int head_root = dfa ? -1 : lx.word_head(lx.head_silwid);
+  if (dfa) {                                                         // init_nodescore(): score = LM score only (:1733)
+    for (int e = 0; e < lx.ninit; e++) {
+      const int id = s_create_token(b);
+      STok &nw = b.tl[b.tn][id];
+      const int node = lx.init_node(e);
+      nw.last_lscore = lx.init_lscore(e); nw.last_tre = -1; nw.last_cword = -1;
+      nw.score = nw.last_lscore;
+      nw.node = node; b.token[node] = id;
+    }
+  } else {                                                           // :1635-1663
+    const int id = s_create_token(b);
+    STok &nw = b.tl[b.tn][id];
+    const int4 nr = lx.node_b(head_root);
+    float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
+    ls = ls * lmw + pen;
+    nw.last_lscore = ls; nw.last_tre = -1; nw.last_cword = -1;
+    nw.score = ls;
+    nw.node = head_root; b.token[head_root] = id;
+  }
+  s_sort_no_order(b, wk.beam);
+  b.thr = JAMD_LOG_ZERO;
+
+  for (int t = 0; t <= T; t++) {                                     // t == T: get_back_trellis_end()'s final call
+    const bool final = t == T;
+    b.tlx = b.tn; b.tn = b.tn ? 0 : 1;
+    const int tl = b.tlx, tn = b.tn;
+    b.we_best_score = JAMD_LOG_ZERO;
+    for (int j = 0; j < b.tnum[tl]; j++) b.token[b.tl[tl][j].node] = -1;
+    for (int j = b.n_start; j <= b.n_end; j++) {                     // :2752-2769
+      const STok tk = b.tl[tl][b.ti[tl][j]];
+      if (tk.score <= JAMD_LOG_ZERO) continue;
+      if (tk.score < b.thr) continue;
+      const int node = tk.node;
+      const int4 na = lx.node_a(node);
+      const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
+      if (a_self != JAMD_LOG_ZERO) s_intra_core(b, tk, node, a_self);
+      if (a_next != JAMD_LOG_ZERO) s_intra_core(b, tk, node + 1, a_next);
+      for (int e = na.z; e < na.w; e++) s_intra_core(b, tk, lx.ac_to(e), lx.ac_a(e));
+    }
+    s_sort_no_order(b, wk.beam);                                     // :2774, over the new tokens
+    for (int j = b.n_start; j <= b.n_end; j++) {                     // :2779-2825
+      const STok tk = b.tl[tn][b.ti[tn][j]];
+      if (tk.score < b.thr) continue;
+      const int node = tk.node;
+      const int sword = lx.node_b(node).x;
+      if (sword < 0) continue;
+      const int tre = s_save_trellis(b, tk, sword, t);
+      if (final || wordmode) continue;
+      if (dfa) {
+        const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
+        for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+          if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(stid))) continue;
+          float tmpsum = tk.score;
+          float ng = lx.penalty1;
+          ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
+          tmpsum += ng;
+          s_enter_word_mp(b, lx, lx.startnode(stid), tmpsum, tre, last_word, ng);
+        }
+      } else if (sword != lx.tail_silwid) {
+        const bool tr = lx.is_transparent(sword) != 0;
+        const int last_word = tr ? tk.last_cword : sword;
+        if (b.we_best_score < tk.score) {                                       // no wordend_a in multipath (:2307)
+          b.we_best_score = tk.score; b.we_best_node = node; b.we_best_tre = tre; b.we_best_cword = tk.last_cword;
+        }
+        for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+          const int next_node = lx.startnode(stid);
+          if (next_node == head_root) continue;                                 // :2336-2341
+          if (lx.start2isolate(stid) == -1) continue;
+          const int wn = lx.scword(lx.scid(next_node));
+          const float p = (last_word < 0) ? 0.0f
+                          : bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn);
+          float tmpsum = tk.score;
+          const float ng = p * lmw + pen;
+          tmpsum += ng;
+          if (tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword)) tmpsum += lx.lm_penalty_trans;
+          s_enter_word_mp(b, lx, next_node, tmpsum, tre, last_word, ng);
+        }
+      }
+    }
+    if (!dfa && b.we_best_score > JAMD_LOG_ZERO) {                               // beam_inter_word_factoring()
+      const int sword = lx.node_b(b.we_best_node).x;
+      const int last_word = lx.is_transparent(sword) ? b.we_best_cword : sword;
+      for (int stid = lx.startnum - 1; stid >= 0; stid--) {
+        const int next_node = lx.startnode(stid);
+        if (next_node == head_root) continue;                                    // :2566-2571
+        if (lx.start2isolate(stid) != -1) continue;
+        const float ng = lx.fscore(-lx.scid(next_node)) * lmw + pen;
+        float tmpsum = b.we_best_score;
+        tmpsum += ng;
+        if (lx.is_transparent(sword) && b.we_best_cword >= 0 && lx.is_transparent(b.we_best_cword)) tmpsum += lx.lm_penalty_trans;
+        if (tmpsum < b.thr) continue;
+        s_enter_word_mp(b, lx, next_node, tmpsum, b.we_best_tre, last_word, ng);
+      }
+    }
+    float pmax = JAMD_LOG_ZERO;
+    if (!final) {                                                                // :2930-2943
+      const float *row = b.sc + (size_t)t * S;
+      for (int j = 0; j < b.tnum[tn]; j++) {
+        STok &tk = b.tl[tn][b.ti[tn][j]];
+        const int4 nr = lx.node_b(tk.node);
+        if (nr.w == JAMD_AS_NONE) continue;                                      // non-output node
+        const int lw = tk.last_tre < 0 ? -1 : b.atoms[tk.last_tre].wid;
+        tk.score += node_outprob(lx, row, nr.w, nr.z, lw);
+        if (pmax < tk.score) pmax = tk.score;
+      }
+    }
+    b.thr = (wk.width >= 0.0f) ? (pmax - wk.width) : JAMD_LOG_ZERO;
+    if (b.tnum[tn] > max_tokens) max_tokens = b.tnum[tn];
+    b.tnum[tl] = 0;
+    s_sort_no_order(b, wk.beam);
+    if (b.tnum[tn] == 0) { if (!final) { status = JAMD_PASS1_DIED; died_at = t; } break; }
+    if (b.overflow) break;
+  }
+  if (status == JAMD_PASS1_OK && !b.overflow) {
+    int best = -1;                                                               // find_1pass_result() :399
+    if (dfa) {
+      int lt = -1;
+      for (int i = b.natom - 1; i >= 0 && lt < 0; i--) if (b.atoms[i].backscore > JAMD_LOG_ZERO) lt = b.atoms[i].endtime;
+      for (int i = 0; i < b.natom; i++) {
+        const jamd_trellis_atom &a = b.atoms[i];
+        if (a.endtime != lt || !(a.backscore > JAMD_LOG_ZERO)) continue;
+        if (best < 0 || b.atoms[best].backscore < a.backscore ||
+            (b.atoms[best].backscore == a.backscore && a.wid < b.atoms[best].wid)) best = i;
+      }
+    } else {
+      for (int i = b.natom - 1; i >= 0; i--)
+        if (b.atoms[i].wid == lx.tail_silwid && b.atoms[i].backscore > JAMD_LOG_ZERO) { best = i; break; }
+    }
+    if (best < 0) status = JAMD_PASS1_FAIL;
+    else {
+      int n = 0, a = best;
+      int rev[MAXSEQ];
+      rev[n++] = b.atoms[a].wid;
+      while (b.atoms[a].begintime > 0 && n < MAXSEQ) { a = b.atoms[a].last_tre; rev[n++] = b.atoms[a].wid; }
+      for (int k = 0; k < n; k++) res->wseq[k] = rev[n - 1 - k];
+      res->wnum = n; res->score = b.atoms[best].backscore;
+    }
+  }
+  if (b.overflow) status = JAMD_PASS1_OVERFLOW;
+  res->status = status; res->died_at = died_at; res->natom = b.natom; res->max_tokens = max_tokens;
+}
+
 template <typename T>
 int upload(T **dst, const T *src, size_t n) {
   JAMD_HIP(hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)));
@@ -1292,6 +1476,7 @@ struct jamd_lexicon {
   jamd_engine *eng = nullptr;
   LexDev d{};
   int maxfan = 2, nscword = 0;
+  bool multipath = false;          // JAMD_LM_MULTIPATH lexicon: strict-order kernel only (beam_strict_mp_kernel)
   std::vector<void *> owned;
 };
 
@@ -1315,9 +1500,18 @@ extern "C" {
 int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon **out) {
   if (!e || !h || !out) { jamd_set_error("jamd_lexicon_create: NULL argument"); return JAMD_EINVAL; }
   *out = nullptr;
-  const bool wordmode = h->lm_type == JAMD_LM_WORD;
-  const bool dfa = h->lm_type == JAMD_LM_DFA || wordmode;      // the two LM_DFA variants share everything but the word boundary
-  if (h->lm_type != JAMD_LM_NGRAM && !dfa) { jamd_set_error("jamd_lexicon_create: lm_type=%d", h->lm_type); return JAMD_EINVAL; }
+  const int lmt = h->lm_type & 0xff;
+  const bool multipath = (h->lm_type & JAMD_LM_MULTIPATH) != 0;
+  const bool wordmode = lmt == JAMD_LM_WORD;
+  const bool dfa = lmt == JAMD_LM_DFA || wordmode;             // the two LM_DFA variants share everything but the word boundary
+  if ((h->lm_type & ~(0xff | JAMD_LM_MULTIPATH)) != 0 || (lmt != JAMD_LM_NGRAM && !dfa)) {
+    jamd_set_error("jamd_lexicon_create: lm_type=%d", h->lm_type); return JAMD_EINVAL;
+  }
+  if (multipath && (getenv("JAMD_EXPERIMENTAL_MULTIPATH") == nullptr || atoi(getenv("JAMD_EXPERIMENTAL_MULTIPATH")) == 0)) {
+    jamd_set_error("jamd_lexicon_create: multipath lexicons are not served yet (the strict-order kernel for them "
+                   "is experimental: JAMD_EXPERIMENTAL_MULTIPATH=1)");
+    return JAMD_EINVAL;
+  }
   if (dfa && (h->ninit < 0 || (h->ninit > 0 && (!h->init_node || !h->init_lscore)) ||
               (!wordmode && (h->ncat <= 0 || !h->cat_pair || !h->start2wid)))) {
     jamd_set_error("jamd_lexicon_create: grammar descriptor incomplete (ncat=%d ninit=%d)", h->ncat, h->ninit);
@@ -1354,7 +1548,7 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   if (h->nword >= (1 << 30)) { jamd_set_error("jamd_lexicon_create: nword=%d too large", h->nword); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(e->device));
   jamd_lexicon *l = new jamd_lexicon();
-  l->eng = e; l->maxfan = maxfan; l->nscword = h->nscword;
+  l->eng = e; l->maxfan = maxfan; l->nscword = h->nscword; l->multipath = multipath;
   LexDev &d = l->d;
   d.nnode = h->nnode; d.nword = h->nword; d.startnum = h->startnum; d.isolatenum = h->isolatenum;
   d.nshared = (int)shared.size(); d.nlc = h->nlc; d.cdset_method = h->cdset_method; d.cdmax_num = h->cdmax_num;
@@ -1406,7 +1600,7 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   UP(ng_uni_prob, h->ng_uni_prob, h->ng_nword); UP(ng_uni_bo, h->ng_uni_bo, h->ng_nword);
   UP(ng_bi_bgn, h->ng_bi_bgn, h->ng_nword); UP(ng_bi_num, h->ng_bi_num, h->ng_nword);
   UP(ng_bi_wid, h->ng_bi_wid, h->ng_nbigram); UP(ng_bi_prob, h->ng_bi_prob, h->ng_nbigram);
-  d.lm_type = h->lm_type; d.ncat = dfa ? h->ncat : 0; d.ninit = dfa ? h->ninit : 0; d.penalty1 = dfa ? h->penalty1 : 0.0f;
+  d.lm_type = lmt; d.ncat = dfa ? h->ncat : 0; d.ninit = dfa ? h->ninit : 0; d.penalty1 = dfa ? h->penalty1 : 0.0f;
   if (dfa) {
     std::vector<int> root_cat(h->startnum, 0);
     for (int s = 0; s < h->startnum && !wordmode; s++) {
@@ -1549,7 +1743,15 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  if (b->strict)
+  if (b->lex->multipath && !b->strict) {
+    jamd_set_error("jamd_beam_pass1_dev: a multipath lexicon is decoded by the strict-order kernel only: "
+                   "jamd_beam_set_strict_order(b, 1)");
+    return JAMD_ESTATE;
+  }
+  if (b->strict && b->lex->multipath)
+    hipLaunchKernelGGL(beam_strict_mp_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
+                       nstate, b->d_utt_off, nutt);
+  else if (b->strict)
     hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
   else {
@@ -1597,6 +1799,10 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
     }
   }
   for (int u = 0; u < nutt; u++) b->stream_frames[u] += chunk_off[u + 1] - chunk_off[u];
+  if (b->lex->multipath && !b->strict) {
+    jamd_set_error("jamd_beam_stream_push_dev: a multipath lexicon is decoded by the strict-order kernel only");
+    return JAMD_ESTATE;
+  }
   if (b->strict) {
     // the strict-order kernel keeps no state between launches: one push carrying everything
     if (!final || b->stream_pushes != 0) {
@@ -1632,7 +1838,8 @@ int jamd_beam_set_strict_order(jamd_beam *b, int on) {
   JAMD_HIP(hipSetDevice(b->eng->device));
   if (on && b->sw.token == nullptr) {
     const size_t U = (size_t)b->max_utts;
-    b->sw.cap = b->w.tok_cap + 2;
+    // a node holds at most one token per frame; multipath frames also create tokens behind every root
+    b->sw.cap = b->lex->multipath ? b->w.nnode + 2 : b->w.tok_cap + 2;
     void *p = nullptr;
     for (int i = 0; i < 2; i++) {
       JAMD_HIP(hipMalloc(&p, U * b->sw.cap * sizeof(STok))); b->owned.push_back(p); b->sw.tl[i] = (STok *)p;

@@ -38,6 +38,7 @@ typedef struct {
   HTK_HMM_INFO *hmminfo;
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam; jamd_gms *gms;
+  int strict;                /* JAMD_STRICT_ORDER, or a multipath model (strict-order kernel only) */
   int nstate;
   int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
   /* streaming state of the current utterance */
@@ -116,10 +117,16 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL &&
       c->nnode == r->wchmm->n && c->nword == r->wchmm->winfo->num && c->dfa == (void *)r->wchmm->dfa) return TRUE;
   ctx_release(c);
-  if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || r->am->hmminfo->multipath || r->config->successive.enabled) {
-    jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
-    return FALSE;
+  {
+    /* multipath models: only the experimental strict-order kernel takes them (JAMD_EXPERIMENTAL_MULTIPATH=1) */
+    const int mp_ok = getenv("JAMD_EXPERIMENTAL_MULTIPATH") != NULL && atoi(getenv("JAMD_EXPERIMENTAL_MULTIPATH")) != 0;
+    if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || (r->am->hmminfo->multipath && !mp_ok) || r->config->successive.enabled) {
+      jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
+      return FALSE;
+    }
   }
+  c->strict = r->am->hmminfo->multipath ||
+              (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0);
   if (r->am->hmmwrk.OP_gshmm != NULL && r->am->dnn != NULL) {
     jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) with a DNN-HMM is not supported\n");
     return FALSE;
@@ -167,7 +174,9 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   }
   {
     jamd_flat_lexicon fl;
-    if (jamd_flatten_lexicon(r, &fl) != JAMD_OK) { jlog("ERROR: jamd: cannot flatten the tree lexicon\n"); return FALSE; }
+    if ((r->am->hmminfo->multipath ? jamd_flatten_lexicon_multipath(r, &fl) : jamd_flatten_lexicon(r, &fl)) != JAMD_OK) {
+      jlog("ERROR: jamd: cannot flatten the tree lexicon\n"); return FALSE;
+    }
     rc = jamd_lexicon_create(g_eng, &fl.desc, &c->lex);
     jamd_flat_lexicon_free(&fl);
     if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
@@ -176,8 +185,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   rc = jamd_beam_create(g_eng, c->lex, r->trellis_beam_width, r->config->pass1.score_pruning_width, 1,
                         1 << 20, &c->beam);
   if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
-  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0 &&
-      jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  if (c->strict && jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
   c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
@@ -236,8 +244,7 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
   for (u = 0; u < n; u++)
     memcpy(frames + (size_t)off[u] * veclen, c->pre[first + u].frames, sizeof(float) * (size_t)c->pre[first + u].T * veclen);
   if (jamd_beam_create(g_eng, c->lex, c->beam_width, c->bs_width, n, 1 << 19, &bb) != JAMD_OK) goto out;
-  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0 &&
-      jamd_beam_set_strict_order(bb, 1) != JAMD_OK) goto out;
+  if (c->strict && jamd_beam_set_strict_order(bb, 1) != JAMD_OK) goto out;
   if (jamd_malloc(g_eng, sizeof(float) * total * veclen, (void **)&d_frames) != JAMD_OK ||
       jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores) != JAMD_OK ||
       jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||
@@ -318,7 +325,7 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   outprob_style_cache_init(r->wchmm);                 /* beam.c:1595: the 2nd pass reuses these caches */
   r->have_interim = FALSE;
   c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
-  if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) c->chunk = 0;   /* one final push */
+  if (c->strict) c->chunk = 0;                        /* one final push */
   if (c->gms != NULL) c->chunk = 0;                   /* the selection carries state from frame to frame */
   c->pushed = 0; c->failed = 0; c->hit = -1;
   if (c->npre > 0 && param->samplenum > 0) {          /* decoded ahead in a batch? */

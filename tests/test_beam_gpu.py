@@ -393,3 +393,57 @@ def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, str
             assert [r.wseq[0]] == list(fw) and r.score == fs
         else:       # branches whose logical triphones share a physical model tie exactly: see assert_grammar_fast
             assert_grammar_fast(atoms, rtr, r, np.array(fw), fs)
+
+
+# ---- multipath lexicons ------------------------------------------------------------------------------
+# beam_strict_mp_kernel was written after this round's device time was spent: these tests have not run
+# on hardware yet and are opt-in (JAMD_RUN_UNVALIDATED=1) until they have; the CPU restatement of the
+# same frame loop is pinned to the reference in tests/test_beam_oracle.py.
+import os
+
+unvalidated = pytest.mark.skipif(os.environ.get("JAMD_RUN_UNVALIDATED") != "1",
+                                 reason="multipath strict-order kernel: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
+
+
+@unvalidated
+def test_multipath_strict_golden(engine, oracle, monkeypatch):
+    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
+    g = load_beam_golden("beam_multipath.npz")
+    assert g["lex"]["lm_type"] == 0x100
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    with pytest.raises(lib.JamdError):                       # the frame-parallel kernel does not take these
+        bm.pass1_host([oracle.gmm_outprob(g["am"], g["utts"][0]["frames"])])
+    bm.set_strict_order(True)
+    res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0
+        assert_trellis_equal(atoms, u["trellis"])
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
+
+
+@unvalidated
+@pytest.mark.parametrize("kind,seed,beam,extra", [
+    ("ngram", 47, 150, ["-sepnum", "4", "-bs", "60", "-multipath"]),
+    ("ngram", 48, 40, ["-sepnum", "0", "-iwcd1", "avg", "-multipath"]),
+    ("grammar", 49, 100, ["-penalty1", "-2.0", "-multipath"]),
+])
+def test_multipath_strict_vs_reference_live(engine, oracle, ref, tmp_path, monkeypatch, kind, seed, beam, extra):
+    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
+    if kind == "ngram":
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra)
+        utts = [synth.make_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(3)]
+    else:
+        eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, extra, nword=70)
+        utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(3)]
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 17)
+    bm.set_strict_order(True)
+    res, tre = bm.pass1_host([oracle.gmm_outprob(am, fr) for fr in utts])
+    for fr, r, atoms in zip(utts, res, tre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert_trellis_equal(atoms, rtr)
+        if r.status == 0:
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore

@@ -400,6 +400,42 @@ def test_verification_gmm_on_device(ref, tmp_path, monkeypatch, so):
             assert fin0[0] < 0 and not want[3]                 # J_RESULT_STATUS_REJECT_GMM
 
 
+@pytest.mark.skipif(__import__("os").environ.get("JAMD_RUN_UNVALIDATED") != "1",
+                    reason="multipath strict-order kernel: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
+@pytest.mark.parametrize("lm", ["ngram", "grammar"])
+def test_multipath_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, lm):
+    """-multipath: the shim flattens the multipath lexicon and decodes it with the strict-order kernel
+    (opt-in, JAMD_EXPERIMENTAL_MULTIPATH=1); trellis, pass-1 and final results as the plain reference."""
+    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    if lm == "ngram":
+        task = synth.make_triphone_task(tmp_path, seed=87, nword=120, nphone=10, S=160)
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                "-input", "htkparam", "-gprune", "none", "-b", "200", "-b2", "30", "-n", "1", "-s", "500", "-sepnum", "5", "-multipath"]
+        utts = [synth.make_utterance(task, nwords=3 + u, seed=8700 + u)[0] for u in range(3)]
+    else:
+        task = synth.make_triphone_grammar(synth.make_triphone_task(tmp_path, seed=88, nword=90, nphone=10, S=160), ncat=3, seed=88)
+        args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
+                "-input", "htkparam", "-gprune", "none", "-b", "200", "-penalty1", "-2.0", "-b2", "30", "-n", "1", "-s", "500", "-multipath"]
+        utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + u, seed=8800 + u)[0] for u in range(3)]
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    assert plain.multipath == 1
+    for fr in utts:
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.mfc")
+        fin0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(tmp_path / "u.mfc")
+        fin1 = amd.final_result()
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k
+        assert np.array_equal(w1, w0) and s1 == s0
+        assert fin1[0] == fin0[0] and np.array_equal(fin1[1], fin0[1]) and fin1[2] == fin0[2]
+
+
 def test_outprob_vector_input_over_device_first_pass(ref, oracle, tmp_path, monkeypatch):
     """`-input outprob`: the input file already holds the [T][S] state scores (what -outprobout
     writes); the shim hands them to the device search unscored and Julius' 2nd pass reads them from
