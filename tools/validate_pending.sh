@@ -1,0 +1,12 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/validate_pending.sh'): everything that was written after the
+# last device time of a round and is therefore opt-in.  Output under gpurun_out/pending/.
+set -u
+mkdir -p gpurun_out/pending
+export JAMD_RUN_UNVALIDATED=1
+# 1. the multipath strict-order kernel (beam_strict_mp_kernel) and its shim path
+timeout 300 python -m pytest tests/test_beam_gpu.py tests/test_shim_gpu.py -k multipath -q 2>&1 | tail -25 | tee gpurun_out/pending/multipath_tests.txt
+# 2. the whole GPU suite with the opt-in tests included
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/pending/gpu_tests_all.txt
+# 3. cost of the selection stage (K7) and, for comparison, the scoring it follows
+PYTHONPATH=. timeout 60 python tools/gms_timing.py 2>&1 | tail -2 | tee gpurun_out/pending/gms_timing.json
