@@ -194,6 +194,17 @@ typedef struct jamd_rejgmm jamd_rejgmm;
 int  jamd_rejgmm_create(jamd_engine *e, const jamd_gmm_desc *gmm, const int *model_state, int nmodel,
                         int gprune_num, jamd_rejgmm **out);
 void jamd_rejgmm_destroy(jamd_rejgmm *m);
+/* A file written by jamd_export (-gmm given: jamd_rejgmm_save(), julius_amd/shim/jamd_flatten.c):
+ * the GMMs, -gmmnum, the model names and which of them -gmmreject names. */
+int  jamd_rejgmm_load(jamd_engine *e, const char *path, jamd_rejgmm **out);
+/* Names and gc->is_voice[] (gmm_init(), gmm.c:466-480: 0 for models named by -gmmreject) for a handle
+ * made with jamd_rejgmm_create(); jamd_rejgmm_load() sets them from the file. */
+int  jamd_rejgmm_set_models(jamd_rejgmm *m, const char *const *names, const unsigned char *is_voice);
+const char *jamd_rejgmm_model_name(const jamd_rejgmm *m, int k);
+/* gmm_end() (gmm.c:614-660) + gmm_valid_input() (:672-679) on one row of utterance sums (host
+ * arithmetic, a few flops): the winning model, its confidence 1 / sum_i 10^(0.05 (score_i - max)), and
+ * whether the input is accepted (the winner is not a rejected model). */
+int  jamd_rejgmm_verdict(const jamd_rejgmm *m, const float *utt_scores, int *winner, float *cm, int *accepted);
 int  jamd_rejgmm_nmodel(const jamd_rejgmm *m);
 int  jamd_rejgmm_veclen(const jamd_rejgmm *m);
 int  jamd_rejgmm_frame_scores_dev(jamd_rejgmm *m, const float *dev_frames, int T, float *dev_out, void *stream);

@@ -149,6 +149,52 @@ int jamd_gms_load(jamd_engine *e, const char *path, jamd_gms **out) {
   return jamd_gms_create(e, &d, map, b["state2gs"].count, gms[0], out);
 }
 
+int jamd_rejgmm_load(jamd_engine *e, const char *path, jamd_rejgmm **out) {
+  if (!e || !path || !out) { jamd_set_error("jamd_rejgmm_load: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  Blob b;
+  if (!read_blob(path, "JAMDGMM1", b)) return JAMD_EINVAL;
+  bool ok = true;
+  const int *ints = view<int>(b, "ints", 0, 6, ok);
+  const int *rej = view<int>(b, "rej", 0, 1, ok);
+  if (!ok) { jamd_set_error("%s: not a verification-GMM file (no \"rej\" record)", path); return JAMD_EINVAL; }
+  jamd_gmm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.nstate = ints[0]; d.veclen = ints[1]; d.ndens = ints[2]; d.nentry = ints[3]; d.nbook = ints[4]; d.nstream = ints[5];
+  if (d.nstate <= 0 || d.veclen <= 0 || d.ndens <= 0 || d.nentry <= 0) { jamd_set_error("%s: bad sizes", path); return JAMD_EINVAL; }
+  d.mean = view<float>(b, "mean", 1, (long long)d.ndens * d.veclen, ok);
+  d.ivar = view<float>(b, "ivar", 1, (long long)d.ndens * d.veclen, ok);
+  d.gconst = view<float>(b, "gconst", 1, d.ndens, ok);
+  d.st_off = view<int>(b, "st_off", 0, d.nstate + 1, ok);
+  d.ent_dens = view<int>(b, "ent_dens", 0, d.nentry, ok);
+  d.ent_logw = view<float>(b, "ent_logw", 1, d.nentry, ok);
+  const int *ms = view<int>(b, "model_state", 0, -1, ok);
+  if (!ok) return JAMD_EINVAL;
+  const int nmodel = b["model_state"].count;
+  const unsigned char *voice = view<unsigned char>(b, "is_voice", 2, nmodel, ok);
+  const unsigned char *nm = view<unsigned char>(b, "model_names", 2, -1, ok);
+  if (!ok) return JAMD_EINVAL;
+  std::vector<std::string> names;
+  {
+    const int len = b["model_names"].count;
+    int at = 0;
+    while (at < len && (int)names.size() < nmodel) {
+      const char *p = (const char *)nm + at;
+      const size_t l = strnlen(p, (size_t)(len - at));
+      names.emplace_back(p, l);
+      at += (int)l + 1;
+    }
+    if ((int)names.size() != nmodel) { jamd_set_error("%s: %d model names for %d models", path, (int)names.size(), nmodel); return JAMD_EINVAL; }
+  }
+  int rc = jamd_rejgmm_create(e, &d, ms, nmodel, rej[0], out);
+  if (rc != JAMD_OK) return rc;
+  std::vector<const char *> np(nmodel);
+  for (int k = 0; k < nmodel; k++) np[k] = names[k].c_str();
+  rc = jamd_rejgmm_set_models(*out, np.data(), voice);
+  if (rc != JAMD_OK) { jamd_rejgmm_destroy(*out); *out = nullptr; }
+  return rc;
+}
+
 int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
   if (!e || !path || !out) { jamd_set_error("jamd_lexicon_load: NULL argument"); return JAMD_EINVAL; }
   *out = nullptr;

@@ -14,12 +14,18 @@
 // additions in frame order (gmm.c:599), one thread per (utterance, model).
 #include "jamd_device.h"
 
+#include <cmath>
+#include <string>
+#include <vector>
+
 struct jamd_rejgmm {
   jamd_engine *eng = nullptr;
   int D = 0, nmodel = 0, gprune_num = 0, maxmix = 0;
   float *d_mean = nullptr, *d_ivar = nullptr, *d_gconst = nullptr, *d_logw = nullptr;
   int *d_st_off = nullptr, *d_ent_dens = nullptr, *d_model_state = nullptr;
   int *d_utt_off = nullptr; int utt_cap = 0;
+  std::vector<std::string> names;          // model names / is_voice: only known when loaded from a file
+  std::vector<unsigned char> is_voice;
 };
 
 namespace {
@@ -142,6 +148,29 @@ void jamd_rejgmm_destroy(jamd_rejgmm *m) {
 }
 
 int jamd_rejgmm_nmodel(const jamd_rejgmm *m) { return m ? m->nmodel : 0; }
+
+int jamd_rejgmm_set_models(jamd_rejgmm *m, const char *const *names, const unsigned char *is_voice) {
+  if (!m || !names || !is_voice) { jamd_set_error("jamd_rejgmm_set_models: NULL argument"); return JAMD_EINVAL; }
+  m->names.assign(names, names + m->nmodel);
+  m->is_voice.assign(is_voice, is_voice + m->nmodel);
+  return JAMD_OK;
+}
+
+const char *jamd_rejgmm_model_name(const jamd_rejgmm *m, int k) {
+  return (m && k >= 0 && k < (int)m->names.size()) ? m->names[k].c_str() : "";
+}
+
+// gmm_end() (gmm.c:614-660) + gmm_valid_input() (:672-679) on one row of utterance sums
+int jamd_rejgmm_verdict(const jamd_rejgmm *m, const float *utt_scores, int *winner, float *cm, int *accepted) {
+  if (!m || !utt_scores || !winner || !cm || !accepted) { jamd_set_error("jamd_rejgmm_verdict: NULL argument"); return JAMD_EINVAL; }
+  float maxprob = JAMD_LOG_ZERO; int maxid = 0; bool found = false;
+  for (int i = 0; i < m->nmodel; i++) if (maxprob < utt_scores[i]) { maxprob = utt_scores[i]; maxid = i; found = true; }
+  float sum = 0.0f;
+  for (int i = 0; i < m->nmodel; i++) sum += (float)pow(10.0, 0.05 * (double)(utt_scores[i] - maxprob));
+  *winner = maxid; *cm = (float)(1.0 / sum);
+  *accepted = found && (m->is_voice.empty() || m->is_voice[maxid]) ? 1 : 0;
+  return JAMD_OK;
+}
 int jamd_rejgmm_veclen(const jamd_rejgmm *m) { return m ? m->D : 0; }
 
 int jamd_rejgmm_frame_scores_dev(jamd_rejgmm *m, const float *dev_frames, int T, float *dev_out, void *stream) {

@@ -2,6 +2,7 @@
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
  *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict] [-shard R N]
+ *              [-rej verification.blob]
  *              (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
  *
  * -shard R N: this process takes the utterances u with u % N == R (one process per GPU, e.g.
@@ -60,10 +61,10 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
 
 int main(int argc, char **argv)
 {
-  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL;
+  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL, *rejp = NULL;
   int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, shard_r = 0, shard_n = 1, i;
   float bs = -1.0f;
-  jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_lexicon *lx; jamd_beam *bm;
+  jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first;
   char line[4096];
   FILE *fl;
@@ -78,6 +79,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
     else if (!strcmp(argv[i], "-gms") && i + 1 < argc) gmsp = argv[++i];
+    else if (!strcmp(argv[i], "-rej") && i + 1 < argc) rejp = argv[++i];
     else if (!strcmp(argv[i], "-dnnconf") && i + 1 < argc) dnnconf = argv[++i];
     else if (!strcmp(argv[i], "-lex") && i + 1 < argc) lexp = argv[++i];
     else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
@@ -99,6 +101,10 @@ int main(int argc, char **argv)
     if (strict && jamd_gms_set_strict_order(gs, 1) != JAMD_OK) die("strict order");
     if (jamd_gms_nstate(gs) != nstate) { fprintf(stderr, "jamd_batch: %s belongs to another acoustic model\n", gmsp); return 1; }
   }
+  if (rejp != NULL) {                                 /* -gmm / -gmmnum / -gmmreject of the exported configuration */
+    if (jamd_rejgmm_load(e, rejp, &rj) != JAMD_OK) die("verification GMMs");
+    if (jamd_rejgmm_veclen(rj) != veclen) { fprintf(stderr, "jamd_batch: %s is for %d-dim input\n", rejp, jamd_rejgmm_veclen(rj)); return 1; }
+  }
   if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
   if (jamd_beam_create(e, lx, beam, bs, 256, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
   if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
@@ -118,6 +124,7 @@ int main(int argc, char **argv)
     const int n = nfile - first < 256 ? nfile - first : 256;
     float *frames = NULL, *d_frames = NULL, *d_scores = NULL; size_t used = 0, cap = 0;
     int off[257], u;
+    float *us = NULL;
     jamd_pass1_result res[256];
     off[0] = 0;
     for (u = 0; u < n; u++) {
@@ -133,15 +140,34 @@ int main(int argc, char **argv)
     if (gs != NULL && jamd_gms_apply_dev(gs, d_frames, off[n], off, n, d_scores, NULL) != JAMD_OK) die("Gaussian mixture selection");
     if (jamd_beam_pass1_dev(bm, d_scores, nstate, off, n, NULL) != JAMD_OK || jamd_engine_sync(e) != JAMD_OK ||
         jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+    if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
+      const int nm = jamd_rejgmm_nmodel(rj);
+      float *d_fs = NULL, *d_us = NULL;
+      us = (float *)malloc(sizeof(float) * (size_t)n * nm);
+      if (us == NULL || jamd_malloc(e, sizeof(float) * (size_t)off[n] * nm, (void **)&d_fs) != JAMD_OK ||
+          jamd_malloc(e, sizeof(float) * (size_t)n * nm, (void **)&d_us) != JAMD_OK ||
+          jamd_rejgmm_frame_scores_dev(rj, d_frames, off[n], d_fs, NULL) != JAMD_OK ||
+          jamd_rejgmm_utt_scores_dev(rj, d_fs, off[n], off, n, d_us, NULL) != JAMD_OK ||
+          jamd_engine_sync(e) != JAMD_OK || jamd_memcpy_d2h(e, us, d_us, sizeof(float) * (size_t)n * nm) != JAMD_OK) die("input verification");
+      jamd_free(e, d_fs); jamd_free(e, d_us);
+    }
     for (u = 0; u < n; u++) {
       int k;
       printf("%s status=%d score=%.9g words=", files[first + u], res[u].status, (double)res[u].score);
       for (k = 0; k < res[u].wnum; k++) printf("%s%d", k ? " " : "", res[u].wseq[k]);
+      if (rj != NULL) {
+        int win, acc; float cm;
+        if (jamd_rejgmm_verdict(rj, us + (size_t)u * jamd_rejgmm_nmodel(rj), &win, &cm, &acc) != JAMD_OK) die("verdict");
+        printf(" gmm=%s gmmscore=%.9g cm=%.9g accepted=%d", jamd_rejgmm_model_name(rj, win),
+               (double)us[(size_t)u * jamd_rejgmm_nmodel(rj) + win], (double)cm, acc);
+      }
       printf("\n");
     }
+    free(us);
     jamd_free(e, d_frames); jamd_free(e, d_scores); free(frames);
   }
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
+  if (rj) jamd_rejgmm_destroy(rj);
   if (gs) jamd_gms_destroy(gs);
   if (gm) jamd_gmm_destroy(gm);
   if (dn) jamd_dnn_destroy(dn);

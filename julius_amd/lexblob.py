@@ -55,10 +55,14 @@ def load_gmm(path) -> dict:
         name = raw[pos:pos + 24].split(b"\0", 1)[0].decode()
         dtype, count = struct.unpack_from("<ii", raw, pos + 24)
         pos += 32
-        rec[name] = np.frombuffer(raw, dtype=_DT[dtype], count=count, offset=pos).copy()
-        pos += 4 * count
+        dt = np.dtype(_DT[dtype])
+        rec[name] = np.frombuffer(raw, dtype=dt, count=count, offset=pos).copy()
+        pos += (count * dt.itemsize + 3) & ~3
     S, D, G, E, nbook, nstream = (int(x) for x in rec.pop("ints"))
     extra = dict(state2gs=rec["state2gs"], nbest=int(rec["gms"][0])) if "gms" in rec else {}
+    if "rej" in rec:                       # verification GMMs (jamd_rejgmm_save)
+        extra.update(model_state=rec["model_state"], gprune_num=int(rec["rej"][0]), is_voice=rec["is_voice"],
+                     model_names=[n.decode() for n in rec["model_names"].tobytes().split(b"\0")[:len(rec["model_state"])]])
     return dict(**extra, mean=rec["mean"].reshape(G, D), ivar=rec["ivar"].reshape(G, D), gconst=rec["gconst"],
                 st_off=rec["st_off"], ent_dens=rec["ent_dens"], ent_logw=rec["ent_logw"],
                 st_book=rec.get("st_book") if nbook > 0 else None, nbook=nbook, nstream=nstream)

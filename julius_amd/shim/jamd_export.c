@@ -10,6 +10,7 @@
  *   PREFIX.am    "JAMDGMM1"  flattened GMM-HMM         (jamd_gmm_save; absent for a DNN-HMM, whose
  *                                                       -dnnconf files the engine reads directly)
  *   PREFIX.gms   "JAMDGMM1"  selection model of -gshmm  (jamd_gms_save; only with -gshmm)
+ *   PREFIX.rej   "JAMDGMM1"  verification GMMs of -gmm   (jamd_rejgmm_save; only with -gmm)
  *   PREFIX.lex   "JAMDLEX1"  tree lexicon + LM tables   (jamd_lexicon_save)
  * for workers that never link Julius (jamd_gmm_load / jamd_lexicon_load / jamd_dnn_load,
  * julius_amd/host/jamd_batch.c).  Compiled inside the Julius tree like the other shim files.
@@ -69,6 +70,25 @@ int main(int argc, char **argv)
       printf("wrote %s (%d selection states, %d selected per frame)\n", path, wrk->gsset_num, wrk->my_nbest);
     }
   } else printf("DNN-HMM: give the -dnnconf file to jamd_dnn_load() / jamd_batch -dnnconf\n");
+  if (recog->gmm != NULL && recog->gc != NULL) {    /* gmm_init() has run inside j_final_fusion() */
+    jamd_flat_gmm fv;
+    HTK_HMM_Data *hd;
+    const int n = recog->gmm->totalhmmnum;
+    int *ms = (int *)malloc(sizeof(int) * (size_t)n), k = 0;
+    unsigned char *voice = (unsigned char *)malloc((size_t)n);
+    const char **names = (const char **)malloc(sizeof(char *) * (size_t)n);
+    if (ms == NULL || voice == NULL || names == NULL || jamd_flatten_hmminfo(recog->gmm, &fv) != 0) {
+      fprintf(stderr, "jamd_export: the verification GMMs cannot be flattened\n"); return 1;
+    }
+    for (hd = recog->gmm->start; hd && k < n; hd = hd->next, k++) {       /* gmm.c:593-598, :466-480 */
+      ms[k] = hd->s[1]->id; voice[k] = recog->gc->is_voice[k] ? 1 : 0; names[k] = hd->name;
+    }
+    snprintf(path, sizeof(path), "%s.rej", prefix);
+    rc = jamd_rejgmm_save(&fv.desc, ms, n, jconf->reject.gmm_gprune_num, voice, names, path);
+    jamd_flat_gmm_free(&fv); free(ms); free(voice); free(names);
+    if (rc != JAMD_OK) { fprintf(stderr, "jamd_export: cannot write %s\n", path); return 1; }
+    printf("wrote %s (%d verification GMMs, -gmmnum %d)\n", path, n, jconf->reject.gmm_gprune_num);
+  }
   {
     jamd_flat_lexicon fl;
     if (jamd_flatten_lexicon(r, &fl) != JAMD_OK) { fprintf(stderr, "jamd_export: this lexicon / LM configuration is not covered by the device first pass\n"); return 1; }

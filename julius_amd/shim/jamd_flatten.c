@@ -189,6 +189,12 @@ static int gmm_put(FILE *f, const char *name, int dtype, int count, const void *
   char nm[24];
   memset(nm, 0, sizeof(nm)); strncpy(nm, name, sizeof(nm) - 1);
   if (fwrite(nm, 1, 24, f) != 24 || fwrite(&dtype, 4, 1, f) != 1 || fwrite(&count, 4, 1, f) != 1) return -1;
+  if (dtype == 2) {                       /* bytes, padded to a multiple of 4 */
+    static const char zero[4] = {0, 0, 0, 0};
+    if (count > 0 && fwrite(data, 1, (size_t)count, f) != (size_t)count) return -1;
+    if ((count & 3) && fwrite(zero, 1, (size_t)(4 - (count & 3)), f) != (size_t)(4 - (count & 3))) return -1;
+    return 0;
+  }
   if (count > 0 && fwrite(data, 4, (size_t)count, f) != (size_t)count) return -1;
   return 0;
 }
@@ -208,10 +214,34 @@ int jamd_gms_save(const jamd_gmm_desc *gs, const int *state2gs, int nstate, int 
   return gmm_save_with(gs, path, state2gs, nstate, nbest);
 }
 
+/* The verification GMMs of -gmm (libjulius/src/gmm.c): the same blob plus "model_state" (state id of
+ * each model's output state, recog->gmm->start order), "rej" {-gmmnum}, "is_voice" (gc->is_voice[]:
+ * 0 for the models named by -gmmreject) and "model_names" (NUL-separated); jamd_rejgmm_load() reads it. */
+typedef struct { const int *model_state; int nmodel, gprune_num; const unsigned char *is_voice; const char *names; int names_len; } rej_extra;
+static const rej_extra *g_rej_extra = NULL;
+
+int jamd_rejgmm_save(const jamd_gmm_desc *gmm, const int *model_state, int nmodel, int gprune_num,
+                     const unsigned char *is_voice, const char *const *names, const char *path)
+{
+  rej_extra x;
+  char *buf; int k, len = 0, rc;
+  if (model_state == NULL || nmodel < 1 || gprune_num < 1 || is_voice == NULL || names == NULL || gmm->nbook > 0) return JAMD_EINVAL;
+  for (k = 0; k < nmodel; k++) len += (int)strlen(names[k]) + 1;
+  buf = (char *)malloc((size_t)len);
+  if (buf == NULL) return JAMD_ENOMEM;
+  for (k = 0, len = 0; k < nmodel; k++) { strcpy(buf + len, names[k]); len += (int)strlen(names[k]) + 1; }
+  x.model_state = model_state; x.nmodel = nmodel; x.gprune_num = gprune_num; x.is_voice = is_voice; x.names = buf; x.names_len = len;
+  g_rej_extra = &x;
+  rc = gmm_save_with(gmm, path, NULL, 0, 0);
+  g_rej_extra = NULL;
+  free(buf);
+  return rc;
+}
+
 static int gmm_save_with(const jamd_gmm_desc *d, const char *path, const int *state2gs, int nstate, int nbest)
 {
   FILE *f = fopen(path, "wb");
-  int nrec = (d->st_book ? 8 : 7) + (state2gs ? 2 : 0), rc = 0, ints[6];
+  int nrec = (d->st_book ? 8 : 7) + (state2gs ? 2 : 0) + (g_rej_extra ? 4 : 0), rc = 0, ints[6];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nstate; ints[1] = d->veclen; ints[2] = d->ndens; ints[3] = d->nentry; ints[4] = d->nbook; ints[5] = d->nstream;
   fwrite("JAMDGMM1", 1, 8, f); fwrite(&nrec, 4, 1, f);
@@ -224,6 +254,12 @@ static int gmm_save_with(const jamd_gmm_desc *d, const char *path, const int *st
   rc |= gmm_put(f, "ent_logw", 1, d->nentry, d->ent_logw);
   if (d->st_book) rc |= gmm_put(f, "st_book", 0, d->nstate, d->st_book);
   if (state2gs) { rc |= gmm_put(f, "state2gs", 0, nstate, state2gs); rc |= gmm_put(f, "gms", 0, 1, &nbest); }
+  if (g_rej_extra) {
+    rc |= gmm_put(f, "model_state", 0, g_rej_extra->nmodel, g_rej_extra->model_state);
+    rc |= gmm_put(f, "rej", 0, 1, &g_rej_extra->gprune_num);
+    rc |= gmm_put(f, "is_voice", 2, g_rej_extra->nmodel, g_rej_extra->is_voice);
+    rc |= gmm_put(f, "model_names", 2, g_rej_extra->names_len, g_rej_extra->names);
+  }
   if (fclose(f) != 0) rc = -1;
   return rc ? JAMD_EINVAL : JAMD_OK;
 }

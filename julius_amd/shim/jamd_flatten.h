@@ -41,6 +41,8 @@ void jamd_flat_gmm_free(jamd_flat_gmm *f);
  * julius_amd/lexblob.py::load_gmm) for workers that do not link Julius. */
 int  jamd_gmm_save(const jamd_gmm_desc *d, const char *path);
 int  jamd_gms_save(const jamd_gmm_desc *gs, const int *state2gs, int nstate, int nbest, const char *path);
+int  jamd_rejgmm_save(const jamd_gmm_desc *gmm, const int *model_state, int nmodel, int gprune_num,
+                      const unsigned char *is_voice, const char *const *names, const char *path);
 
 /* Pack HTK_Param rows (each parvec[t] is a separate allocation,
  * libsent/src/anlz/param_malloc.c:52-77) into one [T][veclen] block. */

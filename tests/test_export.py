@@ -57,3 +57,25 @@ def test_export_selection_model(ref, tmp_path):
     assert np.array_equal(got["state2gs"], want["state2gs"])
     for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
         assert np.array_equal(got[k], want["model"][k]), k
+
+
+def test_export_verification_gmms(ref, tmp_path):
+    """-gmm / -gmmnum / -gmmreject: PREFIX.rej holds the flattened GMM definitions, the output state of
+    every model in recog->gmm->start order, -gmmnum, the names and gc->is_voice[]."""
+    if not EXPORT.exists():
+        pytest.skip("oracle/_ref/jamd_export not built")
+    task = synth.make_triphone_task(tmp_path, seed=94, nword=60)
+    gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=94, null_frac=0.1)
+    args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                             "-input", "htkparam", "-gprune", "none", "-b", "120", "-gmm", gpath, "-gmmnum", "7",
+                             "-gmmreject", "noise,cough"]]
+    out = subprocess.run([str(EXPORT)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True, text=True)
+    assert "m.rej" in out.stdout
+    got = lexblob.load_gmm(tmp_path / "m.rej")
+    want = pyoracle.RefEngine(ref, args).gmm_info()
+    assert got["gprune_num"] == want["gprune_num"] == 7
+    assert np.array_equal(got["model_state"], want["model_state"])
+    for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
+        assert np.array_equal(got[k], want["model"][k]), k
+    assert got["model_names"] == names[::-1]                       # the loader prepends: reverse file order
+    assert [bool(v) for v in got["is_voice"]] == [n not in ("noise", "cough") for n in got["model_names"]]

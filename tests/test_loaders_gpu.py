@@ -153,3 +153,46 @@ def test_export_then_standalone_batch(ref, tmp_path, gms):
         f = line.split(" ", 3)
         assert f[1] == "status=0" and np.float32(float(f[2].split("=")[1])) == np.float32(score)
         assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(wseq)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("JAMD_RUN_UNVALIDATED") != "1",
+                    reason="jamd_batch -rej: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
+def test_export_then_standalone_batch_with_verification(ref, tmp_path):
+    """jamd_export writes PREFIX.rej for a -gmm configuration; jamd_batch -rej scores the verification
+    GMMs of every input on the device and prints gmm_end()'s verdict: winner, confidence, accepted --
+    as the plain reference decides (gc->gmm_score[], gmm_max_cm, gmm_valid_input())."""
+    import subprocess
+    from oracle import pyoracle
+    export = pyoracle.REF_SO.parent / "jamd_export"
+    exe = lib._PKG / "jamd_batch"
+    if not export.exists():
+        pytest.skip("oracle/_ref/jamd_export not built")
+    task = synth.make_triphone_task(tmp_path, seed=95, nword=120, nphone=10, S=160)
+    gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=95, M=24, null_frac=0.05)
+    base = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                             "-input", "htkparam", "-gprune", "none", "-b", "150", "-sepnum", "5", "-1pass",
+                             "-gmm", gpath, "-gmmnum", "6"]]
+    files = []
+    for u in range(4):
+        fr, _ = synth.make_utterance(task, nwords=2 + u, seed=9500 + u)
+        files.append(str(tmp_path / f"u{u}.mfc"))
+        synth.write_htk_param(files[-1], fr)
+    (tmp_path / "list").write_text("\n".join(files) + "\n")
+    probe = pyoracle.RefEngine(ref, base)
+    probe.recognize(files[0])
+    rev = names[::-1]
+    winner_name = rev[probe.gmm_result()[1]]
+    for reject in ([n for n in names if n != winner_name][0], winner_name):
+        args = base + ["-gmmreject", reject]
+        subprocess.run([str(export)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True)
+        eng = pyoracle.RefEngine(ref, args)
+        out = subprocess.run([str(exe), "-am", str(tmp_path / "m.am"), "-lex", str(tmp_path / "m.lex"), "-rej", str(tmp_path / "m.rej"),
+                              "-filelist", str(tmp_path / "list"), "-b", "150", "-strict"],
+                             check=True, capture_output=True, text=True).stdout.strip().splitlines()
+        assert len(out) == len(files)
+        for line, f in zip(out, files):
+            eng.recognize(f)
+            sums, win, cm, valid, _ = eng.gmm_result()
+            kv = dict(x.split("=", 1) for x in line.split(" ") if "=" in x)
+            assert kv["gmm"] == rev[win] and int(kv["accepted"]) == int(valid)
+            assert np.float32(float(kv["gmmscore"])) == sums[win] and np.float32(float(kv["cm"])) == np.float32(cm)
