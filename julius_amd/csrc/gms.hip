@@ -50,7 +50,9 @@ __device__ __forceinline__ void wave_sync() {
 // STRICT: lane 0 runs the reference's heap.  Otherwise every lane ranks its own states against all
 // (broadcast reads), which selects the same set unless two states tie exactly on the boundary; then
 // the lower state id wins where the reference's answer depends on the heap's history.
-template <bool STRICT>
+// VAR 1 (JAMD_GMS_VARIANT=1, not the default until measured): the two latency chains of the default
+// form -- one LDS read per ranking step, one per Gaussian in the max -- are batched four wide.
+template <bool STRICT, int VAR>
 __global__ void __launch_bounds__(64)
 gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ g_st_off, const float *__restrict__ g_logw,
                   const int *__restrict__ utt_off, float *__restrict__ fs_out, int Sgs, int Egs, int EgsPad, int nbest) {
@@ -88,9 +90,24 @@ gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ g_st_o
       float maxprob = row[e0 + first];
       if (maxprob < JAMD_LOG_ZERO) maxprob = JAMD_LOG_ZERO;
       int maxi = first;
-      for (int k = n - 1; k >= 0; k--) {
-        const float p = row[e0 + k];
-        if (k != first && p > maxprob) { maxprob = p; maxi = k; }
+      if constexpr (VAR == 1) {
+        int k = n - 1;
+        for (; k >= 3; k -= 4) {                                     // same visiting order, four loads in flight
+          const float p0 = row[e0 + k], p1 = row[e0 + k - 1], p2 = row[e0 + k - 2], p3 = row[e0 + k - 3];
+          if (k != first && p0 > maxprob) { maxprob = p0; maxi = k; }
+          if (k - 1 != first && p1 > maxprob) { maxprob = p1; maxi = k - 1; }
+          if (k - 2 != first && p2 > maxprob) { maxprob = p2; maxi = k - 2; }
+          if (k - 3 != first && p3 > maxprob) { maxprob = p3; maxi = k - 3; }
+        }
+        for (; k >= 0; k--) {
+          const float p = row[e0 + k];
+          if (k != first && p > maxprob) { maxprob = p; maxi = k; }
+        }
+      } else {
+        for (int k = n - 1; k >= 0; k--) {
+          const float p = row[e0 + k];
+          if (k != first && p > maxprob) { maxprob = p; maxi = k; }
+        }
       }
       last[i] = maxi;
       float sum = 0.0f;
@@ -135,9 +152,25 @@ gms_select_kernel(const float *__restrict__ dens, const int *__restrict__ g_st_o
       for (int i = lane; i < Sgs; i += 64) {                        // rank of state i among all
         const float v = fs[i];
         int rank = 0;
-        for (int j = 0; j < Sgs; j++) {
-          const float w = fs[j];
-          rank += (w > v || (w == v && j < i)) ? 1 : 0;
+        if constexpr (VAR == 1) {
+          const float4 *f4 = reinterpret_cast<const float4 *>(fs);       // fs sits at LDS offset 0
+          int j = 0;
+          for (; j + 4 <= Sgs; j += 4) {
+            const float4 w = f4[j >> 2];
+            rank += (w.x > v || (w.x == v && j < i)) ? 1 : 0;
+            rank += (w.y > v || (w.y == v && j + 1 < i)) ? 1 : 0;
+            rank += (w.z > v || (w.z == v && j + 2 < i)) ? 1 : 0;
+            rank += (w.w > v || (w.w == v && j + 3 < i)) ? 1 : 0;
+          }
+          for (; j < Sgs; j++) {
+            const float w = fs[j];
+            rank += (w > v || (w == v && j < i)) ? 1 : 0;
+          }
+        } else {
+          for (int j = 0; j < Sgs; j++) {
+            const float w = fs[j];
+            rank += (w > v || (w == v && j < i)) ? 1 : 0;
+          }
         }
         fs_out[(size_t)t * Sgs + i] = rank < nbest ? JAMD_LOG_ZERO : v;
       }
@@ -235,7 +268,9 @@ int jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *u
   const int EgsPad = (m->Egs + 63) & ~63;
   const size_t lds = sizeof(float) * ((size_t)3 * m->Sgs + m->Sgs + 1 + m->Egs + 64 + 2 * (size_t)EgsPad);
   if (lds > 159 * 1024) { jamd_set_error("jamd_gms_apply_dev: a selection model of %d states / %d Gaussians does not fit in LDS", m->Sgs, m->Egs); return JAMD_EINVAL; }
-  auto kern = m->strict ? gms_select_kernel<true> : gms_select_kernel<false>;
+  const int var = getenv("JAMD_GMS_VARIANT") ? atoi(getenv("JAMD_GMS_VARIANT")) : 0;          // experiment switch
+  auto kern = m->strict ? (var == 1 ? gms_select_kernel<true, 1> : gms_select_kernel<true, 0>)
+                        : (var == 1 ? gms_select_kernel<false, 1> : gms_select_kernel<false, 0>);
   if (lds > 48 * 1024) JAMD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(nutt), dim3(64), lds, st, m->d_dens, m->d_st_off, m->d_logw, m->d_utt_off,
                      m->d_fs, m->Sgs, m->Egs, EgsPad, m->nbest);

@@ -10,3 +10,4 @@ timeout 300 python -m pytest tests/test_beam_gpu.py tests/test_shim_gpu.py -k mu
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/pending/gpu_tests_all.txt
 # 3. cost of the selection stage (K7) and, for comparison, the scoring it follows
 PYTHONPATH=. timeout 60 python tools/gms_timing.py 2>&1 | tail -2 | tee gpurun_out/pending/gms_timing.json
+JAMD_GMS_VARIANT=1 PYTHONPATH=. timeout 60 python tools/gms_timing.py 2>&1 | tail -2 | tee gpurun_out/pending/gms_timing_variant1.json
