@@ -450,6 +450,31 @@ int  jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate
  * parallel only across the utterances of a batch.  Default is off (the frame-parallel
  * kernel, identical whenever jamd_pass1_result.ties == 0). */
 int  jamd_beam_set_strict_order(jamd_beam *b, int on);
+/* How exact score ties are resolved (they are the only freedom a parallel schedule has; every
+ * float is the reference's float in all modes):
+ *   JAMD_ORDER_EXACT   (default where the beam fits the LDS image, about beam <= 2500, non-multipath):
+ *       frame-parallel kernel with the reference's own semantics -- candidates keyed by their position
+ *       in the reference's visiting order (first writer wins, propagate_token() beam.c:1945-1980,
+ *       wordend_best :2308), token creation order, and the partial heap sort of
+ *       sort_token_no_order() (beam.c:1342-1516) reproduced exactly.  The word trellis equals the
+ *       reference's bit for bit, ties included.
+ *   JAMD_ORDER_EXACT_SERIAL  the same kernel with the heap's extraction loop run sequentially on one
+ *       lane instead of in closed form (cross-check and timing).
+ *   JAMD_ORDER_FAST    frame-parallel kernel with canonical tie breaks (larger source id, smaller node
+ *       on the rank cut): identical to the reference whenever jamd_pass1_result.ties == 0.
+ *   JAMD_ORDER_STRICT  = jamd_beam_set_strict_order(b, 1): the sequential algorithm, one lane per utterance.
+ * jamd_beam_set_strict_order(b, 0) returns to the default of the work area. */
+#define JAMD_ORDER_FAST 0
+#define JAMD_ORDER_STRICT 1
+#define JAMD_ORDER_EXACT 2
+#define JAMD_ORDER_EXACT_SERIAL 3
+int  jamd_beam_set_order_mode(jamd_beam *b, int mode);
+int  jamd_beam_order_mode(const jamd_beam *b);
+/* The rank-pruning step alone (sort_token_no_order(), beam.c:1492): given the scores of the n tokens of
+ * a frame in creation order (host array), writes the token indices the next frame visits, in visiting
+ * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the
+ * exact-order kernel's pruning code on the device; diagnostic / test entry. */
+int  jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, int *nkeep);
 int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
 /* Word trellis of utterance u in emission order (last_tre indexes the same
  * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:

@@ -43,225 +43,13 @@
 // ties == 0 the trellis is the reference's trellis bit for bit.
 #include "jamd_device.h"
 #include <type_traits>
+#include <algorithm>
+
+#include "beam_common.h"
+#include "beam_exact.h"
 
 namespace {
-using namespace jamd;
-
-constexpr int NT = 1024;                // threads per utterance workgroup
-constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
-constexpr int kMaxDynLds = 159 * 1024;  // dynamic LDS budget of the one workgroup a CU holds (160 KB LDS per CU, < 1 KB static)
-constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its space with the first cells (free during step D)
-
-// All lexicon / LM arrays live in ONE device allocation and are addressed as base + 32-bit byte
-// offset: a kernel that carries some forty 64-bit array pointers next to its per-utterance work
-// pointers needs twice the scalar registers the hardware has, and the spilled ones come back
-// through v_readlane -- a third of the first-pass kernel's instructions before this layout.  With a
-// uniform base the loads also take the `global_load v, voffset32, s[base]` form (no 64-bit address
-// arithmetic per access).
-#define JAMD_LEX_ARRAYS(X)                                                                       \
-  X(int4, node_a)          /* [nnode] {self_a bits, next_a bits, ac_off, ac_end} (wchmm->self_a/next_a/ac) */ \
-  X(int4, node_b)          /* [nnode] {stend, scid, out_id, out_kind} (stend, state[].scid, outstyle)      */ \
-  X(int, scid)             /* [nnode] again, for the destination of a transition                           */ \
-  X(int, ac_to) X(float, ac_a)                                                                               \
-  X(int2, iso_root)        /* [isolatenum] {root node, successor word scword[scid[root]]}                  */ \
-  X(float2, shared_root)   /* [nshared]    {root node bits, fscore[-scid[root]]}                           */ \
-  X(int, word_end)         /* [nword] node whose stend is the word                                         */ \
-  X(int, startnode) X(int, start2isolate)   /* [startnum] as in wchmm (the strict-order kernel walks them like beam.c) */ \
-  X(int, lc_tab) X(int, word_lc) X(int, set_off) X(int, set_states)                                          \
-  X(float, wordend_a) X(int, wton) X(float, cprob) X(unsigned char, is_transparent)                          \
-  X(int, word_head) X(float, fscore) X(int, scword)                                                          \
-  X(float, ng_uni_prob) X(float, ng_uni_bo) X(int, ng_bi_bgn) X(int, ng_bi_num) X(int, ng_bi_wid) X(float, ng_bi_prob) \
-  /* grammar (per-category trees): category-pair matrix [ncat][ncat] (dfa_cp()), each root's category         \
-     wton[start2wid[root]], the initial tokens [ninit] */                                                      \
-  X(unsigned char, cat_pair) X(int, root_cat) X(int, init_node) X(float, init_lscore)
-
-struct LexDev {
-  int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
-  int head_silwid, tail_silwid, ng_mode, ng_unk_id;
-  float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
-  int lm_type, ncat, ninit; float penalty1;
-  const unsigned char *base;          // the arena
-#define X(T, name) unsigned o_##name;
-  JAMD_LEX_ARRAYS(X)
-#undef X
-  template <typename T>
-  __device__ __forceinline__ T at(unsigned off, int i) const {
-    return *reinterpret_cast<const T *>(base + (unsigned)(off + (unsigned)i * (unsigned)sizeof(T)));
-  }
-#define X(T, name)                                                                   \
-  __device__ __forceinline__ T name(int i) const { return at<T>(o_##name, i); }      \
-  __device__ __forceinline__ const T *name##_ptr() const { return reinterpret_cast<const T *>(base + o_##name); }
-  JAMD_LEX_ARRAYS(X)
-#undef X
-};
-
-struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/beam.h:35-45
-  int node; float score; int last_tre; int last_cword;
-  float last_lscore; int last_wid; int pad0, pad1;   // last_wid = wid of atoms[last_tre] (-1 for bos)
-};
-
-struct StreamState {     // what a streaming utterance carries from one launch to the next
-  int started, active, frames_done, n_surv, n_atom, ties, ties_we, ties_cut, max_tokens;
-  float thr;
-};
-
-struct Work {            // per-utterance slices are addressed with the strides below
-  StreamState *stream;           // [utt] (allocated by jamd_beam_stream_begin)
-  // Per-utterance arrays live in ONE slice per utterance (slices + utt * utt_stride) and are
-  // addressed as slice base + 32-bit offset, for the same reason as the lexicon arena (LexDev):
-  unsigned char *slices; unsigned long long utt_stride;
-  unsigned o_nodekey;            // u64  [nnode]    Viterbi cells (0 = empty)
-  unsigned o_cur;                // Tok  [tok_cap]  tokens created this frame
-  unsigned o_cur_key;            // u32  [tok_cap]  their order-preserving score bits (compact, for the rank select)
-  unsigned o_touched;            // int2 [tok_cap]  nodes touched this frame: {node, LDS cell slot or -1 = nodekey[]}
-  unsigned o_arcq;               // int2 [tok_cap]  work queue of (survivor, extra arc) pairs
-  unsigned o_atoms;              // jamd_trellis_atom [atom_cap]
-  unsigned o_lmcache;            // u64  [nscword]  LM memo, see below
-  unsigned o_sv;                 // survivor image (sv_bytes) when it does not live in LDS / between streaming launches
-  jamd_pass1_result *res;        // [utt]
-  // the survivor state lives in LDS when it fits (sv_bytes of dynamic shared memory), else at o_sv;
-  // the LM memo holds (context N-gram id << 32 | prob bits) per successor id: the reference's
-  // LM_PROB_CACHE (wchmm.h:117-149, factoring_sub.c:965-986)
-  int nscword;
-  int sv_bytes, use_lds, hsize;  // hsize = slots of the node -> survivor hash (power of two)
-  int cell_slots;                // LDS Viterbi cells of the current frame (power of two, 0 = all cells in nodekey[])
-  int lds_bytes;                 // dynamic LDS per workgroup without the score-row cache
-  int cell_off, node_off, row_off;  // byte offsets in dynamic LDS: cells / histogram, cell owners, score row
-  int row_cache;                 // set per launch: the frame's [nstate] score row is copied to LDS
-  int tok_cap, atom_cap, beam, nnode, nword;
-  float width;
-};
-
-// order-preserving map float -> u32 (larger float <=> larger unsigned)
-__device__ __forceinline__ unsigned ord(float f) {
-  const unsigned b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float unord(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// search_bigram(), ngram_access.c:225-247
-__device__ __forceinline__ int search_bigram(const LexDev &lx, int w_context, int w) {
-  int left = lx.ng_bi_bgn(w_context);
-  if (left < 0) return -1;
-  int right = left + lx.ng_bi_num(w_context) - 1;
-  while (left < right) {
-    const int mid = (left + right) / 2;
-    if (lx.ng_bi_wid(mid) < w) left = mid + 1; else right = mid;
-  }
-  return (lx.ng_bi_wid(left) == w) ? left : -1;
-}
-
-// ngram->bigram_prob as chosen by bi_prob_func_set(), ngram_access.c:288-466
-__device__ float bigram_prob(const LexDev &lx, int w1, int w2) {
-  int n2; float prob;
-  if (lx.ng_mode == JAMD_NG_NORMAL || lx.ng_mode == JAMD_NG_ADDITIONAL_OLD) {
-    if ((n2 = search_bigram(lx, w1, w2)) >= 0) prob = lx.ng_bi_prob(n2);
-    else prob = lx.ng_uni_bo(w1) + lx.ng_uni_prob(w2);
-  } else if (lx.ng_mode == JAMD_NG_ADDITIONAL) {
-    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob(n2);
-    else prob = lx.ng_uni_bo(w1) + lx.ng_uni_prob(w2);
-  } else {
-    if ((n2 = search_bigram(lx, w2, w1)) >= 0) prob = lx.ng_bi_prob(n2);
-    else prob = lx.ng_uni_bo(w2) + lx.ng_uni_prob(w1);
-    prob = prob + lx.ng_uni_prob(w2) - lx.ng_uni_prob(w1);
-  }
-  if (w2 != lx.ng_unk_id) return prob;
-  return prob - lx.ng_unk_num_log;
-}
-
-// max_successor_prob(), factoring_sub.c:942-1008 (UNIGRAM_FACTORING), scid given.
-// `memo` is the per-utterance equivalent of the reference's lastwcache/probcache pair:
-// one (context, value) entry per successor id, a pure memo of the 2-gram lookup.  A token
-// waiting in front of a branch asks for the same pair every frame, so nearly every call
-// is one 8-byte load instead of a binary search.  Entries are written as single 64-bit
-// words, so concurrent writers cannot tear them; NULL disables the memo.
-__device__ __forceinline__ float max_successor_prob(const LexDev &lx, int lastword, int scid,
-                                                    unsigned long long *memo = nullptr) {
-  if (lastword < 0) return 0.0f;
-  if (scid < 0) return lx.fscore(-scid);
-  const int ctx = lx.wton(lastword);
-  if (memo) {
-    const unsigned long long m = memo[scid];
-    if ((int)(unsigned)(m >> 32) == ctx) return __uint_as_float((unsigned)m);
-  }
-  const int w = lx.scword(scid);
-  const float p = bigram_prob(lx, ctx, lx.wton(w)) + lx.cprob(w);
-  if (memo) memo[scid] = ((unsigned long long)(unsigned)ctx << 32) | __float_as_uint(p);
-  return p;
-}
-
-// outprob_style(), outprob_style.c:354-486, with the name lookups replaced by
-// the flattened left-context table
-__device__ float node_outprob(const LexDev &lx, const float *__restrict__ row, int kind, int id, int last_wid) {
-  int ent;
-  if (kind == JAMD_AS_STATE) return row[id];
-  if (kind == JAMD_AS_LSET) ent = ~id;
-  else ent = lx.lc_tab((size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc(last_wid)));
-  if (ent >= 0) return row[ent];
-  ent = ~ent;
-  return cd_reduce(row, lx.set_states_ptr(), lx.set_off(ent), lx.set_off(ent + 1), lx.cdset_method, lx.cdmax_num);
-}
-
-// the state (>= 0) or ~state-set (< 0) that outprob_style() scores for a node
-__device__ __forceinline__ int outprob_entry(const LexDev &lx, int kind, int id, int last_wid) {
-  if (kind == JAMD_AS_STATE) return id;
-  if (kind == JAMD_AS_LSET) return ~id;
-  return lx.lc_tab((size_t)id * (lx.nlc + 1) + (last_wid < 0 ? lx.nlc : lx.word_lc(last_wid)));
-}
-
-// the acoustic scores of the frame being finalized: the [nstate] row in global memory, or its copy
-// in LDS (a frame makes some 15 000 gathers from it: one per new token plus the members of every
-// state set -- a third of all the divergent loads of the frame)
-struct RowRef {
-  const float *g; const float *l; bool lds;
-  __device__ __forceinline__ float operator[](int i) const { return lds ? l[i] : g[i]; }
-};
-
-struct Shared {
-  unsigned long long we_best;       // (ord(score + wordend_a), word that ended)
-  int n_new, n_we, n_arc, n_atom, n_surv, ties, ties_we, ties_cut, best_atom;
-  unsigned maxbits, minbits;
-  unsigned sel_digit, sel_need, sel_count;
-  unsigned wsum[NT / 64];            // per-wave histogram totals of the rank select
-  int eq_n, eq_node[128];           // tokens exactly on the rank cut (tie handling)
-};
-
-// node -> survivor index, open addressing (survivor nodes are distinct)
-__device__ __forceinline__ unsigned hslot(int node, int hmask) {
-  return ((unsigned)node * 2654435761u >> 7) & (unsigned)hmask;
-}
-__device__ __forceinline__ void hash_put(int *hkey, int *hval, int hmask, int node, int j) {
-  unsigned h = hslot(node, hmask);
-  while (atomicCAS(&hkey[h], -1, node) != -1) h = (h + 1) & (unsigned)hmask;
-  hval[h] = j;
-}
-__device__ __forceinline__ int hash_get(const int *hkey, const int *hval, int hmask, int node) {
-  unsigned h = hslot(node, hmask);
-  for (int guard = 0; guard <= hmask; guard++) {
-    const int k = hkey[h];
-    if (k == node) return hval[h];
-    if (k == -1) break;
-    h = (h + 1) & (unsigned)hmask;
-  }
-  return 0;   // unreachable for a live source
-}
-
-// Wave-aggregated slot allocation: the active lanes that want a slot are counted with a
-// ballot, ONE lane bumps the shared counter, every lane takes base + its rank.  Cuts the
-// same-address LDS atomics (thousands per frame on n_new / n_atom / n_surv) by up to 64x.
-__device__ __forceinline__ int wave_alloc(int *counter, bool want) {
-  const unsigned long long m = __ballot(want);
-  if (!want) return -1;
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, __popcll(m));
-  base = __shfl(base, leader, 64);
-  return base + __popcll(m & ((1ull << lane) - 1ull));
-}
-
+using namespace jamdb;
 // candidate ids (low 32 bits of a node key) name the SOURCE of the transition, in
 // terms that do not depend on any scheduling order, so that (score, id) is a
 // canonical total order and the result is deterministic:
@@ -1287,9 +1075,8 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
 // the root's own arcs within the frame, :2467-2510), output probabilities only on emitting nodes
 // (:2930-2943); frame 0 already goes through this (pass1.c:239) and one transition-only call ends the
 // input (:3066-3073).  Kept as its own kernel beside beam_strict_kernel: same helpers, same records.
-// EXPERIMENTAL: written when no device time was left to run it; the CPU restatement of the same frame
-// is pinned to the reference on multipath tasks (tests/test_beam_oracle.py).  Lexicons of this kind are
-// accepted only with JAMD_EXPERIMENTAL_MULTIPATH=1 until tests/test_beam_gpu.py has passed on hardware.
+// Exact by construction like its parent; the CPU restatement of the same frame is pinned to the reference on
+// multipath tasks (tests/test_beam_oracle.py), the kernel against both (tests/test_beam_gpu.py::test_multipath_*).
 __device__ void s_enter_word_mp(SBeam &b, const LexDev &lx, int root, float tmpsum, int tre, int last_word, float ng) {
   const int4 na = lx.node_a(root);
   const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
@@ -1486,7 +1273,11 @@ struct jamd_beam {
   Work w{};
   int max_utts = 0;
   int *d_utt_off = nullptr;
-  bool strict = false;
+  bool strict = false;             // order mode JAMD_ORDER_STRICT
+  bool exact = false;              // order mode JAMD_ORDER_EXACT (beam_exact.hip)
+  int exact_status = -3;           // 0 = the exact-order kernel can serve this work area (xbeam_layout())
+  XWork xw{};
+  unsigned *d_pkeys = nullptr; int *d_pout = nullptr; size_t pcap = 0;   // jamd_beam_prune_order() scratch
   bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
   int stream_pushes = 0;
@@ -1506,11 +1297,6 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   const bool dfa = lmt == JAMD_LM_DFA || wordmode;             // the two LM_DFA variants share everything but the word boundary
   if ((h->lm_type & ~(0xff | JAMD_LM_MULTIPATH)) != 0 || (lmt != JAMD_LM_NGRAM && !dfa)) {
     jamd_set_error("jamd_lexicon_create: lm_type=%d", h->lm_type); return JAMD_EINVAL;
-  }
-  if (multipath && (getenv("JAMD_EXPERIMENTAL_MULTIPATH") == nullptr || atoi(getenv("JAMD_EXPERIMENTAL_MULTIPATH")) == 0)) {
-    jamd_set_error("jamd_lexicon_create: multipath lexicons are not served yet (the strict-order kernel for them "
-                   "is experimental: JAMD_EXPERIMENTAL_MULTIPATH=1)");
-    return JAMD_EINVAL;
   }
   if (dfa && (h->ninit < 0 || (h->ninit > 0 && (!h->init_node || !h->init_lscore)) ||
               (!wordmode && (h->ncat <= 0 || !h->cat_pair || !h->start2wid)))) {
@@ -1576,6 +1362,10 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     nb[i] = make_int4(h->stend[i], h->scid[i], h->out_id[i], (int)h->out_kind[i]);
     if (h->stend[i] >= 0 && h->stend[i] < h->nword) word_end[h->stend[i]] = i;
   }
+  // both root lists in the order beam_inter_word() / beam_inter_word_factoring() visit them (stid from
+  // startnum-1 down to 0, beam.c:2334 / :2562): the exact-order kernel numbers its candidates by list index
+  std::sort(iso.begin(), iso.end(), [](int a, int b) { return a > b; });
+  std::sort(shared.begin(), shared.end(), [](int a, int b) { return a > b; });
   std::vector<int2> iso_root(iso.size());
   for (size_t i = 0; i < iso.size(); i++) {
     const int node = h->startnode[iso[i]];
@@ -1678,7 +1468,9 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     // a frame creates about five tokens per survivor; a table that would run above ~2/3 load
     // costs more in failed probes than it saves, so narrower-than-needed tables are not used
     if (w.cell_slots < 8 * beam_width) w.cell_slots = 0;
+#ifdef JAMD_DEV
     if (getenv("JAMD_BEAM_NO_LDS_CELLS") != nullptr) w.cell_slots = 0;      // development switch (timing comparison)
+#endif
   }
   w.cell_off = w.use_lds ? w.sv_bytes : 0;
   w.node_off = w.cell_off + (8 * w.cell_slots > kHistBytes ? 8 * w.cell_slots : kHistBytes);
@@ -1697,7 +1489,19 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     place(&w.o_arcq, (size_t)w.tok_cap * sizeof(int2));
     place(&w.o_atoms, (size_t)w.atom_cap * sizeof(jamd_trellis_atom));
     place(&w.o_lmcache, (size_t)w.nscword * sizeof(unsigned long long));
-    place(&w.o_sv, (size_t)w.sv_bytes);
+    // exact-order kernel (beam_exact.hip): its LDS layout, and its three extra per-utterance arrays
+    XWork &xw = b->xw;
+    b->exact_status = l->multipath ? -4 : xbeam_layout(&xw, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared);
+    size_t sv_max = (size_t)w.sv_bytes;
+    if (b->exact_status == 0 && (size_t)xw.w.sv_bytes > sv_max) sv_max = (size_t)xw.w.sv_bytes;
+    place(&w.o_sv, sv_max);
+    if (b->exact_status == 0) {
+      // the bitmap holds one bit per visiting index: maxfan per survivor plus startnum per word end
+      size_t bits = (size_t)(beam_width + 2) * (size_t)(l->maxfan + l->d.startnum) + (size_t)l->d.nshared + (size_t)l->d.ninit + 64;
+      place(&xw.o_nodefirst, (size_t)w.nnode * sizeof(unsigned));
+      place(&xw.o_bitmap, (bits + 31) / 32 * 4);
+      place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
+    }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
   }
@@ -1713,6 +1517,14 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
                                            hipGetErrorString(ae)); rc = JAMD_ENODEV; }
   }
   if (rc == JAMD_OK) rc = alloc((void **)&b->d_utt_off, (U + 1) * sizeof(int), true);
+  if (rc == JAMD_OK && b->exact_status == 0) {
+    // same slices, same offsets; only the LDS image differs
+    const int svb = b->xw.w.sv_bytes;
+    b->xw.w = w; b->xw.w.sv_bytes = svb;
+    if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
+  }
+  // default order mode: the exact-order kernel where it can serve the work area, else the frame-parallel one
+  b->exact = b->exact_status == 0;
   if (rc != JAMD_OK) { jamd_beam_destroy(b); return rc; }
   *out = b;
   return JAMD_OK;
@@ -1754,9 +1566,14 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   else if (b->strict)
     hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
+  else if (b->exact)
+    xbeam_launch(b->lex->d, b->xw, dev_scores, nstate, b->d_utt_off, nutt, 0, b->timed, st);
   else {
     Work w = b->w;                                     // the score row joins the LDS image when it still fits
-    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds && getenv("JAMD_BEAM_NO_ROW_CACHE") == nullptr;
+    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds;
+#ifdef JAMD_DEV
+    if (getenv("JAMD_BEAM_NO_ROW_CACHE") != nullptr) w.row_cache = 0;
+#endif
     const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
     if (b->timed)
       hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
@@ -1816,9 +1633,15 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, chunk_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
-  {
+  if (b->exact) {
+    b->xw.w.stream = b->w.stream;
+    xbeam_launch(b->lex->d, b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
+  } else {
     Work w = b->w;
-    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds && getenv("JAMD_BEAM_NO_ROW_CACHE") == nullptr;
+    w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds;
+#ifdef JAMD_DEV
+    if (getenv("JAMD_BEAM_NO_ROW_CACHE") != nullptr) w.row_cache = 0;
+#endif
     const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
     if (b->timed)
       hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
@@ -1848,6 +1671,62 @@ int jamd_beam_set_strict_order(jamd_beam *b, int on) {
     JAMD_HIP(hipMalloc(&p, U * b->w.nnode * sizeof(int))); b->owned.push_back(p); b->sw.token = (int *)p;
   }
   b->strict = on != 0;
+  return JAMD_OK;
+}
+
+int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
+  if (!b) { jamd_set_error("jamd_beam_set_order_mode: NULL"); return JAMD_EINVAL; }
+  if (b->streaming > 0) { jamd_set_error("jamd_beam_set_order_mode: a streaming session is open"); return JAMD_ESTATE; }
+  switch (mode) {
+    case JAMD_ORDER_FAST: b->exact = false; return jamd_beam_set_strict_order(b, 0);
+    case JAMD_ORDER_STRICT: b->exact = false; return jamd_beam_set_strict_order(b, 1);
+    case JAMD_ORDER_EXACT:
+    case JAMD_ORDER_EXACT_SERIAL:
+      if (b->exact_status != 0) {
+        jamd_set_error("jamd_beam_set_order_mode: the exact-order kernel cannot serve this work area (%s)",
+                       b->exact_status == -1 ? "visiting index exceeds 32 bits"
+                       : b->exact_status == -2 ? "beam too wide for the LDS image" : b->exact_status == -4 ? "multipath lexicon" : "no LDS");
+        return JAMD_ESTATE;
+      }
+      b->xw.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;
+      b->exact = true;
+      return jamd_beam_set_strict_order(b, 0);
+    default: jamd_set_error("jamd_beam_set_order_mode: mode=%d", mode); return JAMD_EINVAL;
+  }
+}
+
+int jamd_beam_order_mode(const jamd_beam *b) {
+  if (!b) return -1;
+  return b->strict ? JAMD_ORDER_STRICT : b->exact ? (b->xw.prune_mode ? JAMD_ORDER_EXACT_SERIAL : JAMD_ORDER_EXACT) : JAMD_ORDER_FAST;
+}
+
+int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, int *nkeep) {
+  if (!b || !scores || !order || !nkeep || n < 1) { jamd_set_error("jamd_beam_prune_order: bad argument"); return JAMD_EINVAL; }
+  if (b->exact_status != 0) { jamd_set_error("jamd_beam_prune_order: the exact-order kernel cannot serve this work area"); return JAMD_ESTATE; }
+  if (n > (1 << 20)) { jamd_set_error("jamd_beam_prune_order: n=%d too large", n); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  if ((size_t)n > b->pcap) {
+    void *p = nullptr;
+    const size_t cap = (size_t)n + 1024;
+    JAMD_HIP(hipMalloc(&p, cap * 4)); b->owned.push_back(p); b->d_pkeys = (unsigned *)p;
+    JAMD_HIP(hipMalloc(&p, (cap + 2) * 12)); b->owned.push_back(p); b->d_pout = (int *)p;    // out[cap] + nout + heap u64[cap + 2]
+    b->pcap = cap;
+  }
+  std::vector<unsigned> keys((size_t)n);
+  for (int i = 0; i < n; i++) {
+    float f = scores[i] + 0.0f; unsigned u; memcpy(&u, &f, 4);
+    keys[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+  hipStream_t st = b->eng->stream;
+  JAMD_HIP(hipMemcpyAsync(b->d_pkeys, keys.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  int *d_nout = b->d_pout + b->pcap;
+  unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + ((b->pcap + 2 + 1) & ~(size_t)1));
+  xbeam_prune_order_launch(b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, st);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { jamd_set_error("jamd_beam_prune_order: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  JAMD_HIP(hipMemcpyAsync(nkeep, d_nout, 4, hipMemcpyDeviceToHost, st));
+  JAMD_HIP(hipStreamSynchronize(st));
+  JAMD_HIP(hipMemcpy(order, b->d_pout, 4 * (size_t)*nkeep, hipMemcpyDeviceToHost));
   return JAMD_OK;
 }
 

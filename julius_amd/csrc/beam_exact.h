@@ -1,0 +1,34 @@
+// beam_exact.h -- interface between beam.hip (host side of the first pass) and beam_exact.hip (the
+// exact-order frame-parallel kernel).  Internal, not installed.
+#pragma once
+#include "beam_common.h"
+
+namespace jamdb {
+
+struct XWork {
+  Work w;                      // the slices of the frame-parallel kernel are reused as they are
+  unsigned o_nodefirst;        // u32 [nnode]  ~(first visiting index) of a node whose cell overflowed to nodekey[]
+  unsigned o_bitmap;           // u32 [gbm_words] creation-order bitmap when it outgrows LDS
+  unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
+  int s1, xw;                  // visiting index = (source position << s1) | transition number; roots start at xw
+  int iso_rank_off;
+  int nslot;                   // LDS Viterbi cells (16 bytes each: key, node, first visit)
+  int bm_words;                // LDS bitmap capacity
+  int heap_cap, b_cap;         // pruning step: LDS heap entries, top-k list entries
+  int prune_mode;              // 0 = closed-form extraction, 1 = sequential extraction always (timing / test)
+  // byte offsets in dynamic LDS
+  int off_atom, off_we, off_dbase, off_tpre, off_bm, off_cells, off_lnode, off_lfirst, off_row;
+  int off_comp, off_compr, off_vpos, off_id, off_hist, off_tail, off_heap;   // overlay on the cells
+  int lds_bytes;
+};
+
+// Fills the LDS layout for beam width w.beam.  maxfan = 2 + most extra arcs of a node, nroot = startnum.
+// 0 = ok, -1 = the visiting index does not fit 32 bits, -2 = the survivors do not fit LDS (beam too wide).
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared);
+hipError_t xbeam_prepare();
+void xbeam_launch(const LexDev &lx, const XWork &xw, const float *scores, int nstate, const int *d_utt_off, int nutt,
+                  int smode, bool timed, hipStream_t st);
+void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
+                              unsigned long long *d_hglob, hipStream_t st);
+
+}  // namespace jamdb

@@ -1,0 +1,1114 @@
+// beam_exact.hip -- first-pass token passing with the REFERENCE'S TIE SEMANTICS, frame-parallel (K6x).
+//
+// beam.hip's beam_pass1_kernel resolves exact score ties canonically (larger source id, smaller node on
+// the rank cut); the reference resolves them by its visiting order:
+//   * propagate_token() (libjulius/src/beam.c:1945-1980) replaces a token only on a STRICTLY better score,
+//     so among equal candidates the one visited first wins;
+//   * beam_inter_word() keeps the first of equally good word ends as wordend_best (:2308);
+//   * the visiting order of a frame is tindex[n_start..n_end] as sort_token_no_order() (:1492) left it:
+//     creation order when nothing is pruned, else the output of a partial heap sort
+//     (sort_token_upward / _downward, :1342-1480) over the tokens in creation order;
+//   * creation order is the order of first visits (create_token(), :1148).
+// This kernel reproduces all of that with the whole workgroup:
+//   1. every candidate carries its visiting index vis = (position j of the source in the visiting order,
+//      transition number within the source: self, next, extra arcs in wchmm order, then the roots from
+//      startnum-1 down to 0; the factoring pass of beam_inter_word_factoring() counts as source n_surv).
+//      The Viterbi cell is atomicMax(score bits || ~vis): best score, earliest visit -- first-writer-wins.
+//      A second atomicMax(~vis) per cell keeps the node's FIRST visit.
+//   2. creation order = rank of the first visit: one bit per visiting index in a bitmap, prefix popcount.
+//   3. rank pruning = the reference's heap, exactly:
+//        - heapify runs level by level (the sift-downs of one tree level touch disjoint subtrees and the
+//          reference runs the levels bottom-up, so the level-parallel result is the sequential one);
+//        - the extraction loop of sort_token_upward() is replaced by its closed form.  While the element
+//          taken from the tail is smaller than every element still to be extracted, an extraction is a
+//          hole running down the path of larger children (left on ties): the heap is a tree of stable
+//          merges, and the extraction order is (score descending, PRE-ORDER index of the heap position
+//          ascending).  The exceptions ("events": the tail element is itself among the top k) re-insert
+//          that element at the end of the current max path; they are rare (a few per frame), found and
+//          replayed one by one by a single wave with range queries over the sorted top-k list.  The
+//          equivalence was fuzzed against the sequential code (tests/test_prune_order.py does it on the
+//          device; DESIGN.md section 3 "K6x" has the argument).
+//        - sort_token_downward() (beam < tokens <= 2 beam) and oversize frames run the sequential
+//          extraction on one lane, in LDS.
+// Everything else -- LM factoring, outprob_style(), trellis atoms, score pruning -- is the arithmetic of
+// beam_pass1_kernel.  The word trellis equals the reference's bit for bit, ties included
+// (tests/test_beam_gpu.py::test_exact_*).  N-gram, grammar and word-list lexicons; non-multipath.
+#include "beam_common.h"
+#include "beam_exact.h"
+
+namespace {
+using namespace jamdb;
+
+constexpr int kMaxL = 20;                // heap positions < 2^21
+
+struct XShared {
+  unsigned long long we_best;            // (ord(score + wordend_a), ~j): best word end, earliest visit
+  int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback;
+  unsigned maxbits, minbits;
+  unsigned sel_digit, sel_need, sel_count;
+  unsigned wsum[NT / 64];
+  int scan_total;
+};
+
+struct XCells {
+  unsigned char *ub; unsigned o_nodekey, o_nodefirst, o_touched;
+  unsigned long long *lkey; int *lnode; unsigned *lfirst;
+  int nslot;
+};
+constexpr int kXProbes = 24;
+
+// block-wide exclusive scan of one int per thread (two barriers); total in sh.scan_total
+__device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) sh.wsum[wv] = (unsigned)incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wv; w++) base += (int)sh.wsum[w];
+  if (threadIdx.x == NT - 1) sh.scan_total = base + incl;
+  __syncthreads();
+  return base + incl - v;
+}
+
+__device__ __forceinline__ unsigned ordz(float f) { return ord(f + 0.0f); }   // -0.0 and +0.0 compare equal as floats
+
+// one candidate: propagate_token() :1945 with the visiting index as the tie breaker
+__device__ __forceinline__ void xpush(XShared &sh, const XCells &cl, int node, float score, unsigned vis) {
+  if (score <= JAMD_LOG_ZERO) return;
+  const unsigned long long key = ((unsigned long long)ordz(score) << 32) | (unsigned)(~vis);
+  bool first = false;
+  int slot = -1;
+  if (cl.nslot > 0) {
+    unsigned h = __umulhi((unsigned)node * 2654435761u, (unsigned)cl.nslot);
+    for (int pr = 0; pr < kXProbes; pr++) {
+      const int o = atomicCAS(&cl.lnode[h], -1, node);
+      if (o == -1 || o == node) { slot = (int)h; first = (o == -1); break; }
+      h = (h + 1 == (unsigned)cl.nslot) ? 0u : h + 1;
+    }
+  }
+  if (slot >= 0) {
+    atomicMax(&cl.lkey[slot], key);
+    atomicMax(&cl.lfirst[slot], ~vis);
+  } else {
+    const unsigned long long old =
+        atomicMax(reinterpret_cast<unsigned long long *>(cl.ub + (unsigned)(cl.o_nodekey + 8u * (unsigned)node)), key);
+    atomicMax(reinterpret_cast<unsigned *>(cl.ub + (unsigned)(cl.o_nodefirst + 4u * (unsigned)node)), ~vis);
+    first = (old == 0ull);
+  }
+  const int s = wave_alloc(&sh.n_new, first);
+  if (first) *reinterpret_cast<int2 *>(cl.ub + (unsigned)(cl.o_touched + 8u * (unsigned)s)) = make_int2(node, slot);
+}
+
+// ---- rank pruning with the reference's heap ----------------------------------------------------------
+// pre-order key of heap position p (1-based): bit string of p below its leading one, left aligned, then
+// the depth -- an ancestor sorts before its descendants, a left subtree before the right one
+__device__ __forceinline__ unsigned prekey(unsigned p) {
+  const int L = 31 - __clz((int)p);
+  return (((p - (1u << L)) << (kMaxL - L)) << 5) | (unsigned)L;
+}
+__device__ __forceinline__ unsigned prekey_pos(unsigned key) {
+  const int L = (int)(key & 31u);
+  return (1u << L) + ((key >> 5) >> (kMaxL - L));
+}
+// is heap position p inside the subtree of position c?  (p == 0: nowhere)
+__device__ __forceinline__ bool insub(unsigned p, unsigned c) {
+  if (p < c) return false;
+  const int d = __clz((int)c) - __clz((int)p);
+  return (p >> d) == c;
+}
+
+struct PruneMem {                // LDS regions of the pruning step (they overlay the empty Viterbi cells)
+  unsigned long long *comp;      // [b_cap] top-k composites as collected
+  unsigned long long *compR;     // [b_cap] sorted: (score bits << 32 | ~prekey at collection time)
+  unsigned *vposR;               // [b_cap] current virtual heap position per rank
+  unsigned *idR;                 // [b_cap] token id per rank
+  unsigned *hist;                // [2048]
+  unsigned *tailmask;            // [(beam + 31) / 32 + 1]
+  unsigned *placed;              // [2 * (kMaxL + 2)] elements taken out during a replay: rank, saved position
+  int b_cap;
+};
+
+template <bool UP>
+__device__ __forceinline__ void heap_sift(unsigned long long *H, int n, int parent, unsigned long long s) {
+  const unsigned sv = (unsigned)(s >> 32);
+  int child;
+  while ((child = parent * 2) <= n) {
+    unsigned long long c = H[child];
+    if (child < n) {
+      const unsigned long long c2 = H[child + 1];
+      const unsigned a = (unsigned)(c >> 32), b = (unsigned)(c2 >> 32);
+      if (UP ? (a < b) : (a > b)) { child++; c = c2; }
+    }
+    const unsigned cv = (unsigned)(c >> 32);
+    if (UP ? (sv >= cv) : (sv <= cv)) break;
+    H[parent] = c;
+    parent = child;
+  }
+  H[parent] = s;
+}
+
+// first loop of sort_token_upward/_downward (:1354-1367): level-parallel
+template <bool UP>
+__device__ __forceinline__ void heapify_levels(unsigned long long *H, int n) {
+  const int top = n / 2;
+  if (top >= 1) {
+    for (int L = 31 - __clz(top); L >= 0; L--) {
+      const int lo = 1 << L, hi = min((2 << L) - 1, top);
+      for (int root = lo + (int)threadIdx.x; root <= hi; root += NT) heap_sift<UP>(H, n, root, H[root]);
+      __syncthreads();
+    }
+  }
+}
+
+// second loop (:1368-1383) on one lane
+template <bool UP>
+__device__ __forceinline__ void heap_extract_serial(unsigned long long *H, int n, int cnt) {
+  int m = n;
+  while (m > n - cnt) {
+    const unsigned long long s = H[m];
+    H[m] = H[1];
+    m--;
+    heap_sift<UP>(H, m, 1, s);
+  }
+}
+
+// k-th largest of the score bits in H[1..n] (radix select, 11 bits a pass over the bits in which the
+// frame's max and min differ).  Returns the value; all threads.
+__device__ __forceinline__ unsigned kth_largest(XShared &sh, const unsigned long long *H, int n, int k, unsigned *hist) {
+  unsigned need = (unsigned)k;
+  const unsigned diff = sh.maxbits ^ sh.minbits;
+  int remaining = diff ? 32 - __clz(diff) : 0;
+  unsigned prefix = remaining < 32 ? (sh.maxbits >> remaining) : 0u;
+  const int tid = threadIdx.x;
+  while (remaining > 0) {
+    const int w = remaining < 11 ? remaining : 11;
+    const int shift = remaining - w;
+    const unsigned dmask = (1u << w) - 1u;
+    for (int i = tid; i < 2048; i += NT) hist[i] = 0;
+    __syncthreads();
+    for (int p = 1 + tid; p <= n; p += NT) {
+      const unsigned b = (unsigned)(H[p] >> 32);
+      const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
+      if (hi == prefix) atomicAdd(&hist[(b >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    {
+      const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+      const unsigned pair = h0 + h1;
+      unsigned incl = pair;
+      const int ln = tid & 63;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_down(incl, off, 64);
+        if (ln + off < 64) incl += o;
+      }
+      if (ln == 0) sh.wsum[tid >> 6] = incl;
+      __syncthreads();
+      unsigned above = incl - pair;
+      for (int wv = (tid >> 6) + 1; wv < NT / 64; wv++) above += sh.wsum[wv];
+      if (above < need && need <= above + h1) { sh.sel_digit = 2u * tid + 1u; sh.sel_need = need - above; sh.sel_count = h1; }
+      above += h1;
+      if (above < need && need <= above + h0) { sh.sel_digit = 2u * tid; sh.sel_need = need - above; sh.sel_count = h0; }
+    }
+    __syncthreads();
+    prefix = (prefix << w) | sh.sel_digit;
+    need = sh.sel_need;
+    remaining -= w;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// ---- the events of the extraction loop, replayed by ONE wave (see the file header) -------------------
+// smallest rank r >= start with vposR[r] inside subtree(a); -1 if none.  Wave-uniform.
+__device__ __forceinline__ int first_in_subtree(const volatile unsigned *vposR, int nB, int start, unsigned a, int excl) {
+  const int lane = threadIdx.x & 63;
+  for (int base = start; base < nB; base += 64) {
+    const int r = base + lane;
+    const bool match = r < nB && r != excl && insub(vposR[r], a);
+    const unsigned long long m = __ballot(match);
+    if (m) return base + __ffsll((long long)m) - 1;
+  }
+  return -1;
+}
+
+// Replays extraction i (1-based) when the tail position q = n - i + 1 may hold one of the top elements.
+// Ranks 0..i-2 are out already, rank i-1 is at the root.  Wave 0 only; wave-uniform control flow.
+__device__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
+  volatile unsigned *vposR = pm.vposR;
+  const int lane = threadIdx.x & 63;
+  const unsigned q = (unsigned)(n - i + 1);
+  const int Lq = 31 - __clz((int)q);
+  volatile unsigned *placed_r = pm.placed, *placed_v = pm.placed + (kMaxL + 2);
+  int np = 0, occq = -1;
+  // who sits at q?  Occupants along the chain root -> q: each position holds the best remaining element of
+  // its subtree that is not sitting further up
+  for (int d = 0; d <= Lq; d++) {
+    const unsigned a = q >> (Lq - d);
+    const int r = first_in_subtree(vposR, nB, i - 1, a, -1);
+    if (r < 0) break;
+    if (lane == 0) { placed_r[np] = (unsigned)r; placed_v[np] = vposR[r]; vposR[r] = 0u; }
+    np++;              // taken: in no subtree while the walk goes on
+    __builtin_amdgcn_wave_barrier();
+    if (d == Lq) occq = r;
+  }
+  if (lane == 0) for (int x = 0; x < np; x++) vposR[placed_r[x]] = placed_v[x];
+  __builtin_amdgcn_wave_barrier();
+  if (occq < 0) return;                         // the element has moved up (or out) before its tail turn
+  // event: s leaves q, the root element is output, s runs down the path of larger children among the
+  // elements still in the heap (size n - i) until it is >= the larger child (:1372-1381)
+  const int rs = occq;
+  const unsigned ssc = (unsigned)(pm.compR[rs] >> 32);
+  const unsigned hs = (unsigned)(n - i);
+  unsigned hole = 1u;
+  np = 0;
+  for (;;) {
+    const unsigned c1 = 2u * hole;
+    if (c1 > hs) break;
+    const int rl = first_in_subtree(vposR, nB, i, c1, rs);
+    const int rr = (c1 + 1u <= hs) ? first_in_subtree(vposR, nB, i, c1 + 1u, rs) : -1;
+    if (rl < 0 && rr < 0) break;
+    int best = rl; unsigned bpos = c1;
+    if (rr >= 0 && (rl < 0 || (unsigned)(pm.compR[rl] >> 32) < (unsigned)(pm.compR[rr] >> 32))) { best = rr; bpos = c1 + 1u; }
+    if (ssc >= (unsigned)(pm.compR[best] >> 32)) break;
+    if (lane == 0) { placed_r[np] = (unsigned)best; placed_v[np] = vposR[best]; vposR[best] = 0u; }
+    np++;
+    __builtin_amdgcn_wave_barrier();
+    hole = bpos;
+    if (np >= kMaxL + 1) break;
+  }
+  if (lane == 0) for (int x = 0; x < np; x++) vposR[placed_r[x]] = placed_v[x];
+  __builtin_amdgcn_wave_barrier();
+  // s now counts as the element of position `hole`
+  if (hole >= (unsigned)(n - k + 1) && lane == 0)     // it sits on a tail position again: its turn comes later
+    atomicOr(&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
+  // its place among the equal scores still in the heap (ranks >= i): by pre-order of the positions
+  int g0 = rs, g1 = rs + 1;
+  while (g0 > i && (unsigned)(pm.compR[g0 - 1] >> 32) == ssc) g0--;
+  while (g1 < nB && (unsigned)(pm.compR[g1] >> 32) == ssc) g1++;
+  const unsigned hk = prekey(hole);
+  int cnt = 0;
+  for (int base = g0; base < g1; base += 64) {
+    const int r = base + lane;
+    const bool before = r < g1 && r != rs && prekey(vposR[r]) < hk;
+    cnt += __popcll(__ballot(before));
+  }
+  const int newr = g0 + cnt;
+  if (lane == 0) {
+    const unsigned sid = pm.idR[rs];
+    const unsigned long long sc = pm.compR[rs];
+    if (newr < rs) for (int r = rs; r > newr; r--) { vposR[r] = vposR[r - 1]; pm.idR[r] = pm.idR[r - 1]; pm.compR[r] = pm.compR[r - 1]; }
+    else for (int r = rs; r < newr; r++) { vposR[r] = vposR[r + 1]; pm.idR[r] = pm.idR[r + 1]; pm.compR[r] = pm.compR[r + 1]; }
+    vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// sort_token_no_order() (:1492): the visiting order of the next frame.  keys[i] = score bits of token i in
+// creation order.  Writes the token ids into svid[0..return value).  Whole workgroup.
+__device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsigned long long *H, int heap_cap,
+                           unsigned long long *Hglob, const PruneMem &pm, int *svid, int mode) {
+  const int tid = threadIdx.x;
+  if (n <= k) {
+    for (int j = tid; j < n; j += NT) svid[j] = j;
+    __syncthreads();
+    return n;
+  }
+  const bool upward = k < n - k;
+  const bool in_lds = n <= heap_cap;
+  if (!in_lds) H = Hglob;
+  auto run = [&](unsigned long long *Hh) -> void {
+    for (int i = tid; i < n; i += NT) Hh[i + 1] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
+    __syncthreads();
+    if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n);
+    bool done = false;
+    if (upward && mode != 1 && pm.b_cap > 0) {
+      // closed form of the extraction loop
+      const unsigned vk = kth_largest(sh, Hh, n, k, pm.hist);
+      if (tid == 0) { sh.nB = 0; sh.fallback = 0; }
+      for (int i = tid; i < (k + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
+      __syncthreads();
+      for (int p0 = 1; p0 <= n; p0 += NT) {
+        const int p = p0 + tid;
+        const unsigned hi = p <= n ? (unsigned)(Hh[p] >> 32) : 0u;
+        const bool in = p <= n && hi >= vk;
+        const int slot = wave_alloc(&sh.nB, in);
+        if (in && slot < pm.b_cap) pm.comp[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
+      }
+      __syncthreads();
+      const int nB = sh.nB;
+      if (nB <= pm.b_cap) {
+        // rank by counting: the composites are distinct (one per heap position)
+        for (int e = tid; e < nB; e += NT) {
+          const unsigned long long c = pm.comp[e];
+          int r = 0;
+          for (int x = 0; x < nB; x++) r += (pm.comp[x] > c) ? 1 : 0;
+          const unsigned p = prekey_pos(0xffffffffu - (unsigned)c);
+          pm.compR[r] = c; pm.vposR[r] = p; pm.idR[r] = (unsigned)Hh[p];
+          if (p >= (unsigned)(n - k + 1)) atomicOr(&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
+        }
+        __syncthreads();
+        if (tid < 64) {
+          // tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1)
+          const int nw = (k + 31) / 32;
+          for (int w = 0; w < nw; w++) {
+            unsigned donebits = 0u;
+            for (;;) {
+              const unsigned bits = ((volatile unsigned *)pm.tailmask)[w] & ~donebits;
+              if (!bits) break;
+              const int b = __ffs((int)bits) - 1;
+              donebits |= (b == 31) ? 0xffffffffu : ((2u << b) - 1u);
+              const int i = w * 32 + b + 1;
+              if (i <= k) replay_tail(pm, nB, n, k, i);
+            }
+          }
+        }
+        __syncthreads();
+        for (int j = tid; j < k; j += NT) svid[j] = (int)pm.idR[k - 1 - j];    // tindex[n-k+j]: ascending
+        done = true;
+      }
+    }
+    if (!done) {
+      if (tid == 0) { if (upward) heap_extract_serial<true>(Hh, n, k); else heap_extract_serial<false>(Hh, n, n - k); }
+      __syncthreads();
+      for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)(upward ? Hh[n - k + 1 + j] : Hh[1 + j]);
+    }
+    __syncthreads();
+  };
+  if (in_lds) run(H); else run(Hglob);
+  return k;
+}
+
+template <bool TIMED>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
+  __shared__ XShared sh;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  const Work &wk = xw.w;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
+  StreamState *ss = smode ? wk.stream + u : nullptr;
+  const bool resume = smode && ss->started;
+  const int base = resume ? ss->frames_done : 0;
+  const int T = base + nrows;
+  const bool finish = smode != 1;
+  unsigned char *const ub = wk.slices + (size_t)u * wk.utt_stride;
+#define SLICE(T, off, i) (*reinterpret_cast<T *>(ub + (unsigned)((off) + (unsigned)sizeof(T) * (unsigned)(i))))
+#define NODEKEY(i) SLICE(unsigned long long, wk.o_nodekey, i)
+#define NODEFIRST(i) SLICE(unsigned, xw.o_nodefirst, i)
+#define CUR(i) SLICE(Tok, wk.o_cur, i)
+#define CURKEY(i) SLICE(unsigned, wk.o_cur_key, i)
+#define TOUCHED(i) SLICE(int2, wk.o_touched, i)
+#define ARCQ(i) SLICE(int2, wk.o_arcq, i)
+#define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
+  jamd_pass1_result *res = wk.res + u;
+  // LDS image: survivors in VISITING ORDER (no node hash: a candidate names its source by position)
+  Tok *sv = (Tok *)dyn_lds;
+  int *sv_atom = (int *)(dyn_lds + xw.off_atom);
+  int *welist = (int *)(dyn_lds + xw.off_we);      // word ends of the frame; the pruning step returns its order here
+  int *dbase = (int *)(dyn_lds + xw.off_dbase);    // [beam + 2] first dense visiting index of each source
+  unsigned *tpre = (unsigned *)(dyn_lds + xw.off_tpre);
+  XCells cl;
+  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;
+  cl.nslot = xw.nslot;
+  cl.lkey = (unsigned long long *)(dyn_lds + xw.off_cells);
+  cl.lnode = (int *)(dyn_lds + xw.off_lnode);
+  cl.lfirst = (unsigned *)(dyn_lds + xw.off_lfirst);
+  float *rowc = (float *)(dyn_lds + xw.off_row);
+  PruneMem pm;
+  pm.comp = (unsigned long long *)(dyn_lds + xw.off_comp);
+  pm.compR = (unsigned long long *)(dyn_lds + xw.off_compr);
+  pm.vposR = (unsigned *)(dyn_lds + xw.off_vpos);
+  pm.idR = (unsigned *)(dyn_lds + xw.off_id);
+  pm.hist = (unsigned *)(dyn_lds + xw.off_hist);
+  pm.tailmask = (unsigned *)(dyn_lds + xw.off_tail);
+  pm.placed = pm.tailmask + (xw.w.beam + 31) / 32 + 2;
+  pm.b_cap = xw.b_cap;
+  unsigned long long *Hlds = (unsigned long long *)(dyn_lds + xw.off_heap);
+  unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
+  for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
+  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;
+  const bool wordmode = lx.lm_type == JAMD_LM_WORD;
+  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);
+  const int s1 = xw.s1, XW = xw.xw;
+  const unsigned submask = (1u << s1) - 1u;
+  const int nroot_x = wordmode ? 0 : (dfa ? lx.startnum : lx.isolatenum);
+
+  if (resume) {
+    if (!ss->active) return;
+    {
+      const uint4 *src = (const uint4 *)(ub + wk.o_sv);
+      uint4 *dst = (uint4 *)dyn_lds;
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+    }
+    if (tid == 0) { sh.n_atom = ss->n_atom; sh.n_surv = ss->n_surv; }
+    __syncthreads();
+  } else {
+    if (tid == 0) {
+      sh.n_atom = 0; sh.n_surv = 0;
+      res->status = JAMD_PASS1_OK; res->natom = 0; res->wnum = 0; res->score = JAMD_LOG_ZERO;
+      res->died_at = -1; res->ties = 0; res->ties_node = 0; res->ties_wordend = 0; res->ties_cut = 0;
+      res->frames = T; res->max_tokens = 0;
+      for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
+    }
+    for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;
+    __syncthreads();
+    if (nrows <= 0) {
+      if (tid == 0) { if (smode != 1) res->status = JAMD_PASS1_FAIL; if (ss) { ss->started = 0; ss->active = 1; } }
+      return;
+    }
+    // get_back_trellis_init(): the silB head token (init_nodescore, beam.c:1622-1665); grammar / word list:
+    // the initial tokens enter through the finalize and pruning steps of a pseudo frame 0
+    if (tid == 0 && !dfa) {
+      const int node = lx.word_head(lx.head_silwid);
+      const int4 nr = lx.node_b(node);
+      Tok nw;
+      float ls = (nr.y != 0) ? max_successor_prob(lx, -1, nr.y) : 0.0f;
+      ls = ls * lmw + pen;
+      nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
+      nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
+      nw.pad0 = nr.x; nw.pad1 = 0;
+      sv[0] = nw;
+      sh.n_surv = 1;
+    }
+  }
+  float thr = resume ? ss->thr : JAMD_LOG_ZERO;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64();
+#define PHASE(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
+  int max_tokens = resume ? ss->max_tokens : 1;
+  bool stopped = false;
+  __syncthreads();
+
+  for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
+    const int n_surv = sh.n_surv;
+    __syncthreads();
+    if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
+    const bool last = (t == T);
+    if (wk.row_cache && !last) {
+      const float *__restrict__ rg = scores + (size_t)(t_begin + t - base) * S;
+      for (int i = tid; i < S; i += NT) rowc[i] = rg[i];
+    }
+    // ---- 0: dense visiting indices.  Source j owns XW slots for its word-internal transitions and, when it
+    //         is a word end that may be followed by a word, one slot per root; sources pruned by score own none.
+    int nbits = 0;
+    if (!last) {
+      int carry = 0;
+      for (int j0 = 0; j0 < n_surv; j0 += NT) {
+        const int j = j0 + tid;
+        int cnt = 0;
+        if (j < n_surv) {
+          const float sc = sv[j].score; const int sw = sv[j].pad0;
+          if (sc > JAMD_LOG_ZERO && !(sc < thr)) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
+        }
+        const int ex = block_excl_scan(sh, cnt);
+        if (j < n_surv) dbase[j] = carry + ex;
+        carry += sh.scan_total;
+        __syncthreads();
+      }
+      if (tid == 0) dbase[n_surv] = carry;
+      nbits = carry + (dfa ? (t == 0 ? lx.ninit : 0) : XW + lx.nshared);
+    }
+    const int nwords = (nbits + 31) >> 5;
+    const bool bm_in_lds = nwords <= xw.bm_words;
+    unsigned *bm = bm_in_lds ? (unsigned *)(dyn_lds + xw.off_bm) : reinterpret_cast<unsigned *>(ub + xw.o_bitmap);
+    __syncthreads();
+
+    auto intra_candidate = [&](const Tok &tk, int j, int next_node, float a, int sub) {
+      float tmpsum = tk.score + a;
+      const int nscid = (next_node != tk.node) ? lx.scid(next_node) : 0;
+      if (nscid != 0) {
+        const float ng = max_successor_prob(lx, tk.last_cword, nscid, memo) * lmw + pen;
+        tmpsum -= tk.last_lscore;
+        tmpsum += ng;
+      }
+      xpush(sh, cl, next_node, tmpsum, ((unsigned)j << s1) | (unsigned)sub);
+    };
+    // ---- A: intra-word transitions + word-end atoms (beam.c:2838-2900)
+    for (int j = tid; j < n_surv; j += NT) {
+      const Tok tk = sv[j];
+      const int node = tk.node;
+      const int sword = tk.pad0;                       // stend
+      if (!last) {
+        if (tk.score <= JAMD_LOG_ZERO) continue;
+        if (tk.score < thr) continue;
+        const int4 na = lx.node_a(node);
+        const int e0 = na.z, e1 = na.w;
+        if (e1 > e0) {
+          const int b0 = atomicAdd(&sh.n_arc, e1 - e0);
+          for (int e = e0; e < e1; e++) ARCQ(b0 + e - e0) = make_int2(j | ((2 + e - e0) << 16), e);   // (source | transition number, arc)
+        }
+        { const float a = __int_as_float(na.x); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node, a, 0); }
+        { const float a = __int_as_float(na.y); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node + 1, a, 1); }
+      }
+      if (sword >= 0) {
+        const int ai = wave_alloc(&sh.n_atom, true);       // save_trellis() :2209-2247
+        if (ai < wk.atom_cap) {
+          jamd_trellis_atom a;
+          a.wid = sword; a.last_tre = tk.last_tre; a.backscore = tk.score; a.lscore = tk.last_lscore;
+          a.begintime = (short)((tk.last_tre < 0 ? -1 : ATOM(tk.last_tre).endtime) + 1);
+          a.endtime = (short)(t - 1);
+          ATOM(ai) = a;
+        }
+        sv_atom[j] = ai;
+        if (!last && !wordmode && sword != lx.tail_silwid) {   // beam_inter_word() :2296-2313
+          welist[atomicAdd(&sh.n_we, 1)] = j;
+          const float tmpprob = tk.score + lx.wordend_a(sword);
+          if (!dfa && tmpprob > JAMD_LOG_ZERO)                 // strict < in the reference: the earliest of the best
+            atomicMax(&sh.we_best, ((unsigned long long)ordz(tmpprob) << 32) | (unsigned)(~(unsigned)j));
+        }
+      }
+    }
+    __syncthreads();
+    if (!last) {
+      const int n_arc = sh.n_arc;
+      for (int q = tid; q < n_arc; q += NT) {
+        const int2 it = ARCQ(q);
+        const int j = it.x & 0xffff;
+        intra_candidate(sv[j], j, lx.ac_to(it.y), lx.ac_a(it.y), it.x >> 16);
+      }
+      __syncthreads();
+    }
+    PHASE(0);
+    if (last) break;
+
+    // ---- B: cross-word transitions.  Roots are visited from startnum-1 down to 0 (beam.c:2334, :2562); the
+    //         root lists of the lexicon image are stored in that order.
+    if (dfa) {
+      const int n_we = sh.n_we, nroot = lx.startnum;
+      const int total = n_we * nroot;
+      for (int x = tid; x < total; x += NT) {
+        const int w = x / nroot, rv = x - w * nroot;
+        const int r = nroot - 1 - rv;
+        const int j = welist[w];
+        const Tok tk = sv[j];
+        const int sword = tk.pad0;
+        if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
+        const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
+        float tmpsum = tk.score;
+        tmpsum += lx.wordend_a(sword);
+        float ng = lx.penalty1;
+        ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
+        tmpsum += ng;
+        xpush(sh, cl, lx.startnode(r), tmpsum, ((unsigned)j << s1) | (unsigned)(XW + rv));
+      }
+      if (t == 0)
+        for (int e = tid; e < lx.ninit; e += NT) xpush(sh, cl, lx.init_node(e), lx.init_lscore(e), (unsigned)e);
+    } else {
+      const int n_we = sh.n_we, niso = lx.isolatenum;
+      const int total = n_we * niso;
+      for (int x = tid; x < total; x += NT) {
+        const int w = x / niso, i = x - w * niso;
+        const int j = welist[w];
+        const Tok tk = sv[j];
+        const int sword = tk.pad0;
+        const bool tr = lx.is_transparent(sword) != 0;
+        const int last_word = tr ? tk.last_cword : sword;
+        const int2 ir = lx.iso_root(i);
+        const float p = (last_word < 0) ? 0.0f : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
+        float tmpsum = tk.score;
+        tmpsum += lx.wordend_a(sword);
+        const float ng = p * lmw + pen;
+        tmpsum += ng;
+        if (tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword)) tmpsum += lx.lm_penalty_trans;
+        xpush(sh, cl, ir.x, tmpsum, ((unsigned)j << s1) | (unsigned)(XW + xw.iso_rank_off + i));
+      }
+      if (sh.we_best != 0ull) {                       // beam_inter_word_factoring() :2549-2637
+        const unsigned long long kb = sh.we_best;
+        const float best_score = unord((unsigned)(kb >> 32));
+        const Tok tk = sv[(int)(~(unsigned)kb)];
+        const int sword = tk.pad0;
+        const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
+        for (int r = tid; r < lx.nshared; r += NT) {
+          const float2 sr = lx.shared_root(r);
+          const float ng = sr.y * lmw + pen;
+          float tmpsum = best_score;
+          tmpsum += ng;
+          if (trans2) tmpsum += lx.lm_penalty_trans;
+          if (tmpsum < thr) continue;                               // :2580
+          xpush(sh, cl, __float_as_int(sr.x), tmpsum, ((unsigned)n_surv << s1) | (unsigned)(XW + r));
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) sh.n_arc = 0;
+    PHASE(1);
+
+    // ---- C0: creation order = rank of the node's first visit (create_token() :1148)
+    const int n_new = sh.n_new;
+    if (n_new > max_tokens) max_tokens = n_new;
+    if (n_new > wk.tok_cap) {              // cannot happen (tok_cap bounds the reachable nodes); never write past the arrays
+      if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
+      stopped = true;
+      __syncthreads();
+      break;
+    }
+    const int W = (nwords + NT - 1) / NT;             // bitmap words per thread in the prefix scan
+    {
+      for (int i = tid; i < nwords; i += NT) bm[i] = 0u;
+      __syncthreads();
+      for (int s = tid; s < n_new; s += NT) {
+        const int2 t2 = TOUCHED(s);
+        const unsigned fv = ~(t2.y >= 0 ? cl.lfirst[t2.y] : NODEFIRST(t2.x));
+        const int dense = ((dfa && t == 0) ? 0 : dbase[fv >> s1]) + (int)(fv & submask);
+        atomicOr(&bm[dense >> 5], 1u << (dense & 31));
+      }
+      __syncthreads();
+      int cnt = 0;
+      for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm[w]); }
+      const int ex = block_excl_scan(sh, cnt);
+      tpre[tid] = (unsigned)ex;
+      __syncthreads();
+    }
+    // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951), stored at the
+    //         token's creation index
+    {
+      const RowRef row{scores + (size_t)(t_begin + t - base) * S, rowc, wk.row_cache != 0};
+      unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
+      constexpr int CB = 4;
+      for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
+        bool ok[CB]; int node[CB], slot[CB], tokid[CB]; int4 nr[CB]; unsigned long long key[CB]; unsigned fvis[CB];
+        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB];
+        float l_ls[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const int s = s0 + k * NT;
+          ok[k] = s < n_new;
+          const int2 t2 = ok[k] ? TOUCHED(s) : make_int2(0, -1);
+          node[k] = t2.x; slot[k] = t2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < CB; k++) nr[k] = lx.node_b(node[k]);
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          key[k] = 0ull; fvis[k] = 0u;
+          if (ok[k]) {
+            if (slot[k] >= 0) {
+              key[k] = cl.lkey[slot[k]]; fvis[k] = ~cl.lfirst[slot[k]];
+              cl.lkey[slot[k]] = 0ull; cl.lnode[slot[k]] = -1; cl.lfirst[slot[k]] = 0u;
+            } else {
+              key[k] = atomicExch(&NODEKEY(node[k]), 0ull);
+              fvis[k] = ~atomicExch(&NODEFIRST(node[k]), 0u);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          tokid[k] = 0;
+          if (!ok[k]) continue;
+          const int dense = ((dfa && t == 0) ? 0 : dbase[fvis[k] >> s1]) + (int)(fvis[k] & submask);
+          const int w = dense >> 5, tw = w / W;
+          int r = (int)tpre[tw];
+          for (int x = tw * W; x < w; x++) r += __popc(bm[x]);
+          r += __popc(bm[w] & ((1u << (dense & 31)) - 1u));
+          tokid[k] = r;
+        }
+        // winner's payload from its visiting index
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const unsigned vis = ~(unsigned)key[k];
+          lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f;
+          if (!ok[k]) continue;
+          int j = (int)(vis >> s1);
+          const int sub = (int)(vis & submask);
+          if (dfa && t == 0) {                                 // an initial token of the grammar
+            l_ls[k] = lx.init_lscore(sub);
+          } else if (j < n_surv && sub < XW) {                 // intra-word
+            const Tok tk = sv[j];
+            l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
+            if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
+            else l_ls[k] = tk.last_lscore;
+          } else {
+            const bool iso = j < n_surv;
+            if (!iso) j = (int)(~(unsigned)sh.we_best);        // the factoring pass: from the best word end
+            const Tok tk = sv[j];
+            const int sword = tk.pad0;
+            const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
+            l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
+            if (dfa) {                                       // beam_inter_word() :2452-2461
+              float ng = lx.penalty1;
+              ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
+              l_ls[k] = ng;
+            } else if (iso) {                                // beam_inter_word() :2430-2438
+              const int wn = lx.scword(nr[k].y);
+              const float p = (last_word < 0) ? 0.0f : bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn);
+              l_ls[k] = p * lmw + pen;
+            } else {                                         // beam_inter_word_factoring() :2572-2573
+              l_ls[k] = lx.fscore(-nr[k].y) * lmw + pen;
+            }
+          }
+        }
+        {
+          int ctx[CB]; unsigned long long mm[CB]; float fs[CB];
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            ctx[k] = -1; mm[k] = 0ull; fs[k] = 0.0f;
+            if (lmreq[k] != 0 && l_cword[k] >= 0) {
+              if (lmreq[k] < 0) fs[k] = lx.fscore(-lmreq[k]);
+              else { ctx[k] = lx.wton(l_cword[k]); mm[k] = memo[lmreq[k]]; }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (lmreq[k] == 0) continue;
+            float p = 0.0f;
+            if (l_cword[k] >= 0) {
+              if (lmreq[k] < 0) p = fs[k];
+              else if ((int)(unsigned)(mm[k] >> 32) == ctx[k]) p = __uint_as_float((unsigned)mm[k]);
+              else p = max_successor_prob(lx, l_cword[k], lmreq[k], memo);
+            }
+            l_ls[k] = p * lmw + pen;
+          }
+        }
+        {
+          int col[CB];
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            col[k] = lx.nlc;
+            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc(l_wid[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (nr[k].w == JAMD_AS_STATE) ent[k] = nr[k].z;
+            else if (nr[k].w == JAMD_AS_LSET) ent[k] = ~nr[k].z;
+            else ent[k] = ok[k] ? lx.lc_tab((size_t)nr[k].z * (lx.nlc + 1) + col[k]) : 0;
+          }
+        }
+        float ac[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) ac[k] = (ok[k] && ent[k] >= 0) ? row[ent[k]] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          if (!ok[k]) continue;
+          const int s = tokid[k];
+          const float score = unord((unsigned)(key[k] >> 32));
+          Tok nw;
+          nw.node = node[k]; nw.pad0 = nr[k].x; nw.pad1 = 0;
+          nw.last_tre = l_tre[k]; nw.last_cword = l_cword[k]; nw.last_wid = l_wid[k]; nw.last_lscore = l_ls[k];
+          if (ent[k] >= 0) {
+            nw.score = score + ac[k];
+            const unsigned b = ordz(nw.score);
+            CURKEY(s) = b;
+            if (b > mymax) mymax = b;
+            if (b < mymin) mymin = b;
+          } else {
+            nw.score = score;
+            ARCQ(atomicAdd(&sh.n_arc, 1)) = make_int2(s, ~ent[k]);
+          }
+          CUR(s) = nw;
+        }
+      }
+      __syncthreads();
+      // state-set reductions (outprob_cd(), outprob.c:287-400): four lanes per (token, set)
+      const int n_set = sh.n_arc;
+      const int sub = tid & 3, lane = tid & 63;
+      for (int q0 = 0; q0 < n_set; q0 += NT / 4) {
+        const int q = q0 + (tid >> 2);
+        const bool act = q < n_set;
+        const int2 it = act ? ARCQ(q) : make_int2(0, 0);
+        const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
+        float r;
+        if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
+          float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
+          int n = 0;
+          auto ins = [&](float p) {
+            float t_;
+            if (p > b0) { t_ = b0; b0 = p; p = t_; }
+            if (p > b1) { t_ = b1; b1 = p; p = t_; }
+            if (p > b2) { t_ = b2; b2 = p; p = t_; }
+            if (p > b3) { b3 = p; }
+          };
+          for (int m = a + sub; m < bnd; m += 16) {
+            int ix[4]; float pv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) ix[jj] = (m + 4 * jj < bnd) ? lx.set_states(m + 4 * jj) : -1;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) if (pv[jj] > JAMD_LOG_ZERO) { n++; ins(pv[jj]); }
+          }
+#pragma unroll
+          for (int src = 1; src < 4; src++) {
+            const int from = (lane & ~3) + src;
+            const float c0 = __shfl(b0, from, 64), c1 = __shfl(b1, from, 64), c2 = __shfl(b2, from, 64),
+                        c3 = __shfl(b3, from, 64);
+            const int cn = __shfl(n, from, 64);
+            if (sub == 0) { ins(c0); ins(c1); ins(c2); ins(c3); n += cn; }
+          }
+          if (n > lx.cdmax_num) n = lx.cdmax_num;
+          float sum = 0.0f;
+          if (n > 0) sum += b0;
+          if (n > 1) sum += b1;
+          if (n > 2) sum += b2;
+          if (n > 3) sum += b3;
+          r = sum / (float)n;
+        } else if (lx.cdset_method == JAMD_IWCD_MAX) {
+          float m_ = JAMD_LOG_ZERO;
+          for (int m = a + sub; m < bnd; m += 16) {
+            int ix[4]; float pv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) ix[jj] = (m + 4 * jj < bnd) ? lx.set_states(m + 4 * jj) : -1;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) if (m_ < pv[jj]) m_ = pv[jj];
+          }
+#pragma unroll
+          for (int src = 1; src < 4; src++) { const float c = __shfl(m_, (lane & ~3) + src, 64); if (m_ < c) m_ = c; }
+          r = m_;
+        } else {
+          r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
+        }
+        if (act && sub == 0) {
+          const float sc = CUR(it.x).score + r;
+          CUR(it.x).score = sc;
+          const unsigned b = ordz(sc);
+          CURKEY(it.x) = b;
+          if (b > mymax) mymax = b;
+          if (b < mymin) mymin = b;
+        }
+      }
+      atomicMax(&sh.maxbits, mymax);
+      atomicMin(&sh.minbits, mymin);
+    }
+    __syncthreads();
+    PHASE(2);
+    {
+      const float mx = unord(sh.maxbits);
+      thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;
+      if (t == 0) thr = JAMD_LOG_ZERO;
+    }
+    if (n_new == 0) {
+      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }
+      stopped = true;
+      __syncthreads();
+      break;
+    }
+    if (sh.n_atom > wk.atom_cap) {
+      if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
+      stopped = true;
+      __syncthreads();
+      break;
+    }
+    // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
+    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode);
+    for (int j = tid; j < n_keep; j += NT) sv[j] = CUR(welist[j]);
+    if (tid == 0) sh.n_surv = n_keep;
+    // the pruning step used the cell area: empty it again
+    for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
+    __syncthreads();
+    PHASE(3);
+  }
+  __syncthreads();
+
+  if (smode == 1) {
+    if (!stopped) {
+      uint4 *dst = (uint4 *)(ub + wk.o_sv);
+      const uint4 *src = (const uint4 *)dyn_lds;
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+    }
+    if (tid == 0) {
+      ss->started = 1; ss->active = stopped ? 0 : 1; ss->frames_done = T; ss->n_surv = sh.n_surv; ss->thr = thr;
+      ss->n_atom = sh.n_atom; ss->ties = 0; ss->ties_we = 0; ss->ties_cut = 0;
+      ss->max_tokens = max_tokens;
+      res->natom = min(sh.n_atom, wk.atom_cap); res->frames = T; res->max_tokens = max_tokens;
+      res->ties = 0;
+      if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    }
+    return;
+  }
+  if (ss && tid == 0) { ss->active = 0; ss->started = 1; ss->frames_done = T; }
+
+  // ---- find_1pass_result() :399-431 + trace_backptr() :294-340
+  const int natom = min(sh.n_atom, wk.atom_cap);
+  if (tid == 0) sh.best_atom = -1;
+  __syncthreads();
+  if (res->status == JAMD_PASS1_OK && dfa) {
+    if (tid == 0) { sh.n_arc = -1; sh.we_best = 0ull; }
+    __syncthreads();
+    int lt = -1;
+    for (int i = tid; i < natom; i += NT)
+      if (ATOM(i).backscore > JAMD_LOG_ZERO && ATOM(i).endtime > lt) lt = ATOM(i).endtime;
+    if (lt >= 0) atomicMax(&sh.n_arc, lt);
+    __syncthreads();
+    lt = sh.n_arc;
+    for (int i = tid; i < natom; i += NT)
+      if (ATOM(i).endtime == lt && ATOM(i).backscore > JAMD_LOG_ZERO)
+        atomicMax(&sh.we_best, ((unsigned long long)ord(ATOM(i).backscore) << 32) | (0xffffffffu - (unsigned)ATOM(i).wid));
+    __syncthreads();
+    const unsigned long long kb = sh.we_best;
+    for (int i = tid; i < natom; i += NT)
+      if (kb != 0ull && ATOM(i).endtime == lt && (unsigned)ATOM(i).wid == 0xffffffffu - (unsigned)kb &&
+          ord(ATOM(i).backscore) == (unsigned)(kb >> 32)) sh.best_atom = i;
+  } else if (res->status == JAMD_PASS1_OK) {
+    // the tail-silence word ending latest; atoms of one frame are emitted together, so "latest" is
+    // decided on the end time, not on the index
+    int bt = -1;
+    for (int i = tid; i < natom; i += NT)
+      if (ATOM(i).wid == lx.tail_silwid && ATOM(i).backscore > JAMD_LOG_ZERO && ATOM(i).endtime > bt) bt = ATOM(i).endtime;
+    if (tid == 0) sh.n_arc = -1;
+    __syncthreads();
+    if (bt >= 0) atomicMax(&sh.n_arc, bt);
+    __syncthreads();
+    bt = sh.n_arc;
+    for (int i = tid; i < natom; i += NT)
+      if (bt >= 0 && ATOM(i).wid == lx.tail_silwid && ATOM(i).backscore > JAMD_LOG_ZERO && ATOM(i).endtime == bt) sh.best_atom = i;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    res->natom = natom; res->ties = 0; res->max_tokens = max_tokens;
+    res->ties_node = 0; res->ties_wordend = 0; res->ties_cut = 0;
+    if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    res->frames = T;
+    if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
+    if (res->status == JAMD_PASS1_OK) {
+      const int best = sh.best_atom;
+      if (best < 0) res->status = JAMD_PASS1_FAIL;
+      else {
+        int n = 0, a = best;
+        int rev[MAXSEQ];
+        rev[n++] = ATOM(a).wid;
+        while (ATOM(a).begintime > 0 && n < MAXSEQ) { a = ATOM(a).last_tre; rev[n++] = ATOM(a).wid; }
+        for (int k = 0; k < n; k++) res->wseq[k] = rev[n - 1 - k];
+        res->wnum = n; res->score = ATOM(best).backscore;
+      }
+    }
+  }
+}
+
+// diagnostic: the pruning step alone on given score bits (tests/test_prune_order.py fuzzes it against the
+// sequential heap)
+__global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigned *keys, int n, int k, int *out, int *nout,
+                                                         unsigned long long *hglob) {
+  __shared__ XShared sh;
+  extern __shared__ __align__(16) unsigned char dyn_lds[];
+  PruneMem pm;
+  pm.comp = (unsigned long long *)(dyn_lds + xw.off_comp);
+  pm.compR = (unsigned long long *)(dyn_lds + xw.off_compr);
+  pm.vposR = (unsigned *)(dyn_lds + xw.off_vpos);
+  pm.idR = (unsigned *)(dyn_lds + xw.off_id);
+  pm.hist = (unsigned *)(dyn_lds + xw.off_hist);
+  pm.tailmask = (unsigned *)(dyn_lds + xw.off_tail);
+  pm.placed = pm.tailmask + (xw.w.beam + 31) / 32 + 2;
+  pm.b_cap = xw.b_cap;
+  int *svid = (int *)(dyn_lds + xw.off_we);
+  unsigned mx = 0u, mn = 0xffffffffu;
+  for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }
+  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; }
+  __syncthreads();
+  atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
+  __syncthreads();
+  const int nk = exact_prune(sh, keys, n, k, (unsigned long long *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
+                             xw.prune_mode);
+  for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
+  if (threadIdx.x == 0) *nout = nk;
+}
+
+}  // namespace
+
+namespace jamdb {
+
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared) {
+  xw->w = w;
+  const int beam = w.beam;
+  xw->xw = maxfan;                                   // self, next, extra arcs
+  int need = maxfan + nroot;                         // transition numbers of one source
+  if (ninit > need) need = ninit;
+  if (maxfan + nshared > need) need = maxfan + nshared;
+  int s1 = 1; while ((1 << s1) < need + 1) s1++;
+  int jb = 1; while ((1 << jb) < beam + 2) jb++;
+  if (s1 + jb > 32) return -1;
+  xw->s1 = s1;
+  xw->iso_rank_off = 0;
+  // LDS image
+  int at = beam * (int)sizeof(Tok);
+  auto place = [&](int *off, int bytes) { *off = at; at = (at + bytes + 15) & ~15; };
+  place(&xw->off_atom, 4 * beam);
+  place(&xw->off_we, 4 * beam);
+  place(&xw->off_dbase, 4 * (beam + 2));
+  xw->w.sv_bytes = at;                               // what a streaming session parks between launches
+  place(&xw->off_tpre, 4 * NT);
+  if (at + 8 * 1024 > kMaxDynLds) return -2;         // the survivors do not fit: wider beams use the strict-order kernel
+  // creation-order bitmap: XW bits per source plus a few word ends' worth of roots (a frame that needs more
+  // uses the copy in global memory); at most an eighth of what is left
+  int bm_words = (beam * maxfan + 8 * nroot + nshared + ninit + 31) / 32 + 64;
+  if (bm_words > 4096) bm_words = 4096;
+  if (4 * bm_words > (kMaxDynLds - at) / 8) bm_words = (kMaxDynLds - at) / 32;
+  xw->bm_words = bm_words;
+  place(&xw->off_bm, 4 * bm_words);
+  // the rest: the frame's Viterbi cells (16 bytes a slot); the pruning step overlays them
+  const int cells_at = at;
+  const int region = (kMaxDynLds - cells_at) & ~1023;
+  int nslot = (region / 16) & ~63;
+  if (nslot < 1024) nslot = 0;                       // too few to be worth probing: every cell in nodekey[]
+  xw->nslot = nslot;
+  xw->off_cells = cells_at;
+  xw->off_lnode = cells_at + 8 * nslot;
+  xw->off_lfirst = cells_at + 12 * nslot;
+  // overlay: top-k lists of the closed-form extraction when they leave room for a heap of at least 2 beam + 64
+  // entries, then the heap (a frame with more tokens than it holds builds its heap in global memory)
+  at = cells_at;
+  xw->b_cap = beam + 256;
+  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 2 * (kMaxL + 2));
+  if (24 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) xw->b_cap = 0;
+  place(&xw->off_comp, 8 * xw->b_cap);
+  place(&xw->off_compr, 8 * xw->b_cap);
+  place(&xw->off_vpos, 4 * xw->b_cap);
+  place(&xw->off_id, 4 * xw->b_cap);
+  place(&xw->off_hist, xw->b_cap ? 4 * 2048 : 0);
+  place(&xw->off_tail, tail_bytes);
+  place(&xw->off_heap, 0);
+  xw->heap_cap = (cells_at + region - xw->off_heap) / 8 - 2;
+  if (xw->heap_cap < 0) xw->heap_cap = 0;
+  xw->off_row = cells_at + region;
+  xw->lds_bytes = xw->off_row;
+  xw->prune_mode = 0;
+  return 0;
+}
+
+void xbeam_shrink_for_row(XWork *xw, int nstate) {
+  // make room for the frame's score row when the cell table and the LDS heap can spare it
+  const int want = (4 * nstate + 1023) & ~1023;
+  const int cells_at = xw->off_cells;
+  const int region = xw->off_row - cells_at - want;
+  const int nslot = (region / 16) & ~63;
+  const int heap_cap = (cells_at + region - xw->off_heap) / 8 - 2;
+  if (region <= 0 || nslot < 6 * xw->w.beam || heap_cap < 5 * xw->w.beam) return;   // the row stays in global memory
+  xw->nslot = nslot;
+  xw->off_lnode = cells_at + 8 * nslot;
+  xw->off_lfirst = cells_at + 12 * nslot;
+  xw->heap_cap = heap_cap;
+  xw->off_row = cells_at + region;
+  xw->lds_bytes = xw->off_row;
+}
+
+hipError_t xbeam_prepare() {
+  hipError_t e = hipFuncSetAttribute((const void *)beam_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)beam_exact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prune_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+  return e;
+}
+
+void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int nstate, const int *d_utt_off, int nutt,
+                  int smode, bool timed, hipStream_t st) {
+  XWork xw = xw0;
+  xbeam_shrink_for_row(&xw, nstate);
+  xw.w.row_cache = xw.lds_bytes + 4 * nstate <= kMaxDynLds ? 1 : 0;
+  const int lds = xw.lds_bytes + (xw.w.row_cache ? 4 * nstate : 0);
+  if (timed)
+    hipLaunchKernelGGL(beam_exact_kernel<true>, dim3(nutt), dim3(NT), lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+  else
+    hipLaunchKernelGGL(beam_exact_kernel<false>, dim3(nutt), dim3(NT), lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+}
+
+void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
+                              unsigned long long *d_hglob, hipStream_t st) {
+  hipLaunchKernelGGL(prune_order_kernel, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob);
+}
+
+}  // namespace jamdb

@@ -320,7 +320,9 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
   const int S = n->dims[n->nlayer];
   int nchunk = T >= 131072 ? (T + 32767) / 32768 : 1;  // measured: pays (+4.5 %) only for very long batches
   if (nchunk > 8) nchunk = 8;
+#ifdef JAMD_DEV
   if (getenv("JAMD_DNN_NOCHUNK")) nchunk = 1;
+#endif
   int per = ((T + nchunk - 1) / nchunk + BM - 1) / BM * BM;
   if (nchunk > 1 && n->side == nullptr) {
     JAMD_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));

@@ -768,8 +768,14 @@ int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev
   JAMD_HIP(hipSetDevice(g->eng->device));
   hipStream_t st = jamd_stream(g->eng, stream);
   int rc = JAMD_OK;
-  // JAMD_GMM_VARIANT: experiment switch for the D=39 kernel (bench/profiling only)
+  // JAMD_GMM_VARIANT: experiment switch for the D=39 kernel.  Several variants are ABLATIONS that return wrong
+  // scores, so the switch only exists in a -DJAMD_DEV build (tools/prof_gmm.sh); the shipped library always
+  // runs variant 0.
+#ifdef JAMD_DEV
   static const int var = getenv("JAMD_GMM_VARIANT") ? atoi(getenv("JAMD_GMM_VARIANT")) : 0;
+#else
+  constexpr int var = 0;
+#endif
   if (g->E_plain == 0 && g->ntied == g->S) {
     // all states tied-mixture: nothing for the plain-state kernels to do
   } else if (g->gprune == JAMD_GPRUNE_SAFE && g->gprune_num < g->maxmix) {

@@ -50,7 +50,7 @@ __device__ __forceinline__ void wave_sync() {
 // STRICT: lane 0 runs the reference's heap.  Otherwise every lane ranks its own states against all
 // (broadcast reads), which selects the same set unless two states tie exactly on the boundary; then
 // the lower state id wins where the reference's answer depends on the heap's history.
-// VAR 1 (JAMD_GMS_VARIANT=1, not the default until measured): the two latency chains of the default
+// VAR 1 (the form that is launched; VAR 0 is the scalar ranking loop it replaced, 9.2 vs 7.3 ms): the two latency chains of the default
 // form -- one LDS read per ranking step, one per Gaussian in the max -- are batched four wide.
 template <bool STRICT, int VAR>
 __global__ void __launch_bounds__(64)
@@ -268,9 +268,9 @@ int jamd_gms_apply_dev(jamd_gms *m, const float *dev_frames, int T, const int *u
   const int EgsPad = (m->Egs + 63) & ~63;
   const size_t lds = sizeof(float) * ((size_t)3 * m->Sgs + m->Sgs + 1 + m->Egs + 64 + 2 * (size_t)EgsPad);
   if (lds > 159 * 1024) { jamd_set_error("jamd_gms_apply_dev: a selection model of %d states / %d Gaussians does not fit in LDS", m->Sgs, m->Egs); return JAMD_EINVAL; }
-  const int var = getenv("JAMD_GMS_VARIANT") ? atoi(getenv("JAMD_GMS_VARIANT")) : 0;          // experiment switch
-  auto kern = m->strict ? (var == 1 ? gms_select_kernel<true, 1> : gms_select_kernel<true, 0>)
-                        : (var == 1 ? gms_select_kernel<false, 1> : gms_select_kernel<false, 0>);
+  // the four-wide ranking loop (template argument 1) measured 7.3 ms against 9.2 ms for the scalar one
+  // (profiles/r02a_gms_timing_variants.json) and is the only form launched
+  auto kern = m->strict ? gms_select_kernel<true, 1> : gms_select_kernel<false, 1>;
   if (lds > 48 * 1024) JAMD_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(nutt), dim3(64), lds, st, m->d_dens, m->d_st_off, m->d_logw, m->d_utt_off,
                      m->d_fs, m->Sgs, m->Egs, EgsPad, m->nbest);

@@ -117,6 +117,9 @@ def load():
         "jamd_beam_pass1_dev": (ci, [vp, vp, ci, vp, ci, vp]),
         "jamd_beam_results": (ci, [vp, vp, ci]),
         "jamd_beam_set_strict_order": (ci, [vp, ci]),
+        "jamd_beam_set_order_mode": (ci, [vp, ci]),
+        "jamd_beam_order_mode": (ci, [vp]),
+        "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
@@ -572,6 +575,28 @@ class Beam:
 
     def set_strict_order(self, on: bool = True):
         _check(load().jamd_beam_set_strict_order(self.h, 1 if on else 0), "jamd_beam_set_strict_order")
+
+    ORDER_MODES = {"fast": 0, "strict": 1, "exact": 2, "exact_serial": 3}
+
+    def set_order_mode(self, mode):
+        """'exact' (default where available), 'exact_serial', 'fast' or 'strict' -- see julius_amd.h."""
+        m = self.ORDER_MODES[mode] if isinstance(mode, str) else int(mode)
+        _check(load().jamd_beam_set_order_mode(self.h, m), "jamd_beam_set_order_mode")
+        return self
+
+    def order_mode(self) -> str:
+        m = load().jamd_beam_order_mode(self.h)
+        return {v: k for k, v in self.ORDER_MODES.items()}[m]
+
+    def prune_order(self, scores):
+        """sort_token_no_order() alone: the visiting order the exact-order kernel derives for tokens with
+        these scores (creation order) under this work area's beam width."""
+        sc = _f32(scores)
+        out = np.zeros(len(sc), np.int32)
+        n = C.c_int()
+        _check(load().jamd_beam_prune_order(self.h, sc.ctypes.data, len(sc), out.ctypes.data, C.byref(n)),
+               "jamd_beam_prune_order")
+        return out[:n.value].copy()
 
     def stream_begin(self, nutt: int):
         self._nutt = nutt

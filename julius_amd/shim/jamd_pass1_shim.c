@@ -38,7 +38,8 @@ typedef struct {
   HTK_HMM_INFO *hmminfo;
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam; jamd_gms *gms;
-  int strict;                /* JAMD_STRICT_ORDER, or a multipath model (strict-order kernel only) */
+  int strict;                /* JAMD_STRICT_ORDER=1 / JAMD_ORDER_MODE=strict, or a multipath model (strict-order kernel only) */
+  int order_mode;            /* -1 = the work area's default (exact order where the beam fits), else JAMD_ORDER_* (JAMD_ORDER_MODE) */
   int nstate;
   int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
   /* streaming state of the current utterance */
@@ -117,15 +118,20 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL &&
       c->nnode == r->wchmm->n && c->nword == r->wchmm->winfo->num && c->dfa == (void *)r->wchmm->dfa) return TRUE;
   ctx_release(c);
-  {
-    /* multipath models: only the experimental strict-order kernel takes them (JAMD_EXPERIMENTAL_MULTIPATH=1) */
-    const int mp_ok = getenv("JAMD_EXPERIMENTAL_MULTIPATH") != NULL && atoi(getenv("JAMD_EXPERIMENTAL_MULTIPATH")) != 0;
-    if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || (r->am->hmminfo->multipath && !mp_ok) || r->config->successive.enabled) {
-      jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, non-multipath models, no -spsegment\n");
-      return FALSE;
-    }
+  if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || r->config->successive.enabled) {
+    jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, no -spsegment\n");
+    return FALSE;
   }
-  c->strict = r->am->hmminfo->multipath ||
+  /* tie order (julius_amd.h, JAMD_ORDER_*): default = the reference's order (exact-order kernel); JAMD_ORDER_MODE =
+   * fast | exact | strict chooses; multipath models are served by the strict-order kernel only */
+  c->order_mode = -1;
+  {
+    const char *om = getenv("JAMD_ORDER_MODE");
+    if (om != NULL && !strcmp(om, "fast")) c->order_mode = JAMD_ORDER_FAST;
+    else if (om != NULL && !strcmp(om, "exact")) c->order_mode = JAMD_ORDER_EXACT;
+    else if (om != NULL && !strcmp(om, "strict")) c->order_mode = JAMD_ORDER_STRICT;
+  }
+  c->strict = r->am->hmminfo->multipath || c->order_mode == JAMD_ORDER_STRICT ||
               (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0);
   if (r->am->hmmwrk.OP_gshmm != NULL && r->am->dnn != NULL) {
     jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) with a DNN-HMM is not supported\n");
@@ -167,7 +173,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
       rc = jamd_gms_create(g_eng, &fs.desc, map, c->nstate, wrk->my_nbest, &c->gms);
       jamd_flat_gmm_free(&fs); free(map);
       if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
-      if (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0) jamd_gms_set_strict_order(c->gms, 1);
+      if (c->strict || c->order_mode != JAMD_ORDER_FAST) jamd_gms_set_strict_order(c->gms, 1);   /* the reference's heap decides boundary ties */
       jlog("STAT: jamd: Gaussian mixture selection on the device (%d selection states, %d selected per frame)\n",
            wrk->gsset_num, wrk->my_nbest);
     }
@@ -186,6 +192,10 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
                         1 << 20, &c->beam);
   if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   if (c->strict && jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  if (!c->strict && c->order_mode == JAMD_ORDER_FAST) jamd_beam_set_order_mode(c->beam, JAMD_ORDER_FAST);
+  if (!c->strict && c->order_mode == JAMD_ORDER_EXACT && jamd_beam_set_order_mode(c->beam, JAMD_ORDER_EXACT) != JAMD_OK) {
+    jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE;
+  }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
   c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
@@ -245,6 +255,7 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
     memcpy(frames + (size_t)off[u] * veclen, c->pre[first + u].frames, sizeof(float) * (size_t)c->pre[first + u].T * veclen);
   if (jamd_beam_create(g_eng, c->lex, c->beam_width, c->bs_width, n, 1 << 19, &bb) != JAMD_OK) goto out;
   if (c->strict && jamd_beam_set_strict_order(bb, 1) != JAMD_OK) goto out;
+  if (!c->strict && c->order_mode >= 0 && jamd_beam_set_order_mode(bb, c->order_mode) != JAMD_OK) goto out;
   if (jamd_malloc(g_eng, sizeof(float) * total * veclen, (void **)&d_frames) != JAMD_OK ||
       jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores) != JAMD_OK ||
       jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||

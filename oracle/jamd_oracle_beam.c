@@ -194,6 +194,25 @@ static void sort_token_no_order(beam *b, int neednum)   /* :1492 */
   else { sort_token_downward(b, restnum, totalnum); b->n_start = 0; b->n_end = neednum - 1; }
 }
 
+/* sort_token_no_order() alone (beam.c:1492 over :1342-1480): n tokens with these scores in creation
+ * order (tindex = identity, create_token() :1148) -> the token ids the next frame visits, in visiting
+ * order tindex[n_start..n_end].  Returns how many. */
+int jo_sort_token_no_order(const float *scores, int n, int beam_width, int *order)
+{
+  beam B; int i, k;
+  memset(&B, 0, sizeof(B));
+  B.tn = 0;
+  B.tlist[0] = (tok *)malloc(sizeof(tok) * (n > 0 ? n : 1));
+  B.tindex[0] = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+  for (i = 0; i < n; i++) { B.tlist[0][i].score = scores[i]; B.tindex[0][i] = i; }
+  B.tnum[0] = n;
+  sort_token_no_order(&B, beam_width);
+  k = 0;
+  for (i = B.n_start; i <= B.n_end; i++) order[k++] = B.tindex[0][i];
+  free(B.tlist[0]); free(B.tindex[0]);
+  return k;
+}
+
 /* propagate_token(), beam.c:1945-1980 */
 static void propagate_token(beam *b, int next_node, float next_score, int last_tre, int last_cword,
                             float last_lscore)

@@ -187,6 +187,15 @@ class Oracle:
                                C.byref(natom), _p(wseq), len(wseq), C.byref(wnum), C.byref(score), C.byref(died))
         return atoms[:natom.value].copy(), wseq[:wnum.value].copy(), float(score.value), rc, died.value
 
+    def sort_token_no_order(self, scores, beam_width):
+        """beam.c:1492: visiting order (token ids) of the next frame for tokens with these scores in creation order."""
+        sc = _f32(scores)
+        out = np.zeros(max(len(sc), 1), np.int32)
+        self.lib.jo_sort_token_no_order.restype = C.c_int
+        self.lib.jo_sort_token_no_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        k = self.lib.jo_sort_token_no_order(_p(sc), len(sc), beam_width, _p(out))
+        return out[:k].copy()
+
     def dnn_outprob(self, dnn, frames, simd=DNN_FMA):
         dims = _i32(dnn["dims"])
         nl = len(dims) - 1

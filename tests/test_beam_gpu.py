@@ -211,13 +211,15 @@ def test_full_size_batch_properties(engine):
 
 @pytest.mark.parametrize("name", ["beam_rank.npz", "beam_score.npz", "beam_isolated.npz",
                                   "beam_grammar.npz", "beam_grammar_free.npz"])
-def test_strict_order_golden(engine, oracle, name):
-    """Strict-order mode (the reference's sequential visiting order, one lane per
-    utterance): EXACT equality with the reference's golden trellis, no tie caveat."""
+@pytest.mark.parametrize("mode", ["strict", "exact", "exact_serial"])
+def test_strict_order_golden(engine, oracle, name, mode):
+    """The modes that follow the reference's visiting order -- strict (sequential, one lane per
+    utterance), exact (frame-parallel, beam_exact.hip) and exact with the heap's extraction loop run
+    sequentially: EXACT equality with the reference's golden trellis, no tie caveat."""
     g = load_beam_golden(name)
     lx = lib.Lexicon(engine, g["lex"])
     bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
-    bm.set_strict_order(True)
+    bm.set_order_mode(mode)
     res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])
     for r, atoms, u in zip(res, tre, g["utts"]):
         assert r.status == 0
@@ -232,14 +234,15 @@ def test_strict_order_golden(engine, oracle, name):
     (25, 2000, ["-sepnum", "20"], dict(nword=600, nphone=14, S=260, M=2)),   # the case where the fast kernel's
     (26, 150, ["-sepnum", "4", "-transp", "-1.5"], dict(ntransparent=12)),   # tie rule dropped one atom of 34 842;
 ])                                                                              # transparent words
-def test_strict_order_exact_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw):
+@pytest.mark.parametrize("mode", ["strict", "exact"])
+def test_strict_order_exact_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, task_kw, mode):
     eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra, **task_kw)
     bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
     utts = [synth.make_utterance(task, nwords=2 + 3 * u, seed=100 * seed + u)[0] for u in range(4)]
     scores = [oracle.gmm_outprob(am, fr) for fr in utts]
     lx = lib.Lexicon(engine, lex)
     bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 17)
-    bm.set_strict_order(True)
+    bm.set_order_mode(mode)
     res, tre = bm.pass1_host(scores)
     for fr, r, atoms in zip(utts, res, tre):
         synth.write_htk_param(tmp_path / "u.mfc", fr)
@@ -259,8 +262,9 @@ def test_edge_lengths_in_one_batch(engine, oracle, beam):
     scores = [sc_full[:1], sc_full[:2], sc_full[:3], sc_full]
     lx = lib.Lexicon(engine, g["lex"])
     bm = lib.Beam(engine, lx, beam, -1.0, max_utts=len(scores))
-    for strict in (False, True):
-        bm.set_strict_order(strict)
+    for mode in ("fast", "strict", "exact"):
+        strict = mode != "fast"
+        bm.set_order_mode(mode)
         res, tre = bm.pass1_host(scores)
         for sc, r, atoms in zip(scores, res, tre):
             oatoms, owseq, oscore, rc, died = oracle.beam_pass1(g["lex"], sc, beam, -1.0)
@@ -344,15 +348,16 @@ def test_grammar_golden_batch(engine, oracle, name):
     (42, 50, ["-iwcd1", "max", "-bs", "70"], False),
     (43, 1500, ["-iwcd1", "avg"], False),                      # no rank pruning
 ])
-@pytest.mark.parametrize("strict", [False, True])
-def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, wrap, strict):
+@pytest.mark.parametrize("mode", ["fast", "strict", "exact"])
+def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, wrap, mode):
+    strict = mode != "fast"
     eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, extra, wrap=wrap, nword=90)
     bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
     utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(4)]
     scores = [oracle.gmm_outprob(am, fr) for fr in utts]
     lx = lib.Lexicon(engine, lex)
     bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 16)
-    bm.set_strict_order(strict)
+    bm.set_order_mode(mode)
     res, tre = bm.pass1_host(scores)
     for fr, r, atoms in zip(utts, res, tre):
         synth.write_htk_param(tmp_path / "u.mfc", fr)
@@ -365,10 +370,11 @@ def test_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, ex
             assert_grammar_fast(atoms, rtr, r, rwseq, rscore)
 
 
-@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("mode", ["fast", "strict", "exact"])
 @pytest.mark.parametrize("triphone", [True, False])
-def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, strict):
+def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, mode):
     """Isolated word recognition (-w word list) on the device."""
+    strict = mode != "fast"
     from oracle import pyoracle
     task = synth.make_wordlist_task(tmp_path, seed=7, triphone=triphone, nword=80)
     args = ["-h", task["hmmdefs"]] + (["-hlist", task["hmmlist"]] if triphone else []) + [
@@ -381,7 +387,7 @@ def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, str
     utts = [synth.make_wordlist_utterance(task, seed=u)[0] for u in range(5)]
     lx = lib.Lexicon(engine, lex)
     bm = lib.Beam(engine, lx, eng.beam_width, -1.0, max_utts=len(utts))
-    bm.set_strict_order(strict)
+    bm.set_order_mode(mode)
     res, tre = bm.pass1_host([oracle.gmm_outprob(am, fr) for fr in utts])
     for fr, r, atoms in zip(utts, res, tre):
         synth.write_htk_param(tmp_path / "u.mfc", fr)
@@ -396,18 +402,11 @@ def test_wordlist_vs_reference_live(engine, oracle, ref, tmp_path, triphone, str
 
 
 # ---- multipath lexicons ------------------------------------------------------------------------------
-# beam_strict_mp_kernel was written after this round's device time was spent: these tests have not run
-# on hardware yet and are opt-in (JAMD_RUN_UNVALIDATED=1) until they have; the CPU restatement of the
-# same frame loop is pinned to the reference in tests/test_beam_oracle.py.
-import os
+# beam_strict_mp_kernel (strict-order only): first hardware run at the start of round 2
+# (profiles/r02a_pending_multipath_tests.txt); the CPU restatement of the same frame loop is pinned to the
+# reference in tests/test_beam_oracle.py.
 
-unvalidated = pytest.mark.skipif(os.environ.get("JAMD_RUN_UNVALIDATED") != "1",
-                                 reason="multipath strict-order kernel: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
-
-
-@unvalidated
 def test_multipath_strict_golden(engine, oracle, monkeypatch):
-    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
     g = load_beam_golden("beam_multipath.npz")
     assert g["lex"]["lm_type"] == 0x100
     lx = lib.Lexicon(engine, g["lex"])
@@ -422,14 +421,12 @@ def test_multipath_strict_golden(engine, oracle, monkeypatch):
         assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
 
 
-@unvalidated
 @pytest.mark.parametrize("kind,seed,beam,extra", [
     ("ngram", 47, 150, ["-sepnum", "4", "-bs", "60", "-multipath"]),
     ("ngram", 48, 40, ["-sepnum", "0", "-iwcd1", "avg", "-multipath"]),
     ("grammar", 49, 100, ["-penalty1", "-2.0", "-multipath"]),
 ])
 def test_multipath_strict_vs_reference_live(engine, oracle, ref, tmp_path, monkeypatch, kind, seed, beam, extra):
-    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
     if kind == "ngram":
         eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, extra)
         utts = [synth.make_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(3)]

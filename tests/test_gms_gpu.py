@@ -100,17 +100,3 @@ def test_bad_arguments(engine, fixture):
     stage = lib.Gms(engine, fixture["gs"], z["state2gs"], 8)
     with pytest.raises(lib.JamdError):
         stage.apply_host(z["frames"][:10], np.zeros((10, stage.S), np.float32), utt_off=[0, 5])
-
-
-@pytest.mark.skipif(__import__("os").environ.get("JAMD_RUN_UNVALIDATED") != "1",
-                    reason="JAMD_GMS_VARIANT=1: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
-@pytest.mark.parametrize("strict", [False, True])
-def test_batched_variant(engine, fixture, monkeypatch, strict):
-    """The four-wide form of the selection kernel (experiment switch, to be measured) gives the same output."""
-    monkeypatch.setenv("JAMD_GMS_VARIANT", "1")
-    z, used = fixture["z"], fixture["z"]["state2gs"] >= 0
-    real = lib.Gmm(engine, fixture["full"]).outprob_host(z["frames"])
-    for nbest in (4, 24):
-        stage = lib.Gms(engine, fixture["gs"], z["state2gs"], nbest).set_strict_order(strict)
-        got = stage.apply_host(z["frames"], real, z["utt_off"])
-        assert np.array_equal(got[:, used], z["out_%d" % nbest][:, used])

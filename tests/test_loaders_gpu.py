@@ -155,8 +155,6 @@ def test_export_then_standalone_batch(ref, tmp_path, gms):
         assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(wseq)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("JAMD_RUN_UNVALIDATED") != "1",
-                    reason="jamd_batch -rej: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
 def test_export_then_standalone_batch_with_verification(ref, tmp_path):
     """jamd_export writes PREFIX.rej for a -gmm configuration; jamd_batch -rej scores the verification
     GMMs of every input on the device and prints gmm_end()'s verdict: winner, confidence, accepted --

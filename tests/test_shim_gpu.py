@@ -18,7 +18,18 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("strict", [False, True, "stream"])
+def _order_env(monkeypatch, mode):
+    """mode: 'fast' (canonical tie breaks), 'strict' (sequential kernel), anything else = the shim's default,
+    the exact-order kernel.  Returns whether the trellis must equal the reference's exactly."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    if mode == "fast":
+        monkeypatch.setenv("JAMD_ORDER_MODE", "fast")
+    else:
+        monkeypatch.delenv("JAMD_ORDER_MODE", raising=False)
+    return mode != "fast"
+
+
+@pytest.mark.parametrize("strict", ["fast", "strict", "exact", "stream"])
 @pytest.mark.parametrize("seed,beam,extra", [
     (31, 200, ["-sepnum", "5"]),
     (32, 100, ["-sepnum", "3", "-gprune", "safe", "-tmix", "3"]),
@@ -26,7 +37,7 @@ pytestmark = pytest.mark.gpu
     (34, 150, ["-sepnum", "5", "-rl3"]),       # forward 2-gram for pass 1 + backward 3-gram for the reference's pass 2
 ])
 def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, seed, beam, extra, strict):
-    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if strict is True else "0")
+    exact = _order_env(monkeypatch, strict)
     # "stream": the shim advances the device search every 25 frames from get_back_trellis_proceed()
     monkeypatch.setenv("JAMD_STREAM_CHUNK", "25" if strict == "stream" else "0")
     if not pyoracle.REF_AMD_SO.exists():
@@ -60,7 +71,7 @@ def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, s
         assert np.array_equal(f1, f0) and fs1 == fs0                   # final sentence after pass 2
         # the trellis the 2nd pass consumed: identical -- exactly in strict-order mode, up to the
         # exact-score ties of DESIGN.md section 4 with the frame-parallel kernel
-        if strict is True:
+        if exact:
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
         else:
@@ -185,7 +196,7 @@ def test_c4_dnn_over_device_scores(ref, tmp_path, monkeypatch, so, strict):
             assert np.array_equal(tr1[k], tr0[k]), k
 
 
-@pytest.mark.parametrize("mode", ["fast", "strict", "stream"])
+@pytest.mark.parametrize("mode", ["fast", "strict", "exact", "stream"])
 @pytest.mark.parametrize("kind", ["c1", "triphone", "free"])
 def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kind, mode):
     """Grammar recognition (-dfa) with the FIRST PASS ON THE DEVICE: per-category lexicon trees,
@@ -193,7 +204,7 @@ def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kin
     shim rebuilt.  c1 = BASELINE configs[0] shape (tied-mixture monophones, 100-word loop
     grammar); triphone = cross-word triphones with category-aware state sets; free = any word
     may start a sentence (dozens of initial tokens)."""
-    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    exact = _order_env(monkeypatch, mode)
     monkeypatch.setenv("JAMD_STREAM_CHUNK", "20" if mode == "stream" else "0")
     if not pyoracle.REF_AMD_SO.exists():
         pytest.skip("oracle/_ref/libjref_amd.so not built")
@@ -220,7 +231,7 @@ def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kin
         assert d1 == n1                                                # 2nd pass = cache hits on device scores
         assert st1 == st0
         assert s1 == s0 and fs1 == fs0                                 # pass-1 and final scores
-        if mode == "strict":                                           # the reference's visiting order: exact
+        if exact:                                                      # the reference's visiting order: exact
             assert np.array_equal(w1, w0) and np.array_equal(f1, f0)
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
@@ -229,11 +240,11 @@ def test_grammar_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, kin
             assert_canonical_scores_close(tr1, tr0)
 
 
-@pytest.mark.parametrize("mode", ["fast", "strict"])
+@pytest.mark.parametrize("mode", ["fast", "strict", "exact"])
 def test_wordlist_recognition_over_device_first_pass(ref, tmp_path, monkeypatch, mode):
     """Isolated word recognition (-w) through the shimmed recogniser: the first pass IS the
     recognition, the shim derives the final N-best result from the trellis it rebuilt."""
-    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if mode == "strict" else "0")
+    exact = _order_env(monkeypatch, mode)
     monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
     if not pyoracle.REF_AMD_SO.exists():
         pytest.skip("oracle/_ref/libjref_amd.so not built")
@@ -250,7 +261,7 @@ def test_wordlist_recognition_over_device_first_pass(ref, tmp_path, monkeypatch,
         tr1, _ = amd.recognize(tmp_path / "u.mfc")
         st1, f1, fs1 = amd.final_result()
         assert st1 == st0 and len(f1) == 1
-        if mode == "strict":
+        if exact:
             assert np.array_equal(f1, f0) and fs1 == fs0
             for k in tr0:
                 assert np.array_equal(tr1[k], tr0[k]), k
@@ -400,13 +411,10 @@ def test_verification_gmm_on_device(ref, tmp_path, monkeypatch, so):
             assert fin0[0] < 0 and not want[3]                 # J_RESULT_STATUS_REJECT_GMM
 
 
-@pytest.mark.skipif(__import__("os").environ.get("JAMD_RUN_UNVALIDATED") != "1",
-                    reason="multipath strict-order kernel: first hardware run pending (JAMD_RUN_UNVALIDATED=1)")
 @pytest.mark.parametrize("lm", ["ngram", "grammar"])
 def test_multipath_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, lm):
     """-multipath: the shim flattens the multipath lexicon and decodes it with the strict-order kernel
-    (opt-in, JAMD_EXPERIMENTAL_MULTIPATH=1); trellis, pass-1 and final results as the plain reference."""
-    monkeypatch.setenv("JAMD_EXPERIMENTAL_MULTIPATH", "1")
+; trellis, pass-1 and final results as the plain reference."""
     monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
     monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
     if not pyoracle.REF_AMD_SO.exists():
