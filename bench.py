@@ -83,6 +83,8 @@ def main():
                          "e2e-dnn = configs[3]: MFMA DNN outprob + HIP first pass")
     ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
+    ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
+                    help="e2e: first-pass tie order mode (default: the work area's default = exact)")
     args = ap.parse_args()
     if args.workload == "dnn":
         return main_dnn(args)
@@ -328,6 +330,8 @@ def main_e2e(args):
     T = len(frames)
     lx = lib.Lexicon(eng, lex)
     bm = lib.Beam(eng, lx, args.beam, -1.0, max_utts=args.utts, atoms_per_utt=1 << 17)
+    if args.order:
+        bm.set_order_mode(args.order)
     d_fr = torch.from_numpy(frames).cuda()
     d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()

@@ -41,6 +41,37 @@ using namespace jamdb;
 
 constexpr int kMaxL = 20;                // heap positions < 2^21
 
+// LDS arrays are addressed through pointers that CARRY the address space: a generic pointer that the
+// compiler cannot trace back to LDS (through a struct, a select, a non-inlined call) becomes flat_load /
+// flat_store -- two to three times the latency of ds_read / ds_write and no loop unrolling
+// (measured: the rank-by-counting loop below ran 14x slower through a generic pointer).
+#define JAMD_LDS __attribute__((address_space(3)))
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef JAMD_LDS unsigned long long lds_u64;
+typedef JAMD_LDS unsigned lds_u32;
+typedef JAMD_LDS int lds_i32;
+typedef JAMD_LDS float lds_f32;
+typedef JAMD_LDS u32x4 lds_v4;
+
+// a token record (two 16-byte quads) to / from LDS
+__device__ __forceinline__ Tok lds_tok_load(const lds_v4 *p, int j) {
+  const u32x4 a = p[2 * j], b = p[2 * j + 1];
+  Tok t;
+  t.node = (int)a.x; t.score = __uint_as_float(a.y); t.last_tre = (int)a.z; t.last_cword = (int)a.w;
+  t.last_lscore = __uint_as_float(b.x); t.last_wid = (int)b.y; t.pad0 = (int)b.z; t.pad1 = (int)b.w;
+  return t;
+}
+__device__ __forceinline__ void lds_tok_store(lds_v4 *p, int j, const Tok &t) {
+  u32x4 a, b;
+  a.x = (unsigned)t.node; a.y = __float_as_uint(t.score); a.z = (unsigned)t.last_tre; a.w = (unsigned)t.last_cword;
+  b.x = __float_as_uint(t.last_lscore); b.y = (unsigned)t.last_wid; b.z = (unsigned)t.pad0; b.w = (unsigned)t.pad1;
+  p[2 * j] = a; p[2 * j + 1] = b;
+}
+struct XRowRef {                 // this frame's score row: its LDS copy or the row in global memory
+  const float *g; const lds_f32 *l; bool lds;
+  __device__ __forceinline__ float operator[](int i) const { return lds ? l[i] : g[i]; }
+};
+
 struct XShared {
   unsigned long long we_best;            // (ord(score + wordend_a), ~j): best word end, earliest visit
   int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback;
@@ -52,7 +83,7 @@ struct XShared {
 
 struct XCells {
   unsigned char *ub; unsigned o_nodekey, o_nodefirst, o_touched;
-  unsigned long long *lkey; int *lnode; unsigned *lfirst;
+  lds_u64 *lkey; lds_i32 *lnode; lds_u32 *lfirst;
   int nslot;
 };
 constexpr int kXProbes = 24;
@@ -86,14 +117,14 @@ __device__ __forceinline__ void xpush(XShared &sh, const XCells &cl, int node, f
   if (cl.nslot > 0) {
     unsigned h = __umulhi((unsigned)node * 2654435761u, (unsigned)cl.nslot);
     for (int pr = 0; pr < kXProbes; pr++) {
-      const int o = atomicCAS(&cl.lnode[h], -1, node);
+      const int o = atomicCAS((int *)&cl.lnode[h], -1, node);
       if (o == -1 || o == node) { slot = (int)h; first = (o == -1); break; }
       h = (h + 1 == (unsigned)cl.nslot) ? 0u : h + 1;
     }
   }
   if (slot >= 0) {
-    atomicMax(&cl.lkey[slot], key);
-    atomicMax(&cl.lfirst[slot], ~vis);
+    atomicMax((unsigned long long *)&cl.lkey[slot], key);
+    atomicMax((unsigned *)&cl.lfirst[slot], ~vis);
   } else {
     const unsigned long long old =
         atomicMax(reinterpret_cast<unsigned long long *>(cl.ub + (unsigned)(cl.o_nodekey + 8u * (unsigned)node)), key);
@@ -123,18 +154,16 @@ __device__ __forceinline__ bool insub(unsigned p, unsigned c) {
 }
 
 struct PruneMem {                // LDS regions of the pruning step (they overlay the empty Viterbi cells)
-  unsigned long long *comp;      // [b_cap] top-k composites as collected
-  unsigned long long *compR;     // [b_cap] sorted: (score bits << 32 | ~prekey at collection time)
-  unsigned *vposR;               // [b_cap] current virtual heap position per rank
-  unsigned *idR;                 // [b_cap] token id per rank
-  unsigned *hist;                // [2048]
-  unsigned *tailmask;            // [(beam + 31) / 32 + 1]
-  unsigned *placed;              // [2 * (kMaxL + 2)] elements taken out during a replay: rank, saved position
+  lds_u64 *compR;                // [pow2 >= b_cap] sorted: (score bits << 32 | ~prekey at collection time)
+  lds_u32 *vposR;                // [b_cap] current virtual heap position per rank
+  lds_u32 *idR;                  // [b_cap] token id per rank
+  lds_u32 *hist;                 // [2048]
+  lds_u32 *tailmask;             // [(beam + 31) / 32 + 1]
   int b_cap;
 };
 
-template <bool UP>
-__device__ __forceinline__ void heap_sift(unsigned long long *H, int n, int parent, unsigned long long s) {
+template <bool UP, typename HP>
+__device__ __forceinline__ void heap_sift(HP H, int n, int parent, unsigned long long s) {
   const unsigned sv = (unsigned)(s >> 32);
   int child;
   while ((child = parent * 2) <= n) {
@@ -153,8 +182,8 @@ __device__ __forceinline__ void heap_sift(unsigned long long *H, int n, int pare
 }
 
 // first loop of sort_token_upward/_downward (:1354-1367): level-parallel
-template <bool UP>
-__device__ __forceinline__ void heapify_levels(unsigned long long *H, int n) {
+template <bool UP, typename HP>
+__device__ __forceinline__ void heapify_levels(HP H, int n) {
   const int top = n / 2;
   if (top >= 1) {
     for (int L = 31 - __clz(top); L >= 0; L--) {
@@ -166,8 +195,8 @@ __device__ __forceinline__ void heapify_levels(unsigned long long *H, int n) {
 }
 
 // second loop (:1368-1383) on one lane
-template <bool UP>
-__device__ __forceinline__ void heap_extract_serial(unsigned long long *H, int n, int cnt) {
+template <bool UP, typename HP>
+__device__ __forceinline__ void heap_extract_serial(HP H, int n, int cnt) {
   int m = n;
   while (m > n - cnt) {
     const unsigned long long s = H[m];
@@ -179,7 +208,8 @@ __device__ __forceinline__ void heap_extract_serial(unsigned long long *H, int n
 
 // k-th largest of the score bits in H[1..n] (radix select, 11 bits a pass over the bits in which the
 // frame's max and min differ).  Returns the value; all threads.
-__device__ __forceinline__ unsigned kth_largest(XShared &sh, const unsigned long long *H, int n, int k, unsigned *hist) {
+template <typename HP>
+__device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k, lds_u32 *hist) {
   unsigned need = (unsigned)k;
   const unsigned diff = sh.maxbits ^ sh.minbits;
   int remaining = diff ? 32 - __clz(diff) : 0;
@@ -194,7 +224,7 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, const unsigned long
     for (int p = 1 + tid; p <= n; p += NT) {
       const unsigned b = (unsigned)(H[p] >> 32);
       const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
-      if (hi == prefix) atomicAdd(&hist[(b >> shift) & dmask], 1u);
+      if (hi == prefix) atomicAdd((unsigned *)&hist[(b >> shift) & dmask], 1u);
     }
     __syncthreads();
     {
@@ -225,68 +255,89 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, const unsigned long
 }
 
 // ---- the events of the extraction loop, replayed by ONE wave (see the file header) -------------------
-// smallest rank r >= start with vposR[r] inside subtree(a); -1 if none.  Wave-uniform.
-__device__ __forceinline__ int first_in_subtree(const volatile unsigned *vposR, int nB, int start, unsigned a, int excl) {
-  const int lane = threadIdx.x & 63;
-  for (int base = start; base < nB; base += 64) {
-    const int r = base + lane;
-    const bool match = r < nB && r != excl && insub(vposR[r], a);
-    const unsigned long long m = __ballot(match);
-    if (m) return base + __ffsll((long long)m) - 1;
-  }
-  return -1;
-}
-
 // Replays extraction i (1-based) when the tail position q = n - i + 1 may hold one of the top elements.
 // Ranks 0..i-2 are out already, rank i-1 is at the root.  Wave 0 only; wave-uniform control flow.
-__device__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
-  volatile unsigned *vposR = pm.vposR;
+//
+// Who sits where: a heap position holds the best remaining element of its subtree that is not sitting
+// further up.  Subtrees along a root-to-leaf chain are nested, so the occupants of a chain come out of ONE
+// scan over the remaining ranks in order: the first element inside subtree(a_0) takes a_0, the next one
+// inside subtree(a_1) takes a_1, and so on.
+// A single wave runs this, so every dependent instruction costs its full latency: the scans keep the per-step
+// work to a compare and a ballot (the chain scan reduces "inside subtree(a_d)" to "shares at least d path bits
+// with q", computed once per element), fetch the next 64 ranks while the current ones are walked, and move
+// values between lanes with v_readlane (the ballot's lane index is uniform), not with LDS permutes.
+__device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
+  const lds_u32 *vposR = pm.vposR;
   const int lane = threadIdx.x & 63;
   const unsigned q = (unsigned)(n - i + 1);
   const int Lq = 31 - __clz((int)q);
-  volatile unsigned *placed_r = pm.placed, *placed_v = pm.placed + (kMaxL + 2);
-  int np = 0, occq = -1;
-  // who sits at q?  Occupants along the chain root -> q: each position holds the best remaining element of
-  // its subtree that is not sitting further up
-  for (int d = 0; d <= Lq; d++) {
-    const unsigned a = q >> (Lq - d);
-    const int r = first_in_subtree(vposR, nB, i - 1, a, -1);
-    if (r < 0) break;
-    if (lane == 0) { placed_r[np] = (unsigned)r; placed_v[np] = vposR[r]; vposR[r] = 0u; }
-    np++;              // taken: in no subtree while the walk goes on
-    __builtin_amdgcn_wave_barrier();
-    if (d == Lq) occq = r;
+  const int nchunk = (nB + 63) >> 6;
+  int occq = -1;
+  {
+    int d = 0;
+    bool walking = true;
+    int c = (i - 1) >> 6;
+    unsigned vn = (c * 64 + lane < nB) ? vposR[c * 64 + lane] : 0u;
+    for (; c < nchunk && walking; c++) {
+      const int r = c * 64 + lane;
+      const unsigned v = (r >= i - 1) ? vn : 0u;
+      if (c + 1 < nchunk) vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
+      // m = how many levels of the chain root -> q contain v: v is inside subtree(q >> (Lq - d)) iff d <= m
+      int m = -1;
+      if (v != 0u) {
+        const int Lv = 31 - __clz((int)v);
+        const int L = Lv < Lq ? Lv : Lq;
+        const unsigned x = (v >> (Lv - L)) ^ (q >> (Lq - L));
+        m = L - (x ? 32 - __clz((int)x) : 0);
+      }
+      int from = 0;
+      for (;;) {
+        const unsigned long long mk = __ballot(m >= d && lane >= from);
+        if (!mk) break;
+        const int l = __ffsll((long long)mk) - 1;
+        if (d == Lq) { occq = c * 64 + l; walking = false; break; }
+        d++; from = l + 1;
+      }
+    }
   }
-  if (lane == 0) for (int x = 0; x < np; x++) vposR[placed_r[x]] = placed_v[x];
-  __builtin_amdgcn_wave_barrier();
   if (occq < 0) return;                         // the element has moved up (or out) before its tail turn
   // event: s leaves q, the root element is output, s runs down the path of larger children among the
-  // elements still in the heap (size n - i) until it is >= the larger child (:1372-1381)
+  // elements still in the heap (size n - i) until it is >= the larger child (:1372-1381).  The larger child
+  // of the hole (left on ties) is the best remaining element of the hole's subtree: the same single scan.
   const int rs = occq;
   const unsigned ssc = (unsigned)(pm.compR[rs] >> 32);
   const unsigned hs = (unsigned)(n - i);
   unsigned hole = 1u;
-  np = 0;
-  for (;;) {
-    const unsigned c1 = 2u * hole;
-    if (c1 > hs) break;
-    const int rl = first_in_subtree(vposR, nB, i, c1, rs);
-    const int rr = (c1 + 1u <= hs) ? first_in_subtree(vposR, nB, i, c1 + 1u, rs) : -1;
-    if (rl < 0 && rr < 0) break;
-    int best = rl; unsigned bpos = c1;
-    if (rr >= 0 && (rl < 0 || (unsigned)(pm.compR[rl] >> 32) < (unsigned)(pm.compR[rr] >> 32))) { best = rr; bpos = c1 + 1u; }
-    if (ssc >= (unsigned)(pm.compR[best] >> 32)) break;
-    if (lane == 0) { placed_r[np] = (unsigned)best; placed_v[np] = vposR[best]; vposR[best] = 0u; }
-    np++;
-    __builtin_amdgcn_wave_barrier();
-    hole = bpos;
-    if (np >= kMaxL + 1) break;
+  {
+    bool walking = true;
+    int Lh = 0;
+    int c = i >> 6;
+    unsigned vn = (c * 64 + lane < nB) ? vposR[c * 64 + lane] : 0u;
+    for (; c < nchunk && walking; c++) {
+      const int r = c * 64 + lane;
+      const unsigned v = (r >= i && r != rs) ? vn : 0u;
+      if (c + 1 < nchunk) vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
+      const int Lv = v ? 31 - __clz((int)v) : -1;
+      int from = 0;
+      for (;;) {
+        if (2u * hole > hs) { walking = false; break; }
+        // strictly below the hole, and the child of the hole on the way there is inside the heap
+        const int dd = Lv - Lh;
+        const bool below = dd > 0 && (v >> dd) == hole && (v >> (dd - 1)) <= hs;
+        const unsigned long long mk = __ballot(below && lane >= from);
+        if (!mk) break;
+        const int l = __ffsll((long long)mk) - 1;
+        if (ssc >= (unsigned)(pm.compR[c * 64 + l] >> 32)) { walking = false; break; }
+        const unsigned vl = (unsigned)__builtin_amdgcn_readlane((int)v, l);
+        hole = vl >> ((31 - __clz((int)vl)) - Lh - 1);
+        Lh++;
+        from = l + 1;
+      }
+    }
   }
-  if (lane == 0) for (int x = 0; x < np; x++) vposR[placed_r[x]] = placed_v[x];
-  __builtin_amdgcn_wave_barrier();
   // s now counts as the element of position `hole`
   if (hole >= (unsigned)(n - k + 1) && lane == 0)     // it sits on a tail position again: its turn comes later
-    atomicOr(&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
+    atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
   // its place among the equal scores still in the heap (ranks >= i): by pre-order of the positions
   int g0 = rs, g1 = rs + 1;
   while (g0 > i && (unsigned)(pm.compR[g0 - 1] >> 32) == ssc) g0--;
@@ -295,25 +346,49 @@ __device__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
   int cnt = 0;
   for (int base = g0; base < g1; base += 64) {
     const int r = base + lane;
-    const bool before = r < g1 && r != rs && prekey(vposR[r]) < hk;
+    const bool before = r < g1 && r != rs && prekey(pm.vposR[r]) < hk;
     cnt += __popcll(__ballot(before));
   }
   const int newr = g0 + cnt;
-  if (lane == 0) {
+  if (lane == 0 && (newr != rs || true)) {
     const unsigned sid = pm.idR[rs];
     const unsigned long long sc = pm.compR[rs];
-    if (newr < rs) for (int r = rs; r > newr; r--) { vposR[r] = vposR[r - 1]; pm.idR[r] = pm.idR[r - 1]; pm.compR[r] = pm.compR[r - 1]; }
-    else for (int r = rs; r < newr; r++) { vposR[r] = vposR[r + 1]; pm.idR[r] = pm.idR[r + 1]; pm.compR[r] = pm.compR[r + 1]; }
-    vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc;
+    if (newr < rs) for (int r = rs; r > newr; r--) { pm.vposR[r] = pm.vposR[r - 1]; pm.idR[r] = pm.idR[r - 1]; pm.compR[r] = pm.compR[r - 1]; }
+    else for (int r = rs; r < newr; r++) { pm.vposR[r] = pm.vposR[r + 1]; pm.idR[r] = pm.idR[r + 1]; pm.compR[r] = pm.compR[r + 1]; }
+    pm.vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc;
   }
   __builtin_amdgcn_wave_barrier();
 }
 
+// bitonic sort of a[0..N) (N a power of two, 128 <= N <= 2 NT) into DESCENDING order, whole workgroup.  A step
+// with partner distance j <= 64 stays inside the 128 elements one wave owns (LDS operations of a wave
+// execute in order), so only the j >= 128 steps need workgroup barriers.
+__device__ __forceinline__ void bitonic_desc(volatile lds_u64 *a, int N) {
+  const int t = threadIdx.x;
+  for (int kk = 2; kk <= N; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 128) __syncthreads();
+      if (t < (N >> 1)) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const unsigned long long x = a[i], y = a[l];
+        const bool first_larger = (i & kk) == 0;
+        if (first_larger ? (x < y) : (x > y)) { a[i] = y; a[l] = x; }
+      }
+      if (j >= 128) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 // sort_token_no_order() (:1492): the visiting order of the next frame.  keys[i] = score bits of token i in
 // creation order.  Writes the token ids into svid[0..return value).  Whole workgroup.
-__device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsigned long long *H, int heap_cap,
-                           unsigned long long *Hglob, const PruneMem &pm, int *svid, int mode) {
+__device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
+                           unsigned long long *Hglob, const PruneMem &pm, lds_i32 *svid, int mode,
+                           unsigned long long *tp = nullptr) {
   const int tid = threadIdx.x;
+  unsigned long long tc_ = tp ? wall_clock64() : 0ull;
+#define PTICK(i) do { if (tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; } } while (0)
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
     __syncthreads();
@@ -321,11 +396,11 @@ __device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsi
   }
   const bool upward = k < n - k;
   const bool in_lds = n <= heap_cap;
-  if (!in_lds) H = Hglob;
-  auto run = [&](unsigned long long *Hh) -> void {
+  auto run = [&](auto Hh) -> void {
     for (int i = tid; i < n; i += NT) Hh[i + 1] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
     __syncthreads();
     if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n);
+    PTICK(4);
     bool done = false;
     if (upward && mode != 1 && pm.b_cap > 0) {
       // closed form of the extraction loop
@@ -338,28 +413,32 @@ __device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsi
         const unsigned hi = p <= n ? (unsigned)(Hh[p] >> 32) : 0u;
         const bool in = p <= n && hi >= vk;
         const int slot = wave_alloc(&sh.nB, in);
-        if (in && slot < pm.b_cap) pm.comp[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
+        if (in && slot < pm.b_cap) pm.compR[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
       }
       __syncthreads();
       const int nB = sh.nB;
+      PTICK(5);
       if (nB <= pm.b_cap) {
-        // rank by counting: the composites are distinct (one per heap position)
-        for (int e = tid; e < nB; e += NT) {
-          const unsigned long long c = pm.comp[e];
-          int r = 0;
-          for (int x = 0; x < nB; x++) r += (pm.comp[x] > c) ? 1 : 0;
-          const unsigned p = prekey_pos(0xffffffffu - (unsigned)c);
-          pm.compR[r] = c; pm.vposR[r] = p; pm.idR[r] = (unsigned)Hh[p];
-          if (p >= (unsigned)(n - k + 1)) atomicOr(&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
+        // sort the top list by (score descending, pre-order of the heap position ascending): the composites are
+        // distinct (one per heap position); padding sorts last
+        int N = 128; while (N < nB) N <<= 1;
+        for (int e = nB + tid; e < N; e += NT) pm.compR[e] = 0ull;
+        __syncthreads();
+        bitonic_desc(pm.compR, N);
+        for (int r = tid; r < nB; r += NT) {
+          const unsigned p = prekey_pos(0xffffffffu - (unsigned)pm.compR[r]);
+          pm.vposR[r] = p; pm.idR[r] = (unsigned)Hh[p];
+          if (p >= (unsigned)(n - k + 1)) atomicOr((unsigned *)&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
         }
         __syncthreads();
+        PTICK(6);
         if (tid < 64) {
           // tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1)
           const int nw = (k + 31) / 32;
           for (int w = 0; w < nw; w++) {
             unsigned donebits = 0u;
             for (;;) {
-              const unsigned bits = ((volatile unsigned *)pm.tailmask)[w] & ~donebits;
+              const unsigned bits = ((volatile lds_u32 *)pm.tailmask)[w] & ~donebits;
               if (!bits) break;
               const int b = __ffs((int)bits) - 1;
               donebits |= (b == 31) ? 0xffffffffu : ((2u << b) - 1u);
@@ -369,6 +448,7 @@ __device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsi
           }
         }
         __syncthreads();
+        PTICK(7);
         for (int j = tid; j < k; j += NT) svid[j] = (int)pm.idR[k - 1 - j];    // tindex[n-k+j]: ascending
         done = true;
       }
@@ -382,6 +462,7 @@ __device__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, unsi
   };
   if (in_lds) run(H); else run(Hglob);
   return k;
+#undef PTICK
 }
 
 template <bool TIMED>
@@ -408,28 +489,26 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 #define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
   jamd_pass1_result *res = wk.res + u;
   // LDS image: survivors in VISITING ORDER (no node hash: a candidate names its source by position)
-  Tok *sv = (Tok *)dyn_lds;
-  int *sv_atom = (int *)(dyn_lds + xw.off_atom);
-  int *welist = (int *)(dyn_lds + xw.off_we);      // word ends of the frame; the pruning step returns its order here
-  int *dbase = (int *)(dyn_lds + xw.off_dbase);    // [beam + 2] first dense visiting index of each source
-  unsigned *tpre = (unsigned *)(dyn_lds + xw.off_tpre);
+  lds_v4 *sv = (lds_v4 *)dyn_lds;                          // Tok[beam], two quads each (lds_tok_load / lds_tok_store)
+  lds_i32 *sv_atom = (lds_i32 *)(dyn_lds + xw.off_atom);
+  lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      // word ends of the frame; the pruning step returns its order here
+  lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);    // [beam + 2] first dense visiting index of each source
+  lds_u32 *tpre = (lds_u32 *)(dyn_lds + xw.off_tpre);
   XCells cl;
   cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;
   cl.nslot = xw.nslot;
-  cl.lkey = (unsigned long long *)(dyn_lds + xw.off_cells);
-  cl.lnode = (int *)(dyn_lds + xw.off_lnode);
-  cl.lfirst = (unsigned *)(dyn_lds + xw.off_lfirst);
-  float *rowc = (float *)(dyn_lds + xw.off_row);
+  cl.lkey = (lds_u64 *)(dyn_lds + xw.off_cells);
+  cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);
+  cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);
+  lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);
   PruneMem pm;
-  pm.comp = (unsigned long long *)(dyn_lds + xw.off_comp);
-  pm.compR = (unsigned long long *)(dyn_lds + xw.off_compr);
-  pm.vposR = (unsigned *)(dyn_lds + xw.off_vpos);
-  pm.idR = (unsigned *)(dyn_lds + xw.off_id);
-  pm.hist = (unsigned *)(dyn_lds + xw.off_hist);
-  pm.tailmask = (unsigned *)(dyn_lds + xw.off_tail);
-  pm.placed = pm.tailmask + (xw.w.beam + 31) / 32 + 2;
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr);
+  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
+  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
+  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
+  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.b_cap = xw.b_cap;
-  unsigned long long *Hlds = (unsigned long long *)(dyn_lds + xw.off_heap);
+  lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
   for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
@@ -443,9 +522,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   if (resume) {
     if (!ss->active) return;
     {
-      const uint4 *src = (const uint4 *)(ub + wk.o_sv);
-      uint4 *dst = (uint4 *)dyn_lds;
-      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+      const u32x4 *src = (const u32x4 *)(ub + wk.o_sv);
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) sv[i] = src[i];
     }
     if (tid == 0) { sh.n_atom = ss->n_atom; sh.n_surv = ss->n_surv; }
     __syncthreads();
@@ -474,7 +552,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
       nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
       nw.pad0 = nr.x; nw.pad1 = 0;
-      sv[0] = nw;
+      lds_tok_store(sv, 0, nw);
       sh.n_surv = 1;
     }
   }
@@ -503,7 +581,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int j = j0 + tid;
         int cnt = 0;
         if (j < n_surv) {
-          const float sc = sv[j].score; const int sw = sv[j].pad0;
+          const u32x4 a_ = sv[2 * j], b_ = sv[2 * j + 1];
+          const float sc = __uint_as_float(a_.y); const int sw = (int)b_.z;
           if (sc > JAMD_LOG_ZERO && !(sc < thr)) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
         }
         const int ex = block_excl_scan(sh, cnt);
@@ -516,7 +595,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     }
     const int nwords = (nbits + 31) >> 5;
     const bool bm_in_lds = nwords <= xw.bm_words;
-    unsigned *bm = bm_in_lds ? (unsigned *)(dyn_lds + xw.off_bm) : reinterpret_cast<unsigned *>(ub + xw.o_bitmap);
+    unsigned *bm = bm_in_lds ? (unsigned *)(dyn_lds + xw.off_bm) : reinterpret_cast<unsigned *>(ub + xw.o_bitmap);   // generic on purpose: a few accesses per token
     __syncthreads();
 
     auto intra_candidate = [&](const Tok &tk, int j, int next_node, float a, int sub) {
@@ -531,7 +610,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     };
     // ---- A: intra-word transitions + word-end atoms (beam.c:2838-2900)
     for (int j = tid; j < n_surv; j += NT) {
-      const Tok tk = sv[j];
+      const Tok tk = lds_tok_load(sv, j);
       const int node = tk.node;
       const int sword = tk.pad0;                       // stend
       if (!last) {
@@ -570,7 +649,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       for (int q = tid; q < n_arc; q += NT) {
         const int2 it = ARCQ(q);
         const int j = it.x & 0xffff;
-        intra_candidate(sv[j], j, lx.ac_to(it.y), lx.ac_a(it.y), it.x >> 16);
+        intra_candidate(lds_tok_load(sv, j), j, lx.ac_to(it.y), lx.ac_a(it.y), it.x >> 16);
       }
       __syncthreads();
     }
@@ -586,7 +665,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int w = x / nroot, rv = x - w * nroot;
         const int r = nroot - 1 - rv;
         const int j = welist[w];
-        const Tok tk = sv[j];
+        const Tok tk = lds_tok_load(sv, j);
         const int sword = tk.pad0;
         if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
         const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
@@ -605,7 +684,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       for (int x = tid; x < total; x += NT) {
         const int w = x / niso, i = x - w * niso;
         const int j = welist[w];
-        const Tok tk = sv[j];
+        const Tok tk = lds_tok_load(sv, j);
         const int sword = tk.pad0;
         const bool tr = lx.is_transparent(sword) != 0;
         const int last_word = tr ? tk.last_cword : sword;
@@ -621,7 +700,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       if (sh.we_best != 0ull) {                       // beam_inter_word_factoring() :2549-2637
         const unsigned long long kb = sh.we_best;
         const float best_score = unord((unsigned)(kb >> 32));
-        const Tok tk = sv[(int)(~(unsigned)kb)];
+        const Tok tk = lds_tok_load(sv, (int)(~(unsigned)kb));
         const int sword = tk.pad0;
         const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
         for (int r = tid; r < lx.nshared; r += NT) {
@@ -668,7 +747,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951), stored at the
     //         token's creation index
     {
-      const RowRef row{scores + (size_t)(t_begin + t - base) * S, rowc, wk.row_cache != 0};
+      const XRowRef row{scores + (size_t)(t_begin + t - base) * S, rowc, wk.row_cache != 0};
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
       constexpr int CB = 4;
       for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
@@ -719,14 +798,14 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           if (dfa && t == 0) {                                 // an initial token of the grammar
             l_ls[k] = lx.init_lscore(sub);
           } else if (j < n_surv && sub < XW) {                 // intra-word
-            const Tok tk = sv[j];
+            const Tok tk = lds_tok_load(sv, j);
             l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
             if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
             else l_ls[k] = tk.last_lscore;
           } else {
             const bool iso = j < n_surv;
             if (!iso) j = (int)(~(unsigned)sh.we_best);        // the factoring pass: from the best word end
-            const Tok tk = sv[j];
+            const Tok tk = lds_tok_load(sv, j);
             const int sword = tk.pad0;
             const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
             l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
@@ -896,8 +975,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode);
-    for (int j = tid; j < n_keep; j += NT) sv[j] = CUR(welist[j]);
+    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, TIMED ? ph : nullptr);
+    for (int j = tid; j < n_keep; j += NT) lds_tok_store(sv, j, CUR(welist[j]));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
     for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
@@ -908,9 +987,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 
   if (smode == 1) {
     if (!stopped) {
-      uint4 *dst = (uint4 *)(ub + wk.o_sv);
-      const uint4 *src = (const uint4 *)dyn_lds;
-      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
+      u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = sv[i];
     }
     if (tid == 0) {
       ss->started = 1; ss->active = stopped ? 0 : 1; ss->frames_done = T; ss->n_surv = sh.n_surv; ss->thr = thr;
@@ -988,22 +1066,20 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   PruneMem pm;
-  pm.comp = (unsigned long long *)(dyn_lds + xw.off_comp);
-  pm.compR = (unsigned long long *)(dyn_lds + xw.off_compr);
-  pm.vposR = (unsigned *)(dyn_lds + xw.off_vpos);
-  pm.idR = (unsigned *)(dyn_lds + xw.off_id);
-  pm.hist = (unsigned *)(dyn_lds + xw.off_hist);
-  pm.tailmask = (unsigned *)(dyn_lds + xw.off_tail);
-  pm.placed = pm.tailmask + (xw.w.beam + 31) / 32 + 2;
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr);
+  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
+  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
+  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
+  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.b_cap = xw.b_cap;
-  int *svid = (int *)(dyn_lds + xw.off_we);
+  lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
   for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }
   if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; }
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
-  const int nk = exact_prune(sh, keys, n, k, (unsigned long long *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
+  const int nk = exact_prune(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
                              xw.prune_mode);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
   if (threadIdx.x == 0) *nout = nk;
@@ -1054,10 +1130,11 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   // entries, then the heap (a frame with more tokens than it holds builds its heap in global memory)
   at = cells_at;
   xw->b_cap = beam + 256;
-  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 2 * (kMaxL + 2));
-  if (24 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) xw->b_cap = 0;
-  place(&xw->off_comp, 8 * xw->b_cap);
-  place(&xw->off_compr, 8 * xw->b_cap);
+  int p2 = 128; while (p2 < xw->b_cap) p2 <<= 1;             // the sort pads the list to a power of two
+  const int tail_bytes = 4 * ((beam + 31) / 32 + 2);
+  if (p2 > 2 * NT || 8 * p2 + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) { xw->b_cap = 0; p2 = 0; }
+  xw->off_comp = 0;
+  place(&xw->off_compr, 8 * p2);
   place(&xw->off_vpos, 4 * xw->b_cap);
   place(&xw->off_id, 4 * xw->b_cap);
   place(&xw->off_hist, xw->b_cap ? 4 * 2048 : 0);
