@@ -1,33 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X (driver contract, see README).
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): tied-state
-triphone-sized GMM, S=3000 states x M=16 mixtures x D=39, outprob kernel only.
-One "step" = one pass of the GMM outprob path over one batch of
-`--utts` (default 64) synthetic utterances x 1000 frames (seeded synthetic MFCC) already
+One JSON line per run.  Top level = BASELINE.json configs[1] ("C2"): tied-state
+triphone-sized GMM, S=3000 states x M=16 mixtures x D=39, outprob kernel only.  One "step" = one
+pass of the GMM outprob path over `--utts` (default 64) synthetic utterances x 1000 frames already
 resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
 
-  value   = frame*states scored per second, whole job (all ranks)
-  rtf_inv = audio-seconds per wall-second (100 frames = 1 s)
-  roofline = algorithmic bytes of the frame-synchronous formulation
-             (S*M*(2D+2)*4 + D*4 + S*4 per frame) / HIP-event
-             kernel time, against the 8 TB/s HBM peak; `valu` is the fp32 VALU
-             issue roofline that actually binds the frame-tiled kernel
-             (DESIGN.md "K1 roofline").
-  cpu_baseline = the compiled reference (oracle/_ref, kind "reference") scoring
-             a bounded sample of the same workload on ONE host core, or the
-             oracle port when _ref is absent.
+  value    = frame*states scored per second, whole job (all ranks)
+  roofline = the roof that BINDS the frame-tiled kernel: fp32 VALU issue (4 separately rounded
+             operations per (frame, Gaussian, dimension); no FMA allowed: the reference object code has
+             none).  Sub-object `hbm` carries SURVEY 8d's algorithmic-bytes figure (the model streamed
+             once per FRAME, which the kernel does not do), the compulsory bytes of a launch and the
+             measured HBM traffic (PMC passes, profiles/traffic_gmm_tile.json).
+  e2e      = nested result for configs[2] ("C3"): GMM outprob + first pass on the device over a
+             20k-word lexicon BUILT BY THE REFERENCE (dict + ARPA -> Julius' own loaders and wchmm
+             builder -> jamd_export blobs -> jamd_gmm_load / jamd_lexicon_load), >= 32 distinct
+             utterances, exact-order kernel.  `parity` compares the device result with the compiled
+             reference's first pass (julius -1pass) utterance by utterance, and the exact-order kernel
+             with the canonical-tie ("fast") kernel.
+  dnn      = nested result for the configs[3] scoring half ("C4"): MFMA fp32 DNN.
+  cpu_baseline (top level and nested) = the COMPILED REFERENCE (oracle/_ref, kind "reference") on a
+             bounded sample of the same workload: one host core, plus an N-process figure for C2.
 
-Multi-GPU: one process per GPU (torch.distributed / RCCL used only for the
-barrier and the max-over-ranks clock); utterances are sharded, no data-path
-collective ("weak" scaling: per-GPU batch fixed).
+Multi-GPU: one process per GPU; utterances are sharded, no data-path collective ("weak" scaling:
+per-GPU batch fixed).  RCCL is used for the barrier, the max-over-ranks clock and the gather of the
+per-utterance result records (julius_amd/shard.py).  `--gpus N` without a torch.distributed.run
+environment spawns the N ranks itself.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -40,138 +47,144 @@ S, M, D = 3000, 16, 39
 FRAMES_PER_UTT = 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one fp32 op/lane/clk (no FMA allowed)
+MFMA_F32_PEAK = 157.3          # TFLOP/s, dense fp32 MFMA
 
 
-def cpu_baseline(model, frames, seconds_budget=12.0):
-    """Reference CPU path on a bounded sample (rank 0, N=1 only)."""
+# ------------------------------------------------------------------------------------------------ dist
+class Dist:
+    """torch.distributed (backend nccl = RCCL) when there is more than one rank."""
+
+    def __init__(self, gpus):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if gpus > 1 and self.world != gpus:
+            raise SystemExit(f"--gpus {gpus}: WORLD_SIZE={self.world}")
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(dd: Dist, stream, step, steps, warmup, nevents=2):
+    """W untimed steps, then exactly K steps between barrier+synchronize fences; HIP events on the launch
+    stream around every step.  Returns (wall seconds max over ranks, list of per-step event lists)."""
+    torch = dd.torch
+    for _ in range(warmup):
+        step(None)
+    dd.fence()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nevents)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e in ev:
+        step(lambda i, e=e: e[i].record(stream))
+    dd.fence()
+    elapsed = dd.max_over_ranks(time.perf_counter() - t0)
+    return elapsed, ev
+
+
+# ------------------------------------------------------------------------------------------------ C2
+def ref_gmm_worker(nframes, seed):
+    """One host core of the compiled reference: eager scoring of `nframes` frames x 3000 states."""
+    from julius_amd import synth
     from oracle import pyoracle
+    model = synth.make_gmm(S=S, M=M, D=D, seed=0)
+    frames = synth.make_frames(model, T=nframes, seed=seed)
+    am = pyoracle.Ref().am_from_flat(model)
+    am.outprob(frames[:8], want_out=False)
+    am.outprob(frames, want_out=False)
+    return {"frames": nframes, "seconds": am.last_seconds}
+
+
+def cpu_baseline_gmm(model, frames, spot, budget=10.0):
+    """Compiled reference on a bounded sample: one core, then N processes side by side.  `spot` = (tt, ss,
+    device values): 64 full-size rows checked against the reference's own scores for those frames."""
+    from oracle import pyoracle
+    ref = pyoracle.Ref()
+    am = ref.am_from_flat(model)
+    am.outprob(frames[:20], want_out=False)
+    per = max(am.last_seconds / 20, 1e-5)
+    n = int(min(len(frames), max(50, budget / per)))
+    am.outprob(frames[:n], want_out=False)
+    sec = am.last_seconds
+    tt, ss, got = spot
+    want = am.outprob(frames[tt], want_out=True)[:, ss]
+    parity = bool(np.array_equal(got, want))
+    out = {"value": n * S / sec, "unit": "frame*states/s", "cores": 1, "kind": "reference", "rtf_inv": n / 100.0 / sec,
+           "sample": f"{n} frames x {S} states eager scoring, compiled reference libsent (outprob_state batch loop -> "
+                     f"calc_mix -> gprune_none -> addlog_array), {sec:.2f} s on 1 of {os.cpu_count()} host cores"}
+    ncore = max(1, min(32, (os.cpu_count() or 2) // 2))
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", str(n), str(100 + i)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(ncore)]
+    t0 = time.perf_counter()
+    outs = [p.communicate()[0] for p in procs]
+    wall = time.perf_counter() - t0
     try:
-        ref = pyoracle.Ref()
-        am = ref.am_from_flat(model)
-        am.outprob(frames[:20], want_out=False)          # warm + calibrate
-        per = max(am.last_seconds / 20, 1e-5)
-        n = int(min(len(frames), max(50, seconds_budget / per)))
-        am.outprob(frames[:n], want_out=False)
-        sec = am.last_seconds
-        kind = "reference"
-        what = "compiled reference libsent (outprob_state batch loop -> calc_mix -> gprune_none -> addlog_array)"
-    except (FileNotFoundError, OSError):
-        orc = pyoracle.Oracle()
-        t = time.perf_counter(); orc.gmm_outprob(model, frames[:10]); per = (time.perf_counter() - t) / 10
-        n = int(min(len(frames), max(20, seconds_budget / per)))
-        t = time.perf_counter(); orc.gmm_outprob(model, frames[:n]); sec = time.perf_counter() - t
-        kind = "port"
-        what = "oracle/jamd_oracle_am.c restatement"
-    return {
-        "value": n * S / sec, "unit": "frame*states/s", "cores": 1, "kind": kind,
-        "sample": f"{n} frames x {S} states eager scoring, {what}, {sec:.2f} s on 1 of {os.cpu_count()} host cores",
-        "rtf_inv": n / 100.0 / sec,
-    }
+        recs = [json.loads(o.strip().splitlines()[-1]) for o in outs]
+        slow = max(r["seconds"] for r in recs)
+        out["multi"] = {"value": sum(r["frames"] for r in recs) * S / slow, "unit": "frame*states/s", "cores": ncore,
+                        "rtf_inv": sum(r["frames"] for r in recs) / 100.0 / slow,
+                        "sample": f"{ncore} processes x {n} frames each, slowest {slow:.2f} s (wall incl. start-up {wall:.1f} s)"}
+    except Exception as e:          # a worker died: report what happened, keep the one-core figure
+        out["multi"] = {"error": repr(e)}
+    return out, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--utts", type=int, default=64,
-                    help="utterances (x1000 frames) per GPU per step (64 = one GPU's share of the 512-utterance batch of configs[4])")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="gmm", choices=["gmm", "dnn", "e2e", "e2e-dnn"],
-                    help="gmm = BASELINE configs[1] (the contract default); dnn = configs[3] scoring half; "
-                         "e2e = configs[2]: GMM outprob + HIP first pass on a 20k-word lexicon; "
-                         "e2e-dnn = configs[3]: MFMA DNN outprob + HIP first pass")
-    ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
-    ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
-    ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
-                    help="e2e: first-pass tie order mode (default: the work area's default = exact)")
-    args = ap.parse_args()
-    if args.workload == "dnn":
-        return main_dnn(args)
-    if args.workload in ("e2e", "e2e-dnn"):
-        return main_e2e(args)
-
+def run_gmm(args, dd: Dist, steps, warmup):
     import torch
     from julius_amd import lib, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: always rendezvous
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    # same model on every rank (replicated, SURVEY.md 8e); each rank its own utterances
     model = synth.make_gmm(S=S, M=M, D=D, seed=0)
     T = args.utts * FRAMES_PER_UTT
-    frames = np.concatenate([synth.make_frames(model, T=FRAMES_PER_UTT, seed=1000 + rank * args.utts + u)
+    frames = np.concatenate([synth.make_frames(model, T=FRAMES_PER_UTT, seed=1000 + dd.rank * args.utts + u)
                              for u in range(args.utts)])
-    eng = lib.Engine(local_rank)
+    eng = lib.Engine(dd.local_rank)
     gmm = lib.Gmm(eng, model)
     d_frames = torch.from_numpy(frames).cuda()
     d_out = torch.empty((T, S), dtype=torch.float32, device="cuda")
-    # a non-default stream: its handle is what the C ABI launches on, and the
-    # HIP events below are recorded on that same stream
-    stream = torch.cuda.Stream()
+    stream = torch.cuda.Stream()      # the C ABI launches on this handle; the HIP events are recorded on it too
     torch.cuda.synchronize()
 
-    def step():
+    def step(mark):
+        if mark:
+            mark(0)
         gmm.outprob_dev(d_frames.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
+        if mark:
+            mark(1)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # part of the cpu_baseline leg (rank 0, N=1): a few (t, s) entries of the last output are
-    # also checked against the oracle's values for the same frames
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pyoracle
-        rng = np.random.default_rng(0)
-        ss = np.sort(rng.choice(S, 8, replace=False))
-        tt = np.sort(rng.choice(T, 8, replace=False))
-        sub = dict(model)
-        sub["st_off"] = (np.arange(len(ss) + 1) * M).astype(np.int32)
-        idx = np.concatenate([np.arange(model["st_off"][s], model["st_off"][s + 1]) for s in ss])
-        sub["ent_dens"], sub["ent_logw"] = model["ent_dens"][idx], model["ent_logw"][idx]
-        want = pyoracle.Oracle().gmm_outprob(sub, frames[tt])
-        got = d_out[torch.from_numpy(tt).cuda()][:, torch.from_numpy(ss).cuda()].cpu().numpy()
-        parity = bool(np.array_equal(got, want))
-    else:
-        parity = None
-
-    if rank == 0:
-        total_frames = T * world * args.steps
-        value = total_frames * S / elapsed
+    elapsed, ev = timed_steps(dd, stream, step, steps, warmup)
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    res = None
+    if dd.rank == 0:
+        total_frames = T * dd.world * steps
         E = int(model["st_off"][-1])
         bytes_per_frame = E * (2 * D + 2) * 4 + D * 4 + S * 4
-        alg_bytes = bytes_per_frame * T                  # per launch (one launch per step per rank)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9    # GB/s
-        valu_ops = T * E * D * 4.0                       # sub, mul, mul, add per (frame, Gaussian, dim)
+        alg_bytes = bytes_per_frame * T
+        compulsory = E * (2 * D + 2) * 4 + T * D * 4 + T * S * 4      # model once + frames in + scores out
+        valu_ops = T * E * D * 4.0
         traffic = None
         tfile = ROOT / "profiles" / "traffic_gmm_tile.json"
         if tfile.exists():
@@ -181,238 +194,362 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        line = {
-            "metric": "frames_x_states_scored_per_sec", "value": value, "unit": "frame*states/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        tops = valu_ops / (kern_ms * 1e-3) / 1e12
+        res = {
+            "metric": "frames_x_states_scored_per_sec", "value": total_frames * S / elapsed, "unit": "frame*states/s",
+            "n_gpus": dd.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf_inv": total_frames / 100.0 / elapsed,
             "config": {"workload": "C2 (BASELINE.json configs[1]): tied-state triphone GMM outprob only, "
                                    f"S={S} x M={M} x D={D}, {args.utts} utterances x {FRAMES_PER_UTT} frames per GPU per step, "
-                                   "gprune none", "frames_per_step_per_gpu": T, "parallelism": f"utterance-sharded x{world}",
+                                   "gprune none", "frames_per_step_per_gpu": T, "parallelism": f"utterance-sharded x{dd.world}",
                        "kernel": gmm.last_kernel()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "frame-tiled kernel: the model is streamed once per 512-frame block, so algorithmic "
-                                 "(per-frame) bytes exceed real HBM traffic and frac may exceed 1; see valu",
-                         "valu": {"achieved": valu_ops / (kern_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS,
-                                  "unit": "Tops/s (fp32, unfused)", "frac": valu_ops / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}},
-            "parity_spot_check": parity,
+            "roofline": {"bound": "valu", "achieved": tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (fp32, unfused)",
+                         "frac": tops / VALU_PEAK_TOPS, "traffic": traffic, "kernel_ms": kern_ms,
+                         "ops_per_launch": valu_ops,
+                         "note": "4 separately rounded fp32 operations per (frame, Gaussian, dim) -- the reference's "
+                                 "arithmetic, no FMA -- against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
+                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                                 "algorithmic_GBs": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                                 "algorithmic_frac_of_peak": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "compulsory_bytes_per_launch": compulsory,
+                                 "compulsory_GBs": compulsory / (kern_ms * 1e-3) / 1e9,
+                                 "measured_bytes_per_launch": traffic, "peak_GBs": HBM_PEAK_GBS,
+                                 "note": "SURVEY 8d counts the model once per FRAME (15.37 MB/frame); the kernel tiles "
+                                         "512 frames per model sweep, so that figure exceeds the HBM peak by construction "
+                                         "and is not a roofline; real traffic is the measured / compulsory bytes"}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, frames)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if dd.world == 1 and not args.no_cpu_baseline:
+            rng = np.random.default_rng(0)
+            ss = np.sort(rng.choice(S, 16, replace=False))
+            tt = np.sort(rng.choice(T, 64, replace=False))      # 64 full-size rows against the compiled reference
+            got = d_out[torch.from_numpy(tt).cuda()][:, torch.from_numpy(ss).cuda()].cpu().numpy()
+            res["cpu_baseline"], res["parity_spot_check"] = cpu_baseline_gmm(model, frames, (tt, ss, got))
+    del d_out, d_frames
+    return res
 
 
-def main_dnn(args):
-    """configs[3] scoring half: 528 -> 6 x 2048 table-sigmoid -> 4000 senones, batched frames.
-    Reported against the fp32 MFMA roofline (157.3 TFLOP/s, MI355X_MICROARCH.md)."""
+# ------------------------------------------------------------------------------------------------ C4 scoring
+def run_dnn(args, dd: Dist, steps, warmup):
+    """configs[3] scoring half: 528 -> 6 x 2048 table-sigmoid -> 4000 senones, batched frames, against the fp32
+    MFMA roofline."""
     import torch
     from julius_amd import lib, synth
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dnn = synth.make_dnn(seed=0)
     T = args.utts * FRAMES_PER_UTT
-    frames = np.random.default_rng(100 + rank).normal(0, 1, (T, 528)).astype(np.float32)
-    eng = lib.Engine(local_rank)
+    frames = np.random.default_rng(100 + dd.rank).normal(0, 1, (T, 528)).astype(np.float32)
+    eng = lib.Engine(dd.local_rank)
     net = lib.Dnn(eng, dnn)
     d_fr = torch.from_numpy(frames).cuda()
     d_out = torch.empty((T, net.S), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+
+    def step(mark):
+        if mark:
+            mark(0)
         net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        net.outprob_dev(d_fr.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
-        b.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    if rank != 0:
-        dist.barrier()
-        dist.destroy_process_group()
-        return
+        if mark:
+            mark(1)
+
+    elapsed, ev = timed_steps(dd, stream, step, steps, warmup)
+    ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    if dd.rank != 0:
+        return None
     dims = [int(x) for x in dnn["dims"]]
     flops = 2.0 * T * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-    line = {"metric": "frames_x_states_scored_per_sec", "value": T * world * args.steps * net.S / elapsed,
-            "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": T * world * args.steps / 100.0 / elapsed,
-            "config": {"workload": f"C4 scoring half (BASELINE.json configs[3]): DNN {dims}, {T} frames per GPU per step",
-                       "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel_ms": ms}}
-    if world == 1 and not args.no_cpu_baseline:
-        # cpu_baseline leg: the oracle's restatement of the reference FMA kernel on a bounded sample
-        # (~10 s on one host core); the same rows double as a parity spot check of the device output
+    res = {"metric": "frames_x_states_scored_per_sec", "value": T * dd.world * steps * net.S / elapsed,
+           "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": T * dd.world * steps / 100.0 / elapsed,
+           "config": {"workload": f"C4 scoring half (BASELINE.json configs[3]): DNN {dims}, {T} frames per GPU per step"},
+           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK, "traffic": None, "kernel_ms": ms}}
+    if dd.world == 1 and not args.no_cpu_baseline:
+        # the compiled reference's dnn_calc_outprob() (FMA path) on a bounded sample; the same rows are the parity check
         from oracle import pyoracle
-        orc = pyoracle.Oracle()
-        t0 = time.perf_counter(); orc.dnn_outprob(dnn, frames[:8], pyoracle.DNN_FMA); per = (time.perf_counter() - t0) / 8
-        n = int(min(T, max(16, 10.0 / max(per, 1e-4))))
-        t0 = time.perf_counter(); want = orc.dnn_outprob(dnn, frames[:n], pyoracle.DNN_FMA); sec = time.perf_counter() - t0
-        line["parity_spot_check"] = bool(np.array_equal(d_out[:n].cpu().numpy(), want))
-        line["cpu_baseline"] = {"value": n * net.S / sec, "unit": "frame*states/s", "cores": 1, "kind": "port",
-                                "rtf_inv": n / 100.0 / sec,
-                                "sample": f"{n} frames: oracle restatement of calc_dnn_fma() + table sigmoid/log-softmax, "
-                                          f"{sec:.2f} s on 1 of {os.cpu_count()} host cores"}
-    print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with tempfile.TemporaryDirectory(prefix="jamd_dnn_") as td:
+            rd = pyoracle.Ref().dnn_load(dnn, td, num_threads=1)
+            rd.outprob(frames[:8], want_out=False)
+            per = max(rd.last_seconds / 8, 1e-4)
+            n = int(min(T, max(16, 10.0 / per)))
+            want = rd.outprob(frames[:n], want_out=True)
+            sec = rd.last_seconds
+        res["parity_spot_check"] = bool(np.array_equal(d_out[:n].cpu().numpy(), want))
+        res["cpu_baseline"] = {"value": n * net.S / sec, "unit": "frame*states/s", "cores": 1, "kind": "reference",
+                               "rtf_inv": n / 100.0 / sec,
+                               "sample": f"{n} frames: compiled reference dnn_calc_outprob() (calc_dnn_fma, table sigmoid, "
+                                         f"log-softmax), {sec:.2f} s on 1 of {os.cpu_count()} host cores"}
+    return res
 
 
-def main_e2e(args):
-    """configs[2]: tied-state triphone GMM (S=3000 x M=16 x D=39) + 20k-word tree
-    lexicon with 2-gram, outprob kernel + HIP first pass, end to end on the device:
-    frames in HBM -> [T][S] scores in HBM -> word trellis + pass-1 sentence.
-    One step = `--utts` utterances (one workgroup each) per GPU.  The lexicon is
-    synthetic (julius_amd.synth.make_lexicon, same structural rules as the
-    reference's builder); utterances follow random word sequences through it."""
+# ------------------------------------------------------------------------------------------------ C3 / C4 end to end
+def build_reference_task(workdir: Path, nword: int, beam: int):
+    """The C3 task in the REFERENCE'S OWN FORMATS (HTK hmmdefs + HMMList, HTK dictionary, ARPA 2-gram), then the
+    device blobs through jamd_export = Julius' loaders + wchmm builder + our flattening walk
+    (julius_amd/shim/jamd_export.c; the binary is built beside the compiled reference)."""
+    from julius_amd import synth
+    task = synth.make_triphone_task(workdir, nphone=40, S=S, M=M, nword=nword, nvar=25, seed=0, maxlen=8,
+                                    nbigram_per_word=10)
+    jargs = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+             "-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)]
+    export = ROOT / "oracle" / "_ref" / "jamd_export"
+    if not export.exists():
+        return task, jargs, None
+    prefix = workdir / "c3"
+    subprocess.run([str(export)] + [str(a) for a in jargs] + ["-jamdout", str(prefix)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return task, jargs, prefix
+
+
+def trellis_diff(a, b):
+    """Two canonical trellises (dicts of arrays in (endtime, wid) order): number of entries that are not in both
+    or differ in any field."""
+    ka = a["endtime"].astype(np.int64) * (1 << 32) + a["wid"]
+    kb = b["endtime"].astype(np.int64) * (1 << 32) + b["wid"]
+    common, ia, ib = np.intersect1d(ka, kb, return_indices=True)
+    diff = (len(ka) - len(common)) + (len(kb) - len(common))
+    same = np.ones(len(common), bool)
+    for k in a:
+        same &= a[k][ia] == b[k][ib]
+    return int(diff + (~same).sum())
+
+
+def run_e2e(args, dd: Dist, steps, warmup, use_dnn=False):
     import torch
-    from julius_amd import lib, synth
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: always rendezvous
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    use_dnn = args.workload == "e2e-dnn"
-    eng = lib.Engine(local_rank)
+    from julius_amd import lexblob, lib, shard, synth
+    eng = lib.Engine(dd.local_rank)
+    tmp = tempfile.TemporaryDirectory(prefix="jamd_c3_")
+    wd = Path(tmp.name)
+    ndist = max(1, min(args.utts, args.distinct))
+    ref_built = False
     if use_dnn:
-        # configs[3]: 528 -> 6 x 2048 -> 4000 senones; the lexicon's states index the DNN outputs.
-        # Random-init weights: the scores carry no sentence, the search runs with a saturated beam.
+        # configs[3]: 528 -> 6 x 2048 -> 4000 senones; the lexicon's states index the DNN outputs.  Random-init
+        # weights: the scores carry no sentence, the search runs with a saturated beam.
         dnn = synth.make_dnn(seed=0)
         NS = int(dnn["dims"][-1])
         lex = synth.make_lexicon(nword=args.nword, nphone=40, S=NS, seed=0)
         scorer = lib.Dnn(eng, dnn)
-        rng = np.random.default_rng(1000 + rank)
-        uniq = [(rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32), None)
-                for _ in range(min(args.utts, 16))]
+        lx = lib.Lexicon(eng, lex)
+        rng = np.random.default_rng(1000 + dd.rank)
+        uniq = [rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32) for _ in range(min(ndist, 16))]
         what = f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob"
+        lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
+        task = jargs = None
     else:
         NS = S
-        lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
-        model = synth.make_gmm(S=S, M=M, D=D, seed=0)
-        scorer = lib.Gmm(eng, model)
-        uniq = [synth.make_lexicon_utterance(lex, model, nwords=30, seed=1000 * rank + u) for u in range(min(args.utts, 16))]
+        task, jargs, prefix = build_reference_task(wd, args.nword, args.beam)
+        if prefix is not None:
+            scorer = lib.Gmm.from_file(eng, str(prefix) + ".am")
+            lx = lib.Lexicon.from_file(eng, str(prefix) + ".lex")
+            info = lexblob.load(str(prefix) + ".lex")
+            ref_built = True
+            lexwhat = (f"{args.nword}-word tree lexicon built by the reference (wchmm.c via jamd_export: {info['nnode']} nodes, "
+                       f"{info['startnum']} roots, {info['isolatenum']} isolated) + 2-gram")
+        else:       # no compiled reference on this box: python-made lexicon over the same state inventory
+            lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
+            scorer = lib.Gmm(eng, task["model"])
+            lx = lib.Lexicon(eng, lex)
+            lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
+        uniq = [synth.make_utterance(task, nwords=30, seed=100000 * dd.rank + u)[0] for u in range(ndist)]
         what = f"GMM S={S} x M={M} x D={D} outprob"
     nuniq = len(uniq)
-    utts = [uniq[u % nuniq][0] for u in range(args.utts)]
+    utts = [uniq[u % nuniq] for u in range(args.utts)]
     off = np.zeros(args.utts + 1, np.int32)
     off[1:] = np.cumsum([len(x) for x in utts])
     frames = np.concatenate(utts)
     T = len(frames)
-    lx = lib.Lexicon(eng, lex)
     bm = lib.Beam(eng, lx, args.beam, -1.0, max_utts=args.utts, atoms_per_utt=1 << 17)
     if args.order:
         bm.set_order_mode(args.order)
+    mode = bm.order_mode()
     d_fr = torch.from_numpy(frames).cuda()
     d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
 
-    def step():
+    def step(mark):
+        if mark:
+            mark(0)
         scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+        if mark:
+            mark(1)
         bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
+        if mark:
+            mark(2)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[3 * i].record(stream)
-        scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
-        ev[3 * i + 1].record(stream)
-        bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
-        ev[3 * i + 2].record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gmm_ms = float(np.mean([ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.steps)]))
-    beam_ms = float(np.mean([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)]))
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    if rank == 0:
-        res = bm.results()
-        ok = sum(1 for r in res if r.status == 0)
-        correct = None if use_dnn else sum(1 for u, r in enumerate(res) if list(r.wseq[:r.wnum]) == uniq[u % nuniq][1])
-        total_frames = T * world * args.steps
-        tokens = float(np.mean([r.max_tokens for r in res]))
+    elapsed, ev = timed_steps(dd, stream, step, steps, warmup, nevents=3)
+    sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    beam_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    res_local = bm.results()
+    # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
+    nutt_all = args.utts * dd.world
+    if dd.world > 1:
+        # round-robin table: utterance g lives on rank g % world; this rank's u-th utterance is g = rank + u * world
+        table = shard.gather_results(shard.pack_results(res_local), nutt_all, dd.rank, dd.world, device="cuda")
+    else:
+        table = shard.pack_results(res_local)
+    out = None
+    if dd.rank == 0:
+        ok_all = int((np.asarray(table)[:, 0] == 0).sum())
+        total_frames = T * dd.world * steps
         cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
-        line = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
-                "unit": "frame*states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_inv": total_frames / 100.0 / elapsed,
-                "config": {"workload": f"{cfg}: {what} + HIP first pass, "
-                                       f"{args.nword}-word tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram, "
-                                       f"beam {args.beam}, {args.utts} utterances ({T} frames) per GPU per step",
-                           "parallelism": f"utterance-sharded x{world}"},
-                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                             "traffic": None, "note": "irregular gather/scatter: no algorithmic-bytes roofline "
-                             "(SURVEY.md 8d); figure of merit is end-to-end frames/s",
-                             "score_kernels_ms": gmm_ms, "beam_kernel_ms": beam_ms,
-                             "beam_frames_per_s": T / (beam_ms * 1e-3),
-                             "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
-                "pass1": {"ok": ok, "sentence_correct": correct, "utts": len(res), "mean_peak_tokens": tokens,
-                          "ties": int(sum(r.ties for r in res)), "phase_us_utt0": list(res[0].phase_us)}}
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import pyoracle
-            orc = pyoracle.Oracle()
-            fr0 = utts[0]
-            tt0 = time.perf_counter()
-            if use_dnn:
-                fr0 = fr0[:100]      # ~6 ms per frame on one core
-                sc0 = orc.dnn_outprob(dnn, fr0, pyoracle.DNN_FMA)
+        out = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
+               "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup,
+               "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": total_frames / 100.0 / elapsed,
+               "config": {"workload": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {args.beam}, "
+                                      f"{args.utts} utterances ({T} frames, {nuniq} distinct) per GPU per step",
+                          "lexicon_built_by_reference": ref_built, "order_mode": mode},
+               "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                            "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
+                                    "is frames/s of the first pass over the batch",
+                            "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
+                            "beam_frames_per_s": T / (beam_ms * 1e-3),
+                            "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
+               "pass1": {"ok": ok_all, "utts": nutt_all, "mean_peak_tokens": float(np.mean([r.max_tokens for r in res_local])),
+                         "ties_counted": int(sum(r.ties for r in res_local)), "phase_us_utt0": list(res_local[0].phase_us)}}
+        if dd.world == 1 and not args.no_cpu_baseline and not use_dnn:
+            out["parity"], cpu = e2e_parity(bm, d_sc, off, uniq, nuniq, res_local, jargs, wd, ref_built)
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+    tmp.cleanup()
+    return out
+
+
+def e2e_parity(bm, d_sc, off, uniq, nuniq, res_exact, jargs, wd, ref_built):
+    """Checker leg (after the timed region).  (1) The device first pass against the COMPILED REFERENCE's
+    (julius -1pass over the same files): word trellis entry by entry, pass-1 sentence, score -- which is also the
+    lazy-scoring CPU baseline of SURVEY 8d.  (2) exact-order kernel against the canonical-tie kernel on every
+    distinct utterance."""
+    from julius_amd import lexblob, synth
+    from oracle import pyoracle
+    canon_exact = [lexblob.canonical_trellis(bm.trellis(u)) for u in range(nuniq)]
+    par = {"device_mode": bm.order_mode()}
+    mode0 = bm.order_mode()
+    if mode0 != "fast":
+        bm.set_order_mode("fast")
+        bm.pass1_dev(d_sc.data_ptr(), S, off)
+        res_fast = bm.results()
+        fast = {"utts": nuniq, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": []}
+        for u in range(nuniq):
+            d = trellis_diff(canon_exact[u], lexblob.canonical_trellis(bm.trellis(u)))
+            fast["trellis_identical"] += int(d == 0)
+            fast["atoms_differing"].append(d)
+            fast["pass1_sentence_identical"] += int(list(res_fast[u].wseq[:res_fast[u].wnum]) == list(res_exact[u].wseq[:res_exact[u].wnum]))
+            fast["score_identical"] += int(res_fast[u].score == res_exact[u].score)
+        fast["ties_counted_by_fast_kernel"] = int(sum(r.ties for r in res_fast[:nuniq]))
+        par["fast_kernel_vs_" + mode0 + "_kernel"] = fast
+        bm.set_order_mode(mode0)
+    cpu = None
+    if ref_built:
+        # (1) the compiled reference, one core, lazy scoring: bounded to ~25 s (at least 4 utterances)
+        ref = pyoracle.Ref()
+        t0 = time.perf_counter()
+        rengine = pyoracle.RefEngine(ref, jargs)
+        load_s = time.perf_counter() - t0
+        vs = {"utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
+              "reference_atoms": []}
+        spent, frames_done = 0.0, 0
+        for u in range(nuniq):
+            if u >= 4 and spent > 25.0:
+                break
+            synth.write_htk_param(wd / "u.mfc", uniq[u])
+            t0 = time.perf_counter()
+            rtr, (rw, rs) = rengine.recognize(wd / "u.mfc")
+            spent += time.perf_counter() - t0
+            frames_done += len(uniq[u])
+            d = trellis_diff(canon_exact[u], rtr)
+            vs["utts"] += 1
+            vs["trellis_identical"] += int(d == 0)
+            vs["atoms_differing"].append(d)
+            vs["reference_atoms"].append(int(len(rtr["wid"])))
+            vs["pass1_sentence_identical"] += int(list(res_exact[u].wseq[:res_exact[u].wnum]) == list(rw))
+            vs["score_identical"] += int(float(res_exact[u].score) == float(rs))
+        par["device_vs_compiled_reference"] = vs
+        cpu = {"value": frames_done * S / spent, "unit": "frame*states/s (nominal: the lazy search scores only the states it visits)",
+               "cores": 1, "kind": "reference", "rtf_inv": frames_done / 100.0 / spent,
+               "sample": f"julius -1pass (compiled reference: lazy outprob cache + get_back_trellis_proceed) on {vs['utts']} "
+                         f"utterances = {frames_done} frames, {spent:.1f} s on 1 of {os.cpu_count()} host cores "
+                         f"(model load {load_s:.1f} s not counted)"}
+    return par, cpu
+
+
+# ------------------------------------------------------------------------------------------------ main
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per GPU) and relay."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py")] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps of the top-level workload (default: enough for >= 2 s)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--utts", type=int, default=None,
+                    help="utterances per GPU per step (gmm/dnn: x1000 frames, default 64 = one GPU's share of the "
+                         "512-utterance batch of configs[4]; e2e: default 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="all", choices=["all", "gmm", "dnn", "e2e", "e2e-dnn"],
+                    help="all (default) = gmm at top level with the e2e (C3) and dnn (C4) results nested; gmm = BASELINE "
+                         "configs[1] alone; dnn = configs[3] scoring half; e2e = configs[2]; e2e-dnn = configs[3] end to end")
+    ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
+    ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
+    ap.add_argument("--distinct", type=int, default=32, help="e2e: distinct utterances in the batch")
+    ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
+                    help="e2e: first-pass tie order mode (default: the work area's default = exact)")
+    ap.add_argument("--cpu-worker", nargs=2, default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_worker:
+        print(json.dumps(ref_gmm_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]))))
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+
+    dd = Dist(args.gpus)
+    wl = args.workload
+    nested = wl == "all"
+
+    def pick(v, d):
+        return d if (v is None or nested) else v
+
+    line = None
+    if wl in ("all", "gmm"):
+        a = argparse.Namespace(**vars(args))
+        a.utts = args.utts or 64
+        # 200 x 11 ms: a timed region of >= 2 s; --steps/--warmup address this (the contract's) workload
+        line = run_gmm(a, dd, args.steps if args.steps is not None else 200, args.warmup if args.warmup is not None else 5)
+    if wl in ("all", "e2e", "e2e-dnn"):
+        a = argparse.Namespace(**vars(args))
+        a.utts = pick(args.utts, 256)
+        r = run_e2e(a, dd, pick(args.steps, 8), pick(args.warmup, 1), use_dnn=(wl == "e2e-dnn"))
+        if dd.rank == 0:
+            if nested:
+                line["e2e"] = r
             else:
-                sc0 = orc.gmm_outprob(model, fr0)
-            tt1 = time.perf_counter()
-            atoms, wseq, score, rc, died = orc.beam_pass1(lex, sc0, args.beam, -1.0)
-            tt2 = time.perf_counter()
-            got = d_sc[:len(fr0)].cpu().numpy()
-            line["parity_spot_check"] = bool(np.array_equal(got, sc0)) and (use_dnn or (
-                list(wseq) == list(res[0].wseq[:res[0].wnum]) and float(score) == float(res[0].score)))
-            line["cpu_baseline"] = {"value": len(fr0) * NS / (tt2 - tt0), "unit": "frame*states/s", "cores": 1,
-                                    "kind": "port", "rtf_inv": len(fr0) / 100.0 / (tt2 - tt0),
-                                    "sample": f"1 utterance of {len(fr0)} frames: oracle eager {'DNN' if use_dnn else 'GMM'} scoring {tt1 - tt0:.2f} s + "
-                                              f"oracle first pass {tt2 - tt1:.2f} s on 1 of {os.cpu_count()} host cores"}
+                r.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+                line = r
+    if wl in ("all", "dnn"):
+        a = argparse.Namespace(**vars(args))
+        a.utts = pick(args.utts, 64)
+        r = run_dnn(a, dd, pick(args.steps, 60), pick(args.warmup, 3))
+        if dd.rank == 0:
+            if nested:
+                line["dnn"] = r
+            else:
+                r.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+                line = r
+    if dd.rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dd.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
