@@ -77,8 +77,8 @@ struct XShared {
   int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
-  unsigned wsum[NT / 64];
-  int scan_total;
+  unsigned wsum[NT / 64], wsum2[NT / 64];
+  int scan_total, scan_total2;
 };
 
 struct XCells {
@@ -104,6 +104,24 @@ __device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
   if (threadIdx.x == NT - 1) sh.scan_total = base + incl;
   __syncthreads();
   return base + incl - v;
+}
+
+// the same for two ints per thread (totals in sh.scan_total / sh.scan_total2)
+__device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int &ea, int &eb) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int oa = __shfl_up(ia, off, 64), ob = __shfl_up(ib, off, 64);
+    if (lane >= off) { ia += oa; ib += ob; }
+  }
+  if (lane == 63) { sh.wsum[wv] = (unsigned)ia; sh.wsum2[wv] = (unsigned)ib; }
+  __syncthreads();
+  int ba = 0, bb = 0;
+  for (int w = 0; w < wv; w++) { ba += (int)sh.wsum[w]; bb += (int)sh.wsum2[w]; }
+  if (threadIdx.x == NT - 1) { sh.scan_total = ba + ia; sh.scan_total2 = bb + ib; }
+  __syncthreads();
+  ea = ba + ia - a; eb = bb + ib - b;
 }
 
 __device__ __forceinline__ unsigned ordz(float f) { return ord(f + 0.0f); }   // -0.0 and +0.0 compare equal as floats
@@ -574,24 +592,29 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     }
     // ---- 0: dense visiting indices.  Source j owns XW slots for its word-internal transitions and, when it
     //         is a word end that may be followed by a word, one slot per root; sources pruned by score own none.
+    //         The same scan numbers the trellis words of the frame in visiting order (save_trellis() is called in
+    //         that order, beam.c:2209: the atom array comes out in the reference's creation order).
     int nbits = 0;
-    if (!last) {
-      int carry = 0;
+    {
+      int carry = 0, acarry = sh.n_atom;
       for (int j0 = 0; j0 < n_surv; j0 += NT) {
         const int j = j0 + tid;
-        int cnt = 0;
+        int cnt = 0, isend = 0;
         if (j < n_surv) {
           const u32x4 a_ = sv[2 * j], b_ = sv[2 * j + 1];
           const float sc = __uint_as_float(a_.y); const int sw = (int)b_.z;
-          if (sc > JAMD_LOG_ZERO && !(sc < thr)) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
+          const bool alive = last || (sc > JAMD_LOG_ZERO && !(sc < thr));
+          if (alive && !last) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
+          isend = (alive && sw >= 0) ? 1 : 0;
         }
-        const int ex = block_excl_scan(sh, cnt);
-        if (j < n_surv) dbase[j] = carry + ex;
-        carry += sh.scan_total;
+        int ex, ea;
+        block_excl_scan2(sh, cnt, isend, ex, ea);
+        if (j < n_surv) { dbase[j] = carry + ex; sv_atom[j] = isend ? acarry + ea : -1; }
+        carry += sh.scan_total; acarry += sh.scan_total2;
         __syncthreads();
       }
-      if (tid == 0) dbase[n_surv] = carry;
-      nbits = carry + (dfa ? (t == 0 ? lx.ninit : 0) : XW + lx.nshared);
+      if (tid == 0) { dbase[n_surv] = carry; sh.n_atom = acarry; }
+      nbits = last ? 0 : carry + (dfa ? (t == 0 ? lx.ninit : 0) : XW + lx.nshared);
     }
     const int nwords = (nbits + 31) >> 5;
     const bool bm_in_lds = nwords <= xw.bm_words;
@@ -626,7 +649,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         { const float a = __int_as_float(na.y); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node + 1, a, 1); }
       }
       if (sword >= 0) {
-        const int ai = wave_alloc(&sh.n_atom, true);       // save_trellis() :2209-2247
+        const int ai = sv_atom[j];                         // save_trellis() :2209-2247, numbered in step 0
         if (ai < wk.atom_cap) {
           jamd_trellis_atom a;
           a.wid = sword; a.last_tre = tk.last_tre; a.backscore = tk.score; a.lscore = tk.last_lscore;
@@ -634,7 +657,6 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           a.endtime = (short)(t - 1);
           ATOM(ai) = a;
         }
-        sv_atom[j] = ai;
         if (!last && !wordmode && sword != lx.tail_silwid) {   // beam_inter_word() :2296-2313
           welist[atomicAdd(&sh.n_we, 1)] = j;
           const float tmpprob = tk.score + lx.wordend_a(sword);

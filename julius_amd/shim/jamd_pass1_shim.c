@@ -39,6 +39,7 @@ typedef struct {
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam; jamd_gms *gms;
   int strict;                /* JAMD_STRICT_ORDER=1 / JAMD_ORDER_MODE=strict, or a multipath model (strict-order kernel only) */
+  jamd_trellis_atom *iatoms; int iatom_cap;   /* trellis so far, read back for -progout interim results */
   int order_mode;            /* -1 = the work area's default (exact order where the beam fits), else JAMD_ORDER_* (JAMD_ORDER_MODE) */
   int nstate;
   int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
@@ -81,6 +82,7 @@ static void ctx_release(pass1_ctx *c)
   if (c->gmm) jamd_gmm_destroy(c->gmm);
   if (c->dnn) jamd_dnn_destroy(c->dnn);
   free(c->host_scores); c->host_scores = NULL; c->host_cap = 0;
+  free(c->iatoms); c->iatoms = NULL; c->iatom_cap = 0;
   c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL; c->gms = NULL;
 }
 
@@ -335,6 +337,10 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   d->bos.begintime = d->bos.endtime = -1;
   outprob_style_cache_init(r->wchmm);                 /* beam.c:1595: the 2nd pass reuses these caches */
   r->have_interim = FALSE;
+  /* interval of the progressive output in frames (-progout / -proginterval), beam.c:1886-1887 */
+  r->config->output.progout_interval_frame =
+      (int)((float)r->config->output.progout_interval / ((float)param->header.wshift / 10000.0));
+  if (r->config->output.progout_interval_frame < 1) r->config->output.progout_interval_frame = 1;
   c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
   if (c->strict) c->chunk = 0;                        /* one final push */
   if (c->gms != NULL) c->chunk = 0;                   /* the selection carries state from frame to frame */
@@ -404,6 +410,45 @@ out:
   return ok;
 }
 
+/* bt_current_max(), beam.c:877-914: the best word sequence ending at frame t, from the trellis words the device
+ * has emitted so far.  The reference walks backtrellis->list (newest first) over the atoms with endtime == t and
+ * keeps the first strictly better one: among equal scores the LAST created.  The exact-order kernel emits the
+ * atoms of a frame in the reference's creation order, so the same rule applies to the indices. */
+static void interim_result(RecogProcess *r, const jamd_trellis_atom *atoms, int natom, int t)
+{
+  int i, best = -1;
+  LOGPROB maxscore = LOG_ZERO;
+  for (i = natom - 1; i >= 0; i--) {
+    if (atoms[i].endtime != t) { if (atoms[i].endtime < t) break; else continue; }
+    if (maxscore < atoms[i].backscore) { maxscore = atoms[i].backscore; best = i; }
+  }
+  r->result.status = J_RESULT_STATUS_SUCCESS;
+  r->result.num_frame = t;
+  if (best < 0) { r->result.pass1.word_num = 0; return; }
+  if (r->lmvar == LM_DFA_WORD) {
+    r->result.pass1.word[0] = (WORD_ID)atoms[best].wid;
+    r->result.pass1.word_num = 1;
+    r->result.pass1.score = atoms[best].backscore;
+    r->result.pass1.score_lm = 0.0;
+    r->result.pass1.score_am = atoms[best].backscore;
+  } else {                                            /* trace_backptr(), beam.c:294-340 */
+    WORD_ID rev[MAXSEQNUM];
+    LOGPROB lm = 0.0;
+    int n = 0, a = best;
+    for (;;) {
+      lm += atoms[a].lscore;
+      rev[n++] = (WORD_ID)atoms[a].wid;
+      if (atoms[a].begintime <= 0 || atoms[a].last_tre < 0 || n >= MAXSEQNUM) break;
+      a = atoms[a].last_tre;
+    }
+    for (i = 0; i < n; i++) r->result.pass1.word[i] = rev[n - 1 - i];
+    r->result.pass1.word_num = n;
+    r->result.pass1.score = atoms[best].backscore;
+    r->result.pass1.score_lm = lm;
+    r->result.pass1.score_am = atoms[best].backscore;
+  }
+}
+
 boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boolean final_for_multipath)
 {
   /* Frame t is available.  With JAMD_STREAM_CHUNK = n the device search advances every n frames
@@ -411,6 +456,35 @@ boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boole
   pass1_ctx *c = ctx_get(r);
   r->have_interim = FALSE;
   if (c == NULL || c->beam == NULL || c->failed) return FALSE;
+  /* -progout (beam.c:2983-2992): every progout_interval_frame frames the caller fires
+   * CALLBACK_RESULT_PASS1_INTERIM with the best path so far.  The device search is advanced up to this frame
+   * (the atoms ending at t-1 are emitted while frame t is processed) and the trellis so far is read back.  The
+   * strict-order kernel and the selection stage need the whole input in one piece: no interim results there. */
+  if (r->config->output.progout_flag && t > 0 && ((t - 1) % r->config->output.progout_interval_frame) == 0 &&
+      (c->hit >= 0 || (!c->strict && c->gms == NULL))) {
+    if (c->hit >= 0) {
+      interim_result(r, c->pre[c->hit].atoms, c->pre[c->hit].natom, t - 1);
+      r->have_interim = TRUE;
+    } else {
+      jamd_pass1_result res;
+      int natom = 0;
+      if (c->pushed < t + 1 && !push_frames(c, r, param, t + 1, 0)) return FALSE;
+      if (jamd_beam_results(c->beam, &res, 1) != JAMD_OK) return FALSE;
+      if (res.status == JAMD_PASS1_DIED) {
+        jlog("ERROR: jamd: frame %d: no nodes left in beam, now terminates search\n", res.died_at);
+        return FALSE;
+      }
+      if (c->iatoms == NULL || res.natom > c->iatom_cap) {
+        c->iatom_cap = res.natom + 65536;
+        c->iatoms = (jamd_trellis_atom *)realloc(c->iatoms, sizeof(jamd_trellis_atom) * (size_t)c->iatom_cap);
+      }
+      if (c->iatoms != NULL && jamd_beam_trellis(c->beam, 0, c->iatoms, res.natom, &natom) == JAMD_OK) {
+        interim_result(r, c->iatoms, natom < res.natom ? natom : res.natom, t - 1);
+        r->have_interim = TRUE;
+      }
+    }
+    if (c->hit >= 0) return TRUE;
+  }
   if (c->hit >= 0) return TRUE;                       /* served from the batch at _end() */
   if (c->chunk > 0 && t + 1 - c->pushed >= c->chunk) {
     jamd_pass1_result res;
@@ -474,12 +548,15 @@ void get_back_trellis_end(HTK_Param *param, RecogProcess *r)
   }
   /* what find_1pass_result() (beam.c:372-510) leaves behind */
   if (res.status == JAMD_PASS1_OK) {
+    /* with -progout the result record keeps the last interim result unless -v is given (beam.c:498) */
+    const boolean fill = verbose_flag || !r->config->output.progout_flag;
     r->result.status = J_RESULT_STATUS_SUCCESS;
-    r->result.num_frame = T;
-    for (i = 0; i < res.wnum; i++) r->pass1_wseq[i] = r->result.pass1.word[i] = (WORD_ID)res.wseq[i];
-    r->pass1_wnum = r->result.pass1.word_num = res.wnum;
-    r->pass1_score = r->result.pass1.score = res.score;
-    {                                                   /* trace_backptr(): total LM score */
+    if (fill) r->result.num_frame = T;
+    for (i = 0; i < res.wnum; i++) { r->pass1_wseq[i] = (WORD_ID)res.wseq[i]; if (fill) r->result.pass1.word[i] = (WORD_ID)res.wseq[i]; }
+    r->pass1_wnum = res.wnum;
+    r->pass1_score = res.score;
+    if (fill) { r->result.pass1.word_num = res.wnum; r->result.pass1.score = res.score; }
+    if (fill) {                                         /* trace_backptr(): total LM score */
       LOGPROB lm = 0.0; int a;
       for (a = natom - 1; a >= 0; a--)     /* the atom the device traced back from: the sentence's last word */
         if (atoms[a].wid == res.wseq[res.wnum - 1] && atoms[a].backscore == res.score) break;

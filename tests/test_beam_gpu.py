@@ -160,6 +160,33 @@ def test_full_size_lexicon_vs_oracle(engine, oracle):
     assert_trellis_equal_modulo_ties(tre[0], lexblob.canonical_trellis(oatoms), res[0].ties_node + res[0].ties_cut + res[0].ties_wordend)
 
 
+def test_full_size_reference_built_lexicon_vs_compiled_reference(engine, ref, tmp_path):
+    """BASELINE configs[2] at full size with nothing python-made between the files and the search: dictionary
+    (20 000 words) + ARPA 2-gram + tied-state triphone hmmdefs (3000 states) are loaded by the reference's
+    own readers, the tree lexicon is built by `libjulius/src/wchmm.c:1749 build_wchmm2`, flattened by the
+    shim, and the device first pass (HIP GMM scores -> exact-order kernel) must give the word trellis of
+    the compiled reference's `julius -1pass` on the same parameter files, entry by entry."""
+    eng, lex, am, task = ref_task(ref, tmp_path, 0, 800, [], nphone=40, S=3000, M=16, nword=20000, nvar=25, maxlen=8,
+                                  nbigram_per_word=10)
+    assert lex["nnode"] > 200000 and eng.beam_width == 800
+    utts = [synth.make_utterance(task, nwords=4 + 5 * u, seed=7000 + u)[0] for u in range(4)]
+    gm = lib.Gmm(engine, am)
+    scores = [gm.outprob_host(fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, 800, -1.0, max_utts=len(utts), atoms_per_utt=1 << 17)
+    assert bm.order_mode() == "exact"
+    res, tre = bm.pass1_host(scores)
+    bm.set_order_mode("fast")
+    resf, tref = bm.pass1_host(scores)
+    for fr, r, atoms, rf in zip(utts, res, tre, resf):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert r.status == 0 and len(rtr["wid"]) > 1000
+        assert_trellis_equal(atoms, rtr)                                   # exact, ties included
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+        assert rf.status == 0 and rf.score == rscore                       # canonical-tie kernel: same best path score
+
+
 def test_full_size_batch_properties(engine):
     """Size-independent properties at BASELINE size (20 000-word lexicon, beam 800, a batch of 24
     utterances scored by the HIP GMM kernel on the device): the result of an utterance does not

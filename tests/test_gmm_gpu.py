@@ -90,6 +90,19 @@ def test_full_size_properties(engine, oracle):
         assert np.array_equal(gm.outprob_host(fr[t:t + 1])[0], out[t])
 
 
+def test_full_size_rows_vs_compiled_reference(engine, ref):
+    """BASELINE configs[1] size against the COMPILED REFERENCE (libjref.so: outprob_state batch loop ->
+    calc_mix -> gprune_none -> addlog_array, `outprob.c:230-242`): 64 complete rows of 3000 states, bit for bit."""
+    m = synth.make_gmm(S=3000, M=16, D=39, seed=7)
+    T = 2048
+    fr = synth.make_frames(m, T=T, seed=9)
+    out = lib.Gmm(engine, m).outprob_host(fr)
+    tt = np.sort(np.random.default_rng(1).choice(T, 64, replace=False))
+    want = ref.am_from_flat(m).outprob(fr[tt], want_out=True)
+    assert want.shape == (64, 3000)
+    assert np.array_equal(out[tt], want)
+
+
 def test_device_pointer_entry(engine, oracle):
     """jamd_gmm_outprob_dev with caller-owned device buffers and stream (torch is
     only the allocator here)."""
