@@ -41,11 +41,19 @@ extern "C" {
 
 #define JAMD_LOG_ZERO (-1000000.0f)
 
-/* Gaussian pruning selector; values of GPRUNE_SEL_* that the engine implements
- * on the device (libsent/include/sent/hmm_calc.h:38-45).  heu/beam are
- * frame-order-dependent approximations and stay on the reference's CPU code. */
+/* Gaussian pruning selector (GPRUNE_SEL_*, libsent/include/sent/hmm_calc.h:38-45).
+ * none and safe are served for every model.  heu and beam prune with thresholds taken from
+ * the N best Gaussians of the PREVIOUS frame's codebook cache (last_id), which exists only
+ * for tied-mixture codebooks (calc_tied_mix.c:203-215) and depends on which frames the lazy
+ * CPU search happened to score.  For plain mixture states calc_mix() passes last_id == NULL
+ * (calc_mix.c:63), where both functions ARE safe pruning (gprune_heu.c:337-350,
+ * gprune_beam.c:337-350): a model without tied-mixture states is therefore served with
+ * heu/beam too, bit for bit; a tied-mixture model with heu/beam is refused (it stays on the
+ * reference's CPU code). */
 #define JAMD_GPRUNE_NONE 0  /* gprune_none()  libsent/src/phmm/gprune_none.c:133 */
 #define JAMD_GPRUNE_SAFE 1  /* gprune_safe()  libsent/src/phmm/gprune_safe.c:160 */
+#define JAMD_GPRUNE_HEU  2  /* gprune_heu()   gprune_heu.c:295  (plain mixture states only) */
+#define JAMD_GPRUNE_BEAM 3  /* gprune_beam()  gprune_beam.c:291 (plain mixture states only) */
 
 /* pseudo-phone set reduction (hmminfo->cdset_method, htk_hmm.h:388) */
 #define JAMD_IWCD_MAX   0   /* outprob_cd_max   libsent/src/phmm/outprob.c:332 */

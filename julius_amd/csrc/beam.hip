@@ -1312,16 +1312,40 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     jamd_set_error("jamd_lexicon_create: cdmax_num=%d outside [1,%d]", h->cdmax_num, jamd::kNbestMax);
     return JAMD_EINVAL;
   }
+  // every index a kernel will follow is range-checked here: a truncated or corrupt blob (jamd_lexicon_load)
+  // must fail with JAMD_EINVAL, not read out of bounds on the host or the device
+  if (!h->ac_off || !h->self_a || !h->next_a || !h->stend || !h->scid || !h->out_id || !h->out_kind ||
+      (h->startnum > 0 && !h->startnode) || !h->word_head || !h->wton || h->ac_off[0] != 0) {
+    jamd_set_error("jamd_lexicon_create: NULL or malformed node arrays"); return JAMD_EINVAL;
+  }
   int maxfan = 2;
   for (int i = 0; i < h->nnode; i++) {
     const int x = h->ac_off[i + 1] - h->ac_off[i];
+    if (x < 0) { jamd_set_error("jamd_lexicon_create: ac_off not monotone at node %d", i); return JAMD_EINVAL; }
     if (2 + x > maxfan) maxfan = 2 + x;
+    if (h->stend[i] >= h->nword) { jamd_set_error("jamd_lexicon_create: node %d ends word %d of %d", i, h->stend[i], h->nword); return JAMD_EINVAL; }
+    if (h->scid[i] >= h->nscword || (h->scid[i] < 0 && -h->scid[i] >= h->nfscore)) {
+      jamd_set_error("jamd_lexicon_create: node %d has successor id %d outside the tables", i, h->scid[i]); return JAMD_EINVAL;
+    }
   }
-  std::vector<int> iso(h->isolatenum > 0 ? h->isolatenum : 0), shared;
+  for (int k = 0; k < h->ac_off[h->nnode]; k++)
+    if (h->ac_to[k] < 0 || h->ac_to[k] >= h->nnode) { jamd_set_error("jamd_lexicon_create: arc %d leads to node %d of %d", k, h->ac_to[k], h->nnode); return JAMD_EINVAL; }
+  for (int s = 0; s < h->startnum; s++)
+    if (h->startnode[s] < 0 || h->startnode[s] >= h->nnode) { jamd_set_error("jamd_lexicon_create: root %d is node %d of %d", s, h->startnode[s], h->nnode); return JAMD_EINVAL; }
+  for (int w = 0; w < h->nword; w++)
+    if (h->word_head[w] < -1 || h->word_head[w] >= h->nnode) { jamd_set_error("jamd_lexicon_create: word %d starts at node %d of %d", w, h->word_head[w], h->nnode); return JAMD_EINVAL; }
+  if (h->nset > 0) {
+    if (!h->set_off || !h->set_states || h->set_off[0] != 0) { jamd_set_error("jamd_lexicon_create: state-set table missing"); return JAMD_EINVAL; }
+    for (int i = 0; i < h->nset; i++)
+      if (h->set_off[i + 1] < h->set_off[i]) { jamd_set_error("jamd_lexicon_create: set_off not monotone at %d", i); return JAMD_EINVAL; }
+    for (int k = 0; k < h->set_off[h->nset]; k++)
+      if (h->set_states[k] < 0) { jamd_set_error("jamd_lexicon_create: negative state in set table"); return JAMD_EINVAL; }
+  }
+  std::vector<int> iso(h->isolatenum > 0 ? h->isolatenum : 0, -1), shared;
   for (int s = 0; s < h->startnum && !dfa; s++) {
     const int i = h->start2isolate[s];
     if (i >= 0) {
-      if (i >= h->isolatenum) { jamd_set_error("jamd_lexicon_create: start2isolate out of range"); return JAMD_EINVAL; }
+      if (i >= h->isolatenum || iso[i] >= 0) { jamd_set_error("jamd_lexicon_create: start2isolate out of range or repeated"); return JAMD_EINVAL; }
       iso[i] = s;
       const int sc = h->scid[h->startnode[s]];
       if (sc <= 0 || sc >= h->nscword) { jamd_set_error("jamd_lexicon_create: isolated root without a successor word"); return JAMD_EINVAL; }
@@ -1364,6 +1388,8 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   }
   // both root lists in the order beam_inter_word() / beam_inter_word_factoring() visit them (stid from
   // startnum-1 down to 0, beam.c:2334 / :2562): the exact-order kernel numbers its candidates by list index
+  for (size_t i = 0; i < iso.size() && !dfa; i++)
+    if (iso[i] < 0) { jamd_set_error("jamd_lexicon_create: isolated root %d is not assigned", (int)i); return JAMD_EINVAL; }
   std::sort(iso.begin(), iso.end(), [](int a, int b) { return a > b; });
   std::sort(shared.begin(), shared.end(), [](int a, int b) { return a > b; });
   std::vector<int2> iso_root(iso.size());
@@ -1615,17 +1641,17 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
       jamd_set_error("jamd_beam_stream_push_dev: utterance %d would exceed 32767 frames", u); return JAMD_EINVAL;
     }
   }
-  for (int u = 0; u < nutt; u++) b->stream_frames[u] += chunk_off[u + 1] - chunk_off[u];
   if (b->lex->multipath && !b->strict) {
     jamd_set_error("jamd_beam_stream_push_dev: a multipath lexicon is decoded by the strict-order kernel only");
     return JAMD_ESTATE;
   }
-  if (b->strict) {
+  if (b->strict && (!final || b->stream_pushes != 0)) {
     // the strict-order kernel keeps no state between launches: one push carrying everything
-    if (!final || b->stream_pushes != 0) {
-      jamd_set_error("jamd_beam_stream_push_dev: strict-order mode needs the whole utterance in one final push");
-      return JAMD_ESTATE;
-    }
+    jamd_set_error("jamd_beam_stream_push_dev: strict-order mode needs the whole utterance in one final push");
+    return JAMD_ESTATE;
+  }
+  for (int u = 0; u < nutt; u++) b->stream_frames[u] += chunk_off[u + 1] - chunk_off[u];   // only an accepted push counts
+  if (b->strict) {
     b->streaming = 0;
     return jamd_beam_pass1_dev(b, dev_scores, nstate, chunk_off, nutt, stream);
   }

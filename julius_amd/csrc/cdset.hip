@@ -29,11 +29,12 @@ cdset_kernel(const float *__restrict__ scores, const int *__restrict__ off,
              const int *__restrict__ states, float *__restrict__ cd, int T, int S, int nset,
              int method, int nbest) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
   if (i >= nset) return;
-  const float *row = scores + (size_t)t * S;
-  const float r = jamd::cd_reduce(row, states, off[i], off[i + 1], method, nbest);
-  cd[(size_t)t * nset + i] = r;
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {         // gridDim.y is capped (65535 limit): frames are strided
+    const float *row = scores + (size_t)t * S;
+    const float r = jamd::cd_reduce(row, states, off[i], off[i + 1], method, nbest);
+    cd[(size_t)t * nset + i] = r;
+  }
 }
 
 }  // namespace
@@ -88,7 +89,7 @@ int jamd_cdset_outprob_dev(jamd_cdset *c, const float *dev_scores, int T, int ns
   }
   if (T == 0 || c->nset == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(c->eng->device));
-  const dim3 grid((c->nset + 255) / 256, T);
+  const dim3 grid((c->nset + 255) / 256, T < 4096 ? T : 4096);
   hipLaunchKernelGGL(cdset_kernel, grid, dim3(256), 0, jamd_stream(c->eng, stream), dev_scores,
                      c->d_off, c->d_states, dev_cd, T, nstate, c->nset, c->method, c->nbest);
   hipError_t le = hipGetLastError();

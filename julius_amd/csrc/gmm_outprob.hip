@@ -554,11 +554,15 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
                    d->ndens, d->nentry);
     return JAMD_EINVAL;
   }
-  if (gprune != JAMD_GPRUNE_NONE && gprune != JAMD_GPRUNE_SAFE) {
-    jamd_set_error("jamd_gmm_create: gprune method %d is not implemented on the device "
-                   "(heu/beam are frame-order dependent; use none or safe)", gprune);
+  if (gprune != JAMD_GPRUNE_NONE && gprune != JAMD_GPRUNE_SAFE && gprune != JAMD_GPRUNE_HEU && gprune != JAMD_GPRUNE_BEAM) {
+    jamd_set_error("jamd_gmm_create: unknown gprune method %d", gprune);
     return JAMD_EINVAL;
   }
+  const bool history_pruning = gprune == JAMD_GPRUNE_HEU || gprune == JAMD_GPRUNE_BEAM;
+  // heu / beam on plain mixture states: calc_mix() passes last_id == NULL, the branch that is safe pruning
+  // (gprune_heu.c:337-350, gprune_beam.c:337-350) -- same kernel, same numbers.  Checked below once the
+  // states are classified.
+  if (history_pruning) gprune = JAMD_GPRUNE_SAFE;
   if (!d->mean || !d->ivar || !d->gconst || !d->st_off || (d->nentry && (!d->ent_dens || !d->ent_logw))) {
     jamd_set_error("jamd_gmm_create: NULL model array");
     return JAMD_EINVAL;
@@ -595,6 +599,13 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
   }
   g->E_plain = st_off_plain[g->S];
   g->ntied = (int)tied.size();
+  if (history_pruning && g->ntied > 0) {
+    delete g;
+    jamd_set_error("jamd_gmm_create: gprune heu/beam with tied-mixture states depends on the previous frame's codebook "
+                   "cache and on which frames were scored (calc_tied_mix.c:203-215): not served on the device; use "
+                   "none or safe, or leave scoring to the reference's CPU code");
+    return JAMD_EINVAL;
+  }
   g->nbook = g->ntied ? d->nbook : 0;
   if (gprune == JAMD_GPRUNE_SAFE && gprune_num < 1) {
     delete g; jamd_set_error("jamd_gmm_create: gprune safe needs gprune_num >= 1"); return JAMD_EINVAL;

@@ -142,19 +142,20 @@ tmix_state_kernel(const int *__restrict__ tied_states, int ntied, const int *__r
                   const int *__restrict__ c_num, const float *__restrict__ tbl,
                   float *__restrict__ out, int T, int S, int nbook, int cap, float addmin_f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
   if (i >= ntied) return;
   const int s = tied_states[i];
   const int b = st_book[s];
   const int e0 = st_off[s];
-  const size_t o = ((size_t)t * nbook + b) * cap;
-  const int n = c_num[(size_t)t * nbook + b];
-  float y = JAMD_LOG_ZERO;
-  for (int k = n - 1; k >= 0; k--) {
-    const float x = c_score[o + k] + ent_logw[e0 + c_id[o + k]];  // calc_tied_mix.c:194-196
-    y = addlog_step(y, x, tbl, addmin_f);
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {        // gridDim.y is capped (65535 limit): frames are strided
+    const size_t o = ((size_t)t * nbook + b) * cap;
+    const int n = c_num[(size_t)t * nbook + b];
+    float y = JAMD_LOG_ZERO;
+    for (int k = n - 1; k >= 0; k--) {
+      const float x = c_score[o + k] + ent_logw[e0 + c_id[o + k]];  // calc_tied_mix.c:194-196
+      y = addlog_step(y, x, tbl, addmin_f);
+    }
+    out[(size_t)t * S + s] = finish_state(y);
   }
-  out[(size_t)t * S + s] = finish_state(y);
 }
 
 template <int DT>
@@ -225,7 +226,7 @@ int jamd_gmm_launch_tmix(jamd_gmm *g, const float *frames, int T, float *out, fl
     default: rc = launch_book<0>(g, frames, T, c_score, c_id, c_num, st); break;
   }
   if (rc != JAMD_OK || !out) return rc;
-  const dim3 grid((g->ntied + 255) / 256, T);
+  const dim3 grid((g->ntied + 255) / 256, T < 4096 ? T : 4096);
   hipLaunchKernelGGL(tmix_state_kernel, grid, dim3(256), 0, st, g->d_tied_states, g->ntied,
                      g->d_st_off, g->d_st_book, g->d_ent_logw, c_score, c_id, c_num,
                      g->eng->d_addlog, out, T, g->S, g->nbook, g->tm_cap, g->eng->addmin_f);

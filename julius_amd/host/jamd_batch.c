@@ -74,7 +74,10 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-b") && i + 1 < argc) beam = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-bs") && i + 1 < argc) bs = (float)atof(argv[++i]);
     else if (!strcmp(argv[i], "-gprune") && i + 1 < argc) {
-      if (!strcmp(argv[++i], "safe") && i + 1 < argc) { gprune = JAMD_GPRUNE_SAFE; gnum = atoi(argv[++i]); }
+      ++i;
+      if (!strcmp(argv[i], "safe") && i + 1 < argc) { gprune = JAMD_GPRUNE_SAFE; gnum = atoi(argv[++i]); }
+      else if (!strcmp(argv[i], "heu") && i + 1 < argc) { gprune = JAMD_GPRUNE_HEU; gnum = atoi(argv[++i]); }
+      else if (!strcmp(argv[i], "beam") && i + 1 < argc) { gprune = JAMD_GPRUNE_BEAM; gnum = atoi(argv[++i]); }
     } else if (!strcmp(argv[i], "-strict")) strict = 1;
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];

@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libjulius_amd.so"
 
 LOG_ZERO = -1000000.0
-GPRUNE_NONE, GPRUNE_SAFE = 0, 1
+GPRUNE_NONE, GPRUNE_SAFE, GPRUNE_HEU, GPRUNE_BEAM = 0, 1, 2, 3
 IWCD_MAX, IWCD_AVG, IWCD_NBEST = 0, 1, 2
 
 

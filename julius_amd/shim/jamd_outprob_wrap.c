@@ -102,6 +102,8 @@ static void examine(wrap_ctx *c)
   }
   if (wrk->compute_gaussset == gprune_none) gprune = JAMD_GPRUNE_NONE;
   else if (wrk->compute_gaussset == gprune_safe) gprune = JAMD_GPRUNE_SAFE;
+  else if (wrk->compute_gaussset == gprune_heu && !wrk->OP_hmminfo->is_tied_mixture) gprune = JAMD_GPRUNE_HEU;
+  else if (wrk->compute_gaussset == gprune_beam && !wrk->OP_hmminfo->is_tied_mixture) gprune = JAMD_GPRUNE_BEAM;
   else {
     jlog("Stat: jamd: this -gprune method depends on the previous frame; scoring stays on libsent's CPU code\n");
     return;

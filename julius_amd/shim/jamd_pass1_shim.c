@@ -150,8 +150,10 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     switch (r->am->config->gprune_method) {      /* jconf.h:94, values hmm_calc.h:38-45 */
     case GPRUNE_SEL_NONE: gprune = JAMD_GPRUNE_NONE; break;
     case GPRUNE_SEL_SAFE: gprune = JAMD_GPRUNE_SAFE; break;
+    case GPRUNE_SEL_HEURISTIC: gprune = JAMD_GPRUNE_HEU; break;     /* plain mixture states only: jamd_gmm_create() */
+    case GPRUNE_SEL_BEAM: gprune = JAMD_GPRUNE_BEAM; break;         /* refuses tied-mixture models with these two   */
     default:
-      jlog("ERROR: jamd: run with -gprune none or -gprune safe (heu/beam are frame-order dependent)\n");
+      jlog("ERROR: jamd: unknown -gprune method\n");
       return FALSE;
     }
     {

@@ -103,6 +103,41 @@ def test_full_size_rows_vs_compiled_reference(engine, ref):
     assert np.array_equal(out[tt], want)
 
 
+@pytest.mark.parametrize("method,code", [("heu", lib.GPRUNE_HEU), ("beam", lib.GPRUNE_BEAM)])
+@pytest.mark.parametrize("num", [2, 5])
+def test_gprune_heu_beam_on_plain_states_vs_compiled_reference(engine, ref, method, code, num):
+    """SURVEY 8a A7, the plain-mixture half: calc_mix() calls the pruning function with last_id == NULL
+    (`calc_mix.c:63`), where gprune_heu() / gprune_beam() are safe pruning (`gprune_heu.c:337-350`,
+    `gprune_beam.c:337-350`).  The device serves such models with these methods, bit for bit with the compiled
+    reference running the real gprune_heu / gprune_beam.  A tied-mixture model is still refused."""
+    m = synth.make_gmm(S=90, M=12, D=39, seed=21, ragged=True, null_frac=0.05)
+    fr = synth.make_frames(m, T=300, seed=22)
+    want = ref.am_from_flat(m, gprune=method, gprune_num=num).outprob(fr, want_out=True)
+    got = lib.Gmm(engine, m, code, num).outprob_host(fr)
+    assert np.array_equal(got, want)
+    tied = synth.make_tied_gmm(S=30, nbook=2, K=16, D=39, seed=3)
+    with pytest.raises(lib.JamdError):
+        lib.Gmm(engine, tied, code, num)
+
+
+def test_tied_mixture_more_than_65535_frames(engine):
+    """A launch over more frames than the grid's y dimension allows (a batch of utterances easily is): the
+    per-frame kernels of the tied-mixture and state-set paths stride over the frames; row t of the long call
+    equals the same frame scored alone."""
+    tied = synth.make_tied_gmm(S=24, nbook=2, K=16, D=39, seed=5)
+    base = synth.make_frames(tied, T=700, seed=6)
+    T = 70000
+    fr = np.tile(base, (T // len(base), 1))
+    gm = lib.Gmm(engine, tied, lib.GPRUNE_SAFE, 2)
+    out = gm.outprob_host(fr)
+    small = gm.outprob_host(base)
+    assert out.shape == (T, 24)
+    for r in (0, 1, 99):
+        assert np.array_equal(out[r * 700:(r + 1) * 700], small)
+    got = lib.CdSet(engine, np.array([0, 3, 7], np.int32), np.arange(7, dtype=np.int32), lib.IWCD_MAX, 3).outprob_host(out)
+    assert np.array_equal(got[:, 0], out[:, 0:3].max(1)) and np.array_equal(got[:, 1], out[:, 3:7].max(1))
+
+
 def test_device_pointer_entry(engine, oracle):
     """jamd_gmm_outprob_dev with caller-owned device buffers and stream (torch is
     only the allocator here)."""
