@@ -90,6 +90,9 @@ def load():
         "jamd_rejgmm_utt_scores_dev": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_rejgmm_scores_host": (ci, [vp, vp, ci, vp, ci, vp, vp]),
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
+        "jamd_gmm_load_binhmm": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
+        "jamd_binhmm_to_blob": (ci, [C.c_char_p, C.c_char_p]),
+        "jamd_bingram_to_blob": (ci, [C.c_char_p, C.c_char_p]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),
@@ -248,6 +251,19 @@ class Gmm:
         self.eng, self._keep = eng, {}
         h = C.c_void_p()
         _check(lib.jamd_gmm_load(eng.h, str(path).encode(), gprune, gprune_num, C.byref(h)), "jamd_gmm_load")
+        self.h = h
+        self.S, self.D = lib.jamd_gmm_nstate(h), lib.jamd_gmm_veclen(h)
+        self.nbook, self.gprune_num = lib.jamd_gmm_nbook(h), gprune_num
+        return self
+
+    @classmethod
+    def from_binhmm(cls, eng: Engine, path, gprune: int = GPRUNE_NONE, gprune_num: int = 0):
+        """jamd_gmm_load_binhmm(): Julius' binary HMM definition read by the library itself."""
+        lib = load()
+        self = cls.__new__(cls)
+        self.eng, self._keep = eng, {}
+        h = C.c_void_p()
+        _check(lib.jamd_gmm_load_binhmm(eng.h, str(path).encode(), gprune, gprune_num, C.byref(h)), "jamd_gmm_load_binhmm")
         self.h = h
         self.S, self.D = lib.jamd_gmm_nstate(h), lib.jamd_gmm_veclen(h)
         self.nbook, self.gprune_num = lib.jamd_gmm_nbook(h), gprune_num

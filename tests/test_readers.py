@@ -1,0 +1,110 @@
+"""Julius' BINARY model files read directly (julius_amd/csrc/readers.hip), without a Julius
+process -- checked against the reference's own readers: the binary files are written by the reference's
+write_binhmm() / ngram_write_bin() (what mkbinhmm / mkbingram do), loaded by Julius' read_binhmm() /
+ngram_read_bin() inside jamd_export, flattened by the shim, and the direct conversion must give the same
+bytes.  Host code only: runs without a GPU."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+from julius_amd import lexblob, lib, synth
+from oracle import pyoracle
+
+EXPORT = pyoracle.REF_SO.parent / "jamd_export"
+
+
+def _ref():
+    if not pyoracle.REF_SO.exists() or not EXPORT.exists():
+        pytest.skip("oracle/_ref not built")
+    r = pyoracle.Ref()
+    r.lib.jref_write_binhmm.argtypes = [C.c_char_p, C.c_char_p]
+    r.lib.jref_write_bingram.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    return r
+
+
+def _blob_records(path, magic):
+    """{name: (dtype, bytes)} of a JAMD* container."""
+    raw = open(path, "rb").read()
+    assert raw[:8] == magic
+    n = int(np.frombuffer(raw[8:12], np.int32)[0])
+    at, out = 12, {}
+    for _ in range(n):
+        name = raw[at:at + 24].split(b"\0")[0].decode()
+        dtype, count = np.frombuffer(raw[at + 24:at + 32], np.int32)
+        nbytes = (int(count) * (1 if dtype == 2 else 4) + 3) & ~3
+        out[name] = (int(dtype), raw[at + 32:at + 32 + nbytes])
+        at += 32 + nbytes
+    assert at == len(raw)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["triphone", "tied_mixture"])
+def test_binhmm_direct_equals_export(tmp_path, kind):
+    ref = _ref()
+    if kind == "triphone":
+        task = synth.make_triphone_task(tmp_path, seed=71, nword=60, nphone=8, S=120, M=4)
+        extra = ["-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"]]
+    else:                                     # BASELINE configs[0] shape: <TMix> codebooks
+        task = synth.make_grammar_task(tmp_path, seed=72)
+        extra = ["-dfa", task["dfa"], "-v", task["dict"]]
+    binhmm = tmp_path / "model.binhmm"
+    assert ref.lib.jref_write_binhmm(str(task["hmmdefs"]).encode(), str(binhmm).encode()) == 0
+    # Julius' own reader on the binary file -> shim -> blob
+    subprocess.run([str(EXPORT), "-h", str(binhmm)] + [str(a) for a in extra] + ["-input", "htkparam", "-jamdout", str(tmp_path / "exp")],
+                   check=True, capture_output=True)
+    # the product's direct reader
+    L = lib.load()
+    rc = L.jamd_binhmm_to_blob(str(binhmm).encode(), str(tmp_path / "direct.am").encode())
+    assert rc == 0, L.jamd_last_error()
+    assert open(tmp_path / "direct.am", "rb").read() == open(tmp_path / "exp.am", "rb").read()
+    # and the same model as the ASCII hmmdefs gives (ids and density numbering may differ: compare scores)
+    a = lexblob.load_gmm(tmp_path / "direct.am")
+    assert a["mean"].shape[1] == 39 and len(a["st_off"]) - 1 > 10
+    # error paths
+    (tmp_path / "junk").write_bytes(b"JBINHMMV2\0_Q\0" + b"\0" * 64)
+    assert L.jamd_binhmm_to_blob(str(tmp_path / "junk").encode(), str(tmp_path / "x").encode()) != 0
+    (tmp_path / "trunc").write_bytes(open(binhmm, "rb").read()[:3000])
+    assert L.jamd_binhmm_to_blob(str(tmp_path / "trunc").encode(), str(tmp_path / "x").encode()) != 0
+
+
+@pytest.mark.parametrize("with_rl", [False, True])
+def test_bingram_direct_equals_export(tmp_path, with_rl):
+    """Forward 2-gram alone (DIR_LR) and backward 3-gram + additional forward 2-gram (the -nlr/-nrl pair):
+    the 1-gram / 2-gram tables of the direct reader equal the ng_* records of jamd_export's lexicon blob."""
+    ref = _ref()
+    task = synth.make_triphone_task(tmp_path, seed=73, nword=80, nphone=8, S=120, M=2, with_rl3=with_rl)
+    bingram = tmp_path / "lm.bingram"
+    rc = ref.lib.jref_write_bingram(str(task["arpa"]).encode(), str(task["arpa_rl"]).encode() if with_rl else None,
+                                    str(bingram).encode())
+    assert rc == 0
+    subprocess.run([str(EXPORT), "-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-d", str(bingram),
+                    "-input", "htkparam", "-jamdout", str(tmp_path / "exp")], check=True, capture_output=True)
+    L = lib.load()
+    rc = L.jamd_bingram_to_blob(str(bingram).encode(), str(tmp_path / "direct.ngr").encode())
+    assert rc == 0, L.jamd_last_error()
+    got = _blob_records(tmp_path / "direct.ngr", b"JAMDNGR1")
+    want = _blob_records(tmp_path / "exp.lex", b"JAMDLEX1")
+    for k in ("ng_uni_prob", "ng_uni_bo", "ng_bi_bgn", "ng_bi_num", "ng_bi_wid", "ng_bi_prob"):
+        assert got[k] == want[k], k
+    ints = np.frombuffer(got["ints"][1], np.int32)
+    lex = lexblob.load(tmp_path / "exp.lex")
+    assert int(ints[0]) == int(lex["ng_mode"]) and int(ints[1]) == int(lex["ng_nword"]) and int(ints[2]) == int(lex["ng_nbigram"])
+    assert ints[3] == (3 if with_rl else 2)
+    names = got["wname"][1].split(b"\0")
+    assert b"<s>" in names and b"</s>" in names
+
+
+@pytest.mark.gpu
+def test_device_model_from_binhmm(engine, tmp_path):
+    """jamd_gmm_load_binhmm(): same scores as the descriptor path on the same model."""
+    ref = _ref()
+    task = synth.make_triphone_task(tmp_path, seed=74, nword=60, nphone=8, S=120, M=4)
+    binhmm = tmp_path / "model.binhmm"
+    assert ref.lib.jref_write_binhmm(str(task["hmmdefs"]).encode(), str(binhmm).encode()) == 0
+    fr = synth.make_frames(task["model"], T=200, seed=3)
+    am = ref.am_load(str(binhmm)).export()                     # Julius' read_binhmm() -> flat
+    want = lib.Gmm(engine, am).outprob_host(fr)
+    got = lib.Gmm.from_binhmm(engine, binhmm).outprob_host(fr)
+    assert np.array_equal(got, want)
