@@ -177,6 +177,10 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   lds_u32 *idR;                  // [b_cap] token id per rank
   lds_u32 *hist;                 // [2048]
   lds_u32 *tailmask;             // [(beam + 31) / 32 + 1]
+  lds_i32 *cand;                 // [kMaxCand] tail candidates in the order of their turns: extraction index i
+  lds_i32 *occ;                  // [kMaxCand] rank of the element at the candidate's tail position, -1 = none
+  lds_i32 *need;                 // [kMaxCand + 4] 1 = (re)scan wanted; [kMaxCand..] = ncand, cursor, finished
+  lds_i32 *takers;               // [kMaxCand + 1][kTakers + 1] chain occupants per candidate (+ their count); last row: serial form
   int b_cap;
 };
 
@@ -284,45 +288,58 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
 // work to a compare and a ballot (the chain scan reduces "inside subtree(a_d)" to "shares at least d path bits
 // with q", computed once per element), fetch the next 64 ranks while the current ones are walked, and move
 // values between lanes with v_readlane (the ballot's lane index is uniform), not with LDS permutes.
-__device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
+constexpr int kMaxCand = 64;             // tail candidates replayed with the parallel scheme; more fall back to the serial loop
+constexpr int kTakers = kMaxL + 2;       // occupants of one root-to-leaf chain
+
+// Occupants of the chain root -> q (q = n - i + 1) after i - 1 extractions, found by one scan over the remaining
+// ranks (see above).  Returns the rank of the element sitting AT q, or -1 when the chain ends earlier (the
+// element has moved up, or out, before its tail turn).  takers[0..*ntake) receives the ranks of the occupants
+// in chain order (the replay uses them to tell which later candidates an event can affect).  One wave.
+__device__ __noinline__ int chain_scan(const PruneMem &pm, int nB, int n, int i, lds_i32 *takers, int *ntake) {
   const lds_u32 *vposR = pm.vposR;
   const int lane = threadIdx.x & 63;
   const unsigned q = (unsigned)(n - i + 1);
   const int Lq = 31 - __clz((int)q);
   const int nchunk = (nB + 63) >> 6;
-  int occq = -1;
-  {
-    int d = 0;
-    bool walking = true;
-    int c = (i - 1) >> 6;
-    unsigned vn = (c * 64 + lane < nB) ? vposR[c * 64 + lane] : 0u;
-    for (; c < nchunk && walking; c++) {
-      const int r = c * 64 + lane;
-      const unsigned v = (r >= i - 1) ? vn : 0u;
-      if (c + 1 < nchunk) vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
-      // m = how many levels of the chain root -> q contain v: v is inside subtree(q >> (Lq - d)) iff d <= m
-      int m = -1;
-      if (v != 0u) {
-        const int Lv = 31 - __clz((int)v);
-        const int L = Lv < Lq ? Lv : Lq;
-        const unsigned x = (v >> (Lv - L)) ^ (q >> (Lq - L));
-        m = L - (x ? 32 - __clz((int)x) : 0);
-      }
-      int from = 0;
-      for (;;) {
-        const unsigned long long mk = __ballot(m >= d && lane >= from);
-        if (!mk) break;
-        const int l = __ffsll((long long)mk) - 1;
-        if (d == Lq) { occq = c * 64 + l; walking = false; break; }
-        d++; from = l + 1;
-      }
+  int occq = -1, d = 0;
+  bool walking = true;
+  int c = (i - 1) >> 6;
+  unsigned vn = (c * 64 + lane < nB) ? vposR[c * 64 + lane] : 0u;
+  for (; c < nchunk && walking; c++) {
+    const int r = c * 64 + lane;
+    const unsigned v = (r >= i - 1) ? vn : 0u;
+    if (c + 1 < nchunk) vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
+    // m = how many levels of the chain root -> q contain v: v is inside subtree(q >> (Lq - d)) iff d <= m
+    int m = -1;
+    if (v != 0u) {
+      const int Lv = 31 - __clz((int)v);
+      const int L = Lv < Lq ? Lv : Lq;
+      const unsigned x = (v >> (Lv - L)) ^ (q >> (Lq - L));
+      m = L - (x ? 32 - __clz((int)x) : 0);
+    }
+    int from = 0;
+    for (;;) {
+      const unsigned long long mk = __ballot(m >= d && lane >= from);
+      if (!mk) break;
+      const int l = __ffsll((long long)mk) - 1;
+      if (lane == 0 && d < kTakers) takers[d] = c * 64 + l;
+      if (d == Lq) { occq = c * 64 + l; d++; walking = false; break; }
+      d++; from = l + 1;
     }
   }
-  if (occq < 0) return;                         // the element has moved up (or out) before its tail turn
-  // event: s leaves q, the root element is output, s runs down the path of larger children among the
-  // elements still in the heap (size n - i) until it is >= the larger child (:1372-1381).  The larger child
-  // of the hole (left on ties) is the best remaining element of the hole's subtree: the same single scan.
-  const int rs = occq;
+  *ntake = d < kTakers ? d : kTakers;
+  return occq;
+}
+
+// The event itself: the element of rank rs leaves the tail position q = n - i + 1, the root element is output,
+// and s runs down the path of larger children among the elements still in the heap (size n - i) until it is
+// >= the larger child (:1372-1381).  The larger child of the hole (left on ties) is the best remaining element
+// of the hole's subtree: the same kind of single scan.  Then s takes its place among the equal scores still in
+// the heap (ranks >= i) by the pre-order of the positions.  Returns the new rank; *hole_out = its new position.
+__device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k, int i, int rs, unsigned *hole_out) {
+  const lds_u32 *vposR = pm.vposR;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = (nB + 63) >> 6;
   const unsigned ssc = (unsigned)(pm.compR[rs] >> 32);
   const unsigned hs = (unsigned)(n - i);
   unsigned hole = 1u;
@@ -353,10 +370,6 @@ __device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int 
       }
     }
   }
-  // s now counts as the element of position `hole`
-  if (hole >= (unsigned)(n - k + 1) && lane == 0)     // it sits on a tail position again: its turn comes later
-    atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
-  // its place among the equal scores still in the heap (ranks >= i): by pre-order of the positions
   int g0 = rs, g1 = rs + 1;
   while (g0 > i && (unsigned)(pm.compR[g0 - 1] >> 32) == ssc) g0--;
   while (g1 < nB && (unsigned)(pm.compR[g1] >> 32) == ssc) g1++;
@@ -368,13 +381,27 @@ __device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int 
     cnt += __popcll(__ballot(before));
   }
   const int newr = g0 + cnt;
-  if (lane == 0 && (newr != rs || true)) {
+  if (lane == 0) {
     const unsigned sid = pm.idR[rs];
     const unsigned long long sc = pm.compR[rs];
     if (newr < rs) for (int r = rs; r > newr; r--) { pm.vposR[r] = pm.vposR[r - 1]; pm.idR[r] = pm.idR[r - 1]; pm.compR[r] = pm.compR[r - 1]; }
     else for (int r = rs; r < newr; r++) { pm.vposR[r] = pm.vposR[r + 1]; pm.idR[r] = pm.idR[r + 1]; pm.compR[r] = pm.compR[r + 1]; }
     pm.vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc;
   }
+  __builtin_amdgcn_wave_barrier();
+  *hole_out = hole;
+  return newr;
+}
+
+// one tail candidate handled start to finish by one wave (the serial form: more than kMaxCand candidates)
+__device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
+  int nt;
+  const int occ = chain_scan(pm, nB, n, i, pm.takers + kMaxCand * (kTakers + 1), &nt);
+  if (occ < 0) return;
+  unsigned hole;
+  apply_event(pm, nB, n, k, i, occ, &hole);
+  if (hole >= (unsigned)(n - k + 1) && (threadIdx.x & 63) == 0)     // it sits on a tail position again: its turn comes later
+    atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -450,18 +477,120 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         }
         __syncthreads();
         PTICK(6);
+        // Tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1).  The chain
+        // scans only READ the rank lists, so all candidates are scanned at once, one wave each; wave 0 then walks
+        // the candidates in turn order and applies the events.  An event moves one element (and shifts the ranks
+        // inside its tie group): a later candidate is scanned again only if that can change its chain.
+        lds_i32 *ctl = pm.need + kMaxCand;                    // ncand, cursor, finished
         if (tid < 64) {
-          // tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1)
           const int nw = (k + 31) / 32;
+          int nc = 0;
           for (int w = 0; w < nw; w++) {
-            unsigned donebits = 0u;
-            for (;;) {
-              const unsigned bits = ((volatile lds_u32 *)pm.tailmask)[w] & ~donebits;
-              if (!bits) break;
+            unsigned bits = pm.tailmask[w];
+            while (bits) {
               const int b = __ffs((int)bits) - 1;
-              donebits |= (b == 31) ? 0xffffffffu : ((2u << b) - 1u);
+              bits &= bits - 1u;
               const int i = w * 32 + b + 1;
-              if (i <= k) replay_tail(pm, nB, n, k, i);
+              if (i <= k) { if (nc < kMaxCand && tid == 0) { pm.cand[nc] = i; pm.need[nc] = 1; } nc++; }
+            }
+          }
+          if (tid == 0) { ctl[0] = nc; ctl[1] = 0; ctl[2] = 0; }
+        }
+        __syncthreads();
+        const int ncand0 = ctl[0];
+        if (ncand0 > kMaxCand) {
+          if (tid < 64) {                                     // serial form, straight off the mask
+            const int nw = (k + 31) / 32;
+            for (int w = 0; w < nw; w++) {
+              unsigned donebits = 0u;
+              for (;;) {
+                const unsigned bits = ((volatile lds_u32 *)pm.tailmask)[w] & ~donebits;
+                if (!bits) break;
+                const int b = __ffs((int)bits) - 1;
+                donebits |= (b == 31) ? 0xffffffffu : ((2u << b) - 1u);
+                const int i = w * 32 + b + 1;
+                if (i <= k) replay_tail(pm, nB, n, k, i);
+              }
+            }
+          }
+        } else if (ncand0 > 0) {
+          for (;;) {
+            // (re)scan: candidate c on wave c % 16
+            {
+              const int ncand = ctl[0], wv = tid >> 6;
+              for (int c = ctl[1] + wv; c < ncand; c += NT / 64) {
+                if (!pm.need[c]) continue;
+                lds_i32 *tk = pm.takers + c * (kTakers + 1);
+                int nt;
+                const int oc = chain_scan(pm, nB, n, pm.cand[c], tk, &nt);
+                if ((tid & 63) == 0) { pm.occ[c] = oc; tk[kTakers] = nt; pm.need[c] = 0; }
+              }
+            }
+            __syncthreads();
+            if (tid < 64) {
+              int ncand = ctl[0], c = ctl[1];
+              for (; c < ncand; c++) {
+                if (pm.need[c]) break;                        // invalidated by an earlier event: next round
+                const int rs = pm.occ[c];
+                if (rs < 0) continue;
+                const int i = pm.cand[c];
+                unsigned hole;
+                const int newr = apply_event(pm, nB, n, k, i, rs, &hole);
+                const int lo = newr < rs ? newr : rs, hi = newr < rs ? rs : newr;
+                // which later candidates can this change?  (ranks outside [lo, hi] keep their numbers)  One lane each.
+                for (int c0 = c + 1; c0 < ncand; c0 += 64) {
+                  const int c2 = c0 + (tid & 63);
+                  if (c2 >= ncand || pm.need[c2]) continue;
+                  const int i2 = pm.cand[c2];
+                  if (hi < i2 - 1) continue;                  // s is out before that turn
+                  const lds_i32 *tk = pm.takers + c2 * (kTakers + 1);
+                  const int nt = tk[kTakers], oc2 = pm.occ[c2];
+                  bool hit = false; int dat = 0;
+                  for (int x = 0; x < nt; x++) { const int tr = tk[x]; if (tr >= lo && tr <= hi) hit = true; if (tr < lo) dat++; }
+                  if (!hit && !(oc2 >= 0 && oc2 < lo)) {
+                    // would s, now at `hole`, be taken when the walk passes it?  It shares m levels with the chain.
+                    const unsigned q2 = (unsigned)(n - i2 + 1);
+                    const int Lq2 = 31 - __clz((int)q2), Lv = 31 - __clz((int)hole);
+                    const int L = Lv < Lq2 ? Lv : Lq2;
+                    const unsigned x = (hole >> (Lv - L)) ^ (q2 >> (Lq2 - L));
+                    const int m = L - (x ? 32 - __clz((int)x) : 0);
+                    hit = m >= dat;
+                  }
+                  if (hit) pm.need[c2] = 1;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (hole >= (unsigned)(n - k + 1)) {          // s sits on a tail position again: a new candidate, later turn
+                  const int inew = n - (int)hole + 1;
+                  if (ncand >= kMaxCand) { if (tid == 0) { ctl[0] = kMaxCand + 1; } ncand = kMaxCand + 1; break; }   // overflow: finish serially
+                  int at = ncand;
+                  while (at > c + 1 && pm.cand[at - 1] > inew) at--;
+                  if (!(at > c + 1 && pm.cand[at - 1] == inew) && !(at < ncand && pm.cand[at] == inew)) {
+                    if (tid == 0) {
+                      for (int x = ncand; x > at; x--) {
+                        pm.cand[x] = pm.cand[x - 1]; pm.occ[x] = pm.occ[x - 1]; pm.need[x] = pm.need[x - 1];
+                        for (int y = 0; y <= kTakers; y++) pm.takers[x * (kTakers + 1) + y] = pm.takers[(x - 1) * (kTakers + 1) + y];
+                      }
+                      pm.cand[at] = inew; pm.need[at] = 1; pm.occ[at] = -1;
+                      ctl[0] = ncand + 1;
+                    }
+                    ncand++;
+                  } else if (tid == 0) {                      // already a candidate: two elements share the position now
+                    const int e = (at > c + 1 && pm.cand[at - 1] == inew) ? at - 1 : at;
+                    pm.need[e] = 1;
+                  }
+                  __builtin_amdgcn_wave_barrier();
+                }
+              }
+              if (tid == 0) { ctl[1] = c; ctl[2] = (c >= ncand || ncand > kMaxCand) ? 1 : 0; }
+            }
+            __syncthreads();
+            if (ctl[2]) break;
+          }
+          if (ctl[0] > kMaxCand && tid < 64) {                // candidate table overflowed mid-way: the rest serially
+            for (int i = pm.cand[ctl[1]]; i <= k; i++) {
+              bool any = false;
+              for (int r0 = 0; r0 < nB; r0 += 64) { const int r = r0 + (tid & 63); if (__ballot(r < nB && pm.vposR[r] == (unsigned)(n - i + 1))) { any = true; break; } }
+              if (any) replay_tail(pm, nB, n, k, i);
             }
           }
         }
@@ -525,6 +654,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
+  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
+  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
   pm.b_cap = xw.b_cap;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
@@ -1093,6 +1224,8 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
+  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
+  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
   pm.b_cap = xw.b_cap;
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
@@ -1153,7 +1286,7 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   at = cells_at;
   xw->b_cap = beam + 256;
   int p2 = 128; while (p2 < xw->b_cap) p2 <<= 1;             // the sort pads the list to a power of two
-  const int tail_bytes = 4 * ((beam + 31) / 32 + 2);
+  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 3 * kMaxCand + 4 + (kMaxCand + 1) * (kTakers + 1));
   if (p2 > 2 * NT || 8 * p2 + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) { xw->b_cap = 0; p2 = 0; }
   xw->off_comp = 0;
   place(&xw->off_compr, 8 * p2);
