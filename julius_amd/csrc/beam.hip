@@ -347,6 +347,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         const int2 ir = lx.iso_root(i);                    // {root node, successor word}
         // one entry of max_successor_prob_iw()'s array (factoring_sub.c:1119-1143)
         const float p = (last_word < 0) ? 0.0f
+                        : lx.iwtab ? lx.iwtab[(size_t)lx.wton(last_word) * niso + i]
                         : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
         float tmpsum = tk.score;
         tmpsum += lx.wordend_a(sword);
@@ -1250,6 +1251,16 @@ beam_strict_mp_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict
   res->status = status; res->died_at = died_at; res->natom = b.natom; res->max_tokens = max_tokens;
 }
 
+// the cross-word LM table (LexDev::iwtab): one thread per (context, isolated root)
+constexpr size_t kIwTabMaxBytes = (size_t)2 << 30;
+__global__ void __launch_bounds__(256) iwtab_build_kernel(LexDev lx, float *tab, int nctx, int niso) {
+  const size_t x = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (x >= (size_t)nctx * niso) return;
+  const int ctx = (int)(x / niso), i = (int)(x - (size_t)ctx * niso);
+  const int w = lx.iso_root(i).y;
+  tab[x] = bigram_prob(lx, ctx, lx.wton(w)) + lx.cprob(w);
+}
+
 template <typename T>
 int upload(T **dst, const T *src, size_t n) {
   JAMD_HIP(hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)));
@@ -1440,6 +1451,16 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     rc = upload(&dev, arena.data(), arena.size());
     d.base = dev;
     if (dev) l->owned.push_back((void *)dev);
+  }
+  if (rc == JAMD_OK && !dfa && h->isolatenum > 0 && h->ng_nword > 0 &&
+      (size_t)h->ng_nword * h->isolatenum * sizeof(float) <= kIwTabMaxBytes) {
+    const size_t cells = (size_t)h->ng_nword * h->isolatenum;
+    float *tab = nullptr;
+    if (hipMalloc((void **)&tab, cells * sizeof(float)) == hipSuccess) {
+      l->owned.push_back((void *)tab);
+      hipLaunchKernelGGL(iwtab_build_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d, tab, h->ng_nword, h->isolatenum);
+      if (hipGetLastError() == hipSuccess && hipStreamSynchronize(e->stream) == hipSuccess) d.iwtab = tab;
+    } else (void)hipGetLastError();             // no room: the kernels compute the entries on the fly
   }
   if (rc != JAMD_OK) { jamd_lexicon_destroy(l); return rc; }
   *out = l;

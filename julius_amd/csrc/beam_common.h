@@ -42,6 +42,11 @@ struct LexDev {
   float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
   int lm_type, ncat, ninit; float penalty1;
   const unsigned char *base;          // the arena
+  // Cross-word LM table (N-gram lexicons): iwtab[ctx * isolatenum + i] = bigram_prob(ctx, wton(w_i)) + cprob(w_i) for the
+  // word w_i behind isolated root i -- every entry max_successor_prob_iw() (factoring_sub.c:1049-1143) can ever put
+  // into its per-last-word cache iw_sc_cache, computed once when the lexicon is created (same arithmetic, same
+  // floats) and kept in HBM: 20 000 contexts x 189 roots = 15 MB.  NULL when it would exceed kIwTabMaxBytes.
+  const float *iwtab;
 #define X(T, name) unsigned o_##name;
   JAMD_LEX_ARRAYS(X)
 #undef X

@@ -842,7 +842,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const bool tr = lx.is_transparent(sword) != 0;
         const int last_word = tr ? tk.last_cword : sword;
         const int2 ir = lx.iso_root(i);
-        const float p = (last_word < 0) ? 0.0f : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
+        const float p = (last_word < 0) ? 0.0f
+                        : lx.iwtab ? lx.iwtab[(size_t)lx.wton(last_word) * niso + i]
+                        : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
         float tmpsum = tk.score;
         tmpsum += lx.wordend_a(sword);
         const float ng = p * lmw + pen;
