@@ -10,5 +10,5 @@ BENCH="python $REPO/bench.py --workload e2e --utts $UTTS --no-cpu-baseline --ste
 pass() { n=$1; shift; rocprofv3 --pmc "$@" -d $OUT/$n -o pmc -- $BENCH > $OUT/$n.log 2>&1; }
 pass a SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 pass b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU GRBM_GUI_ACTIVE
-python $REPO/tools/rocpd_summary.py $OUT "beam_pass1" > $OUT/summary.json 2>/dev/null
+python $REPO/tools/rocpd_summary.py $OUT "beam_" > $OUT/summary.json 2>/dev/null
 find $OUT -name "*.db" -delete
