@@ -43,6 +43,7 @@ typedef struct {
   int order_mode;            /* -1 = the work area's default (exact order where the beam fits), else JAMD_ORDER_* (JAMD_ORDER_MODE) */
   int nstate;
   int nnode, nword; void *dfa; /* further identity of the lexicon tree (grammar updates) */
+  float cfg_key[10];           /* scalar configuration baked into the device lexicon / scorer (cfg_key_of()) */
   /* streaming state of the current utterance */
   int chunk;                   /* JAMD_STREAM_CHUNK: push every this many frames from _proceed(); 0 = all at _end() */
   int pushed;                  /* frames already handed to the device */
@@ -100,8 +101,19 @@ static pass1_ctx *ctx_get(RecogProcess *r)
   return &g_ctx[g_nctx++];
 }
 
+/* every scalar the device handles were built with: a change between inputs (module-mode commands, user code
+ * editing the Jconf) must rebuild them */
+static void cfg_key_of(RecogProcess *r, float *k)
+{
+  k[0] = r->config->lmp.lm_weight; k[1] = r->config->lmp.lm_penalty; k[2] = r->config->lmp.lm_penalty_trans;
+  k[3] = r->config->lmp.penalty1; k[4] = (float)r->am->hmminfo->cdset_method; k[5] = (float)r->am->hmminfo->cdmax_num;
+  k[6] = (float)r->am->config->gprune_method; k[7] = (float)r->am->hmmwrk.OP_gprune_num;
+  k[8] = (float)(r->am->hmmwrk.OP_gshmm != NULL ? r->am->hmmwrk.my_nbest : 0); k[9] = (float)r->lmvar;
+}
+
 static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
 {
+  float key[10];
   int gprune = JAMD_GPRUNE_NONE, rc;
   if (jamd_abi_version() != JAMD_ABI_VERSION) {   /* header this shim was compiled with vs the loaded library */
     jlog("ERROR: jamd: libjulius_amd.so has ABI %d, this shim was built for %d\n", jamd_abi_version(), JAMD_ABI_VERSION);
@@ -118,7 +130,8 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
    * also catch most rebuilt trees that landed on the old address */
   if (c->wchmm == r->wchmm && c->hmminfo == r->am->hmminfo && c->beam_width == r->trellis_beam_width &&
       c->bs_width == r->config->pass1.score_pruning_width && c->beam != NULL &&
-      c->nnode == r->wchmm->n && c->nword == r->wchmm->winfo->num && c->dfa == (void *)r->wchmm->dfa) return TRUE;
+      c->nnode == r->wchmm->n && c->nword == r->wchmm->winfo->num && c->dfa == (void *)r->wchmm->dfa &&
+      (cfg_key_of(r, key), memcmp(key, c->cfg_key, sizeof(key)) == 0)) return TRUE;
   ctx_release(c);
   if ((r->lmtype != LM_PROB && r->lmtype != LM_DFA) || r->config->successive.enabled) {
     jlog("ERROR: jamd: the device first pass covers N-gram and grammar LMs, no -spsegment\n");
@@ -202,6 +215,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
+  cfg_key_of(r, c->cfg_key);
   c->beam_width = r->trellis_beam_width; c->bs_width = r->config->pass1.score_pruning_width;
   jlog("STAT: jamd: first pass on HIP device %d (beam %d, %d states, %d lexicon nodes)\n",
        jamd_engine_device(g_eng), c->beam_width, c->nstate, r->wchmm->n);
