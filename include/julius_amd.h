@@ -82,6 +82,10 @@ int  jamd_engine_sync(jamd_engine *e);
 /* Device allocation helpers for callers without their own HIP runtime. */
 int  jamd_malloc(jamd_engine *e, size_t bytes, void **dev);
 int  jamd_free(jamd_engine *e, void *dev);
+/* Page-locked host memory: copies to and from it run at the PCIe rate instead of the pageable-memory rate
+ * (about 3x); the bindings keep the score rows they hand to Julius' outprob cache in such buffers. */
+int  jamd_host_alloc(jamd_engine *e, size_t bytes, void **host);
+int  jamd_host_free(jamd_engine *e, void *host);
 int  jamd_memcpy_h2d(jamd_engine *e, void *dev, const void *host, size_t bytes);
 int  jamd_memcpy_d2h(jamd_engine *e, void *host, const void *dev, size_t bytes);
 

@@ -114,6 +114,18 @@ int jamd_free(jamd_engine *e, void *dev) {
   if (dev) JAMD_HIP(hipFree(dev));
   return JAMD_OK;
 }
+int jamd_host_alloc(jamd_engine *e, size_t bytes, void **host) {
+  if (!e || !host) { jamd_set_error("jamd_host_alloc: NULL argument"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  JAMD_HIP(hipHostMalloc(host, bytes ? bytes : 4, hipHostMallocDefault));
+  return JAMD_OK;
+}
+int jamd_host_free(jamd_engine *e, void *host) {
+  if (!e) { jamd_set_error("jamd_host_free: NULL engine"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  if (host) JAMD_HIP(hipHostFree(host));
+  return JAMD_OK;
+}
 int jamd_memcpy_h2d(jamd_engine *e, void *dev, const void *host, size_t bytes) {
   if (!e) { jamd_set_error("jamd_memcpy_h2d: NULL engine"); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(e->device));

@@ -541,8 +541,10 @@ int ensure(float **p, size_t *cap, size_t need) {
 
 extern "C" {
 
-int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gprune_num,
-                    jamd_gmm **out) {
+void jamd_gmm_destroy(jamd_gmm *g);
+// the allocations of jamd_gmm_create(); on any failure the caller releases *gp through jamd_gmm_destroy()
+static int gmm_create_impl(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gprune_num, jamd_gmm **gp) {
+  jamd_gmm **out = gp;
   if (!e || !d || !out) { jamd_set_error("jamd_gmm_create: NULL argument"); return JAMD_EINVAL; }
   *out = nullptr;
   if (d->nstream != 1) {
@@ -573,6 +575,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
   }
   JAMD_HIP(hipSetDevice(e->device));
   jamd_gmm *g = new jamd_gmm();
+  *gp = g;                             // owned by the caller from here on
   g->eng = e; g->S = d->nstate; g->D = d->veclen; g->E = d->nentry;
   g->gprune = gprune; g->gprune_num = gprune_num;
   const int D = g->D;
@@ -582,14 +585,14 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
   std::vector<int> book_first(d->nbook > 0 ? d->nbook : 0, -1);
   for (int s = 0; s < g->S; s++) {
     const int n = d->st_off[s + 1] - d->st_off[s];
-    if (n < 0) { delete g; jamd_set_error("jamd_gmm_create: st_off not monotone at %d", s); return JAMD_EINVAL; }
+    if (n < 0) { jamd_set_error("jamd_gmm_create: st_off not monotone at %d", s); return JAMD_EINVAL; }
     const int b = have_books ? d->st_book[s] : -1;
-    if (b >= d->nbook) { delete g; jamd_set_error("jamd_gmm_create: codebook id %d out of range", b); return JAMD_EINVAL; }
+    if (b >= d->nbook) { jamd_set_error("jamd_gmm_create: codebook id %d out of range", b); return JAMD_EINVAL; }
     if (b >= 0) {
       tied.push_back(s);
       if (book_first[b] < 0) book_first[b] = s;
       else if (n != d->st_off[book_first[b] + 1] - d->st_off[book_first[b]]) {
-        delete g; jamd_set_error("jamd_gmm_create: states of codebook %d disagree on its size", b); return JAMD_EINVAL;
+        jamd_set_error("jamd_gmm_create: states of codebook %d disagree on its size", b); return JAMD_EINVAL;
       }
       st_off_plain[s + 1] = st_off_plain[s];
     } else {
@@ -600,7 +603,6 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
   g->E_plain = st_off_plain[g->S];
   g->ntied = (int)tied.size();
   if (history_pruning && g->ntied > 0) {
-    delete g;
     jamd_set_error("jamd_gmm_create: gprune heu/beam with tied-mixture states depends on the previous frame's codebook "
                    "cache and on which frames were scored (calc_tied_mix.c:203-215): not served on the device; use "
                    "none or safe, or leave scoring to the reference's CPU code");
@@ -608,10 +610,10 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
   }
   g->nbook = g->ntied ? d->nbook : 0;
   if (gprune == JAMD_GPRUNE_SAFE && gprune_num < 1) {
-    delete g; jamd_set_error("jamd_gmm_create: gprune safe needs gprune_num >= 1"); return JAMD_EINVAL;
+    jamd_set_error("jamd_gmm_create: gprune safe needs gprune_num >= 1"); return JAMD_EINVAL;
   }
   if (gprune == JAMD_GPRUNE_SAFE && gprune_num > 64) {
-    delete g; jamd_set_error("jamd_gmm_create: gprune_num %d > 64 is not supported on the device", gprune_num);
+    jamd_set_error("jamd_gmm_create: gprune_num %d > 64 is not supported on the device", gprune_num);
     return JAMD_EINVAL;
   }
   auto fill_rec = [&](float *r, int dn, float lw) -> bool {
@@ -635,7 +637,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
     for (int k = 0; k < d->st_off[s + 1] - d->st_off[s]; k++) {
       const int en = d->st_off[s] + k;
       if (!fill_rec(rec.data() + (size_t)(st_off_plain[s] + k) * g->rec, d->ent_dens[en], d->ent_logw[en])) {
-        delete g; jamd_set_error("jamd_gmm_create: density index %d out of range", d->ent_dens[en]); return JAMD_EINVAL;
+        jamd_set_error("jamd_gmm_create: density index %d out of range", d->ent_dens[en]); return JAMD_EINVAL;
       }
     }
   }
@@ -678,7 +680,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
       for (int k = 0; k < book_off[b + 1] - book_off[b]; k++) {
         if (!fill_rec(brec.data() + (size_t)(book_off[b] + k) * g->rec,
                       d->ent_dens[d->st_off[book_first[b]] + k], 0.0f)) {
-          delete g; jamd_set_error("jamd_gmm_create: codebook density index out of range"); return JAMD_EINVAL;
+          jamd_set_error("jamd_gmm_create: codebook density index out of range"); return JAMD_EINVAL;
         }
       }
     }
@@ -695,6 +697,17 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
     JAMD_HIP(hipMalloc(&g->d_tied_states, sizeof(int) * g->ntied));
     JAMD_HIP(hipMemcpy(g->d_tied_states, tied.data(), sizeof(int) * g->ntied, hipMemcpyHostToDevice));
   }
+  return JAMD_OK;
+}
+
+
+int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gprune_num,
+                    jamd_gmm **out) {
+  if (!e || !d || !out) { jamd_set_error("jamd_gmm_create: NULL argument"); return JAMD_EINVAL; }
+  *out = nullptr;
+  jamd_gmm *g = nullptr;
+  const int rc = gmm_create_impl(e, d, gprune, gprune_num, &g);
+  if (rc != JAMD_OK) { if (g) jamd_gmm_destroy(g); return rc; }   // no leak on a failed allocation or a bad descriptor
   *out = g;
   return JAMD_OK;
 }

@@ -1,7 +1,7 @@
 /*
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
- *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N] [-strict] [-shard R N]
+ *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N|heu N|beam N] [-order exact|fast|strict] [-shard R N]
  *              [-rej verification.blob]
  *              (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
  *
@@ -62,7 +62,7 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
 int main(int argc, char **argv)
 {
   const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL, *rejp = NULL;
-  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, shard_r = 0, shard_n = 1, i;
+  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, order = -1, shard_r = 0, shard_n = 1, i;
   float bs = -1.0f;
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first;
@@ -79,6 +79,13 @@ int main(int argc, char **argv)
       else if (!strcmp(argv[i], "heu") && i + 1 < argc) { gprune = JAMD_GPRUNE_HEU; gnum = atoi(argv[++i]); }
       else if (!strcmp(argv[i], "beam") && i + 1 < argc) { gprune = JAMD_GPRUNE_BEAM; gnum = atoi(argv[++i]); }
     } else if (!strcmp(argv[i], "-strict")) strict = 1;
+    else if (!strcmp(argv[i], "-order") && i + 1 < argc) {          /* exact (default) | fast | strict */
+      ++i;
+      if (!strcmp(argv[i], "fast")) order = JAMD_ORDER_FAST;
+      else if (!strcmp(argv[i], "exact")) order = JAMD_ORDER_EXACT;
+      else if (!strcmp(argv[i], "strict")) strict = 1;
+      else die("-order exact|fast|strict");
+    }
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
     else if (!strcmp(argv[i], "-gms") && i + 1 < argc) gmsp = argv[++i];
@@ -90,7 +97,7 @@ int main(int argc, char **argv)
   }
   if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) {
     fprintf(stderr, "usage: jamd_batch (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
-                    "[-d dev] [-b beam] [-bs width] [-gprune safe N] [-strict] [-shard R N]\n");
+                    "[-d dev] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N]\n");
     return 2;
   }
   if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
@@ -111,6 +118,7 @@ int main(int argc, char **argv)
   if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
   if (jamd_beam_create(e, lx, beam, bs, 256, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
   if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
+  if (!strict && order >= 0 && jamd_beam_set_order_mode(bm, order) != JAMD_OK) die("order mode");
 
   if ((fl = fopen(list, "r")) == NULL) { fprintf(stderr, "jamd_batch: cannot open %s\n", list); return 1; }
   while (fgets(line, sizeof(line), fl)) {

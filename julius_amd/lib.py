@@ -67,6 +67,8 @@ def load():
         "jamd_engine_sync": (ci, [vp]),
         "jamd_malloc": (ci, [vp, C.c_size_t, P(vp)]),
         "jamd_free": (ci, [vp, vp]),
+        "jamd_host_alloc": (ci, [vp, C.c_size_t, P(vp)]),
+        "jamd_host_free": (ci, [vp, vp]),
         "jamd_memcpy_h2d": (ci, [vp, vp, vp, C.c_size_t]),
         "jamd_memcpy_d2h": (ci, [vp, vp, vp, C.c_size_t]),
         "jamd_gmm_create": (ci, [vp, P(GmmDesc), ci, ci, P(vp)]),

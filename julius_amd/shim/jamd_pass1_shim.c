@@ -82,7 +82,8 @@ static void ctx_release(pass1_ctx *c)
   if (c->gms) jamd_gms_destroy(c->gms);
   if (c->gmm) jamd_gmm_destroy(c->gmm);
   if (c->dnn) jamd_dnn_destroy(c->dnn);
-  free(c->host_scores); c->host_scores = NULL; c->host_cap = 0;
+  if (c->host_scores != NULL && g_eng != NULL) jamd_host_free(g_eng, c->host_scores);
+  c->host_scores = NULL; c->host_cap = 0;
   free(c->iatoms); c->iatoms = NULL; c->iatom_cap = 0;
   c->beam = NULL; c->lex = NULL; c->gmm = NULL; c->dnn = NULL; c->gms = NULL;
 }
@@ -405,9 +406,15 @@ static boolean push_frames(pass1_ctx *c, RecogProcess *r, HTK_Param *param, int 
                 : jamd_gmm_outprob_dev(c->gmm, d_frames, n, d_scores, NULL)) != JAMD_OK ||
         (c->gms && jamd_gms_apply_dev(c->gms, d_frames, n, NULL, 0, d_scores, NULL) != JAMD_OK)) goto out;
     if (keep) {                                      /* rows for the reference's outprob cache (2nd pass) */
-      if (upto > c->host_cap) {
-        c->host_cap = upto + 1024;
-        c->host_scores = (float *)realloc(c->host_scores, sizeof(float) * (size_t)c->host_cap * c->nstate);
+      if (upto > c->host_cap) {                      /* page-locked: the D2H copy of the rows runs at the PCIe rate */
+        const int ncap = upto + (upto > 4096 ? upto / 2 : 2048);
+        void *nb = NULL;
+        if (jamd_host_alloc(g_eng, sizeof(float) * (size_t)ncap * c->nstate, &nb) != JAMD_OK) goto out;
+        if (c->host_scores != NULL) {
+          memcpy(nb, c->host_scores, sizeof(float) * (size_t)c->pushed * c->nstate);
+          jamd_host_free(g_eng, c->host_scores);
+        }
+        c->host_scores = (float *)nb; c->host_cap = ncap;
       }
       if (c->host_scores == NULL ||
           jamd_memcpy_d2h(g_eng, c->host_scores + (size_t)c->pushed * c->nstate, d_scores,
