@@ -51,6 +51,10 @@ gmm_safe_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
                 float *__restrict__ out, int T, int S, int D, int REC, int cap, int nsb,
                 float addmin_f) {
   extern __shared__ __align__(16) float dyn[];
+  // results of NS states x the wave's 128 frames are staged in a wave-private LDS tile and written as 64-byte
+  // row segments (a lane storing its own [t][s] element makes 64 scattered 4-byte stores per instruction)
+  constexpr int NS = 16;
+  __shared__ float tile[kWaves][128][NS + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = (blockIdx.x * kWaves + wave) * 128;
   if (t0 >= T) return;
@@ -58,8 +62,10 @@ gmm_safe_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
   float *vt = dyn + (size_t)wave * D * 128;
   load_frames<DT>(v, vt, frames, t0, T, D, lane);
   const int s_begin = blockIdx.y * nsb, s_end = min(S, s_begin + nsb);
-  const int ta = t0 + lane, tb = ta + 64;
-  for (int s = s_begin; s < s_end; s++) {
+  for (int sg = s_begin; sg < s_end; sg += NS) {
+   const int ns = min(NS, s_end - sg);
+   for (int si = 0; si < ns; si++) {
+    const int s = sg + si;
     const int e0 = st_off[s], e1 = st_off[s + 1];
     float sc0[NMAX], sc1[NMAX];
     int id0[NMAX], id1[NMAX];
@@ -78,8 +84,22 @@ gmm_safe_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
       if (i < len0) y0 = addlog_step(y0, sc0[i] + rec[(size_t)(e0 + id0[i]) * REC + 2 * D + 1], tbl, addmin_f);
       if (i < len1) y1 = addlog_step(y1, sc1[i] + rec[(size_t)(e0 + id1[i]) * REC + 2 * D + 1], tbl, addmin_f);
     }
-    if (ta < T) out[(size_t)ta * S + s] = finish_state(y0);
-    if (tb < T) out[(size_t)tb * S + s] = finish_state(y1);
+    tile[wave][lane][si] = finish_state(y0);
+    tile[wave][64 + lane][si] = finish_state(y1);
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   constexpr int RPI = 64 / NS;              // rows per store instruction
+   const int col = lane % NS, rsub = lane / NS;
+#pragma unroll 4
+   for (int it = 0; it < 128 / RPI; it++) {
+     const int rr = it * RPI + rsub;
+     const int t = t0 + rr;
+     if (t < T && col < ns) out[(size_t)t * S + sg + col] = tile[wave][rr][col];
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
   }
 }
 
