@@ -1,0 +1,108 @@
+"""The closed form of sort_token_upward()'s extraction loop that the exact-order first-pass kernel uses
+(julius_amd/csrc/beam_exact.hip, DESIGN.md section 3 "K6x"), restated in plain Python and checked against the
+oracle's sequential restatement of libjulius/src/beam.c:1342-1516 on tie-heavy random inputs.  CPU only.
+
+Model.  After heapify, let B = the elements with score >= the k-th largest, each with its heap position ("virtual
+position").  While the element taken from the tail of the array is not in B, an extraction is a hole running down
+the path of larger children (left on ties): every heap position then emits its own element followed by the stable
+merge of its children's streams, so the extraction order is (score descending, PRE-ORDER index of the position
+ascending).  An extraction whose tail element IS in B ("event") re-inserts that element: it runs down the current max
+path and stops at the first hole whose larger child is not greater -- from then on it counts as the element of that
+position.  Who sits where at a given time follows from the order alone: a position holds the best remaining element
+of its subtree that is not sitting further up, and because the subtrees along a root-to-leaf chain are nested, the
+occupants of a chain come out of ONE scan over the remaining elements in order."""
+import numpy as np
+import pytest
+
+MAXL = 20
+
+
+def prekey(p):
+    L = p.bit_length() - 1
+    return (((p - (1 << L)) << (MAXL - L)) << 5) | L
+
+
+def insub(p, c):
+    d = p.bit_length() - c.bit_length()
+    return d >= 0 and (p >> d) == c
+
+
+def heapify_upward(score):
+    """First loop of sort_token_upward() (beam.c:1354-1367); returns the index array (1-based heap in a 0-based list)."""
+    n = len(score)
+    ti = list(range(n))
+    for root in range(n // 2, 0, -1):
+        s, parent = ti[root - 1], root
+        while True:
+            child = parent * 2
+            if child > n:
+                break
+            if child < n and score[ti[child - 1]] < score[ti[child]]:
+                child += 1
+            if score[s] >= score[ti[child - 1]]:
+                break
+            ti[parent - 1] = ti[child - 1]
+            parent = child
+        ti[parent - 1] = s
+    return ti
+
+
+def closed_form_order(score, k):
+    """tindex[n-k .. n-1] after sort_token_upward(k, n), without running its second loop."""
+    n = len(score)
+    heap = heapify_upward(score)
+    vk = sorted(score, reverse=True)[k - 1]
+    vpos = {idx: pos for pos, idx in enumerate(heap, 1) if score[idx] >= vk}
+    key = lambda x: (-score[x], prekey(vpos[x]))
+    order = sorted(vpos, key=key)
+    out = []
+    for i in range(1, k + 1):
+        out.append(order[i - 1])
+        q = n - i + 1
+        if not any(vpos[e] == q for e in order[i:]):
+            continue
+        # occupants of the chain root -> q: one scan over the remaining elements in order
+        Lq, d, occq = q.bit_length() - 1, 0, None
+        for x in order[i - 1:]:
+            if insub(vpos[x], q >> (Lq - d)):
+                if d == Lq:
+                    occq = x
+                    break
+                d += 1
+        if occq is None:
+            continue                       # the element moved up (or out) before its tail turn
+        s, hs, hole = occq, n - i, 1        # event: s runs down the max path of the heap of size n - i
+        for x in order[i:]:
+            if x == s:
+                continue
+            if 2 * hole > hs:
+                break
+            v = vpos[x]
+            if insub(v, hole) and v != hole:
+                c = v >> (v.bit_length() - hole.bit_length() - 1)
+                if c > hs:
+                    continue
+                if score[s] >= score[x]:
+                    break
+                hole = c
+        vpos[s] = hole
+        order[i:] = sorted(order[i:], key=key)
+    return out[::-1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_closed_form_equals_sequential_heap(oracle, seed):
+    rng = np.random.default_rng(seed)
+    checked = events = 0
+    for _ in range(120):
+        n = int(rng.integers(5, 160))
+        k = int(rng.integers(1, max(2, (n - 1) // 2)))
+        if not k < n - k:
+            continue
+        levels = int(rng.choice([2, 3, 5, 10, 30, 1000]))
+        score = [float(x) for x in -rng.integers(0, levels, n) * 0.5 - 100.0]
+        want = list(oracle.sort_token_no_order(np.array(score, np.float32), k))
+        got = closed_form_order(score, k)
+        assert got == want, (n, k, levels)
+        checked += 1
+    assert checked > 60
