@@ -214,6 +214,15 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   if (!c->strict && c->order_mode == JAMD_ORDER_EXACT && jamd_beam_set_order_mode(c->beam, JAMD_ORDER_EXACT) != JAMD_OK) {
     jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE;
   }
+  {
+    static const char *const names[] = {"fast (canonical tie breaks)", "strict (sequential)", "exact (reference tie order)", "exact (sequential extraction)"};
+    const int m = jamd_beam_order_mode(c->beam);
+    jlog("Stat: jamd: first pass on HIP device %d, beam %d, tie order: %s\n", jamd_engine_device(g_eng), r->trellis_beam_width,
+         (m >= 0 && m < 4) ? names[m] : "?");
+    if (m == JAMD_ORDER_FAST && c->order_mode != JAMD_ORDER_FAST)
+      jlog("Warning: jamd: beam %d is too wide for the exact-order kernel's LDS image; exactly tied hypotheses are resolved canonically, not in the "
+           "reference's visiting order (JAMD_ORDER_MODE=strict gives the reference's order, slowly)\n", r->trellis_beam_width);
+  }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
   cfg_key_of(r, c->cfg_key);
