@@ -112,7 +112,7 @@ __device__ __forceinline__ unsigned long long push(Shared &sh, const Cells &cl, 
 #ifndef JAMD_BEAM_WPE
 #define JAMD_BEAM_WPE 4                 // waves per SIMD the register allocation targets (4 = one workgroup per CU)
 #endif
-template <bool TIMED>
+template <bool TIMED, bool SVLDS>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(JAMD_BEAM_WPE, JAMD_BEAM_WPE)))
 beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
                   const int *__restrict__ utt_off, int smode) {
@@ -139,16 +139,16 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   jamd_pass1_result *res = wk.res + u;
   // survivor state of the previous frame (tokens, the atom each word end emitted, the
   // frame's word-end list, node -> survivor hash)
-  unsigned char *svb = wk.use_lds ? dyn_lds : ub + wk.o_sv;
-  Tok *sv = (Tok *)svb;
-  int *sv_atom = (int *)(svb + (size_t)wk.beam * sizeof(Tok));
-  int *welist = sv_atom + wk.beam;
-  int *hkey = welist + wk.beam;
-  int *hval = hkey + wk.hsize;
+  SvImage<SVLDS> svi;                       // SVLDS == (wk.use_lds != 0): chosen at launch
+  svi.bind(dyn_lds, ub + wk.o_sv, wk.beam, wk.hsize);
+  const auto sv_atom = svi.atom;
+  const auto welist = svi.we;
+  const auto hkey = svi.hkey;
+  const auto hval = svi.hval;
   const int hmask = wk.hsize - 1;
   // the frame's Viterbi cells: LDS table behind the survivor image (16-byte aligned), see Cells
   Cells cl;
-  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_touched = wk.o_touched; cl.nslot = wk.use_lds ? wk.cell_slots : 0;
+  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_touched = wk.o_touched; cl.nslot = SVLDS ? wk.cell_slots : 0;
   cl.lkey = (unsigned long long *)(dyn_lds + wk.cell_off);
   cl.lnode = (int *)(dyn_lds + wk.node_off);
   unsigned *hist = (unsigned *)(dyn_lds + wk.cell_off);    // step D only: the cells are all empty then
@@ -162,9 +162,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 
   if (resume) {
     if (!ss->active) return;                                 // died / overflowed / finished earlier
-    if (wk.use_lds) {                                        // survivor image back into LDS
-      const uint4 *src = (const uint4 *)(ub + wk.o_sv);
-      uint4 *dst = (uint4 *)dyn_lds;
+    if (SVLDS) {                                             // survivor image back into LDS
+      const u32x4 *src = (const u32x4 *)(ub + wk.o_sv);
+      lds_v4 *dst = (lds_v4 *)dyn_lds;
       for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
     }
     if (tid == 0) {
@@ -198,7 +198,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
       nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
       nw.pad0 = nw.pad1 = 0;
-      sv[0] = nw;
+      svi.store(0, nw);
       hash_put(hkey, hval, hmask, node, 0);
       sh.n_surv = 1;
     }
@@ -243,7 +243,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
         // a genuine tie, resolved by the larger source id and counted.
         bool same = false;
         if (((unsigned)tie >> 31) == 0u) {
-          const Tok o = sv[hash_get(hkey, hval, hmask, (int)(unsigned)tie)];
+          const Tok o = svi.load(hash_get(hkey, hval, hmask, (int)(unsigned)tie));
           // the LM score is recomputed from last_cword on entering a factoring
           // node from another node (see step C); otherwise it is inherited
           const bool re_o = next_node != o.node && lx.scid(next_node) != 0;
@@ -255,7 +255,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
     };
     // ---- A: intra-word transitions + word-end atoms (main loop, beam.c:2838-2900)
     for (int j = tid; j < n_surv; j += NT) {
-      const Tok tk = sv[j];
+      const Tok tk = svi.load(j);
       const int node = tk.node;
       const int4 na = lx.node_a(node);               // {self_a, next_a, ac_off, ac_end}
       const int sword = lx.node_b(node).x;           // stend
@@ -304,7 +304,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const int n_arc = sh.n_arc;
       for (int q = tid; q < n_arc; q += NT) {
         const int2 it = ARCQ(q);
-        intra_candidate(sv[it.x], lx.ac_to(it.y), lx.ac_a(it.y));
+        intra_candidate(svi.load(it.x), lx.ac_to(it.y), lx.ac_a(it.y));
       }
       __syncthreads();
     }
@@ -320,7 +320,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const int total = n_we * nroot;
       for (int x = tid; x < total; x += NT) {
         const int w = x / nroot, r = x - w * nroot;
-        const Tok tk = sv[welist[w]];
+        const Tok tk = svi.load(welist[w]);
         const int sword = lx.node_b(tk.node).x;
         if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
         const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
@@ -340,7 +340,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const int total = n_we * niso;
       for (int x = tid; x < total; x += NT) {
         const int w = x / niso, i = x - w * niso;
-        const Tok tk = sv[welist[w]];
+        const Tok tk = svi.load(welist[w]);
         const int sword = lx.node_b(tk.node).x;
         const bool tr = lx.is_transparent(sword) != 0;
         const int last_word = tr ? tk.last_cword : sword;
@@ -364,7 +364,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       const unsigned long long kb = sh.we_best;
       const float best_score = unord((unsigned)(kb >> 32));
       const int sword = (int)(unsigned)kb;
-      const Tok tk = sv[hash_get(hkey, hval, hmask, lx.word_end(sword))];
+      const Tok tk = svi.load(hash_get(hkey, hval, hmask, lx.word_end(sword)));
       const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
       for (int r = tid; r < lx.nshared; r += NT) {
         const float2 sr = lx.shared_root(r);               // {root node (bits), fscore}
@@ -418,7 +418,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
           lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f;
           if (!ok[k]) continue;
           if ((id >> 31) == 0u) {                      // intra-word, id = source node
-            const Tok tk = sv[hash_get(hkey, hval, hmask, (int)id)];
+            const Tok tk = svi.load(hash_get(hkey, hval, hmask, (int)id));
             l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
             if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
             else l_ls[k] = tk.last_lscore;
@@ -428,7 +428,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
             const bool iso = (id >> 30) == 2u;
             const int sword = iso ? (int)(id & 0x3fffffffu) : (int)(unsigned)sh.we_best;
             const int j = hash_get(hkey, hval, hmask, lx.word_end(sword));
-            const Tok tk = sv[j];
+            const Tok tk = svi.load(j);
             const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
             l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
             if (dfa) {                                       // beam_inter_word() :2452-2461
@@ -702,7 +702,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
       if (keep) {
         const Tok me = CUR(s);
         const int j = wave_alloc(&sh.n_surv, true);
-        sv[j] = me;
+        svi.store(j, me);
         hash_put(hkey, hval, hmask, me.node, j);
       }
     }
@@ -712,9 +712,9 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   __syncthreads();
 
   if (smode == 1) {            // not finished: park the state for the next launch
-    if (wk.use_lds && !stopped) {
-      uint4 *dst = (uint4 *)(ub + wk.o_sv);
-      const uint4 *src = (const uint4 *)dyn_lds;
+    if (SVLDS && !stopped) {
+      u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
+      const lds_v4 *src = (const lds_v4 *)dyn_lds;
       for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = src[i];
     }
     if (tid == 0) {
@@ -1297,6 +1297,19 @@ struct jamd_beam {
   std::vector<void *> owned;
 };
 
+// the frame-parallel (canonical tie) kernel: instantiation by where the survivor image lives and by instrumentation
+static void launch_pass1(jamd_beam *b, const Work &w, int lds, int nutt, const float *dev_scores, int nstate, int smode,
+                         hipStream_t st) {
+  const dim3 grid(nutt), block(NT);
+  if (w.use_lds) {
+    if (b->timed) hipLaunchKernelGGL((beam_pass1_kernel<true, true>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
+    else hipLaunchKernelGGL((beam_pass1_kernel<false, true>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
+  } else {
+    if (b->timed) hipLaunchKernelGGL((beam_pass1_kernel<true, false>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
+    else hipLaunchKernelGGL((beam_pass1_kernel<false, false>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
+  }
+}
+
 extern "C" {
 
 int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon **out) {
@@ -1556,10 +1569,14 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
   if (rc == JAMD_OK) {
     // the attribute is per kernel, not per work area: always ask for the whole budget
-    hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         kMaxDynLds);
     if (ae == hipSuccess)
-      ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+      ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if (ae == hipSuccess)
+      ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if (ae == hipSuccess)
+      ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     if (ae != hipSuccess) { jamd_set_error("jamd_beam_create: cannot reserve %d bytes of LDS: %s", w.sv_bytes,
                                            hipGetErrorString(ae)); rc = JAMD_ENODEV; }
   }
@@ -1622,12 +1639,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
     if (getenv("JAMD_BEAM_NO_ROW_CACHE") != nullptr) w.row_cache = 0;
 #endif
     const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
-    if (b->timed)
-      hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
-                         b->d_utt_off, 0);
-    else
-      hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
-                         b->d_utt_off, 0);
+    launch_pass1(b, w, lds, nutt, dev_scores, nstate, 0, st);
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
@@ -1690,12 +1702,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
     if (getenv("JAMD_BEAM_NO_ROW_CACHE") != nullptr) w.row_cache = 0;
 #endif
     const int lds = w.lds_bytes + (w.row_cache ? 4 * nstate : 0);
-    if (b->timed)
-      hipLaunchKernelGGL(beam_pass1_kernel<true>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
-                         b->d_utt_off, final ? 2 : 1);
-    else
-      hipLaunchKernelGGL(beam_pass1_kernel<false>, dim3(nutt), dim3(NT), lds, st, b->lex->d, w, dev_scores, nstate,
-                         b->d_utt_off, final ? 2 : 1);
+    launch_pass1(b, w, lds, nutt, dev_scores, nstate, final ? 2 : 1, st);
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_stream_push_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }

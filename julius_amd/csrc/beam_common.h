@@ -194,16 +194,71 @@ struct Shared {
   int eq_n, eq_node[128];           // tokens exactly on the rank cut (tie handling)
 };
 
+// LDS arrays are addressed through pointers that CARRY the address space: a generic pointer that the
+// compiler cannot trace back to LDS (through a struct, a select, a non-inlined call) becomes flat_load /
+// flat_store -- two to three times the latency of ds_read / ds_write and no loop unrolling
+// (measured: the rank-by-counting loop below ran 14x slower through a generic pointer).
+#define JAMD_LDS __attribute__((address_space(3)))
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef JAMD_LDS unsigned long long lds_u64;
+typedef JAMD_LDS unsigned lds_u32;
+typedef JAMD_LDS int lds_i32;
+typedef JAMD_LDS float lds_f32;
+typedef JAMD_LDS u32x4 lds_v4;
+
+// a token record (two 16-byte quads) to / from LDS
+__device__ __forceinline__ Tok lds_tok_load(const lds_v4 *p, int j) {
+  const u32x4 a = p[2 * j], b = p[2 * j + 1];
+  Tok t;
+  t.node = (int)a.x; t.score = __uint_as_float(a.y); t.last_tre = (int)a.z; t.last_cword = (int)a.w;
+  t.last_lscore = __uint_as_float(b.x); t.last_wid = (int)b.y; t.pad0 = (int)b.z; t.pad1 = (int)b.w;
+  return t;
+}
+__device__ __forceinline__ void lds_tok_store(lds_v4 *p, int j, const Tok &t) {
+  u32x4 a, b;
+  a.x = (unsigned)t.node; a.y = __float_as_uint(t.score); a.z = (unsigned)t.last_tre; a.w = (unsigned)t.last_cword;
+  b.x = __float_as_uint(t.last_lscore); b.y = (unsigned)t.last_wid; b.z = (unsigned)t.pad0; b.w = (unsigned)t.pad1;
+  p[2 * j] = a; p[2 * j + 1] = b;
+}
+
+// The survivor image of the frame-parallel kernel (tokens, the atom each word end emitted, the frame's word-end
+// list, node -> survivor hash), in LDS (typed pointers, ds_* instructions) or -- beams too wide for LDS -- in the
+// utterance's global slice (plain pointers).  One kernel instantiation per case: a run-time select between the two
+// bases turns every access into a flat_* instruction at two to three times the LDS latency.
+template <bool LDS> struct SvImage;
+template <> struct SvImage<true> {
+  lds_v4 *tok; lds_i32 *atom, *we, *hkey, *hval;
+  __device__ __forceinline__ void bind(unsigned char *lds_base, unsigned char *, int beam, int hsize) {
+    tok = (lds_v4 *)lds_base;
+    atom = (lds_i32 *)(lds_base + (size_t)beam * sizeof(Tok));
+    we = atom + beam; hkey = we + beam; hval = hkey + hsize;
+  }
+  __device__ __forceinline__ Tok load(int j) const { return lds_tok_load(tok, j); }
+  __device__ __forceinline__ void store(int j, const Tok &t) const { lds_tok_store(tok, j, t); }
+};
+template <> struct SvImage<false> {
+  Tok *tok; int *atom, *we, *hkey, *hval;
+  __device__ __forceinline__ void bind(unsigned char *, unsigned char *glob_base, int beam, int hsize) {
+    tok = (Tok *)glob_base;
+    atom = (int *)(glob_base + (size_t)beam * sizeof(Tok));
+    we = atom + beam; hkey = we + beam; hval = hkey + hsize;
+  }
+  __device__ __forceinline__ Tok load(int j) const { return tok[j]; }
+  __device__ __forceinline__ void store(int j, const Tok &t) const { tok[j] = t; }
+};
+
 // node -> survivor index, open addressing (survivor nodes are distinct)
 __device__ __forceinline__ unsigned hslot(int node, int hmask) {
   return ((unsigned)node * 2654435761u >> 7) & (unsigned)hmask;
 }
-__device__ __forceinline__ void hash_put(int *hkey, int *hval, int hmask, int node, int j) {
+template <typename KP, typename VP>
+__device__ __forceinline__ void hash_put(KP hkey, VP hval, int hmask, int node, int j) {
   unsigned h = hslot(node, hmask);
-  while (atomicCAS(&hkey[h], -1, node) != -1) h = (h + 1) & (unsigned)hmask;
+  while (atomicCAS((int *)&hkey[h], -1, node) != -1) h = (h + 1) & (unsigned)hmask;
   hval[h] = j;
 }
-__device__ __forceinline__ int hash_get(const int *hkey, const int *hval, int hmask, int node) {
+template <typename KP, typename VP>
+__device__ __forceinline__ int hash_get(KP hkey, VP hval, int hmask, int node) {
   unsigned h = hslot(node, hmask);
   for (int guard = 0; guard <= hmask; guard++) {
     const int k = hkey[h];

@@ -41,32 +41,6 @@ using namespace jamdb;
 
 constexpr int kMaxL = 20;                // heap positions < 2^21
 
-// LDS arrays are addressed through pointers that CARRY the address space: a generic pointer that the
-// compiler cannot trace back to LDS (through a struct, a select, a non-inlined call) becomes flat_load /
-// flat_store -- two to three times the latency of ds_read / ds_write and no loop unrolling
-// (measured: the rank-by-counting loop below ran 14x slower through a generic pointer).
-#define JAMD_LDS __attribute__((address_space(3)))
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef JAMD_LDS unsigned long long lds_u64;
-typedef JAMD_LDS unsigned lds_u32;
-typedef JAMD_LDS int lds_i32;
-typedef JAMD_LDS float lds_f32;
-typedef JAMD_LDS u32x4 lds_v4;
-
-// a token record (two 16-byte quads) to / from LDS
-__device__ __forceinline__ Tok lds_tok_load(const lds_v4 *p, int j) {
-  const u32x4 a = p[2 * j], b = p[2 * j + 1];
-  Tok t;
-  t.node = (int)a.x; t.score = __uint_as_float(a.y); t.last_tre = (int)a.z; t.last_cword = (int)a.w;
-  t.last_lscore = __uint_as_float(b.x); t.last_wid = (int)b.y; t.pad0 = (int)b.z; t.pad1 = (int)b.w;
-  return t;
-}
-__device__ __forceinline__ void lds_tok_store(lds_v4 *p, int j, const Tok &t) {
-  u32x4 a, b;
-  a.x = (unsigned)t.node; a.y = __float_as_uint(t.score); a.z = (unsigned)t.last_tre; a.w = (unsigned)t.last_cword;
-  b.x = __float_as_uint(t.last_lscore); b.y = (unsigned)t.last_wid; b.z = (unsigned)t.pad0; b.w = (unsigned)t.pad1;
-  p[2 * j] = a; p[2 * j + 1] = b;
-}
 struct XRowRef {                 // this frame's score row: its LDS copy or the row in global memory
   const float *g; const lds_f32 *l; bool lds;
   __device__ __forceinline__ float operator[](int i) const { return lds ? l[i] : g[i]; }
