@@ -39,6 +39,9 @@
 namespace {
 using namespace jamdb;
 
+#ifndef JAMD_XBEAM_CB
+#define JAMD_XBEAM_CB 4                 // tokens per thread carried together through the finalize step
+#endif
 constexpr int kMaxL = 20;                // heap positions < 2^21
 
 struct XRowRef {                 // this frame's score row: its LDS copy or the row in global memory
@@ -878,7 +881,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     {
       const XRowRef row{scores + (size_t)(t_begin + t - base) * S, rowc, wk.row_cache != 0};
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu;
-      constexpr int CB = 4;
+      constexpr int CB = JAMD_XBEAM_CB;
       for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
         bool ok[CB]; int node[CB], slot[CB], tokid[CB]; int4 nr[CB]; unsigned long long key[CB]; unsigned fvis[CB];
         int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB];
