@@ -11,14 +11,13 @@ struct XWork {
   unsigned o_bitmap;           // u32 [gbm_words] creation-order bitmap when it outgrows LDS
   unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
   int s1, xw;                  // visiting index = (source position << s1) | transition number; roots start at xw
-  int iso_rank_off;
   int nslot;                   // LDS Viterbi cells (16 bytes each: key, node, first visit)
   int bm_words;                // LDS bitmap capacity
   int heap_cap, b_cap;         // pruning step: LDS heap entries, top-k list entries
   int prune_mode;              // 0 = closed-form extraction, 1 = sequential extraction always (timing / test)
   // byte offsets in dynamic LDS
   int off_atom, off_we, off_dbase, off_tpre, off_bm, off_cells, off_lnode, off_lfirst, off_row;
-  int off_comp, off_compr, off_vpos, off_id, off_hist, off_tail, off_heap;   // overlay on the cells
+  int off_compr, off_vpos, off_id, off_hist, off_tail, off_heap;   // the pruning step's overlay on the cells
   int lds_bytes;
 };
 

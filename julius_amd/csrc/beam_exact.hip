@@ -43,6 +43,9 @@ using namespace jamdb;
 #define JAMD_XBEAM_CB 4                 // tokens per thread carried together through the finalize step
 #endif
 constexpr int kMaxL = 20;                // heap positions < 2^21
+#ifndef JAMD_XBEAM_PROBE
+#define JAMD_XBEAM_PROBE 0              // development builds: 1 / 2 / 3 put sub-step clocks of steps 0-B / C / the event replay into phase_us[4..7]
+#endif
 
 struct XRowRef {                 // this frame's score row: its LDS copy or the row in global memory
   const float *g; const lds_f32 *l; bool lds;
@@ -51,7 +54,7 @@ struct XRowRef {                 // this frame's score row: its LDS copy or the 
 
 struct XShared {
   unsigned long long we_best;            // (ord(score + wordend_a), ~j): best word end, earliest visit
-  int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback;
+  int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback, i_last;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
   unsigned wsum[NT / 64], wsum2[NT / 64];
@@ -101,12 +104,21 @@ __device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int 
   ea = ba + ia - a; eb = bb + ib - b;
 }
 
+// A value every lane of the wave holds alike, moved to a scalar register: the compiler cannot know that a value read
+// from LDS (or passed to a function that is not inlined) is uniform, and would run the loops it controls under
+// execution masks.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename T>
+__device__ __forceinline__ T JAMD_LDS *uni(T JAMD_LDS *p) {
+  return (T JAMD_LDS *)(unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)p);
+}
+
 __device__ __forceinline__ unsigned ordz(float f) { return ord(f + 0.0f); }   // -0.0 and +0.0 compare equal as floats
 
-// one candidate: propagate_token() :1945 with the visiting index as the tie breaker
-__device__ __forceinline__ void xpush(XShared &sh, const XCells &cl, int node, float score, unsigned vis) {
-  if (score <= JAMD_LOG_ZERO) return;
-  const unsigned long long key = ((unsigned long long)ordz(score) << 32) | (unsigned)(~vis);
+// Candidates for one node: key = the best of them (score bits || ~visiting index), nfirst = ~(their earliest
+// visiting index).  propagate_token() :1945 with the visiting index as the tie breaker.
+__device__ __forceinline__ void xpush_key(XShared &sh, const XCells &cl, int node, unsigned long long key, unsigned nfirst) {
   bool first = false;
   int slot = -1;
   if (cl.nslot > 0) {
@@ -119,15 +131,20 @@ __device__ __forceinline__ void xpush(XShared &sh, const XCells &cl, int node, f
   }
   if (slot >= 0) {
     atomicMax((unsigned long long *)&cl.lkey[slot], key);
-    atomicMax((unsigned *)&cl.lfirst[slot], ~vis);
+    atomicMax((unsigned *)&cl.lfirst[slot], nfirst);
   } else {
     const unsigned long long old =
         atomicMax(reinterpret_cast<unsigned long long *>(cl.ub + (unsigned)(cl.o_nodekey + 8u * (unsigned)node)), key);
-    atomicMax(reinterpret_cast<unsigned *>(cl.ub + (unsigned)(cl.o_nodefirst + 4u * (unsigned)node)), ~vis);
+    atomicMax(reinterpret_cast<unsigned *>(cl.ub + (unsigned)(cl.o_nodefirst + 4u * (unsigned)node)), nfirst);
     first = (old == 0ull);
   }
   const int s = wave_alloc(&sh.n_new, first);
   if (first) *reinterpret_cast<int2 *>(cl.ub + (unsigned)(cl.o_touched + 8u * (unsigned)s)) = make_int2(node, slot);
+}
+// one candidate
+__device__ __forceinline__ void xpush(XShared &sh, const XCells &cl, int node, float score, unsigned vis) {
+  if (score <= JAMD_LOG_ZERO) return;
+  xpush_key(sh, cl, node, ((unsigned long long)ordz(score) << 32) | (unsigned)(~vis), ~vis);
 }
 
 // ---- rank pruning with the reference's heap ----------------------------------------------------------
@@ -149,7 +166,7 @@ __device__ __forceinline__ bool insub(unsigned p, unsigned c) {
 }
 
 struct PruneMem {                // LDS regions of the pruning step (they overlay the empty Viterbi cells)
-  lds_u64 *compR;                // [pow2 >= b_cap] sorted: (score bits << 32 | ~prekey at collection time)
+  lds_u64 *compR, *compT;        // [b_cap] each: the sorted top list (score bits << 32 | ~prekey at collection time), and scratch for sorting it
   lds_u32 *vposR;                // [b_cap] current virtual heap position per rank
   lds_u32 *idR;                  // [b_cap] token id per rank
   lds_u32 *hist;                 // [2048]
@@ -158,6 +175,7 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   lds_i32 *occ;                  // [kMaxCand] rank of the element at the candidate's tail position, -1 = none
   lds_i32 *need;                 // [kMaxCand + 4] 1 = (re)scan wanted; [kMaxCand..] = ncand, cursor, finished
   lds_i32 *takers;               // [kMaxCand + 1][kTakers + 1] chain occupants per candidate (+ their count); last row: serial form
+  lds_i32 *ordv;                 // [kMaxCand] candidate slots in the order of their turns
   int b_cap;
 };
 
@@ -210,9 +228,9 @@ __device__ __forceinline__ void heap_extract_serial(HP H, int n, int cnt) {
 template <typename HP>
 __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k, lds_u32 *hist) {
   unsigned need = (unsigned)k;
-  const unsigned diff = sh.maxbits ^ sh.minbits;
+  const unsigned maxb = uni(sh.maxbits), diff = maxb ^ uni(sh.minbits);
   int remaining = diff ? 32 - __clz(diff) : 0;
-  unsigned prefix = remaining < 32 ? (sh.maxbits >> remaining) : 0u;
+  unsigned prefix = remaining < 32 ? (maxb >> remaining) : 0u;
   const int tid = threadIdx.x;
   while (remaining > 0) {
     const int w = remaining < 11 ? remaining : 11;
@@ -245,8 +263,8 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
       if (above < need && need <= above + h0) { sh.sel_digit = 2u * tid; sh.sel_need = need - above; sh.sel_count = h0; }
     }
     __syncthreads();
-    prefix = (prefix << w) | sh.sel_digit;
-    need = sh.sel_need;
+    prefix = (prefix << w) | uni(sh.sel_digit);
+    need = uni(sh.sel_need);
     remaining -= w;
     __syncthreads();
   }
@@ -265,6 +283,13 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
 // work to a compare and a ballot (the chain scan reduces "inside subtree(a_d)" to "shares at least d path bits
 // with q", computed once per element), fetch the next 64 ranks while the current ones are walked, and move
 // values between lanes with v_readlane (the ballot's lane index is uniform), not with LDS permutes.
+// the LDS operations of one wave execute in order: this only keeps the compiler from moving them across
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ bool scR_eq(const PruneMem &pm, int r, unsigned sc) { return ((const lds_u32 *)pm.compR)[2 * r + 1] == sc; }
 constexpr int kMaxCand = 64;             // tail candidates replayed with the parallel scheme; more fall back to the serial loop
 constexpr int kTakers = kMaxL + 2;       // occupants of one root-to-leaf chain
 
@@ -272,8 +297,11 @@ constexpr int kTakers = kMaxL + 2;       // occupants of one root-to-leaf chain
 // ranks (see above).  Returns the rank of the element sitting AT q, or -1 when the chain ends earlier (the
 // element has moved up, or out, before its tail turn).  takers[0..*ntake) receives the ranks of the occupants
 // in chain order (the replay uses them to tell which later candidates an event can affect).  One wave.
-__device__ __noinline__ int chain_scan(const PruneMem &pm, int nB, int n, int i, lds_i32 *takers, int *ntake) {
-  const lds_u32 *vposR = pm.vposR;
+// (Everything goes in and out by value: a reference or an out parameter of a function that is not inlined is a round
+// trip through scratch memory.)  Returns (rank at q, or -1) << 32 | number of occupants written.
+__device__ __noinline__ unsigned long long chain_scan(const lds_u32 *vposR, int nB, int n, int i, lds_i32 *takers) {
+  vposR = uni(vposR);
+  nB = uni(nB); n = uni(n); i = uni(i); takers = uni(takers);
   const int lane = threadIdx.x & 63;
   const unsigned q = (unsigned)(n - i + 1);
   const int Lq = 31 - __clz((int)q);
@@ -304,16 +332,18 @@ __device__ __noinline__ int chain_scan(const PruneMem &pm, int nB, int n, int i,
       d++; from = l + 1;
     }
   }
-  *ntake = d < kTakers ? d : kTakers;
-  return occq;
+  return ((unsigned long long)(unsigned)occq << 32) | (unsigned)(d < kTakers ? d : kTakers);
 }
 
 // The event itself: the element of rank rs leaves the tail position q = n - i + 1, the root element is output,
 // and s runs down the path of larger children among the elements still in the heap (size n - i) until it is
 // >= the larger child (:1372-1381).  The larger child of the hole (left on ties) is the best remaining element
 // of the hole's subtree: the same kind of single scan.  Then s takes its place among the equal scores still in
-// the heap (ranks >= i) by the pre-order of the positions.  Returns the new rank; *hole_out = its new position.
-__device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k, int i, int rs, unsigned *hole_out) {
+// the heap (ranks >= i) by the pre-order of the positions.  Returns the new rank and the new position (packed, see the end).
+__device__ __noinline__ unsigned long long apply_event(lds_u64 *compR_, lds_u32 *vposR_, lds_u32 *idR_, int nB, int n, int k, int i, int rs) {
+  PruneMem pm;
+  pm.compR = uni(compR_); pm.vposR = uni(vposR_); pm.idR = uni(idR_);
+  nB = uni(nB); n = uni(n); k = uni(k); i = uni(i); rs = uni(rs);
   const lds_u32 *vposR = pm.vposR;
   const int lane = threadIdx.x & 63;
   const int nchunk = (nB + 63) >> 6;
@@ -324,11 +354,17 @@ __device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k
     bool walking = true;
     int Lh = 0;
     int c = i >> 6;
+    const lds_u32 *scR = (const lds_u32 *)pm.compR;      // score bits = the high word of a composite
     unsigned vn = (c * 64 + lane < nB) ? vposR[c * 64 + lane] : 0u;
+    unsigned sn = (c * 64 + lane < nB) ? scR[2 * (c * 64 + lane) + 1] : 0u;
     for (; c < nchunk && walking; c++) {
       const int r = c * 64 + lane;
       const unsigned v = (r >= i && r != rs) ? vn : 0u;
-      if (c + 1 < nchunk) vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
+      const unsigned scv = sn;
+      if (c + 1 < nchunk) {
+        vn = ((c + 1) * 64 + lane < nB) ? vposR[(c + 1) * 64 + lane] : 0u;
+        sn = ((c + 1) * 64 + lane < nB) ? scR[2 * ((c + 1) * 64 + lane) + 1] : 0u;
+      }
       const int Lv = v ? 31 - __clz((int)v) : -1;
       int from = 0;
       for (;;) {
@@ -339,7 +375,7 @@ __device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k
         const unsigned long long mk = __ballot(below && lane >= from);
         if (!mk) break;
         const int l = __ffsll((long long)mk) - 1;
-        if (ssc >= (unsigned)(pm.compR[c * 64 + l] >> 32)) { walking = false; break; }
+        if (ssc >= (unsigned)__builtin_amdgcn_readlane((int)scv, l)) { walking = false; break; }
         const unsigned vl = (unsigned)__builtin_amdgcn_readlane((int)v, l);
         hole = vl >> ((31 - __clz((int)vl)) - Lh - 1);
         Lh++;
@@ -347,9 +383,19 @@ __device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k
       }
     }
   }
-  int g0 = rs, g1 = rs + 1;
-  while (g0 > i && (unsigned)(pm.compR[g0 - 1] >> 32) == ssc) g0--;
-  while (g1 < nB && (unsigned)(pm.compR[g1] >> 32) == ssc) g1++;
+  // the equal scores still in the heap, [g0, g1): one look at the 64 ranks around rs, loops only past its edges
+  int g0, g1;
+  {
+    const int r = rs - 32 + lane;
+    const bool eq = r >= i && r < nB && scR_eq(pm, r, ssc);
+    const unsigned long long mk = __ballot(eq);
+    const unsigned below = (unsigned)mk, above = (unsigned)(mk >> 33);     // ranks rs-32..rs-1 / rs+1..rs+31
+    const int ndn = below == 0xffffffffu ? 32 : __clz((int)~below);
+    const int nup = (above & 0x7fffffffu) == 0x7fffffffu ? 31 : __ffs((int)~above) - 1;
+    g0 = rs - ndn; g1 = rs + 1 + nup;
+    if (ndn == 32) while (g0 > i && scR_eq(pm, g0 - 1, ssc)) g0--;
+    if (nup == 31) while (g1 < nB && scR_eq(pm, g1, ssc)) g1++;
+  }
   const unsigned hk = prekey(hole);
   int cnt = 0;
   for (int base = g0; base < g1; base += 64) {
@@ -358,59 +404,57 @@ __device__ __noinline__ int apply_event(const PruneMem &pm, int nB, int n, int k
     cnt += __popcll(__ballot(before));
   }
   const int newr = g0 + cnt;
-  if (lane == 0) {
+  {
+    // the ranks between the old and the new place move by one: 64 at a time, every lane reads before any lane writes
     const unsigned sid = pm.idR[rs];
     const unsigned long long sc = pm.compR[rs];
-    if (newr < rs) for (int r = rs; r > newr; r--) { pm.vposR[r] = pm.vposR[r - 1]; pm.idR[r] = pm.idR[r - 1]; pm.compR[r] = pm.compR[r - 1]; }
-    else for (int r = rs; r < newr; r++) { pm.vposR[r] = pm.vposR[r + 1]; pm.idR[r] = pm.idR[r + 1]; pm.compR[r] = pm.compR[r + 1]; }
-    pm.vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc;
+    if (newr < rs) {
+      for (int top = rs; top > newr; top -= 64) {            // r-1 -> r for r in (newr, top], highest block first
+        const int r = top - lane;
+        const bool mv = r > newr;
+        const unsigned a = mv ? pm.vposR[r - 1] : 0u, b = mv ? pm.idR[r - 1] : 0u;
+        const unsigned long long cc = mv ? pm.compR[r - 1] : 0ull;
+        wave_sync();
+        if (mv) { pm.vposR[r] = a; pm.idR[r] = b; pm.compR[r] = cc; }
+        wave_sync();
+      }
+    } else {
+      for (int bot = rs; bot < newr; bot += 64) {            // r+1 -> r for r in [bot, newr), lowest block first
+        const int r = bot + lane;
+        const bool mv = r < newr;
+        const unsigned a = mv ? pm.vposR[r + 1] : 0u, b = mv ? pm.idR[r + 1] : 0u;
+        const unsigned long long cc = mv ? pm.compR[r + 1] : 0ull;
+        wave_sync();
+        if (mv) { pm.vposR[r] = a; pm.idR[r] = b; pm.compR[r] = cc; }
+        wave_sync();
+      }
+    }
+    if (lane == 0) { pm.vposR[newr] = hole; pm.idR[newr] = sid; pm.compR[newr] = sc; }
   }
   __builtin_amdgcn_wave_barrier();
-  *hole_out = hole;
-  return newr;
+  // new rank | bit 31: an equal score is still in the heap || new position
+  return ((unsigned long long)hole << 32) | (unsigned)newr | (g1 - g0 > 1 ? 0x80000000u : 0u);
 }
 
 // one tail candidate handled start to finish by one wave (the serial form: more than kMaxCand candidates)
 __device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
-  int nt;
-  const int occ = chain_scan(pm, nB, n, i, pm.takers + kMaxCand * (kTakers + 1), &nt);
+  const int occ = uni((int)(chain_scan(pm.vposR, nB, n, i, pm.takers + kMaxCand * (kTakers + 1)) >> 32));
   if (occ < 0) return;
-  unsigned hole;
-  apply_event(pm, nB, n, k, i, occ, &hole);
+  const unsigned hole = uni((unsigned)(apply_event(pm.compR, pm.vposR, pm.idR, nB, n, k, i, occ) >> 32));
   if (hole >= (unsigned)(n - k + 1) && (threadIdx.x & 63) == 0)     // it sits on a tail position again: its turn comes later
     atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
   __builtin_amdgcn_wave_barrier();
 }
 
-// bitonic sort of a[0..N) (N a power of two, 128 <= N <= 2 NT) into DESCENDING order, whole workgroup.  A step
-// with partner distance j <= 64 stays inside the 128 elements one wave owns (LDS operations of a wave
-// execute in order), so only the j >= 128 steps need workgroup barriers.
-__device__ __forceinline__ void bitonic_desc(volatile lds_u64 *a, int N) {
-  const int t = threadIdx.x;
-  for (int kk = 2; kk <= N; kk <<= 1) {
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-      if (j >= 128) __syncthreads();
-      if (t < (N >> 1)) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long x = a[i], y = a[l];
-        const bool first_larger = (i & kk) == 0;
-        if (first_larger ? (x < y) : (x > y)) { a[i] = y; a[l] = x; }
-      }
-      if (j >= 128) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-}
-
 // sort_token_no_order() (:1492): the visiting order of the next frame.  keys[i] = score bits of token i in
 // creation order.  Writes the token ids into svid[0..return value).  Whole workgroup.
 __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
-                           unsigned long long *Hglob, const PruneMem &pm, lds_i32 *svid, int mode,
+                           unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode,
                            unsigned long long *tp = nullptr) {
   const int tid = threadIdx.x;
-  unsigned long long tc_ = tp ? wall_clock64() : 0ull;
-#define PTICK(i) do { if (tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; } } while (0)
+  unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
+#define PTICK(i) do { if (tp && tid == 0 && (JAMD_XBEAM_PROBE != 3 || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
+#define PTICK3(i) do { if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
     __syncthreads();
@@ -427,30 +471,68 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     if (upward && mode != 1 && pm.b_cap > 0) {
       // closed form of the extraction loop
       const unsigned vk = kth_largest(sh, Hh, n, k, pm.hist);
-      if (tid == 0) { sh.nB = 0; sh.fallback = 0; }
+      // The top list sorted by (score descending, pre-order of the heap position ascending).  A bitonic network is 55
+      // dependent steps at this size; the scores are spread well over their range, so the list is sorted by counting
+      // instead: 2048 score bins between the k-th largest score and the maximum (monotone in the score, equal scores
+      // in one bin), a prefix sum over the bins, a scatter by bin, and inside its bin (a handful of entries unless many
+      // scores are equal) every entry counts the composites greater than its own.  The composites are distinct.
+      const unsigned span = uni(sh.maxbits) - vk;
+      const int bshift = span ? max(0, 32 - __clz(span) - 11) : 0;
+      auto bin_of = [&](unsigned scb) { return (int)min(2047u, (scb - vk) >> bshift); };
+      if (tid == 0) { sh.nB = 0; sh.fallback = 0; sh.i_last = 0; }
       for (int i = tid; i < (k + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
+      for (int i = tid; i < 2048; i += NT) pm.hist[i] = 0u;
       __syncthreads();
       for (int p0 = 1; p0 <= n; p0 += NT) {
         const int p = p0 + tid;
         const unsigned hi = p <= n ? (unsigned)(Hh[p] >> 32) : 0u;
         const bool in = p <= n && hi >= vk;
         const int slot = wave_alloc(&sh.nB, in);
-        if (in && slot < pm.b_cap) pm.compR[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
+        if (in && slot < pm.b_cap) {
+          pm.compT[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
+          atomicAdd((unsigned *)&pm.hist[bin_of(hi)], 1u);
+        }
       }
       __syncthreads();
-      const int nB = sh.nB;
+      const int nB = uni(sh.nB);
       PTICK(5);
       if (nB <= pm.b_cap) {
-        // sort the top list by (score descending, pre-order of the heap position ascending): the composites are
-        // distinct (one per heap position); padding sorts last
-        int N = 128; while (N < nB) N <<= 1;
-        for (int e = nB + tid; e < N; e += NT) pm.compR[e] = 0ull;
-        __syncthreads();
-        bitonic_desc(pm.compR, N);
+        {
+          // exclusive prefix from the top bin down: thread t owns bins 2047 - 2t and 2046 - 2t
+          const unsigned c1 = pm.hist[2047 - 2 * tid], c0 = pm.hist[2046 - 2 * tid];
+          const int ex = block_excl_scan(sh, (int)(c1 + c0));
+          pm.hist[2047 - 2 * tid] = (unsigned)ex; pm.hist[2046 - 2 * tid] = (unsigned)ex + c1;
+          __syncthreads();
+          for (int e = tid; e < nB; e += NT) {                  // by bin, any order inside; hist[b] ends as the END of bin b
+            const unsigned long long c = pm.compT[e];
+            pm.compR[atomicAdd((unsigned *)&pm.hist[bin_of((unsigned)(c >> 32))], 1u)] = c;
+          }
+          __syncthreads();
+          for (int e = tid; e < nB; e += NT) {
+            const unsigned long long c = pm.compR[e];
+            const int b = bin_of((unsigned)(c >> 32));
+            const int lo = b == 2047 ? 0 : (int)pm.hist[b + 1], hi = (int)pm.hist[b];
+            int r = lo;
+            for (int x = lo; x < hi; x++) r += pm.compR[x] > c ? 1 : 0;
+            pm.compT[r] = c;
+          }
+          __syncthreads();
+        }
+        { lds_u64 *t_ = pm.compR; pm.compR = pm.compT; pm.compT = t_; }     // the sorted list is what the replay calls compR
+        // An event re-inserts ONE element; the other elements keep their places in the order, and an element whose
+        // score is unique in the list is ranked by its score wherever it sits.  So the replay can stop behind the last
+        // turn at which a TIED element may sit on the tail position (sh.i_last; such an element is one that starts on a
+        // tail position, possibly re-inserted on a later one): the events after it cannot change the order.
         for (int r = tid; r < nB; r += NT) {
-          const unsigned p = prekey_pos(0xffffffffu - (unsigned)pm.compR[r]);
+          const unsigned long long cr = pm.compR[r];
+          const unsigned p = prekey_pos(0xffffffffu - (unsigned)cr);
           pm.vposR[r] = p; pm.idR[r] = (unsigned)Hh[p];
-          if (p >= (unsigned)(n - k + 1)) atomicOr((unsigned *)&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
+          if (p >= (unsigned)(n - k + 1)) {
+            atomicOr((unsigned *)&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
+            const unsigned sc = (unsigned)(cr >> 32);
+            const bool tied = (r > 0 && (unsigned)(pm.compR[r - 1] >> 32) == sc) || (r + 1 < nB && (unsigned)(pm.compR[r + 1] >> 32) == sc);
+            if (tied) atomicMax(&sh.i_last, n - (int)p + 1);
+          }
         }
         __syncthreads();
         PTICK(6);
@@ -458,23 +540,32 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         // scans only READ the rank lists, so all candidates are scanned at once, one wave each; wave 0 then walks
         // the candidates in turn order and applies the events.  An event moves one element (and shifts the ranks
         // inside its tie group): a later candidate is scanned again only if that can change its chain.
-        lds_i32 *ctl = pm.need + kMaxCand;                    // ncand, cursor, finished
+        lds_i32 *ctl = pm.need + kMaxCand;                    // ncand, cursor, finished, last turn that matters
         if (tid < 64) {
-          const int nw = (k + 31) / 32;
+          const int nw = (k + 31) / 32, lim = k;              // all of them: the last turn that matters can move back
           int nc = 0;
-          for (int w = 0; w < nw; w++) {
-            unsigned bits = pm.tailmask[w];
+          for (int w0 = 0; w0 < nw; w0 += 64) {                // one mask word per lane
+            const int w = w0 + tid, rem = lim - w * 32;        // turns i = w * 32 + b + 1 <= lim
+            unsigned bits = w < nw ? pm.tailmask[w] : 0u;
+            bits &= rem >= 32 ? 0xffffffffu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+            const int c = __popc(bits);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (tid >= off) incl += o; }
+            int at = nc + incl - c;
             while (bits) {
               const int b = __ffs((int)bits) - 1;
               bits &= bits - 1u;
-              const int i = w * 32 + b + 1;
-              if (i <= k) { if (nc < kMaxCand && tid == 0) { pm.cand[nc] = i; pm.need[nc] = 1; } nc++; }
+              if (at < kMaxCand) { pm.cand[at] = w * 32 + b + 1; pm.need[at] = 1; pm.ordv[at] = at; }
+              at++;
             }
+            nc += __shfl(incl, 63, 64);
           }
-          if (tid == 0) { ctl[0] = nc; ctl[1] = 0; ctl[2] = 0; }
+          if (tid == 0) { ctl[0] = nc; ctl[1] = 0; ctl[2] = 0; ctl[3] = sh.i_last; }
         }
         __syncthreads();
-        const int ncand0 = ctl[0];
+        if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tc3_ = wall_clock64();   // slot 7 - (4 + 5 + 6) = everything before the replay
+        const int ncand0 = uni(ctl[0]);
         if (ncand0 > kMaxCand) {
           if (tid < 64) {                                     // serial form, straight off the mask
             const int nw = (k + 31) / 32;
@@ -490,40 +581,53 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
               }
             }
           }
-        } else if (ncand0 > 0) {
+        } else if (ncand0 > 0 && uni(ctl[3]) > 0) {
+          // A candidate keeps its slot (turn, occupant, chain occupants); ordv[] lists the slots in turn order, so a
+          // candidate born of an event is one shifted int per later candidate.
           for (;;) {
-            // (re)scan: candidate c on wave c % 16
+            // (re)scan: the candidate at position c on wave c % 16
             {
-              const int ncand = ctl[0], wv = tid >> 6;
-              for (int c = ctl[1] + wv; c < ncand; c += NT / 64) {
-                if (!pm.need[c]) continue;
-                lds_i32 *tk = pm.takers + c * (kTakers + 1);
-                int nt;
-                const int oc = chain_scan(pm, nB, n, pm.cand[c], tk, &nt);
-                if ((tid & 63) == 0) { pm.occ[c] = oc; tk[kTakers] = nt; pm.need[c] = 0; }
+              const int ncand = uni(ctl[0]), wv = uni(tid >> 6), ilast = uni(ctl[3]);
+              for (int c = uni(ctl[1]) + wv; c < ncand; c += NT / 64) {
+                const int sl = uni(pm.ordv[c]);
+                const int turn = uni(pm.cand[sl]);
+                if (!uni(pm.need[sl]) || turn > ilast) continue;
+                lds_i32 *tk = pm.takers + sl * (kTakers + 1);
+                const unsigned long long cs = chain_scan(pm.vposR, nB, n, turn, tk);
+                if ((tid & 63) == 0) { pm.occ[sl] = (int)(cs >> 32); tk[kTakers] = (int)(unsigned)cs; pm.need[sl] = 0; }
               }
             }
             __syncthreads();
+            PTICK3(4);
             if (tid < 64) {
-              int ncand = ctl[0], c = ctl[1];
+              const int lane = tid;
+              int ncand = uni(ctl[0]), c = uni(ctl[1]), ilast = uni(ctl[3]);
               for (; c < ncand; c++) {
-                if (pm.need[c]) break;                        // invalidated by an earlier event: next round
-                const int rs = pm.occ[c];
+                const int sl = uni(pm.ordv[c]);
+                const int i = uni(pm.cand[sl]), nd = uni(pm.need[sl]), rs = uni(pm.occ[sl]);
+                if (i > ilast) { c = ncand; break; }          // nothing behind this turn can change the order
+                if (nd) break;                                // invalidated by an earlier event: next round
                 if (rs < 0) continue;
-                const int i = pm.cand[c];
-                unsigned hole;
-                const int newr = apply_event(pm, nB, n, k, i, rs, &hole);
+                const unsigned long long ev = apply_event(pm.compR, pm.vposR, pm.idR, nB, n, k, i, rs);
+                const unsigned hole = uni((unsigned)(ev >> 32));
+                const int newr = uni((int)((unsigned)ev & 0x7fffffffu));
+                const bool tied = (uni((unsigned)ev) & 0x80000000u) != 0u;
+                if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tp[6] += 100;   // events (1 us each)
                 const int lo = newr < rs ? newr : rs, hi = newr < rs ? rs : newr;
-                // which later candidates can this change?  (ranks outside [lo, hi] keep their numbers)  One lane each.
-                for (int c0 = c + 1; c0 < ncand; c0 += 64) {
-                  const int c2 = c0 + (tid & 63);
-                  if (c2 >= ncand || pm.need[c2]) continue;
-                  const int i2 = pm.cand[c2];
-                  if (hi < i2 - 1) continue;                  // s is out before that turn
-                  const lds_i32 *tk = pm.takers + c2 * (kTakers + 1);
-                  const int nt = tk[kTakers], oc2 = pm.occ[c2];
+                // which later candidates can this change?  (ranks outside [lo, hi] keep their numbers)  One lane each;
+                // the chain occupants are read with a fixed trip count so the loads go out together.
+                const int c2 = c + 1 + lane;                  // ncand <= kMaxCand = 64: one pass
+                int sl2 = 0, i2 = 0x7fffffff;
+                if (c2 < ncand) { sl2 = pm.ordv[c2]; i2 = pm.cand[sl2]; }
+                if (c2 < ncand && !pm.need[sl2] && hi >= i2 - 1) {        // (hi < i2 - 1: s is out before that turn)
+                  const lds_i32 *tk = pm.takers + sl2 * (kTakers + 1);
+                  const int nt = tk[kTakers], oc2 = pm.occ[sl2];
                   bool hit = false; int dat = 0;
-                  for (int x = 0; x < nt; x++) { const int tr = tk[x]; if (tr >= lo && tr <= hi) hit = true; if (tr < lo) dat++; }
+#pragma unroll
+                  for (int x = 0; x < kTakers; x++) {
+                    const int tr = tk[x];
+                    if (x < nt) { if (tr >= lo && tr <= hi) hit = true; if (tr < lo) dat++; }
+                  }
                   if (!hit && !(oc2 >= 0 && oc2 < lo)) {
                     // would s, now at `hole`, be taken when the walk passes it?  It shares m levels with the chain.
                     const unsigned q2 = (unsigned)(n - i2 + 1);
@@ -533,38 +637,36 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
                     const int m = L - (x ? 32 - __clz((int)x) : 0);
                     hit = m >= dat;
                   }
-                  if (hit) pm.need[c2] = 1;
+                  if (hit) pm.need[sl2] = 1;
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (hole >= (unsigned)(n - k + 1)) {          // s sits on a tail position again: a new candidate, later turn
+                wave_sync();
+                if (hole >= (unsigned)(n - k + 1)) {          // s sits on a tail position again: a candidate with a later turn
                   const int inew = n - (int)hole + 1;
-                  if (ncand >= kMaxCand) { if (tid == 0) { ctl[0] = kMaxCand + 1; } ncand = kMaxCand + 1; break; }   // overflow: finish serially
-                  int at = ncand;
-                  while (at > c + 1 && pm.cand[at - 1] > inew) at--;
-                  if (!(at > c + 1 && pm.cand[at - 1] == inew) && !(at < ncand && pm.cand[at] == inew)) {
-                    if (tid == 0) {
-                      for (int x = ncand; x > at; x--) {
-                        pm.cand[x] = pm.cand[x - 1]; pm.occ[x] = pm.occ[x - 1]; pm.need[x] = pm.need[x - 1];
-                        for (int y = 0; y <= kTakers; y++) pm.takers[x * (kTakers + 1) + y] = pm.takers[(x - 1) * (kTakers + 1) + y];
-                      }
-                      pm.cand[at] = inew; pm.need[at] = 1; pm.occ[at] = -1;
-                      ctl[0] = ncand + 1;
-                    }
+                  if (tied && inew > ilast) ilast = inew;
+                  const unsigned long long eqm = __ballot(c2 < ncand && i2 == inew);
+                  if (eqm) {                                  // already a candidate: two elements share the position now
+                    const int e = c + 1 + (__ffsll((long long)eqm) - 1);
+                    if (lane == 0) pm.need[pm.ordv[e]] = 1;
+                  } else {
+                    if (ncand >= kMaxCand) { if (lane == 0) ctl[0] = kMaxCand + 1; ncand = kMaxCand + 1; break; }   // overflow: finish serially
+                    const int at = c + 1 + __popcll(__ballot(c2 < ncand && i2 < inew));
+                    const int mvslot = (c2 >= at && c2 < ncand) ? sl2 : -1;
+                    wave_sync();
+                    if (mvslot >= 0) pm.ordv[c2 + 1] = mvslot;
+                    if (lane == 0) { pm.ordv[at] = ncand; pm.cand[ncand] = inew; pm.need[ncand] = 1; pm.occ[ncand] = -1; ctl[0] = ncand + 1; }
                     ncand++;
-                  } else if (tid == 0) {                      // already a candidate: two elements share the position now
-                    const int e = (at > c + 1 && pm.cand[at - 1] == inew) ? at - 1 : at;
-                    pm.need[e] = 1;
                   }
-                  __builtin_amdgcn_wave_barrier();
+                  wave_sync();
                 }
               }
-              if (tid == 0) { ctl[1] = c; ctl[2] = (c >= ncand || ncand > kMaxCand) ? 1 : 0; }
+              if (lane == 0) { ctl[1] = c; ctl[2] = (c >= ncand || ncand > kMaxCand) ? 1 : 0; ctl[3] = ilast; }
             }
             __syncthreads();
-            if (ctl[2]) break;
+            PTICK3(5);
+            if (uni(ctl[2])) break;
           }
           if (ctl[0] > kMaxCand && tid < 64) {                // candidate table overflowed mid-way: the rest serially
-            for (int i = pm.cand[ctl[1]]; i <= k; i++) {
+            for (int i = pm.cand[pm.ordv[ctl[1]]]; i <= k; i++) {
               bool any = false;
               for (int r0 = 0; r0 < nB; r0 += 64) { const int r = r0 + (tid & 63); if (__ballot(r < nB && pm.vposR[r] == (unsigned)(n - i + 1))) { any = true; break; } }
               if (any) replay_tail(pm, nB, n, k, i);
@@ -626,13 +728,14 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);
   lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);
   PruneMem pm;
-  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr);
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
   pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
   pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
+  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
   pm.b_cap = xw.b_cap;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
@@ -683,14 +786,16 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     }
   }
   float thr = resume ? ss->thr : JAMD_LOG_ZERO;
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64();
-#define PHASE(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; } } while (0)
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tc2 = tc;
+  const unsigned long long cyc0 = clock64(), wall0 = tc;   // JAMD_XBEAM_PROBE == 4: shader clock under this kernel
+#define PHASE(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; tc2 = n_; } } while (0)
+#define PROBE(g, i) do { if (TIMED && JAMD_XBEAM_PROBE == (g) && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc2; tc2 = n_; } } while (0)
   int max_tokens = resume ? ss->max_tokens : 1;
   bool stopped = false;
   __syncthreads();
 
   for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
-    const int n_surv = sh.n_surv;
+    const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
     const bool last = (t == T);
@@ -724,14 +829,15 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       if (tid == 0) { dbase[n_surv] = carry; sh.n_atom = acarry; }
       nbits = last ? 0 : carry + (dfa ? (t == 0 ? lx.ninit : 0) : XW + lx.nshared);
     }
+    PROBE(1, 4);
     const int nwords = (nbits + 31) >> 5;
     const bool bm_in_lds = nwords <= xw.bm_words;
     unsigned *bm = bm_in_lds ? (unsigned *)(dyn_lds + xw.off_bm) : reinterpret_cast<unsigned *>(ub + xw.o_bitmap);   // generic on purpose: a few accesses per token
     __syncthreads();
 
-    auto intra_candidate = [&](const Tok &tk, int j, int next_node, float a, int sub) {
+    // nscid = successor id of next_node (0 for the self loop): the caller loads it beside the transition record
+    auto intra_candidate = [&](const Tok &tk, int j, int next_node, float a, int sub, int nscid) {
       float tmpsum = tk.score + a;
-      const int nscid = (next_node != tk.node) ? lx.scid(next_node) : 0;
       if (nscid != 0) {
         const float ng = max_successor_prob(lx, tk.last_cword, nscid, memo) * lmw + pen;
         tmpsum -= tk.last_lscore;
@@ -748,13 +854,14 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         if (tk.score <= JAMD_LOG_ZERO) continue;
         if (tk.score < thr) continue;
         const int4 na = lx.node_a(node);
+        const int nscid1 = (node + 1 < lx.nnode) ? lx.scid(node + 1) : 0;   // independent of na: both loads in flight together
         const int e0 = na.z, e1 = na.w;
         if (e1 > e0) {
           const int b0 = atomicAdd(&sh.n_arc, e1 - e0);
           for (int e = e0; e < e1; e++) ARCQ(b0 + e - e0) = make_int2(j | ((2 + e - e0) << 16), e);   // (source | transition number, arc)
         }
-        { const float a = __int_as_float(na.x); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node, a, 0); }
-        { const float a = __int_as_float(na.y); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node + 1, a, 1); }
+        { const float a = __int_as_float(na.x); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node, a, 0, 0); }
+        { const float a = __int_as_float(na.y); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node + 1, a, 1, nscid1); }
       }
       if (sword >= 0) {
         const int ai = sv_atom[j];                         // save_trellis() :2209-2247, numbered in step 0
@@ -774,12 +881,15 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       }
     }
     __syncthreads();
+    PROBE(1, 5);
     if (!last) {
-      const int n_arc = sh.n_arc;
+      const int n_arc = uni(sh.n_arc);
       for (int q = tid; q < n_arc; q += NT) {
         const int2 it = ARCQ(q);
         const int j = it.x & 0xffff;
-        intra_candidate(lds_tok_load(sv, j), j, lx.ac_to(it.y), lx.ac_a(it.y), it.x >> 16);
+        const int to = lx.ac_to(it.y);
+        const Tok tk = lds_tok_load(sv, j);
+        intra_candidate(tk, j, to, lx.ac_a(it.y), it.x >> 16, to != tk.node ? lx.scid(to) : 0);
       }
       __syncthreads();
     }
@@ -809,26 +919,60 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       if (t == 0)
         for (int e = tid; e < lx.ninit; e += NT) xpush(sh, cl, lx.init_node(e), lx.init_lscore(e), (unsigned)e);
     } else {
-      const int n_we = sh.n_we, niso = lx.isolatenum;
-      const int total = n_we * niso;
-      for (int x = tid; x < total; x += NT) {
-        const int w = x / niso, i = x - w * niso;
-        const int j = welist[w];
-        const Tok tk = lds_tok_load(sv, j);
-        const int sword = tk.pad0;
-        const bool tr = lx.is_transparent(sword) != 0;
-        const int last_word = tr ? tk.last_cword : sword;
-        const int2 ir = lx.iso_root(i);
-        const float p = (last_word < 0) ? 0.0f
-                        : lx.iwtab ? lx.iwtab[(size_t)lx.wton(last_word) * niso + i]
-                        : bigram_prob(lx, lx.wton(last_word), lx.wton(ir.y)) + lx.cprob(ir.y);
-        float tmpsum = tk.score;
-        tmpsum += lx.wordend_a(sword);
-        const float ng = p * lmw + pen;
-        tmpsum += ng;
-        if (tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword)) tmpsum += lx.lm_penalty_trans;
-        xpush(sh, cl, ir.x, tmpsum, ((unsigned)j << s1) | (unsigned)(XW + xw.iso_rank_off + i));
+      // beam_inter_word() :2296-2440, root by root: a word end is reduced to (score + exit transition, LM context,
+      // source position) once, then every isolated root takes the best candidate and the earliest visit over the
+      // word ends with independent, coalesced reads of the cross-word LM table -- one cell update per root
+      // instead of one per (word end, root).  The result is the one of pushing the candidates one by one
+      // (a cell keeps a maximum and the first visit a minimum).
+      const int n_we = uni(sh.n_we), niso = lx.isolatenum;
+      lds_v4 *werec = (lds_v4 *)tpre;                           // [kWeChunk] (tpre is free until step C0)
+      constexpr int kWeChunk = NT / 4;
+      for (int w0 = 0; w0 < n_we; w0 += kWeChunk) {
+        const int nrec = min(kWeChunk, n_we - w0);
+        if (tid < nrec) {
+          const int j = welist[w0 + tid];
+          const Tok tk = lds_tok_load(sv, j);
+          const int sword = tk.pad0;
+          const bool tr = lx.is_transparent(sword) != 0;
+          const int last_word = tr ? tk.last_cword : sword;
+          float bs = tk.score;
+          bs += lx.wordend_a(sword);
+          const bool trans2 = tr && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
+          u32x4 rec;
+          rec.x = __float_as_uint(bs); rec.y = (unsigned)(last_word < 0 ? -1 : lx.wton(last_word));
+          rec.z = (unsigned)j | (trans2 ? 0x80000000u : 0u); rec.w = (unsigned)last_word;
+          werec[tid] = rec;
+        }
+        __syncthreads();
+        int parts = NT / (niso > 0 ? niso : 1);
+        if (parts < 1) parts = 1;
+        if (parts > nrec) parts = nrec;
+        const int total = niso * parts;
+        for (int x = tid; x < total; x += NT) {
+          const int part = x / niso, i = x - part * niso;
+          const int2 ir = lx.iso_root(i);
+          unsigned long long best = 0ull; unsigned nfirst = 0u;
+          for (int w = part; w < nrec; w += parts) {
+            const u32x4 rec = werec[w];
+            const int ctx = (int)rec.y;
+            const float p = (ctx < 0) ? 0.0f
+                            : lx.iwtab ? lx.iwtab[(size_t)ctx * niso + i]
+                            : bigram_prob(lx, ctx, lx.wton(ir.y)) + lx.cprob(ir.y);
+            float tmpsum = __uint_as_float(rec.x);
+            const float ng = p * lmw + pen;
+            tmpsum += ng;
+            if (rec.z & 0x80000000u) tmpsum += lx.lm_penalty_trans;
+            if (tmpsum <= JAMD_LOG_ZERO) continue;
+            const unsigned nv = ~(((rec.z & 0x7fffffffu) << s1) | (unsigned)(XW + i));
+            const unsigned long long key = ((unsigned long long)ordz(tmpsum) << 32) | nv;
+            if (key > best) best = key;
+            if (nv > nfirst) nfirst = nv;
+          }
+          if (best != 0ull) xpush_key(sh, cl, ir.x, best, nfirst);
+        }
+        __syncthreads();
       }
+      PROBE(1, 7);
       if (sh.we_best != 0ull) {                       // beam_inter_word_factoring() :2549-2637
         const unsigned long long kb = sh.we_best;
         const float best_score = unord((unsigned)(kb >> 32));
@@ -851,7 +995,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     PHASE(1);
 
     // ---- C0: creation order = rank of the node's first visit (create_token() :1148)
-    const int n_new = sh.n_new;
+    const int n_new = uni(sh.n_new);
     if (n_new > max_tokens) max_tokens = n_new;
     if (n_new > wk.tok_cap) {              // cannot happen (tok_cap bounds the reachable nodes); never write past the arrays
       if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
@@ -870,11 +1014,13 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         atomicOr(&bm[dense >> 5], 1u << (dense & 31));
       }
       __syncthreads();
+      PROBE(2, 4);
       int cnt = 0;
       for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm[w]); }
       const int ex = block_excl_scan(sh, cnt);
       tpre[tid] = (unsigned)ex;
       __syncthreads();
+      PROBE(2, 5);
     }
     // ---- C: finalize the touched nodes: winner's payload + acoustic score (:2944-2951), stored at the
     //         token's creation index
@@ -946,8 +1092,11 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
               ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
               l_ls[k] = ng;
             } else if (iso) {                                // beam_inter_word() :2430-2438
-              const int wn = lx.scword(nr[k].y);
-              const float p = (last_word < 0) ? 0.0f : bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn);
+              float p = 0.0f;
+              if (last_word >= 0) {
+                if (lx.iwtab) p = lx.iwtab[(size_t)lx.wton(last_word) * lx.isolatenum + (sub - XW)];
+                else { const int wn = lx.scword(nr[k].y); p = bigram_prob(lx, lx.wton(last_word), lx.wton(wn)) + lx.cprob(wn); }
+              }
               l_ls[k] = p * lmw + pen;
             } else {                                         // beam_inter_word_factoring() :2572-2573
               l_ls[k] = lx.fscore(-nr[k].y) * lmw + pen;
@@ -1015,8 +1164,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         }
       }
       __syncthreads();
+      PROBE(2, 6);
       // state-set reductions (outprob_cd(), outprob.c:287-400): four lanes per (token, set)
-      const int n_set = sh.n_arc;
+      const int n_set = uni(sh.n_arc);
       const int sub = tid & 3, lane = tid & 63;
       for (int q0 = 0; q0 < n_set; q0 += NT / 4) {
         const int q = q0 + (tid >> 2);
@@ -1107,7 +1257,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, TIMED ? ph : nullptr);
+    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3)) ? ph : nullptr);
     for (int j = tid; j < n_keep; j += NT) lds_tok_store(sv, j, CUR(welist[j]));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
@@ -1174,6 +1324,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     res->natom = natom; res->ties = 0; res->max_tokens = max_tokens;
     res->ties_node = 0; res->ties_wordend = 0; res->ties_cut = 0;
     if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+    if (TIMED && JAMD_XBEAM_PROBE == 4) res->phase_us[7] = (int)((clock64() - cyc0) * 100ull / (wall_clock64() - wall0));   // MHz
     res->frames = T;
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
@@ -1198,13 +1349,14 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   PruneMem pm;
-  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr);
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
   pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
   pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
+  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
   pm.b_cap = xw.b_cap;
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
@@ -1234,7 +1386,6 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   int jb = 1; while ((1 << jb) < beam + 2) jb++;
   if (s1 + jb > 32) return -1;
   xw->s1 = s1;
-  xw->iso_rank_off = 0;
   // LDS image
   int at = beam * (int)sizeof(Tok);
   auto place = [&](int *off, int bytes) { *off = at; at = (at + bytes + 15) & ~15; };
@@ -1264,11 +1415,9 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   // entries, then the heap (a frame with more tokens than it holds builds its heap in global memory)
   at = cells_at;
   xw->b_cap = beam + 256;
-  int p2 = 128; while (p2 < xw->b_cap) p2 <<= 1;             // the sort pads the list to a power of two
-  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 3 * kMaxCand + 4 + (kMaxCand + 1) * (kTakers + 1));
-  if (p2 > 2 * NT || 8 * p2 + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) { xw->b_cap = 0; p2 = 0; }
-  xw->off_comp = 0;
-  place(&xw->off_compr, 8 * p2);
+  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 4 * kMaxCand + 4 + (kMaxCand + 1) * (kTakers + 1));
+  if (16 * xw->b_cap + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) xw->b_cap = 0;
+  place(&xw->off_compr, 16 * xw->b_cap);
   place(&xw->off_vpos, 4 * xw->b_cap);
   place(&xw->off_id, 4 * xw->b_cap);
   place(&xw->off_hist, xw->b_cap ? 4 * 2048 : 0);

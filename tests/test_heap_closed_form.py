@@ -10,7 +10,13 @@ ascending).  An extraction whose tail element IS in B ("event") re-inserts that 
 path and stops at the first hole whose larger child is not greater -- from then on it counts as the element of that
 position.  Who sits where at a given time follows from the order alone: a position holds the best remaining element
 of its subtree that is not sitting further up, and because the subtrees along a root-to-leaf chain are nested, the
-occupants of a chain come out of ONE scan over the remaining elements in order."""
+occupants of a chain come out of ONE scan over the remaining elements in order.
+
+Which events matter.  An event changes the place of ONE element (the re-inserted one); an element whose score is unique in
+B is ranked by its score wherever it sits.  The elements that can ever be re-inserted are those that start on a tail
+position.  So the replay may stop behind the last turn at which a TIED element can sit on the tail position (`i_last`,
+moved back when a tied element is re-inserted on a later tail position); earlier events of untied elements are still
+replayed, because they decide who sits where when that turn comes."""
 import numpy as np
 import pytest
 
@@ -47,17 +53,24 @@ def heapify_upward(score):
     return ti
 
 
-def closed_form_order(score, k):
-    """tindex[n-k .. n-1] after sort_token_upward(k, n), without running its second loop."""
+def closed_form_order(score, k, skip=True, stats=None):
+    """tindex[n-k .. n-1] after sort_token_upward(k, n), without running its second loop.  skip: stop the replay of
+    the events behind the last turn that can change the order."""
     n = len(score)
     heap = heapify_upward(score)
     vk = sorted(score, reverse=True)[k - 1]
     vpos = {idx: pos for pos, idx in enumerate(heap, 1) if score[idx] >= vk}
     key = lambda x: (-score[x], prekey(vpos[x]))
     order = sorted(vpos, key=key)
+    mult = {}
+    for e in vpos:
+        mult[score[e]] = mult.get(score[e], 0) + 1
+    i_last = max([n - p + 1 for e, p in vpos.items() if p >= n - k + 1 and mult[score[e]] > 1], default=0)
     out = []
     for i in range(1, k + 1):
         out.append(order[i - 1])
+        if skip and i > i_last:
+            continue
         q = n - i + 1
         if not any(vpos[e] == q for e in order[i:]):
             continue
@@ -86,6 +99,10 @@ def closed_form_order(score, k):
                     break
                 hole = c
         vpos[s] = hole
+        if stats is not None:
+            stats[0] += 1
+        if hole >= n - k + 1 and any(score[x] == score[s] for x in order[i:] if x != s):
+            i_last = max(i_last, n - hole + 1)     # a tied element on a later tail position
         order[i:] = sorted(order[i:], key=key)
     return out[::-1]
 
@@ -102,7 +119,10 @@ def test_closed_form_equals_sequential_heap(oracle, seed):
         levels = int(rng.choice([2, 3, 5, 10, 30, 1000]))
         score = [float(x) for x in -rng.integers(0, levels, n) * 0.5 - 100.0]
         want = list(oracle.sort_token_no_order(np.array(score, np.float32), k))
-        got = closed_form_order(score, k)
-        assert got == want, (n, k, levels)
+        full, cut = [0], [0]
+        assert closed_form_order(score, k, skip=False, stats=full) == want, (n, k, levels)
+        assert closed_form_order(score, k, skip=True, stats=cut) == want, (n, k, levels)
+        assert cut[0] <= full[0]
         checked += 1
-    assert checked > 60
+        events += full[0]
+    assert checked > 60 and events > 0

@@ -17,7 +17,7 @@ def _scores(rng, n, levels):
 
 
 @pytest.mark.parametrize("mode", ["exact", "exact_serial"])
-@pytest.mark.parametrize("beam", [1, 2, 7, 33, 200, 800])
+@pytest.mark.parametrize("beam", [1, 2, 7, 33, 200, 800, 1500])
 def test_prune_order_fuzz(engine, oracle, beam, mode):
     g = load_beam_golden("beam_rank.npz")
     lx = lib.Lexicon(engine, g["lex"])
