@@ -33,6 +33,7 @@
 // Everything else -- LM factoring, outprob_style(), trellis atoms, score pruning -- is the arithmetic of
 // beam_pass1_kernel.  The word trellis equals the reference's bit for bit, ties included
 // (tests/test_beam_gpu.py::test_exact_*).  N-gram, grammar and word-list lexicons; non-multipath.
+#include <type_traits>
 #include "beam_common.h"
 #include "beam_exact.h"
 
@@ -112,6 +113,13 @@ __device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin
 template <typename T>
 __device__ __forceinline__ T JAMD_LDS *uni(T JAMD_LDS *p) {
   return (T JAMD_LDS *)(unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)p);
+}
+
+// the LDS operations of one wave execute in order: this only keeps the compiler from moving them across
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ unsigned ordz(float f) { return ord(f + 0.0f); }   // -0.0 and +0.0 compare equal as floats
@@ -211,6 +219,94 @@ __device__ __forceinline__ void heapify_levels(HP H, int n) {
   }
 }
 
+// The same loop for a heap in LDS, with the levels overlapped.  A sift-down that starts at depth L is at depth L + t
+// after t steps, where it reads the two children below and writes its own level; the sift that started one level
+// further down wrote that children's level one step earlier IF it started one step earlier.  So the sifts of
+// different levels can run together, one step apart (deepest level first), as long as a step's reads come before
+// its writes and see the writes of the step before -- which is how the lanes of ONE wave execute.  Each wave takes
+// four of the 64 subtrees rooted at depth 6 (several sifts per lane, their LDS reads in flight together); after one
+// workgroup barrier wave 0 finishes depths 5..0 the same way.  A heap of 3 000 entries takes 10 + 17 dependent steps
+// and one barrier instead of 66 steps and 11 barriers; the result is the sequential one (every sift reads
+// exactly the values it would read in the reference's order).
+struct SiftSlot { int parent, t0; unsigned long long s; bool live; };
+
+template <bool UP, int R>
+__device__ __forceinline__ void sift_overlapped(lds_u64 *H, int n, SiftSlot (&sl)[R], int gsteps) {
+  for (int g = 0; g < gsteps; g++) {
+    u32x4 ch[R]; bool run[R], leaf[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {                              // reads of this step
+      run[r] = sl[r].live && g >= sl[r].t0;
+      leaf[r] = 2 * sl[r].parent > n;
+      ch[r] = u32x4{0u, 0u, 0u, 0u};
+      if (run[r] && !leaf[r]) ch[r] = *(const lds_v4 *)&H[2 * sl[r].parent];
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) {                              // decisions and writes
+      if (!run[r]) { any |= sl[r].live; continue; }
+      const int child = 2 * sl[r].parent;
+      const unsigned a = ch[r].y, b = ch[r].w, sv = (unsigned)(sl[r].s >> 32);
+      const bool right = child < n && (UP ? (a < b) : (a > b));
+      const unsigned cv = right ? b : a;
+      if (leaf[r] || (UP ? (sv >= cv) : (sv <= cv))) { H[sl[r].parent] = sl[r].s; sl[r].live = false; }
+      else {
+        H[sl[r].parent] = right ? (((unsigned long long)ch[r].w << 32) | ch[r].z) : (((unsigned long long)ch[r].y << 32) | ch[r].x);
+        sl[r].parent = child + (right ? 1 : 0);
+        any = true;
+      }
+    }
+    wave_sync();
+    if (!__any(any)) break;
+  }
+}
+
+constexpr int kSplitLevel = 6;           // depths >= 6: 64 subtrees, four per wave; depths < 6: wave 0
+template <bool UP, int R>
+__device__ __forceinline__ void heapify_subtrees(lds_u64 *H, int n, int Ltop, int Lmax) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int D = Ltop - kSplitLevel + 1, top = n / 2;       // a subtree has 2^D - 1 roots: index 1 .. 2^D - 1 inside it
+  SiftSlot sl[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int idx = r * 64 + lane;                          // R * 64 = 4 << D
+    const int sub = idx >> D, within = idx & ((1 << D) - 1);
+    const int d = within ? 31 - __clz(within) : 0;
+    const int pos = (((1 << kSplitLevel) + 4 * wv + sub) << d) + (within - (1 << d));
+    sl[r].live = within != 0 && sub < 4 && pos <= top;
+    sl[r].parent = pos; sl[r].t0 = Ltop - (kSplitLevel + d);
+    sl[r].s = sl[r].live ? H[pos] : 0ull;
+  }
+  sift_overlapped<UP, R>(H, n, sl, (Ltop - kSplitLevel) + (Lmax - kSplitLevel + 1));
+}
+
+// returns false when the heap is too deep for the register slots (the caller runs heapify_levels)
+template <bool UP>
+__device__ __forceinline__ bool heapify_overlapped(lds_u64 *H, int n) {
+  const int top = n / 2;
+  if (top < 1) return true;
+  const int Ltop = 31 - __clz(top), Lmax = 31 - __clz(n);
+  if (Ltop >= kSplitLevel) {
+    const int D = Ltop - kSplitLevel + 1;
+    if (D <= 5) heapify_subtrees<UP, 2>(H, n, Ltop, Lmax);
+    else if (D == 6) heapify_subtrees<UP, 4>(H, n, Ltop, Lmax);
+    else if (D == 7) heapify_subtrees<UP, 8>(H, n, Ltop, Lmax);
+    else return false;
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) {
+    const int r = (int)threadIdx.x + 1, L = 31 - __clz(r);
+    const int Lt = Ltop < kSplitLevel ? Ltop : kSplitLevel - 1;
+    SiftSlot sl[1];
+    sl[0].live = r <= top && L <= Lt;
+    sl[0].parent = r; sl[0].t0 = Lt - L;
+    sl[0].s = sl[0].live ? H[r] : 0ull;
+    sift_overlapped<UP, 1>(H, n, sl, Lt + (Lmax + 1));
+  }
+  __syncthreads();
+  return true;
+}
+
 // second loop (:1368-1383) on one lane
 template <bool UP, typename HP>
 __device__ __forceinline__ void heap_extract_serial(HP H, int n, int cnt) {
@@ -232,12 +328,12 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
   int remaining = diff ? 32 - __clz(diff) : 0;
   unsigned prefix = remaining < 32 ? (maxb >> remaining) : 0u;
   const int tid = threadIdx.x;
+  for (int i = tid; i < 2048; i += NT) hist[i] = 0;      // every pass leaves the histogram cleared (three barriers a pass)
+  __syncthreads();
   while (remaining > 0) {
     const int w = remaining < 11 ? remaining : 11;
     const int shift = remaining - w;
     const unsigned dmask = (1u << w) - 1u;
-    for (int i = tid; i < 2048; i += NT) hist[i] = 0;
-    __syncthreads();
     for (int p = 1 + tid; p <= n; p += NT) {
       const unsigned b = (unsigned)(H[p] >> 32);
       const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
@@ -246,6 +342,7 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
     __syncthreads();
     {
       const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+      hist[2 * tid] = 0u; hist[2 * tid + 1] = 0u;
       const unsigned pair = h0 + h1;
       unsigned incl = pair;
       const int ln = tid & 63;
@@ -263,10 +360,9 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
       if (above < need && need <= above + h0) { sh.sel_digit = 2u * tid; sh.sel_need = need - above; sh.sel_count = h0; }
     }
     __syncthreads();
-    prefix = (prefix << w) | uni(sh.sel_digit);
+    prefix = (prefix << w) | uni(sh.sel_digit);      // (written again only behind two more barriers)
     need = uni(sh.sel_need);
     remaining -= w;
-    __syncthreads();
   }
   return prefix;
 }
@@ -283,12 +379,6 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
 // work to a compare and a ballot (the chain scan reduces "inside subtree(a_d)" to "shares at least d path bits
 // with q", computed once per element), fetch the next 64 ranks while the current ones are walked, and move
 // values between lanes with v_readlane (the ballot's lane index is uniform), not with LDS permutes.
-// the LDS operations of one wave execute in order: this only keeps the compiler from moving them across
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ bool scR_eq(const PruneMem &pm, int r, unsigned sc) { return ((const lds_u32 *)pm.compR)[2 * r + 1] == sc; }
 constexpr int kMaxCand = 64;             // tail candidates replayed with the parallel scheme; more fall back to the serial loop
 constexpr int kTakers = kMaxL + 2;       // occupants of one root-to-leaf chain
@@ -453,7 +543,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
                            unsigned long long *tp = nullptr) {
   const int tid = threadIdx.x;
   unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
-#define PTICK(i) do { if (tp && tid == 0 && (JAMD_XBEAM_PROBE != 3 || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
+#define PTICK(i) do { if (tp && tid == 0 && ((JAMD_XBEAM_PROBE != 3 && JAMD_XBEAM_PROBE != 5) || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
+#define PTICK5(i) do { if (JAMD_XBEAM_PROBE == 5 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
 #define PTICK3(i) do { if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
@@ -465,7 +556,11 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
   auto run = [&](auto Hh) -> void {
     for (int i = tid; i < n; i += NT) Hh[i + 1] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
     __syncthreads();
-    if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n);
+    PTICK5(4);
+    bool heaped = false;
+    if constexpr (std::is_same<decltype(Hh), lds_u64 *>::value) heaped = upward ? heapify_overlapped<true>(Hh, n) : heapify_overlapped<false>(Hh, n);
+    if (!heaped) { if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n); }
+    PTICK5(5);
     PTICK(4);
     bool done = false;
     if (upward && mode != 1 && pm.b_cap > 0) {
@@ -481,8 +576,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       auto bin_of = [&](unsigned scb) { return (int)min(2047u, (scb - vk) >> bshift); };
       if (tid == 0) { sh.nB = 0; sh.fallback = 0; sh.i_last = 0; }
       for (int i = tid; i < (k + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
-      for (int i = tid; i < 2048; i += NT) pm.hist[i] = 0u;
-      __syncthreads();
+      __syncthreads();                                   // (kth_largest() left the histogram cleared)
       for (int p0 = 1; p0 <= n; p0 += NT) {
         const int p = p0 + tid;
         const unsigned hi = p <= n ? (unsigned)(Hh[p] >> 32) : 0u;
@@ -1257,7 +1351,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3)) ? ph : nullptr);
+    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
     for (int j = tid; j < n_keep; j += NT) lds_tok_store(sv, j, CUR(welist[j]));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
