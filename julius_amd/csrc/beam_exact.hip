@@ -1259,14 +1259,17 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       }
       __syncthreads();
       PROBE(2, 6);
-      // state-set reductions (outprob_cd(), outprob.c:287-400): four lanes per (token, set)
+      // state-set reductions (outprob_cd(), outprob.c:287-400): four, two or one lane per (token, set), so that the
+      // frame's sets go through in one round when they can; eight member loads in flight per lane
       const int n_set = uni(sh.n_arc);
-      const int sub = tid & 3, lane = tid & 63;
-      for (int q0 = 0; q0 < n_set; q0 += NT / 4) {
-        const int q = q0 + (tid >> 2);
+      const int lps = n_set <= NT / 4 ? 4 : (n_set <= NT / 2 ? 2 : 1), lsh = lps == 4 ? 2 : (lps == 2 ? 1 : 0);
+      const int sub = tid & (lps - 1), lane = tid & 63;
+      for (int q0 = 0; q0 < n_set; q0 += NT >> lsh) {
+        const int q = q0 + (tid >> lsh);
         const bool act = q < n_set;
         const int2 it = act ? ARCQ(q) : make_int2(0, 0);
         const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
+        const float sc0 = (act && sub == 0) ? CUR(it.x).score : 0.0f;      // in flight beside the member loads
         float r;
         if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
           float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
@@ -1278,18 +1281,17 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
             if (p > b2) { t_ = b2; b2 = p; p = t_; }
             if (p > b3) { b3 = p; }
           };
-          for (int m = a + sub; m < bnd; m += 16) {
-            int ix[4]; float pv[4];
+          for (int m = a + sub; m < bnd; m += 8 * lps) {
+            int ix[8]; float pv[8];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) ix[jj] = (m + 4 * jj < bnd) ? lx.set_states(m + 4 * jj) : -1;
+            for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+            for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) if (pv[jj] > JAMD_LOG_ZERO) { n++; ins(pv[jj]); }
+            for (int jj = 0; jj < 8; jj++) if (pv[jj] > JAMD_LOG_ZERO) { n++; ins(pv[jj]); }
           }
-#pragma unroll
-          for (int src = 1; src < 4; src++) {
-            const int from = (lane & ~3) + src;
+          for (int src = 1; src < lps; src++) {
+            const int from = (lane & ~(lps - 1)) + src;
             const float c0 = __shfl(b0, from, 64), c1 = __shfl(b1, from, 64), c2 = __shfl(b2, from, 64),
                         c3 = __shfl(b3, from, 64);
             const int cn = __shfl(n, from, 64);
@@ -1304,23 +1306,22 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           r = sum / (float)n;
         } else if (lx.cdset_method == JAMD_IWCD_MAX) {
           float m_ = JAMD_LOG_ZERO;
-          for (int m = a + sub; m < bnd; m += 16) {
-            int ix[4]; float pv[4];
+          for (int m = a + sub; m < bnd; m += 8 * lps) {
+            int ix[8]; float pv[8];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) ix[jj] = (m + 4 * jj < bnd) ? lx.set_states(m + 4 * jj) : -1;
+            for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+            for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) if (m_ < pv[jj]) m_ = pv[jj];
+            for (int jj = 0; jj < 8; jj++) if (m_ < pv[jj]) m_ = pv[jj];
           }
-#pragma unroll
-          for (int src = 1; src < 4; src++) { const float c = __shfl(m_, (lane & ~3) + src, 64); if (m_ < c) m_ = c; }
+          for (int src = 1; src < lps; src++) { const float c = __shfl(m_, (lane & ~(lps - 1)) + src, 64); if (m_ < c) m_ = c; }
           r = m_;
         } else {
           r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
         }
         if (act && sub == 0) {
-          const float sc = CUR(it.x).score + r;
+          const float sc = sc0 + r;
           CUR(it.x).score = sc;
           const unsigned b = ordz(sc);
           CURKEY(it.x) = b;
