@@ -48,6 +48,9 @@ constexpr int kMaxL = 20;                // heap positions < 2^21
 #define JAMD_XBEAM_PROBE 0              // development builds: 1 / 2 / 3 put sub-step clocks of steps 0-B / C / the event replay into phase_us[4..7]
 #endif
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 struct XRowRef {                 // this frame's score row: its LDS copy or the row in global memory
   const float *g; const lds_f32 *l; bool lds;
   __device__ __forceinline__ float operator[](int i) const { return lds ? l[i] : g[i]; }
@@ -888,15 +891,21 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   bool stopped = false;
   __syncthreads();
 
+  // The frame's score row goes to LDS by LDS-DMA (no registers, nothing waits on it): the row of frame t + 1 is
+  // requested when step C of frame t is done with the buffer, and has landed by the pruning step's first barrier.
+  auto row_request = [&](int tt) {
+    if (!wk.row_cache || tt >= T) return;
+    const float *rg = scores + (size_t)(t_begin + tt - base) * S;
+    const int ln = tid & 63;
+    for (int b = uni((int)(tid >> 6)) * 64; b < S; b += NT)
+      if (b + ln < S) __builtin_amdgcn_global_load_lds((glb_void *)(rg + b + ln), (lds_void *)(rowc + b), 4, 0, 0);
+  };
+  row_request(resume ? base : (dfa ? 0 : 1));
   for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
     const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
     const bool last = (t == T);
-    if (wk.row_cache && !last) {
-      const float *__restrict__ rg = scores + (size_t)(t_begin + t - base) * S;
-      for (int i = tid; i < S; i += NT) rowc[i] = rg[i];
-    }
     // ---- 0: dense visiting indices.  Source j owns XW slots for its word-internal transitions and, when it
     //         is a word end that may be followed by a word, one slot per root; sources pruned by score own none.
     //         The same scan numbers the trellis words of the frame in visiting order (save_trellis() is called in
@@ -926,7 +935,10 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     PROBE(1, 4);
     const int nwords = (nbits + 31) >> 5;
     const bool bm_in_lds = nwords <= xw.bm_words;
-    unsigned *bm = bm_in_lds ? (unsigned *)(dyn_lds + xw.off_bm) : reinterpret_cast<unsigned *>(ub + xw.o_bitmap);   // generic on purpose: a few accesses per token
+    // the creation-order bitmap: in LDS, or (a frame with more visiting indices than fit) in the utterance's slice
+    lds_u32 *bm_l = (lds_u32 *)(dyn_lds + xw.off_bm);
+    unsigned *bm_g = reinterpret_cast<unsigned *>(ub + xw.o_bitmap);
+    auto bm_get = [&](int w) -> unsigned { return bm_in_lds ? bm_l[w] : bm_g[w]; };
     __syncthreads();
 
     // nscid = successor id of next_node (0 for the self loop): the caller loads it beside the transition record
@@ -1099,18 +1111,18 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     }
     const int W = (nwords + NT - 1) / NT;             // bitmap words per thread in the prefix scan
     {
-      for (int i = tid; i < nwords; i += NT) bm[i] = 0u;
+      for (int i = tid; i < nwords; i += NT) { if (bm_in_lds) bm_l[i] = 0u; else bm_g[i] = 0u; }
       __syncthreads();
       for (int s = tid; s < n_new; s += NT) {
         const int2 t2 = TOUCHED(s);
         const unsigned fv = ~(t2.y >= 0 ? cl.lfirst[t2.y] : NODEFIRST(t2.x));
         const int dense = ((dfa && t == 0) ? 0 : dbase[fv >> s1]) + (int)(fv & submask);
-        atomicOr(&bm[dense >> 5], 1u << (dense & 31));
+        if (bm_in_lds) atomicOr((unsigned *)&bm_l[dense >> 5], 1u << (dense & 31)); else atomicOr(&bm_g[dense >> 5], 1u << (dense & 31));
       }
       __syncthreads();
       PROBE(2, 4);
       int cnt = 0;
-      for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm[w]); }
+      for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm_get(w)); }
       const int ex = block_excl_scan(sh, cnt);
       tpre[tid] = (unsigned)ex;
       __syncthreads();
@@ -1155,8 +1167,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           const int dense = ((dfa && t == 0) ? 0 : dbase[fvis[k] >> s1]) + (int)(fvis[k] & submask);
           const int w = dense >> 5, tw = w / W;
           int r = (int)tpre[tw];
-          for (int x = tw * W; x < w; x++) r += __popc(bm[x]);
-          r += __popc(bm[w] & ((1u << (dense & 31)) - 1u));
+          for (int x = tw * W; x < w; x++) r += __popc(bm_get(x));
+          r += __popc(bm_get(w) & ((1u << (dense & 31)) - 1u));
           tokid[k] = r;
         }
         // winner's payload from its visiting index
@@ -1333,6 +1345,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       atomicMin(&sh.minbits, mymin);
     }
     __syncthreads();
+    row_request(t + 1);
     PHASE(2);
     {
       const float mx = unord(sh.maxbits);
