@@ -1109,7 +1109,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       __syncthreads();
       break;
     }
-    const int W = (nwords + NT - 1) / NT;             // bitmap words per thread in the prefix scan
+    int Wsh = 0;                                      // bitmap words per thread in the prefix scan: a power of two
+    while ((NT << Wsh) < nwords) Wsh++;
+    const int W = 1 << Wsh;
     {
       for (int i = tid; i < nwords; i += NT) { if (bm_in_lds) bm_l[i] = 0u; else bm_g[i] = 0u; }
       __syncthreads();
@@ -1165,7 +1167,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           tokid[k] = 0;
           if (!ok[k]) continue;
           const int dense = ((dfa && t == 0) ? 0 : dbase[fvis[k] >> s1]) + (int)(fvis[k] & submask);
-          const int w = dense >> 5, tw = w / W;
+          const int w = dense >> 5, tw = w >> Wsh;
           int r = (int)tpre[tw];
           for (int x = tw * W; x < w; x++) r += __popc(bm_get(x));
           r += __popc(bm_get(w) & ((1u << (dense & 31)) - 1u));
