@@ -17,15 +17,17 @@
 //      A second atomicMax(~vis) per cell keeps the node's FIRST visit.
 //   2. creation order = rank of the first visit: one bit per visiting index in a bitmap, prefix popcount.
 //   3. rank pruning = the reference's heap, exactly:
-//        - heapify runs level by level (the sift-downs of one tree level touch disjoint subtrees and the
-//          reference runs the levels bottom-up, so the level-parallel result is the sequential one);
+//        - heapify runs level-parallel (the sift-downs of one tree level touch disjoint subtrees and the
+//          reference runs the levels bottom-up, so the result is the sequential one), with the levels
+//          overlapped inside a wave (heapify_overlapped());
 //        - the extraction loop of sort_token_upward() is replaced by its closed form.  While the element
 //          taken from the tail is smaller than every element still to be extracted, an extraction is a
 //          hole running down the path of larger children (left on ties): the heap is a tree of stable
 //          merges, and the extraction order is (score descending, PRE-ORDER index of the heap position
 //          ascending).  The exceptions ("events": the tail element is itself among the top k) re-insert
 //          that element at the end of the current max path; they are rare (a few per frame), found and
-//          replayed one by one by a single wave with range queries over the sorted top-k list.  The
+//          replayed one by one by a single wave with range queries over the top-k list (sorted by counting
+//          over score bins), and only up to the last turn that can still change the order.  The
 //          equivalence was fuzzed against the sequential code (tests/test_prune_order.py does it on the
 //          device; DESIGN.md section 3 "K6x" has the argument).
 //        - sort_token_downward() (beam < tokens <= 2 beam) and oversize frames run the sequential
