@@ -790,6 +790,43 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
 #undef PTICK
 }
 
+// outprob_cd() with IWCD_NBEST (outprob.c:330-365): the mean of the K best member scores of a state set, `lps` lanes
+// per set (a power of two, the lanes of a set adjacent).  Each lane keeps the K best of its members in descending
+// order (insertion by max / min), the lanes merge in a butterfly; the sum runs from the best down as in the reference.
+template <int K>
+__device__ __forceinline__ float nbest_of_set(const LexDev &lx, const XRowRef &row, int a, int bnd, int sub, int lps) {
+  float b[K];
+#pragma unroll
+  for (int i = 0; i < K; i++) b[i] = JAMD_LOG_ZERO;
+  int n = 0;
+  auto ins = [&](float p) {
+#pragma unroll
+    for (int i = 0; i < K; i++) { const float hi = __builtin_fmaxf(b[i], p); p = __builtin_fminf(b[i], p); b[i] = hi; }
+  };
+  for (int m = a + sub; m < bnd; m += 8 * lps) {
+    int ix[8]; float pv[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) { n += pv[jj] > JAMD_LOG_ZERO ? 1 : 0; ins(pv[jj]); }
+  }
+  for (int off = 1; off < lps; off <<= 1) {
+    float c[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) c[i] = __shfl_xor(b[i], off, 64);
+    n += __shfl_xor(n, off, 64);
+#pragma unroll
+    for (int i = 0; i < K; i++) ins(c[i]);
+  }
+  if (n > lx.cdmax_num) n = lx.cdmax_num;
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < K; i++) if (n > i) sum += b[i];
+  return sum / (float)n;
+}
+
 template <bool TIMED>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
@@ -1288,38 +1325,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const float sc0 = (act && sub == 0) ? CUR(it.x).score : 0.0f;      // in flight beside the member loads
         float r;
         if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
-          float b0 = JAMD_LOG_ZERO, b1 = JAMD_LOG_ZERO, b2 = JAMD_LOG_ZERO, b3 = JAMD_LOG_ZERO;
-          int n = 0;
-          auto ins = [&](float p) {
-            float t_;
-            if (p > b0) { t_ = b0; b0 = p; p = t_; }
-            if (p > b1) { t_ = b1; b1 = p; p = t_; }
-            if (p > b2) { t_ = b2; b2 = p; p = t_; }
-            if (p > b3) { b3 = p; }
-          };
-          for (int m = a + sub; m < bnd; m += 8 * lps) {
-            int ix[8]; float pv[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) if (pv[jj] > JAMD_LOG_ZERO) { n++; ins(pv[jj]); }
-          }
-          for (int src = 1; src < lps; src++) {
-            const int from = (lane & ~(lps - 1)) + src;
-            const float c0 = __shfl(b0, from, 64), c1 = __shfl(b1, from, 64), c2 = __shfl(b2, from, 64),
-                        c3 = __shfl(b3, from, 64);
-            const int cn = __shfl(n, from, 64);
-            if (sub == 0) { ins(c0); ins(c1); ins(c2); ins(c3); n += cn; }
-          }
-          if (n > lx.cdmax_num) n = lx.cdmax_num;
-          float sum = 0.0f;
-          if (n > 0) sum += b0;
-          if (n > 1) sum += b1;
-          if (n > 2) sum += b2;
-          if (n > 3) sum += b3;
-          r = sum / (float)n;
+          r = lx.cdmax_num <= 3 ? nbest_of_set<3>(lx, row, a, bnd, sub, lps) : nbest_of_set<4>(lx, row, a, bnd, sub, lps);
         } else if (lx.cdset_method == JAMD_IWCD_MAX) {
           float m_ = JAMD_LOG_ZERO;
           for (int m = a + sub; m < bnd; m += 8 * lps) {
