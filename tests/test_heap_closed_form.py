@@ -126,3 +126,63 @@ def test_closed_form_equals_sequential_heap(oracle, seed):
         checked += 1
         events += full[0]
     assert checked > 60 and events > 0
+
+
+def heapify_overlapped(score, split=3):
+    """The schedule of heapify_overlapped() in beam_exact.hip, lane by lane: the sift-downs of ALL levels of a subtree
+    run together, the sift of depth L starting one step after the sifts of depth L + 1; within a step every active
+    sift first READS the two children of its hole (all reads see the state left by the previous step), then all
+    WRITE.  Subtrees rooted at depth `split` first (independent of each other), then depths split-1 .. 0."""
+    n = len(score)
+    H = [None] + list(range(n))                       # 1-based heap of token ids
+    top = n // 2
+    if top < 1:
+        return H[1:]
+    val = lambda idx: score[idx]
+
+    def run(roots, ldeep):
+        # roots: list of (position, depth); every sift starts at step ldeep - depth
+        sifts = [dict(parent=p, s=H[p], t0=ldeep - d, live=True) for p, d in roots]
+        g = 0
+        while any(x["live"] for x in sifts):
+            reads = []
+            for x in sifts:                            # reads of this step
+                if not x["live"] or g < x["t0"]:
+                    reads.append(None)
+                    continue
+                c = 2 * x["parent"]
+                reads.append((H[c] if c <= n else None, H[c + 1] if c + 1 <= n else None))
+            for x, rd in zip(sifts, reads):            # decisions and writes
+                if rd is None:
+                    continue
+                left, right = rd
+                if left is None:
+                    H[x["parent"]] = x["s"]; x["live"] = False
+                    continue
+                child, cid = 2 * x["parent"], left
+                if right is not None and val(left) < val(right):
+                    child, cid = child + 1, right
+                if val(x["s"]) >= val(cid):
+                    H[x["parent"]] = x["s"]; x["live"] = False
+                else:
+                    H[x["parent"]] = cid; x["parent"] = child
+            g += 1
+
+    ltop = top.bit_length() - 1
+    if ltop >= split:
+        roots = [(p, p.bit_length() - 1) for p in range(1 << split, top + 1)]
+        run(roots, ltop)                               # (the device runs four subtrees per wave; they do not interact)
+    lt = min(ltop, split - 1)
+    run([(p, p.bit_length() - 1) for p in range(1, min(top, (2 << lt) - 1) + 1)], lt)
+    return H[1:]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_overlapped_heapify_equals_sequential(seed):
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(150):
+        n = int(rng.integers(1, 700))
+        levels = int(rng.choice([2, 3, 10, 1000, 10 ** 6]))
+        score = [float(x) for x in -rng.integers(0, levels, n) * 0.25 - 50.0]
+        for split in (1, 3, 6):
+            assert heapify_overlapped(score, split) == heapify_upward(score), (n, levels, split)
