@@ -47,7 +47,10 @@ using namespace jamdb;
 #endif
 constexpr int kMaxL = 20;                // heap positions < 2^21
 #ifndef JAMD_XBEAM_PROBE
-#define JAMD_XBEAM_PROBE 0              // development builds: 1 / 2 / 3 put sub-step clocks of steps 0-B / C / the event replay into phase_us[4..7]
+// development builds (tools/build_variant.sh, tools/exact_probe.sh): JAMD_XBEAM_PROBE = 1 / 2 / 3 / 5 puts the sub-step
+// clocks of steps 0-B / step C / the event replay / heap fill + heapify into phase_us[4..7] instead of the pruning
+// step's four parts; 4 reports the shader clock (MHz) under the kernel in phase_us[7]
+#define JAMD_XBEAM_PROBE 0
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -60,7 +63,7 @@ struct XRowRef {                 // this frame's score row: its LDS copy or the 
 
 struct XShared {
   unsigned long long we_best;            // (ord(score + wordend_a), ~j): best word end, earliest visit
-  int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, fallback, i_last;
+  int n_new, n_we, n_arc, n_atom, n_surv, best_atom, nB, i_last;
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
   unsigned wsum[NT / 64], wsum2[NT / 64];
@@ -579,7 +582,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       const unsigned span = uni(sh.maxbits) - vk;
       const int bshift = span ? max(0, 32 - __clz(span) - 11) : 0;
       auto bin_of = [&](unsigned scb) { return (int)min(2047u, (scb - vk) >> bshift); };
-      if (tid == 0) { sh.nB = 0; sh.fallback = 0; sh.i_last = 0; }
+      if (tid == 0) { sh.nB = 0; sh.i_last = 0; }
       for (int i = tid; i < (k + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
       __syncthreads();                                   // (kth_largest() left the histogram cleared)
       for (int p0 = 1; p0 <= n; p0 += NT) {
