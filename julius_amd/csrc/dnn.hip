@@ -13,30 +13,29 @@
 // multiply-add chain over k = l, l+8, l+16, ..., and finally adds lanes 0..7
 // left to right and then the bias (calc_dnn_fma.c:53-60).
 // v_mfma_f32_32x32x2_f32 is, per output element, exactly a k-ordered fmaf chain
-// (cdna_hip_programming.md section 3), so each 32x32 output tile keeps EIGHT
-// MFMA accumulators, accumulator l being fed only k == l (mod 8) in ascending
-// order (lanes 0-31 supply k, lanes 32-63 supply k+8), and the epilogue adds the
-// eight accumulators left to right, then the bias.  Same MFMA count as a single
-// accumulator; the price is 128 accumulator registers per wave tile.
+// (cdna_hip_programming.md section 3; lanes 0-31 supply k, lanes 32-63 the next
+// k of the chain), so a chain is one MFMA accumulator fed the k of its residue
+// class in ascending order.  The eight chains are independent; they run ONE
+// AFTER THE OTHER over all of K and are folded into the sum in the reference's
+// order (dnn_layer_rs_kernel below) -- two accumulators per 32x32 tile.  (The
+// first version kept all eight side by side: 128 accumulator registers per
+// 32x32 wave tile, no fragment reuse, 104 TFLOP/s; this form: 110.)
 //
-// GEMM shape: C[t][o] = sum_k X[t][k] * W[o][k]  (both operands K-contiguous).
-// Block = 4 waves = 64 frames x 64 outputs, K slab 64 staged through a DOUBLE-
-// BUFFERED LDS tile filled by LDS-DMA (global_load_lds_dwordx4, one barrier per
-// slab: the DMA of the next slab is issued before the MFMAs of the current one
-// and lands in the other buffer); rows are unpadded and quad-swizzled (quad c of
-// row r at position c ^ (r & 15)) so that the ds_read_b128 fragment reads (one
-// 16-byte quad of k per lane) are conflict free for the instruction's 16-lane
-// groups (MI355X_MICROARCH.md, LDS).
+// GEMM shape: C[t][o] = sum_k X[t][k] * W[o][k], operands in residue-major
+// rows.  Block = 4 waves = 128 frames x 128 outputs, wave tile 64 x 64, slabs
+// of 32 chain entries staged through a DOUBLE-BUFFERED LDS tile filled by
+// LDS-DMA (global_load_lds_dwordx4, one barrier per slab: the DMA of the next
+// slab is issued before the MFMAs of the current one and lands in the other
+// buffer); rows are unpadded and quad-swizzled so that the ds_read_b128
+// fragment reads are conflict free for the instruction's 16-lane groups
+// (MI355X_MICROARCH.md, LDS).
 #include "jamd_device.h"
-#ifndef JAMD_DNN_RS
-#define JAMD_DNN_RS 1
-#endif
 
 struct jamd_dnn {
   jamd_engine *eng = nullptr;
   int nlayer = 0;
   std::vector<int> dims;
-  std::vector<float *> d_w, d_b;   // W[l]: [dims[l+1]][dims[l]] as given
+  std::vector<float *> d_b;
   std::vector<float *> d_wr;       // W[l] in residue-major rows (see dnn_layer_rs_kernel), [dims[l+1]][8 * kmp[l]]
   std::vector<int> kmp;            // per layer input: padded length of one residue segment = ceil(dims[l] / 8 / 8) * 8
   float *d_xr = nullptr; size_t xr_cap = 0;   // the frames in residue-major rows
@@ -57,132 +56,8 @@ using namespace jamd;
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, KS = 64;
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
-
-// ACT: 1 = table logistic (hidden layer), 0 = raw (output layer).
-// zero16: 16 bytes of zeros in global memory, the source of every out-of-range quad (zero
-// padding keeps every chain exact: fma(0,0,acc) == acc).
-template <int ACT>
-__global__ void __launch_bounds__(256, 2)
-dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
-                 const float *__restrict__ bias, const float *__restrict__ sig,
-                 float *__restrict__ Y, int T, int K, int N, int ldx, int ldy, int nmb,
-                 const float *__restrict__ zero16) {
-  // K slab of the X tile and of the W tile, two buffers each, UNPADDED rows of 16 quads: the
-  // tiles arrive by LDS-DMA (global_load_lds_dwordx4: a wave writes 1 KB = 4 rows lane-linearly,
-  // no VGPR round trip, no ds_write), so padding is impossible; instead quad c of row r is kept
-  // at position c ^ (r & 15) -- the permutation is applied to the per-lane SOURCE address --
-  // which makes the ds_read_b128 fragment reads of 16 consecutive rows conflict free.
-  __shared__ __align__(16) float Xs[2][BM][KS];
-  __shared__ __align__(16) float Ws[2][BN][KS];
-  const int nnb = (N + BN - 1) / BN;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q = b >> 3;
-  // The dispatcher puts block b on XCD b % 8.  Each XCD owns every eighth 64-output tile for ALL
-  // frame strips: its share of W (1/8 of the layer, 2 MB at 2048 x 2048) stays in its 4 MB L2
-  // while the strips of X stream through -- instead of all of W streaming through every L2
-  // once per strip (17 GB -> 5 GB of L2 fills per hidden layer at 64 000 frames).
-  const int tpx = (nnb + 7) / 8;
-  const int nb = xcd + 8 * (q % tpx), mb = q / tpx;
-  if (mb >= nmb || nb >= nnb) return;
-  const int t0 = mb * BM, o0 = nb * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-
-  // staging: 32 DMA instructions per slab (16 for X, 16 for W), eight per wave.  Instruction
-  // id = 8 * wave + j moves rows 4 * (id & 15) .. + 3 of X (id < 16) or W; lane = 16 * (row in
-  // group) + position, and fetches the quad that belongs at that position.
-  constexpr int NI = 8;
-  const float *src[NI];     // row base + 4 * quad (or the zero block), K offset added per slab
-  int cq[NI];               // 4 * logical quad (k offset inside the slab) of this lane
-  int kmask[NI];            // ~0, or 0 for a W row past N: the source stays on the zero block
-#pragma unroll
-  for (int j = 0; j < NI; j++) {
-    const int id = 8 * wave + j, r = 4 * (id & 15) + (lane >> 4);
-    const int c = (lane & 15) ^ (r & 15);
-    cq[j] = 4 * c;
-    if (id < 16) {
-      int tr = t0 + r; if (tr > T - 1) tr = T - 1;
-      src[j] = X + (size_t)tr * ldx + 4 * c; kmask[j] = ~0;
-    } else {
-      const int orow = o0 + r;
-      kmask[j] = orow < N ? ~0 : 0;
-      src[j] = orow < N ? W + (size_t)orow * K + 4 * c : zero16;
-    }
-  }
-  // K is a multiple of 8 (jamd_dnn_create), so a quad is either fully inside a row or fully
-  // past its end
-  // a slab that lies completely inside K needs no per-quad test (all but the last slab of a
-  // layer whose K is not a multiple of 64)
-  auto stage = [&](int buf, int k0) {
-    const bool full = k0 + KS <= K;
-#pragma unroll
-    for (int j = 0; j < NI; j++) {
-      const int id = 8 * wave + j;
-      const float *g = src[j] + (k0 & kmask[j]);
-      if (!full && !(k0 + cq[j] < K)) g = zero16;
-      float *dst = (id < 16) ? &Xs[buf][4 * (id & 15)][0] : &Ws[buf][4 * (id & 15)][0];
-      __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)dst, 16, 0, 0);
-    }
-  };
-
-  f16v acc[8];
-#pragma unroll
-  for (int l = 0; l < 8; l++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[l][r] = 0.0f;
-
-  stage(0, 0);
-  __syncthreads();          // carries the vmcnt(0) that lands the DMA
-  const int arow = wm + (lane & 31), brow = wn + (lane & 31), half = lane >> 5;
-  const int asw = arow & 15, bsw = brow & 15;
-  int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += KS) {
-    if (k0 + KS < K) stage(cur ^ 1, k0 + KS);   // the other buffer was last read before the previous barrier
-#pragma unroll
-    for (int g = 0; g < KS; g += 16) {
-      // lanes 0-31 take k = g+0..7, lanes 32-63 k = g+8..15: accumulator l sees
-      // k = g+l then g+8+l -- ascending within its residue class mod 8
-      const int q0 = g / 4 + 2 * half;
-      const f4v a0 = *(const f4v *)&Xs[cur][arow][4 * (q0 ^ asw)];
-      const f4v a1 = *(const f4v *)&Xs[cur][arow][4 * ((q0 + 1) ^ asw)];
-      const f4v b0 = *(const f4v *)&Ws[cur][brow][4 * (q0 ^ bsw)];
-      const f4v b1 = *(const f4v *)&Ws[cur][brow][4 * ((q0 + 1) ^ bsw)];
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        acc[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[l], b0[l], acc[l], 0, 0, 0);
-        acc[l + 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[l], b1[l], acc[l + 4], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // epilogue: lanes add 0..7 left to right, then the bias (calc_dnn_fma.c:53-60)
-  const int j = o0 + wn + (lane & 31);
-  const float bj = (j < N) ? bias[j] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int t = t0 + wm + i;
-    float s = acc[0][r] + acc[1][r];
-#pragma unroll
-    for (int l = 2; l < 8; l++) s = s + acc[l][r];
-    s = s + bj;
-    if (ACT) {
-      // calc_dnn.c:813-818: clamp at +-8, else table[(int)((x + 8.0f) * 20000 + 0.5)]
-      float y;
-      if (s <= -8.0f) y = (float)0.000334;
-      else if (s >= 8.0f) y = (float)0.999666;
-      else y = sig[(int)((double)((s + 8.0f) * (float)JAMD_LOGISTIC_FACTOR) + 0.5)];
-      s = y;
-    }
-    if (t < T && j < N) Y[(size_t)t * ldy + j] = s;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Residue-serial form of the layer.  The reference's eight partial sums per output are eight INDEPENDENT fused
@@ -191,7 +66,7 @@ dnn_layer_kernel(const float *__restrict__ X, const float *__restrict__ W,
 // sum S = (((a0 + a1) + a2) + ...) -- the same floats, with TWO accumulators per 32x32 tile instead of eight.
 // The registers that frees buy a 64x64 wave tile (2x2 MFMA tiles) and a 128x128 block tile: every LDS fragment is
 // used by two MFMAs instead of one and a byte fetched into LDS feeds twice the flops, i.e. half the fragment
-// reads, half the LDS-DMA pieces and half the barriers per MFMA of the eight-accumulator kernel above.
+// reads, half the LDS-DMA pieces and half the barriers per MFMA of a kernel that keeps the eight chains side by side.
 //
 // Operands are read in "residue-major" rows: row r holds, for l = 0..7, the segment {x[8m + l]: m = 0..K/8-1}
 // padded with zeros to kmp = a multiple of 8 entries; inside each group of eight m the even ones come first
@@ -444,14 +319,11 @@ int jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out) {
   n->dims.assign(d->dims, d->dims + d->nlayer + 1);
   for (int v : n->dims) if (v > n->maxdim) n->maxdim = v;
   for (int l = 0; l < d->nlayer; l++) {
-    float *w = nullptr, *b = nullptr;
-    const size_t nw = (size_t)n->dims[l + 1] * n->dims[l];
-    JAMD_HIP(hipMalloc(&w, sizeof(float) * nw));
-    JAMD_HIP(hipMemcpy(w, d->w[l], sizeof(float) * nw, hipMemcpyHostToDevice));
+    float *b = nullptr;
     JAMD_HIP(hipMalloc(&b, sizeof(float) * n->dims[l + 1]));
     JAMD_HIP(hipMemcpy(b, d->b[l], sizeof(float) * n->dims[l + 1], hipMemcpyHostToDevice));
-    n->d_w.push_back(w); n->d_b.push_back(b);
-    // the same weights as residue-major rows (dnn_layer_rs_kernel)
+    n->d_b.push_back(b);
+    // the weights as residue-major rows (dnn_layer_rs_kernel)
     const int K = n->dims[l], N = n->dims[l + 1], kmp = ((K / 8 + 7) / 8) * 8;
     std::vector<float> wr((size_t)N * 8 * kmp, 0.0f);
     for (int o = 0; o < N; o++)
@@ -476,7 +348,6 @@ int jamd_dnn_create(jamd_engine *e, const jamd_dnn_desc *d, jamd_dnn **out) {
 void jamd_dnn_destroy(jamd_dnn *n) {
   if (!n) return;
   (void)hipSetDevice(n->eng->device);
-  for (float *p : n->d_w) (void)hipFree(p);
   for (float *p : n->d_wr) (void)hipFree(p);
   if (n->d_xr) (void)hipFree(n->d_xr);
   for (float *p : n->d_b) (void)hipFree(p);
@@ -505,12 +376,8 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
   int rc;
   // hidden activations ping-pong between two [T][maxhidden] buffers
   int maxh = 1;
-#if JAMD_DNN_RS
   for (int l = 1; l < n->nlayer; l++) if (8 * n->kmp[l] > maxh) maxh = 8 * n->kmp[l];
   if ((rc = ensure(&n->d_xr, &n->xr_cap, sizeof(float) * (size_t)T * 8 * n->kmp[0])) != JAMD_OK) return rc;
-#else
-  for (int l = 1; l < n->nlayer; l++) if (n->dims[l] > maxh) maxh = n->dims[l];
-#endif
   const size_t need = sizeof(float) * (size_t)T * maxh;
   if (n->act_cap < need) {
     for (int k = 0; k < 2; k++) { if (n->d_act[k]) JAMD_HIP(hipFree(n->d_act[k])); n->d_act[k] = nullptr; }
@@ -544,7 +411,6 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
   }
   for (int c = 0, t0 = 0; t0 < T; c++, t0 += per) {
     const int Tc = (T - t0 < per) ? T - t0 : per;
-#if JAMD_DNN_RS
     {
       const int L0 = 8 * n->kmp[0], nmb = (Tc + RB - 1) / RB;
       float *xr = n->d_xr + (size_t)t0 * L0;
@@ -568,24 +434,6 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
         src = dst;
       }
     }
-#else
-    const int nmb = (Tc + BM - 1) / BM;
-    const float *src = dev_frames + (size_t)t0 * n->dims[0];
-    for (int l = 0; l < n->nlayer; l++) {
-      const int K = n->dims[l], N = n->dims[l + 1];
-      const bool last = (l == n->nlayer - 1);
-      float *dst = last ? dev_out + (size_t)t0 * S : n->d_act[l & 1];
-      const int nnb = (N + BN - 1) / BN;
-      const int grid = 8 * ((nnb + 7) / 8) * nmb;
-      if (last)
-        hipLaunchKernelGGL((dnn_layer_kernel<0>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
-                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb, n->d_zero);
-      else
-        hipLaunchKernelGGL((dnn_layer_kernel<1>), dim3(grid), dim3(256), 0, st, src, n->d_w[l], n->d_b[l],
-                           n->eng->d_logistic, dst, Tc, K, N, K, N, nmb, n->d_zero);
-      src = dst;
-    }
-#endif
     hipStream_t ts = st;
     if (nchunk > 1) {
       JAMD_HIP(hipEventRecord(n->ev_gemm[c], st));
