@@ -251,7 +251,16 @@ dnn_lse_kernel(const float *__restrict__ x, const float *__restrict__ tbl, float
   if (t >= T) return;
   const float *row = x + (size_t)t * S;
   float y = JAMD_LOG_ZERO;
-  for (int n = S - 1; n >= 0; n--) y = addlog_step(y, row[n], tbl, addmin_f);
+  int n = S - 1;
+  // the step's latency is the dependent table gather; the row values do not depend on it: sixteen at a time, ahead
+  for (; n >= 15; n -= 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = row[n - j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) y = addlog_step(y, v[j], tbl, addmin_f);
+  }
+  for (; n >= 0; n--) y = addlog_step(y, row[n], tbl, addmin_f);
   lse[t] = y;
 }
 
