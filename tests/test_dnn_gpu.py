@@ -26,7 +26,10 @@ def test_golden_dnn_small(engine):
 
 
 @pytest.mark.parametrize("dims,T", [((48, 64, 64, 40), 1), ((48, 64, 64, 40), 65), ((40, 72, 72, 72, 33), 130),
-                                    ((528, 256, 256, 100), 77), ((16, 8, 8, 5), 9)])
+                                    ((528, 256, 256, 100), 77), ((16, 8, 8, 5), 9),
+                                    # tiles of the 128 x 128 layer kernel: widths / frame counts just past a tile, chains
+                                    # with a short last slab (136 / 8 = 17 entries, 1032 / 8 = 129)
+                                    ((24, 136, 200, 129), 257), ((64, 1032, 8, 3), 129)])
 def test_vs_oracle_shapes(engine, oracle, dims, T):
     dnn = synth.make_dnn(dims=dims, seed=T)
     fr = np.random.default_rng(T).normal(0, 1.5, (T, dims[0])).astype(np.float32)
