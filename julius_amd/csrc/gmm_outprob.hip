@@ -411,24 +411,14 @@ template <int D, int FPL, int NS, int ABL = 0>
 int launch_tile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
   constexpr int FPB = kWaves * 64 * FPL;
   const int nfb = (T + FPB - 1) / FPB;
-  // states per block, in multiples of NS: large enough to amortise the frame-vector load,
-  // small enough for >= 12 blocks per CU, and -- because block b runs on XCD b % 8 and a state
-  // range is pinned to one XCD -- with a range count that spreads evenly over the 8 XCDs
-  // (12 ranges would give four XCDs twice the work of the others: measured -20 %).
-  int nsb = NS;
-  {
-    const long want = (long)g->eng->num_cu * 12;
-    double best = 1e30;
-    for (int k = 1; k <= 16; k++) {
-      const int cand = NS * k;
-      const int nr = (g->S + cand - 1) / cand;
-      const long blocks = (long)nfb * nr;
-      const double imbalance = (double)(8 * ((nr + 7) / 8)) / nr;              // max XCD load / mean
-      const double small = blocks >= want ? 1.0 : (double)want / blocks;      // too few blocks
-      const double cost = imbalance * small * (1.0 + 0.1 / k);                // mildly prefer longer ranges
-      if (cost < best - 1e-9) { best = cost; nsb = cand; }
-    }
-  }
+  // States per block: NS, the width of the output tile -- the smallest there is.  A block's fixed cost (its 128
+  // frames per wave loaded into registers) is nothing against 16 states x 16 Gaussians of arithmetic, and short
+  // blocks are what keeps the last wave of blocks of a launch short: at 64 000 frames a launch is four rounds of
+  // 96-state blocks or twenty-three rounds of 16-state ones, 10.97 vs 9.93 ms (sweep on MI355X: 16 / 32 / 48 / 64 /
+  // 96 / 128 states -> 9.93 / 10.02 / 10.35 / 10.62 / 10.97 / 11.22 ms; 384 000 frames: 60.4 vs 61.8 ms; 16 000:
+  // 2.63 vs 2.78 ms).  Block b runs on XCD b % 8 and a state range is pinned to one XCD (decode_block), so the
+  // blocks that share a range share an L2.
+  const int nsb = NS;
   const int nstb = (g->S + nsb - 1) / nsb;
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
   hipLaunchKernelGGL((gmm_tile_kernel<D, FPL, NS, ABL>), dim3(grid), dim3(64 * kWaves), 0, st,
@@ -461,9 +451,7 @@ template <int FPL, int NS>
 int launch_tile_generic(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
   constexpr int FPB = kWaves * 64 * FPL;
   const int nfb = (T + FPB - 1) / FPB;
-  int nsb = NS;
-  const int want = g->eng->num_cu * 8;
-  while (nsb < 16 * NS && (long)nfb * ((g->S + 2 * nsb - 1) / (2 * nsb)) >= want) nsb *= 2;
+  const int nsb = NS;   // as launch_tile()
   const int nstb = (g->S + nsb - 1) / nsb;
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
   const size_t dyn = sizeof(float) * kWaves * g->D * 64 * FPL;
