@@ -181,7 +181,8 @@ tmix_state_kernel(const int *__restrict__ tied_states, int ntied, const int *__r
 template <int DT>
 int launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
   const int nfb = (T + 128 * kWaves - 1) / (128 * kWaves);
-  const int nsb = 16;   // one output tile of states per block: short blocks keep a launch's last round short (see launch_tile())
+  int nsb = 16;         // one output tile of states per block: short blocks keep a launch's last round short (see launch_tile())
+  while ((g->S + nsb - 1) / nsb > 65535) nsb *= 2;   // grid.y limit
   const dim3 grid(nfb, (g->S + nsb - 1) / nsb);
   const size_t dyn = DT > 0 ? 0 : sizeof(float) * kWaves * g->D * 128;
   const int cap = g->gprune_num < g->maxmix ? g->gprune_num : g->maxmix;
