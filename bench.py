@@ -523,8 +523,8 @@ def main():
     if wl in ("all", "gmm"):
         a = argparse.Namespace(**vars(args))
         a.utts = args.utts or 64
-        # 200 x 11 ms: a timed region of >= 2 s; --steps/--warmup address this (the contract's) workload
-        line = run_gmm(a, dd, args.steps if args.steps is not None else 200, args.warmup if args.warmup is not None else 5)
+        # 240 x 10 ms: a timed region of >= 2 s; --steps/--warmup address this (the contract's) workload
+        line = run_gmm(a, dd, args.steps if args.steps is not None else 240, args.warmup if args.warmup is not None else 5)
     if wl in ("all", "e2e", "e2e-dnn"):
         a = argparse.Namespace(**vars(args))
         a.utts = pick(args.utts, 256)
