@@ -18,12 +18,19 @@ resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
              utterances, exact-order kernel.  `parity` compares the device result with the compiled
              reference's first pass (julius -1pass) utterance by utterance, and the exact-order kernel
              with the canonical-tie ("fast") kernel.
+  e2e_strong = the same task as configs[4] specifies it: the FIXED batch of 512 utterances sharded over
+             the GPUs of the run (512 on one GPU at N=1, 64 per GPU at N=8), scaling "strong", with
+             whole-job and per-GPU frames/s.
+  e2e_dnn  = nested result for configs[3] ("C4") END TO END at the reference recipe's beam (-b 4000):
+             hmmdefs (4000 states) + dnnconf/.npy + dict + ARPA loaded by Julius' own readers, lexicon
+             built by wchmm.c, MFMA DNN scores -> exact-order first pass; `parity` against the compiled
+             reference's julius -1pass (its own dnn_calc_outprob + beam.c) utterance by utterance.
   dnn      = nested result for the configs[3] scoring half ("C4"): MFMA fp32 DNN.
   cpu_baseline (top level and nested) = the COMPILED REFERENCE (oracle/_ref, kind "reference") on a
              bounded sample of the same workload: one host core, plus an N-process figure for C2.
 
 Multi-GPU: one process per GPU; utterances are sharded, no data-path collective ("weak" scaling:
-per-GPU batch fixed).  RCCL is used for the barrier, the max-over-ranks clock and the gather of the
+per-GPU batch fixed; `e2e_strong` / `--workload e2e --strong` = the fixed 512-utterance batch).  RCCL is used for the barrier, the max-over-ranks clock and the gather of the
 per-utterance result records (julius_amd/shard.py).  `--gpus N` without a torch.distributed.run
 environment spawns the N ranks itself.
 """
@@ -45,6 +52,8 @@ sys.path.insert(0, str(ROOT))
 
 S, M, D = 3000, 16, 39
 FRAMES_PER_UTT = 1000
+LAUNCHES_PER_STEP = 12         # C2: one step = 12 sub-batches of --utts utterances (>= 100 ms of kernel time per step)
+C5_TOTAL_UTTS = 512            # BASELINE.json configs[4]: the fixed batch that is sharded over the GPUs
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one fp32 op/lane/clk (no FMA allowed)
 MFMA_F32_PEAK = 157.3          # TFLOP/s, dense fp32 MFMA
@@ -155,31 +164,38 @@ def cpu_baseline_gmm(model, frames, spot, budget=10.0):
 
 
 def run_gmm(args, dd: Dist, steps, warmup):
+    """One step = LAUNCHES_PER_STEP sub-batches (each --utts utterances x 1000 frames, its own frames and its own
+    [T][S] output rows, all resident in HBM) scored back to back: 12 x 64 000 frames = 768 000 frames x 3000 states
+    per GPU per step.  HIP events bracket every launch, so kernel_ms is per LAUNCH (what the roofline is quoted on)."""
     import torch
     from julius_amd import lib, synth
     model = synth.make_gmm(S=S, M=M, D=D, seed=0)
-    T = args.utts * FRAMES_PER_UTT
-    frames = np.concatenate([synth.make_frames(model, T=FRAMES_PER_UTT, seed=1000 + dd.rank * args.utts + u)
-                             for u in range(args.utts)])
+    L = LAUNCHES_PER_STEP
+    T = args.utts * FRAMES_PER_UTT                       # frames per launch
+    nutt = args.utts * L
+    rng_seed = 1000 + dd.rank * nutt
+    frames = np.concatenate([synth.make_frames(model, T=FRAMES_PER_UTT, seed=rng_seed + u) for u in range(nutt)])
     eng = lib.Engine(dd.local_rank)
     gmm = lib.Gmm(eng, model)
     d_frames = torch.from_numpy(frames).cuda()
-    d_out = torch.empty((T, S), dtype=torch.float32, device="cuda")
+    d_out = torch.empty((L * T, S), dtype=torch.float32, device="cuda")       # 9.2 GB at the default size
     stream = torch.cuda.Stream()      # the C ABI launches on this handle; the HIP events are recorded on it too
     torch.cuda.synchronize()
+    fr_ptr, out_ptr = d_frames.data_ptr(), d_out.data_ptr()
 
     def step(mark):
+        for l in range(L):
+            if mark:
+                mark(l)
+            gmm.outprob_dev(fr_ptr + l * T * D * 4, T, out_ptr + l * T * S * 4, stream.cuda_stream)
         if mark:
-            mark(0)
-        gmm.outprob_dev(d_frames.data_ptr(), T, d_out.data_ptr(), stream.cuda_stream)
-        if mark:
-            mark(1)
+            mark(L)
 
-    elapsed, ev = timed_steps(dd, stream, step, steps, warmup)
-    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    elapsed, ev = timed_steps(dd, stream, step, steps, warmup, nevents=L + 1)
+    kern_ms = float(np.mean([e[l].elapsed_time(e[l + 1]) for e in ev for l in range(L)]))
     res = None
     if dd.rank == 0:
-        total_frames = T * dd.world * steps
+        total_frames = L * T * dd.world * steps
         E = int(model["st_off"][-1])
         bytes_per_frame = E * (2 * D + 2) * 4 + D * 4 + S * 4
         alg_bytes = bytes_per_frame * T
@@ -202,9 +218,10 @@ def run_gmm(args, dd: Dist, steps, warmup):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf_inv": total_frames / 100.0 / elapsed,
             "config": {"workload": "C2 (BASELINE.json configs[1]): tied-state triphone GMM outprob only, "
-                                   f"S={S} x M={M} x D={D}, {args.utts} utterances x {FRAMES_PER_UTT} frames per GPU per step, "
-                                   "gprune none", "frames_per_step_per_gpu": T, "parallelism": f"utterance-sharded x{dd.world}",
-                       "kernel": gmm.last_kernel()},
+                                   f"S={S} x M={M} x D={D}, one step = {L} launches x {args.utts} utterances x {FRAMES_PER_UTT} "
+                                   f"frames per GPU ({L * T} frames per GPU per step), gprune none",
+                       "frames_per_step_per_gpu": L * T, "frames_per_launch": T, "launches_per_step": L,
+                       "parallelism": f"utterance-sharded x{dd.world}", "kernel": gmm.last_kernel()},
             "roofline": {"bound": "valu", "achieved": tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (fp32, unfused)",
                          "frac": tops / VALU_PEAK_TOPS, "traffic": traffic, "kernel_ms": kern_ms,
                          "ops_per_launch": valu_ops,
@@ -223,7 +240,7 @@ def run_gmm(args, dd: Dist, steps, warmup):
         if dd.world == 1 and not args.no_cpu_baseline:
             rng = np.random.default_rng(0)
             ss = np.sort(rng.choice(S, 16, replace=False))
-            tt = np.sort(rng.choice(T, 64, replace=False))      # 64 full-size rows against the compiled reference
+            tt = np.sort(rng.choice(L * T, 64, replace=False))  # 64 full-size rows (any launch of the step) against the compiled reference
             got = d_out[torch.from_numpy(tt).cuda()][:, torch.from_numpy(ss).cuda()].cpu().numpy()
             res["cpu_baseline"], res["parity_spot_check"] = cpu_baseline_gmm(model, frames, (tt, ss, got))
     del d_out, d_frames
@@ -284,19 +301,28 @@ def run_dnn(args, dd: Dist, steps, warmup):
 
 
 # ------------------------------------------------------------------------------------------------ C3 / C4 end to end
-def build_reference_task(workdir: Path, nword: int, beam: int):
-    """The C3 task in the REFERENCE'S OWN FORMATS (HTK hmmdefs + HMMList, HTK dictionary, ARPA 2-gram), then the
-    device blobs through jamd_export = Julius' loaders + wchmm builder + our flattening walk
-    (julius_amd/shim/jamd_export.c; the binary is built beside the compiled reference)."""
+def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None):
+    """The C3 / C4 task in the REFERENCE'S OWN FORMATS (HTK hmmdefs + HMMList, HTK dictionary, ARPA 2-gram; for C4
+    also the dnnconf with its .npy weight files and the state prior list), then the device blobs through jamd_export
+    = Julius' loaders + wchmm builder + our flattening walk (julius_amd/shim/jamd_export.c, built next to the library).
+    C4: the hmmdefs carries 4000 one-Gaussian states only to name them -- with -dnnconf the reference scores state i
+    with DNN output i (libsent/src/phmm/outprob.c:218-226)."""
     from julius_amd import synth
-    task = synth.make_triphone_task(workdir, nphone=40, S=S, M=M, nword=nword, nvar=25, seed=0, maxlen=8,
-                                    nbigram_per_word=10)
-    jargs = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
-             "-input", "htkparam", "-1pass", "-gprune", "none", "-b", str(beam)]
-    export = ROOT / "oracle" / "_ref" / "jamd_export"
+    if dnn is None:
+        task = synth.make_triphone_task(workdir, nphone=40, S=S, M=M, nword=nword, nvar=25, seed=0, maxlen=8,
+                                        nbigram_per_word=10)
+        am = ["-gprune", "none"]
+    else:
+        task = synth.make_triphone_task(workdir, nphone=40, S=int(dnn["dims"][-1]), M=1, nword=nword, nvar=25, seed=0,
+                                        maxlen=8, nbigram_per_word=10)
+        task["dnnconf"] = synth.write_dnnconf(workdir, dnn, context_len=11)
+        am = ["-dnnconf", task["dnnconf"], "-notypecheck"]
+    jargs = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"]] + am + [
+        "-input", "htkparam", "-1pass", "-b", str(beam)]
+    export = ROOT / "julius_amd" / "jamd_export"
     if not export.exists():
         return task, jargs, None
-    prefix = workdir / "c3"
+    prefix = workdir / "task"
     subprocess.run([str(export)] + [str(a) for a in jargs] + ["-jamdout", str(prefix)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return task, jargs, prefix
@@ -315,161 +341,179 @@ def trellis_diff(a, b):
     return int(diff + (~same).sum())
 
 
-def run_e2e(args, dd: Dist, steps, warmup, use_dnn=False):
+def run_e2e(args, dd: Dist, runs, use_dnn=False):
+    """configs[2] (GMM) / configs[3] (DNN) end to end on the device: acoustic scores -> exact-order first pass.
+    `runs` = list of (key, utterances per GPU, steps, warmup, scaling): every run shares the models, the lexicon and the
+    distinct utterances; the FIRST run carries the parity block and the CPU baseline.  Returns {key: result}."""
     import torch
     from julius_amd import lexblob, lib, shard, synth
     eng = lib.Engine(dd.local_rank)
-    tmp = tempfile.TemporaryDirectory(prefix="jamd_c3_")
+    tmp = tempfile.TemporaryDirectory(prefix="jamd_e2e_")
     wd = Path(tmp.name)
-    ndist = max(1, min(args.utts, args.distinct))
-    ref_built = False
-    if use_dnn:
-        # configs[3]: 528 -> 6 x 2048 -> 4000 senones; the lexicon's states index the DNN outputs.  Random-init
-        # weights: the scores carry no sentence, the search runs with a saturated beam.
-        dnn = synth.make_dnn(seed=0)
-        NS = int(dnn["dims"][-1])
+    beam = args.beam if args.beam else (4000 if use_dnn else 800)
+    dnn = synth.make_dnn(seed=0) if use_dnn else None
+    NS = int(dnn["dims"][-1]) if use_dnn else S
+    task, jargs, prefix = build_reference_task(wd, args.nword, beam, dnn)
+    ref_built = prefix is not None
+    if ref_built:
+        lx = lib.Lexicon.from_file(eng, str(prefix) + ".lex")
+        info = lexblob.load(str(prefix) + ".lex")
+        lexwhat = (f"{args.nword}-word tree lexicon built by the reference (wchmm.c via jamd_export: {info['nnode']} nodes, "
+                   f"{info['startnum']} roots, {info['isolatenum']} isolated) + 2-gram")
+    else:           # no Julius tree on this box to build jamd_export from: python-made lexicon over the same state inventory
         lex = synth.make_lexicon(nword=args.nword, nphone=40, S=NS, seed=0)
-        scorer = lib.Dnn(eng, dnn)
         lx = lib.Lexicon(eng, lex)
-        rng = np.random.default_rng(1000 + dd.rank)
+        lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
+    maxu = max(r[1] for r in runs)
+    ndist = max(1, min(maxu, args.distinct))
+    if use_dnn:
+        # random-init weights (there are no trained ones offline): the scores carry no sentence, the beam is saturated
+        scorer = lib.Dnn.from_dnnconf(eng, task["dnnconf"]) if ref_built else lib.Dnn(eng, dnn)
+        rng = np.random.default_rng(1000)
         uniq = [rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32) for _ in range(min(ndist, 16))]
         what = f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob"
-        lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
-        task = jargs = None
     else:
-        NS = S
-        task, jargs, prefix = build_reference_task(wd, args.nword, args.beam)
-        if prefix is not None:
-            scorer = lib.Gmm.from_file(eng, str(prefix) + ".am")
-            lx = lib.Lexicon.from_file(eng, str(prefix) + ".lex")
-            info = lexblob.load(str(prefix) + ".lex")
-            ref_built = True
-            lexwhat = (f"{args.nword}-word tree lexicon built by the reference (wchmm.c via jamd_export: {info['nnode']} nodes, "
-                       f"{info['startnum']} roots, {info['isolatenum']} isolated) + 2-gram")
-        else:       # no compiled reference on this box: python-made lexicon over the same state inventory
-            lex = synth.make_lexicon(nword=args.nword, nphone=40, S=S, seed=0)
-            scorer = lib.Gmm(eng, task["model"])
-            lx = lib.Lexicon(eng, lex)
-            lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
-        uniq = [synth.make_utterance(task, nwords=30, seed=100000 * dd.rank + u)[0] for u in range(ndist)]
+        scorer = lib.Gmm.from_file(eng, str(prefix) + ".am") if ref_built else lib.Gmm(eng, task["model"])
+        uniq = [synth.make_utterance(task, nwords=30, seed=u)[0] for u in range(ndist)]
         what = f"GMM S={S} x M={M} x D={D} outprob"
     nuniq = len(uniq)
-    utts = [uniq[u % nuniq] for u in range(args.utts)]
-    off = np.zeros(args.utts + 1, np.int32)
-    off[1:] = np.cumsum([len(x) for x in utts])
-    frames = np.concatenate(utts)
-    T = len(frames)
-    bm = lib.Beam(eng, lx, args.beam, -1.0, max_utts=args.utts, atoms_per_utt=1 << 17)
+    bm = lib.Beam(eng, lx, beam, -1.0, max_utts=maxu, atoms_per_utt=1 << (18 if beam > 1600 else 17))
     if args.order:
         bm.set_order_mode(args.order)
     mode = bm.order_mode()
-    d_fr = torch.from_numpy(frames).cuda()
-    d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
+    out = {}
+    for ri, (key, nutt, steps, warmup, scaling) in enumerate(runs):
+        # the batch is a global list (utterance g = distinct utterance g % nuniq) dealt round-robin: rank r holds g = r + u * world
+        utts = [uniq[(dd.rank + u * dd.world) % nuniq] for u in range(nutt)]
+        off = np.zeros(nutt + 1, np.int32)
+        off[1:] = np.cumsum([len(x) for x in utts])
+        frames = np.concatenate(utts)
+        T = len(frames)
+        d_fr = torch.from_numpy(frames).cuda()
+        d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
 
-    def step(mark):
-        if mark:
-            mark(0)
-        scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
-        if mark:
-            mark(1)
-        bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
-        if mark:
-            mark(2)
+        def step(mark):
+            if mark:
+                mark(0)
+            scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+            if mark:
+                mark(1)
+            bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
+            if mark:
+                mark(2)
 
-    elapsed, ev = timed_steps(dd, stream, step, steps, warmup, nevents=3)
-    sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    beam_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    res_local = bm.results()
-    # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
-    nutt_all = args.utts * dd.world
-    if dd.world > 1:
-        # round-robin table: utterance g lives on rank g % world; this rank's u-th utterance is g = rank + u * world
-        table = shard.gather_results(shard.pack_results(res_local), nutt_all, dd.rank, dd.world, device="cuda")
-    else:
-        table = shard.pack_results(res_local)
-    out = None
-    if dd.rank == 0:
-        ok_all = int((np.asarray(table)[:, 0] == 0).sum())
-        total_frames = T * dd.world * steps
-        cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
-        out = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
-               "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup,
-               "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": total_frames / 100.0 / elapsed,
-               "config": {"workload": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {args.beam}, "
-                                      f"{args.utts} utterances ({T} frames, {nuniq} distinct) per GPU per step",
-                          "lexicon_built_by_reference": ref_built, "order_mode": mode},
-               "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                            "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
-                                    "is frames/s of the first pass over the batch",
-                            "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
-                            "beam_frames_per_s": T / (beam_ms * 1e-3),
-                            "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
-               "pass1": {"ok": ok_all, "utts": nutt_all, "mean_peak_tokens": float(np.mean([r.max_tokens for r in res_local])),
-                         "ties_counted": int(sum(r.ties for r in res_local)), "phase_us_utt0": list(res_local[0].phase_us)}}
-        if dd.world == 1 and not args.no_cpu_baseline and not use_dnn:
-            out["parity"], cpu = e2e_parity(bm, d_sc, off, uniq, nuniq, res_local, jargs, wd, ref_built)
-            if cpu is not None:
-                out["cpu_baseline"] = cpu
+        elapsed, ev = timed_steps(dd, stream, step, steps, warmup, nevents=3)
+        sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        beam_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        res_local = bm.results()
+        # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
+        nutt_all = nutt * dd.world
+        if dd.world > 1:
+            # round-robin table: utterance g lives on rank g % world; this rank's u-th utterance is g = rank + u * world
+            table = shard.gather_results(shard.pack_results(res_local), nutt_all, dd.rank, dd.world, device="cuda")
+        else:
+            table = shard.pack_results(res_local)
+        if dd.rank == 0:
+            st = np.asarray(table)[:, 0]
+            total_frames = T * dd.world * steps
+            cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
+            if scaling == "strong":
+                cfg += f" as configs[4]: the fixed batch of {nutt_all} utterances sharded over {dd.world} GPU(s)"
+            r = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
+                 "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup, "scaling": scaling,
+                 "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": total_frames / 100.0 / elapsed,
+                 "frames_per_s": total_frames / elapsed, "frames_per_s_per_gpu": total_frames / elapsed / dd.world,
+                 "config": {"workload": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {beam}, "
+                                        f"{nutt} utterances ({T} frames, {nuniq} distinct) per GPU per step",
+                            "lexicon_built_by_reference": ref_built, "order_mode": mode, "beam": beam,
+                            "utts_per_gpu": nutt, "utts_total": nutt_all},
+                 "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                              "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
+                                      "is frames/s of the first pass over the batch",
+                              "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
+                              "beam_frames_per_s": T / (beam_ms * 1e-3),
+                              "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
+                 "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,
+                           "mean_peak_tokens": float(np.mean([x.max_tokens for x in res_local])),
+                           "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us)}}
+            if ri == 0 and dd.world == 1 and not args.no_cpu_baseline:
+                r["parity"], cpu = e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_local, jargs, wd, ref_built, use_dnn)
+                if cpu is not None:
+                    r["cpu_baseline"] = cpu
+            out[key] = r
+        del d_fr, d_sc
+    bm.close()
     tmp.cleanup()
     return out
 
 
-def e2e_parity(bm, d_sc, off, uniq, nuniq, res_exact, jargs, wd, ref_built):
+def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, use_dnn):
     """Checker leg (after the timed region).  (1) The device first pass against the COMPILED REFERENCE's
-    (julius -1pass over the same files): word trellis entry by entry, pass-1 sentence, score -- which is also the
-    lazy-scoring CPU baseline of SURVEY 8d.  (2) exact-order kernel against the canonical-tie kernel on every
-    distinct utterance."""
+    (julius -1pass over the same files: for C4 that is the reference's own dnn_calc_outprob() + beam.c): word trellis
+    entry by entry, pass-1 sentence, score -- which is also the lazy-scoring CPU baseline of SURVEY 8d.  (2) exact-order
+    kernel against the canonical-tie kernel on every distinct utterance."""
     from julius_amd import lexblob, synth
     from oracle import pyoracle
     canon_exact = [lexblob.canonical_trellis(bm.trellis(u)) for u in range(nuniq)]
     par = {"device_mode": bm.order_mode()}
     mode0 = bm.order_mode()
+
+    def sent(r):
+        return list(r.wseq[:r.wnum]) if r.status == 0 else None
+
     if mode0 != "fast":
         bm.set_order_mode("fast")
-        bm.pass1_dev(d_sc.data_ptr(), S, off)
+        bm.pass1_dev(d_sc.data_ptr(), NS, off)
         res_fast = bm.results()
         fast = {"utts": nuniq, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": []}
         for u in range(nuniq):
             d = trellis_diff(canon_exact[u], lexblob.canonical_trellis(bm.trellis(u)))
             fast["trellis_identical"] += int(d == 0)
             fast["atoms_differing"].append(d)
-            fast["pass1_sentence_identical"] += int(list(res_fast[u].wseq[:res_fast[u].wnum]) == list(res_exact[u].wseq[:res_exact[u].wnum]))
-            fast["score_identical"] += int(res_fast[u].score == res_exact[u].score)
+            fast["pass1_sentence_identical"] += int(sent(res_fast[u]) == sent(res_exact[u]))
+            fast["score_identical"] += int(res_fast[u].status == res_exact[u].status and
+                                           (res_fast[u].status != 0 or res_fast[u].score == res_exact[u].score))
         fast["ties_counted_by_fast_kernel"] = int(sum(r.ties for r in res_fast[:nuniq]))
         par["fast_kernel_vs_" + mode0 + "_kernel"] = fast
         bm.set_order_mode(mode0)
     cpu = None
     if ref_built:
-        # (1) the compiled reference, one core, lazy scoring: bounded to ~25 s (at least 4 utterances)
+        # (1) the compiled reference, one core, lazy scoring: bounded to ~25 s (at least 4 utterances; C4: at least 2)
         ref = pyoracle.Ref()
         t0 = time.perf_counter()
         rengine = pyoracle.RefEngine(ref, jargs)
         load_s = time.perf_counter() - t0
         vs = {"utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
-              "reference_atoms": []}
+              "reference_atoms": [], "reference_found_a_sentence": 0}
         spent, frames_done = 0.0, 0
         for u in range(nuniq):
-            if u >= 4 and spent > 25.0:
+            if u >= (2 if use_dnn else 4) and spent > 25.0:
                 break
-            synth.write_htk_param(wd / "u.mfc", uniq[u])
+            synth.write_htk_param(wd / "u.mfc", uniq[u], parmkind=synth.PARM_USER if use_dnn else synth.MFCC_E_D_A)
             t0 = time.perf_counter()
             rtr, (rw, rs) = rengine.recognize(wd / "u.mfc")
             spent += time.perf_counter() - t0
             frames_done += len(uniq[u])
+            rfound = len(rw) > 0                       # (a failed first pass leaves pass1_wnum = 0)
             d = trellis_diff(canon_exact[u], rtr)
             vs["utts"] += 1
             vs["trellis_identical"] += int(d == 0)
             vs["atoms_differing"].append(d)
             vs["reference_atoms"].append(int(len(rtr["wid"])))
-            vs["pass1_sentence_identical"] += int(list(res_exact[u].wseq[:res_exact[u].wnum]) == list(rw))
-            vs["score_identical"] += int(float(res_exact[u].score) == float(rs))
+            vs["reference_found_a_sentence"] += int(rfound)
+            dsent = sent(res_exact[u])
+            vs["pass1_sentence_identical"] += int((dsent == list(rw)) if rfound else (dsent is None))
+            vs["score_identical"] += int((res_exact[u].status == 0 and float(res_exact[u].score) == float(rs)) if rfound
+                                         else res_exact[u].status != 0)
         par["device_vs_compiled_reference"] = vs
-        cpu = {"value": frames_done * S / spent, "unit": "frame*states/s (nominal: the lazy search scores only the states it visits)",
+        what = ("julius -1pass (compiled reference: dnn_calc_outprob FMA path, 1 thread, + get_back_trellis_proceed)" if use_dnn
+                else "julius -1pass (compiled reference: lazy outprob cache + get_back_trellis_proceed)")
+        cpu = {"value": frames_done * NS / spent, "unit": "frame*states/s" + ("" if use_dnn else " (nominal: the lazy search scores only the states it visits)"),
                "cores": 1, "kind": "reference", "rtf_inv": frames_done / 100.0 / spent,
-               "sample": f"julius -1pass (compiled reference: lazy outprob cache + get_back_trellis_proceed) on {vs['utts']} "
-                         f"utterances = {frames_done} frames, {spent:.1f} s on 1 of {os.cpu_count()} host cores "
-                         f"(model load {load_s:.1f} s not counted)"}
+               "sample": f"{what} on {vs['utts']} utterances = {frames_done} frames, {spent:.1f} s on 1 of {os.cpu_count()} "
+                         f"host cores (model load {load_s:.1f} s not counted)"}
     return par, cpu
 
 
@@ -497,9 +541,16 @@ def main():
                          "512-utterance batch of configs[4]; e2e: default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="all", choices=["all", "gmm", "dnn", "e2e", "e2e-dnn"],
-                    help="all (default) = gmm at top level with the e2e (C3) and dnn (C4) results nested; gmm = BASELINE "
-                         "configs[1] alone; dnn = configs[3] scoring half; e2e = configs[2]; e2e-dnn = configs[3] end to end")
-    ap.add_argument("--beam", type=int, default=800, help="e2e: rank beam (-b; reference default for triphone models)")
+                    help="all (default) = gmm at top level with e2e (C3), e2e_strong (C5 batch), e2e_dnn (C4) and dnn (C4 scoring "
+                         "half) nested; gmm = BASELINE configs[1] alone; dnn = configs[3] scoring half; e2e = configs[2] "
+                         "(--strong: configs[4]); e2e-dnn = configs[3] end to end")
+    ap.add_argument("--beam", type=int, default=None,
+                    help="e2e: rank beam (-b; default 800 = the reference's default for triphone models, e2e-dnn: 4000 = the "
+                         "reference's DNN recipe)")
+    ap.add_argument("--strong", action="store_true",
+                    help="e2e: run configs[4] as specified -- the FIXED batch of --batch-total utterances sharded over the GPUs "
+                         "(strong scaling) -- instead of --utts utterances per GPU")
+    ap.add_argument("--batch-total", type=int, default=None, help="e2e --strong: utterances in the fixed batch (default 512)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
     ap.add_argument("--distinct", type=int, default=32, help="e2e: distinct utterances in the batch")
     ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
@@ -519,22 +570,44 @@ def main():
     def pick(v, d):
         return d if (v is None or nested) else v
 
+    def top(r):
+        r.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic"})
+        r.setdefault("scaling", "weak")
+        return r
+
     line = None
     if wl in ("all", "gmm"):
         a = argparse.Namespace(**vars(args))
         a.utts = args.utts or 64
-        # 240 x 10 ms: a timed region of >= 2 s; --steps/--warmup address this (the contract's) workload
-        line = run_gmm(a, dd, args.steps if args.steps is not None else 240, args.warmup if args.warmup is not None else 5)
-    if wl in ("all", "e2e", "e2e-dnn"):
-        a = argparse.Namespace(**vars(args))
-        a.utts = pick(args.utts, 256)
-        r = run_e2e(a, dd, pick(args.steps, 8), pick(args.warmup, 1), use_dnn=(wl == "e2e-dnn"))
+        # one step = 12 launches ~ 120 ms: 20 steps time >= 2 s; --steps/--warmup address this (the contract's) workload
+        line = run_gmm(a, dd, args.steps if args.steps is not None else 20, args.warmup if args.warmup is not None else 2)
+    if wl in ("all", "e2e"):
+        # configs[2] weak (fixed utterances per GPU) and configs[4] strong (the fixed 512-utterance batch sharded over the
+        # GPUs: 64 per GPU at N = 8, all 512 on one GPU at N = 1), same models, lexicon and utterances
+        per_gpu = pick(args.utts, 256)
+        strong_total = args.batch_total or C5_TOTAL_UTTS
+        runs = []
+        if wl == "all" or not args.strong:
+            runs.append(("e2e", per_gpu, pick(args.steps, 8), pick(args.warmup, 1), "weak"))
+        if wl == "all" or args.strong:
+            runs.append(("e2e_strong", max(1, strong_total // dd.world), pick(args.steps, 4), pick(args.warmup, 1), "strong"))
+        r = run_e2e(args, dd, runs, use_dnn=False)
         if dd.rank == 0:
             if nested:
-                line["e2e"] = r
+                line.update(r)
             else:
-                r.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
-                line = r
+                line = top(r[runs[0][0]])
+                for k in list(r)[1:]:
+                    line[k] = r[k]
+    if wl in ("all", "e2e-dnn"):
+        # configs[3] end to end at the reference recipe's beam (-b 4000), reference-built lexicon, parity vs julius -1pass
+        runs = [("e2e_dnn", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")]
+        r = run_e2e(args, dd, runs, use_dnn=True)
+        if dd.rank == 0:
+            if nested:
+                line.update(r)
+            else:
+                line = top(r["e2e_dnn"])
     if wl in ("all", "dnn"):
         a = argparse.Namespace(**vars(args))
         a.utts = pick(args.utts, 64)
@@ -543,8 +616,7 @@ def main():
             if nested:
                 line["dnn"] = r
             else:
-                r.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
-                line = r
+                line = top(r)
     if dd.rank == 0:
         print(json.dumps(line), flush=True)
     dd.close()

@@ -1561,6 +1561,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       place(&xw.o_nodefirst, (size_t)w.nnode * sizeof(unsigned));
       place(&xw.o_bitmap, (bits + 31) / 32 * 4);
       place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
+      place(&xw.o_collect, ((size_t)beam_width + 256) * 16);
     }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
@@ -1739,7 +1740,8 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
       if (b->exact_status != 0) {
         jamd_set_error("jamd_beam_set_order_mode: the exact-order kernel cannot serve this work area (%s)",
                        b->exact_status == -1 ? "visiting index exceeds 32 bits"
-                       : b->exact_status == -2 ? "beam too wide for the LDS image" : b->exact_status == -4 ? "multipath lexicon" : "no LDS");
+                       : b->exact_status == -2 ? "beam too wide for the LDS image" : b->exact_status == -3 ? "more than 2^21 tokens per frame"
+                       : b->exact_status == -4 ? "multipath lexicon" : "no LDS");
         return JAMD_ESTATE;
       }
       b->xw.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;
@@ -1761,9 +1763,10 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   JAMD_HIP(hipSetDevice(b->eng->device));
   if ((size_t)n > b->pcap) {
     void *p = nullptr;
-    const size_t cap = (size_t)n + 1024;
+    const size_t cap = ((size_t)n + 1024 + 3) & ~(size_t)3;     // multiple of 4: the heap and the top-list scratch stay aligned
     JAMD_HIP(hipMalloc(&p, cap * 4)); b->owned.push_back(p); b->d_pkeys = (unsigned *)p;
-    JAMD_HIP(hipMalloc(&p, (cap + 2) * 12)); b->owned.push_back(p); b->d_pout = (int *)p;    // out[cap] + nout + heap u64[cap + 2]
+    // out[cap] + nout (+ pad) | heap u64[cap + 2] | top-list scratch u32x4[beam + 256] (wide layout)
+    JAMD_HIP(hipMalloc(&p, 4 * (cap + 4) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256))); b->owned.push_back(p); b->d_pout = (int *)p;
     b->pcap = cap;
   }
   std::vector<unsigned> keys((size_t)n);
@@ -1774,12 +1777,14 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   hipStream_t st = b->eng->stream;
   JAMD_HIP(hipMemcpyAsync(b->d_pkeys, keys.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
   int *d_nout = b->d_pout + b->pcap;
-  unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + ((b->pcap + 2 + 1) & ~(size_t)1));
-  xbeam_prune_order_launch(b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, st);
+  unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 4);
+  u32x4 *d_collect = reinterpret_cast<u32x4 *>(d_heap + b->pcap + 2);
+  xbeam_prune_order_launch(b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, st);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_prune_order: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpyAsync(nkeep, d_nout, 4, hipMemcpyDeviceToHost, st));
   JAMD_HIP(hipStreamSynchronize(st));
+  if (*nkeep < 0 || *nkeep > n) { jamd_set_error("jamd_beam_prune_order: the kernel reported %d of %d tokens kept", *nkeep, n); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpy(order, b->d_pout, 4 * (size_t)*nkeep, hipMemcpyDeviceToHost));
   return JAMD_OK;
 }

@@ -10,6 +10,11 @@ struct XWork {
   unsigned o_nodefirst;        // u32 [nnode]  ~(first visiting index) of a node whose cell overflowed to nodekey[]
   unsigned o_bitmap;           // u32 [gbm_words] creation-order bitmap when it outgrows LDS
   unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
+  unsigned o_collect;          // u32x4 [beam + 256] wide layout: the top list on its way from the heap to the sorted lists
+  int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
+                               //     the whole LDS image but welist[] (see xbeam_layout())
+  int cells_at, fixed_end;     // start of the per-launch part of the image (cells / pruning overlay / score row)
+  int off_dov;                 // start of the pruning step's overlay (narrow: = cells_at; wide: behind welist[])
   int s1, xw;                  // visiting index = (source position << s1) | transition number; roots start at xw
   int nslot;                   // LDS Viterbi cells (16 bytes each: key, node, first visit)
   int bm_words;                // LDS bitmap capacity
@@ -17,17 +22,20 @@ struct XWork {
   int prune_mode;              // 0 = closed-form extraction, 1 = sequential extraction always (timing / test)
   // byte offsets in dynamic LDS
   int off_atom, off_we, off_dbase, off_tpre, off_bm, off_cells, off_lnode, off_lfirst, off_row;
-  int off_compr, off_vpos, off_id, off_hist, off_tail, off_heap;   // the pruning step's overlay on the cells
+  int off_compr, off_vpos, off_id, off_idt, off_hist, off_tail, off_heap;   // the pruning step's overlay
   int lds_bytes;
 };
 
 // Fills the LDS layout for beam width w.beam.  maxfan = 2 + most extra arcs of a node, nroot = startnum.
-// 0 = ok, -1 = the visiting index does not fit 32 bits, -2 = the survivors do not fit LDS (beam too wide).
+// 0 = ok, -1 = the visiting index does not fit 32 bits, -2 = the per-survivor arrays do not fit LDS (beam too wide
+// even for the wide layout), -3 = more tokens per frame than the heap's position keys can number.
 int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared);
+// places the per-launch part of the image (cells, pruning overlay, score row of nstate floats or none)
+void xbeam_place(XWork *xw, int nstate);
 hipError_t xbeam_prepare();
 void xbeam_launch(const LexDev &lx, const XWork &xw, const float *scores, int nstate, const int *d_utt_off, int nutt,
                   int smode, bool timed, hipStream_t st);
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, hipStream_t st);
+                              unsigned long long *d_hglob, u32x4 *d_collect, hipStream_t st);
 
 }  // namespace jamdb

@@ -46,10 +46,12 @@ using namespace jamdb;
 #define JAMD_XBEAM_CB 4                 // tokens per thread carried together through the finalize step
 #endif
 constexpr int kMaxL = 20;                // heap positions < 2^21
-#ifndef JAMD_XBEAM_PROBE
-// development builds (tools/build_variant.sh, tools/exact_probe.sh): JAMD_XBEAM_PROBE = 1 / 2 / 3 / 5 puts the sub-step
-// clocks of steps 0-B / step C / the event replay / heap fill + heapify into phase_us[4..7] instead of the pruning
-// step's four parts; 4 reports the shader clock (MHz) under the kernel in phase_us[7]
+// The instrumented instantiation (JAMD_BEAM_TIMING=1) reports the four steps of a frame and the four parts of the
+// pruning step in phase_us[0..7].  Finer probes exist only in development builds (-DJAMD_DEV, tools/build_variant.sh,
+// tools/exact_probe.sh): JAMD_XBEAM_PROBE = 1 / 2 / 3 / 5 puts the sub-step clocks of steps 0-B / step C / the event
+// replay / heap fill + heapify into phase_us[4..7] instead; 4 reports the shader clock (MHz) in phase_us[7].
+#if !defined(JAMD_DEV) || !defined(JAMD_XBEAM_PROBE)
+#undef JAMD_XBEAM_PROBE
 #define JAMD_XBEAM_PROBE 0
 #endif
 
@@ -185,6 +187,7 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   lds_u64 *compR, *compT;        // [b_cap] each: the sorted top list (score bits << 32 | ~prekey at collection time), and scratch for sorting it
   lds_u32 *vposR;                // [b_cap] current virtual heap position per rank
   lds_u32 *idR;                  // [b_cap] token id per rank
+  lds_u32 *idT;                  // [b_cap] wide layout: token ids beside compT while the list is being sorted
   lds_u32 *hist;                 // [2048]
   lds_u32 *tailmask;             // [(beam + 31) / 32 + 1]
   lds_i32 *cand;                 // [kMaxCand] tail candidates in the order of their turns: extraction index i
@@ -349,6 +352,7 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
     }
     __syncthreads();
     {
+      static_assert(NT == 1024, "the 2048 radix bins are scanned two per thread");
       const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
       hist[2 * tid] = 0u; hist[2 * tid + 1] = 0u;
       const unsigned pair = h0 + h1;
@@ -546,14 +550,25 @@ __device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int 
 
 // sort_token_no_order() (:1492): the visiting order of the next frame.  keys[i] = score bits of token i in
 // creation order.  Writes the token ids into svid[0..return value).  Whole workgroup.
+//
+// WIDE (the wide-beam layout): the heap is laid over the list areas -- it is dead once the top elements are
+// collected, so they travel through `G` (a scratch array in the utterance's slice) with their token ids, and the
+// sorted list is built where the heap was; vposR lies over the sorting scratch.
+template <bool WIDE>
 __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
-                           unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode,
+                           unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode, u32x4 *G,
                            unsigned long long *tp = nullptr) {
   const int tid = threadIdx.x;
   unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
+  (void)tc3_;
 #define PTICK(i) do { if (tp && tid == 0 && ((JAMD_XBEAM_PROBE != 3 && JAMD_XBEAM_PROBE != 5) || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
+#ifdef JAMD_DEV
 #define PTICK5(i) do { if (JAMD_XBEAM_PROBE == 5 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
 #define PTICK3(i) do { if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
+#else
+#define PTICK5(i) ((void)0)
+#define PTICK3(i) ((void)0)
+#endif
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
     __syncthreads();
@@ -587,11 +602,14 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       __syncthreads();                                   // (kth_largest() left the histogram cleared)
       for (int p0 = 1; p0 <= n; p0 += NT) {
         const int p = p0 + tid;
-        const unsigned hi = p <= n ? (unsigned)(Hh[p] >> 32) : 0u;
+        const unsigned long long hv = p <= n ? Hh[p] : 0ull;
+        const unsigned hi = (unsigned)(hv >> 32);
         const bool in = p <= n && hi >= vk;
         const int slot = wave_alloc(&sh.nB, in);
         if (in && slot < pm.b_cap) {
-          pm.compT[slot] = ((unsigned long long)hi << 32) | (unsigned)(0xffffffffu - prekey((unsigned)p));
+          const unsigned pk = 0xffffffffu - prekey((unsigned)p);
+          if constexpr (WIDE) G[slot] = u32x4{pk, hi, (unsigned)hv, 0u};
+          else pm.compT[slot] = ((unsigned long long)hi << 32) | pk;
           atomicAdd((unsigned *)&pm.hist[bin_of(hi)], 1u);
         }
       }
@@ -600,14 +618,21 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       PTICK(5);
       if (nB <= pm.b_cap) {
         {
-          // exclusive prefix from the top bin down: thread t owns bins 2047 - 2t and 2046 - 2t
+          // exclusive prefix from the top bin down: thread t owns bins 2047 - 2t and 2046 - 2t (NT == 1024, as above)
           const unsigned c1 = pm.hist[2047 - 2 * tid], c0 = pm.hist[2046 - 2 * tid];
           const int ex = block_excl_scan(sh, (int)(c1 + c0));
           pm.hist[2047 - 2 * tid] = (unsigned)ex; pm.hist[2046 - 2 * tid] = (unsigned)ex + c1;
           __syncthreads();
           for (int e = tid; e < nB; e += NT) {                  // by bin, any order inside; hist[b] ends as the END of bin b
-            const unsigned long long c = pm.compT[e];
-            pm.compR[atomicAdd((unsigned *)&pm.hist[bin_of((unsigned)(c >> 32))], 1u)] = c;
+            if constexpr (WIDE) {                               // (the heap is dead: every thread is past the barrier behind the collection)
+              const u32x4 g = G[e];
+              const unsigned at = atomicAdd((unsigned *)&pm.hist[bin_of(g.y)], 1u);
+              pm.compR[at] = ((unsigned long long)g.y << 32) | g.x;
+              pm.idT[at] = g.z;
+            } else {
+              const unsigned long long c = pm.compT[e];
+              pm.compR[atomicAdd((unsigned *)&pm.hist[bin_of((unsigned)(c >> 32))], 1u)] = c;
+            }
           }
           __syncthreads();
           for (int e = tid; e < nB; e += NT) {
@@ -617,10 +642,12 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
             int r = lo;
             for (int x = lo; x < hi; x++) r += pm.compR[x] > c ? 1 : 0;
             pm.compT[r] = c;
+            if constexpr (WIDE) pm.idR[r] = pm.idT[e];
           }
           __syncthreads();
         }
         { lds_u64 *t_ = pm.compR; pm.compR = pm.compT; pm.compT = t_; }     // the sorted list is what the replay calls compR
+        if constexpr (WIDE) pm.vposR = (lds_u32 *)pm.compT;                 // (the sorting scratch is free from here on)
         // An event re-inserts ONE element; the other elements keep their places in the order, and an element whose
         // score is unique in the list is ranked by its score wherever it sits.  So the replay can stop behind the last
         // turn at which a TIED element may sit on the tail position (sh.i_last; such an element is one that starts on a
@@ -628,7 +655,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         for (int r = tid; r < nB; r += NT) {
           const unsigned long long cr = pm.compR[r];
           const unsigned p = prekey_pos(0xffffffffu - (unsigned)cr);
-          pm.vposR[r] = p; pm.idR[r] = (unsigned)Hh[p];
+          pm.vposR[r] = p;
+          if constexpr (!WIDE) pm.idR[r] = (unsigned)Hh[p];
           if (p >= (unsigned)(n - k + 1)) {
             atomicOr((unsigned *)&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
             const unsigned sc = (unsigned)(cr >> 32);
@@ -666,7 +694,9 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           if (tid == 0) { ctl[0] = nc; ctl[1] = 0; ctl[2] = 0; ctl[3] = sh.i_last; }
         }
         __syncthreads();
+#ifdef JAMD_DEV
         if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tc3_ = wall_clock64();   // slot 7 - (4 + 5 + 6) = everything before the replay
+#endif
         const int ncand0 = uni(ctl[0]);
         if (ncand0 > kMaxCand) {
           if (tid < 64) {                                     // serial form, straight off the mask
@@ -714,7 +744,9 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
                 const unsigned hole = uni((unsigned)(ev >> 32));
                 const int newr = uni((int)((unsigned)ev & 0x7fffffffu));
                 const bool tied = (uni((unsigned)ev) & 0x80000000u) != 0u;
+#ifdef JAMD_DEV
                 if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tp[6] += 100;   // events (1 us each)
+#endif
                 const int lo = newr < rs ? newr : rs, hi = newr < rs ? rs : newr;
                 // which later candidates can this change?  (ranks outside [lo, hi] keep their numbers)  One lane each;
                 // the chain occupants are read with a fixed trip count so the loads go out together.
@@ -830,7 +862,33 @@ __device__ __forceinline__ float nbest_of_set(const LexDev &lx, const XRowRef &r
   return sum / (float)n;
 }
 
-template <bool TIMED>
+// The survivors of the frame, in visiting order: in LDS (narrow layout) or in the utterance's slice (wide layout:
+// steps 0 and A read them in order, only the winner look-ups of step C are gathers -- from L2).
+template <bool WIDE> struct XSv;
+template <> struct XSv<false> {
+  lds_v4 *p;
+  __device__ __forceinline__ Tok load(int j) const { return lds_tok_load(p, j); }
+  __device__ __forceinline__ void store(int j, const Tok &t) const { lds_tok_store(p, j, t); }
+  __device__ __forceinline__ void quads(int j, u32x4 &a, u32x4 &b) const { a = p[2 * j]; b = p[2 * j + 1]; }
+};
+template <> struct XSv<true> {
+  u32x4 *p;
+  __device__ __forceinline__ void quads(int j, u32x4 &a, u32x4 &b) const { a = p[2 * j]; b = p[2 * j + 1]; }
+  __device__ __forceinline__ Tok load(int j) const {
+    u32x4 a, b;
+    quads(j, a, b);
+    Tok t;
+    t.node = (int)a.x; t.score = __uint_as_float(a.y); t.last_tre = (int)a.z; t.last_cword = (int)a.w;
+    t.last_lscore = __uint_as_float(b.x); t.last_wid = (int)b.y; t.pad0 = (int)b.z; t.pad1 = (int)b.w;
+    return t;
+  }
+  __device__ __forceinline__ void store(int j, const Tok &t) const {
+    p[2 * j] = u32x4{(unsigned)t.node, __float_as_uint(t.score), (unsigned)t.last_tre, (unsigned)t.last_cword};
+    p[2 * j + 1] = u32x4{__float_as_uint(t.last_lscore), (unsigned)t.last_wid, (unsigned)t.pad0, (unsigned)t.pad1};
+  }
+};
+
+template <bool TIMED, bool WIDE>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
   __shared__ XShared sh;
@@ -854,7 +912,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 #define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
   jamd_pass1_result *res = wk.res + u;
   // LDS image: survivors in VISITING ORDER (no node hash: a candidate names its source by position)
-  lds_v4 *sv = (lds_v4 *)dyn_lds;                          // Tok[beam], two quads each (lds_tok_load / lds_tok_store)
+  XSv<WIDE> sv;                                            // Tok[beam], two quads each
+  if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + wk.o_sv); else sv.p = (lds_v4 *)dyn_lds;
   lds_i32 *sv_atom = (lds_i32 *)(dyn_lds + xw.off_atom);
   lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      // word ends of the frame; the pruning step returns its order here
   lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);    // [beam + 2] first dense visiting index of each source
@@ -870,6 +929,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
   pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
+  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
@@ -878,6 +938,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.b_cap = xw.b_cap;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
+  u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
   for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
   const float lmw = lx.lm_weight, pen = lx.lm_penalty;
   const bool dfa = lx.lm_type != JAMD_LM_NGRAM;
@@ -889,9 +950,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 
   if (resume) {
     if (!ss->active) return;
-    {
+    if constexpr (!WIDE) {
       const u32x4 *src = (const u32x4 *)(ub + wk.o_sv);
-      for (int i = tid; i < wk.sv_bytes / 16; i += NT) sv[i] = src[i];
+      for (int i = tid; i < wk.sv_bytes / 16; i += NT) sv.p[i] = src[i];
     }
     if (tid == 0) { sh.n_atom = ss->n_atom; sh.n_surv = ss->n_surv; }
     __syncthreads();
@@ -920,15 +981,22 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = ls;
       nw.score = node_outprob(lx, scores + (size_t)t_begin * S, nr.w, nr.z, -1) + ls;
       nw.pad0 = nr.x; nw.pad1 = 0;
-      lds_tok_store(sv, 0, nw);
+      sv.store(0, nw);
       sh.n_surv = 1;
     }
   }
   float thr = resume ? ss->thr : JAMD_LOG_ZERO;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tc2 = tc;
+  (void)tc2;
+#ifdef JAMD_DEV
   const unsigned long long cyc0 = clock64(), wall0 = tc;   // JAMD_XBEAM_PROBE == 4: shader clock under this kernel
+#endif
 #define PHASE(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc; tc = n_; tc2 = n_; } } while (0)
+#ifdef JAMD_DEV
 #define PROBE(g, i) do { if (TIMED && JAMD_XBEAM_PROBE == (g) && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc2; tc2 = n_; } } while (0)
+#else
+#define PROBE(g, i) ((void)0)
+#endif
   int max_tokens = resume ? ss->max_tokens : 1;
   bool stopped = false;
   __syncthreads();
@@ -959,7 +1027,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int j = j0 + tid;
         int cnt = 0, isend = 0;
         if (j < n_surv) {
-          const u32x4 a_ = sv[2 * j], b_ = sv[2 * j + 1];
+          u32x4 a_, b_;
+          sv.quads(j, a_, b_);
           const float sc = __uint_as_float(a_.y); const int sw = (int)b_.z;
           const bool alive = last || (sc > JAMD_LOG_ZERO && !(sc < thr));
           if (alive && !last) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
@@ -995,7 +1064,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     };
     // ---- A: intra-word transitions + word-end atoms (beam.c:2838-2900)
     for (int j = tid; j < n_surv; j += NT) {
-      const Tok tk = lds_tok_load(sv, j);
+      const Tok tk = sv.load(j);
       const int node = tk.node;
       const int sword = tk.pad0;                       // stend
       if (!last) {
@@ -1036,7 +1105,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int2 it = ARCQ(q);
         const int j = it.x & 0xffff;
         const int to = lx.ac_to(it.y);
-        const Tok tk = lds_tok_load(sv, j);
+        const Tok tk = sv.load(j);
         intra_candidate(tk, j, to, lx.ac_a(it.y), it.x >> 16, to != tk.node ? lx.scid(to) : 0);
       }
       __syncthreads();
@@ -1053,7 +1122,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int w = x / nroot, rv = x - w * nroot;
         const int r = nroot - 1 - rv;
         const int j = welist[w];
-        const Tok tk = lds_tok_load(sv, j);
+        const Tok tk = sv.load(j);
         const int sword = tk.pad0;
         if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
         const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
@@ -1079,7 +1148,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int nrec = min(kWeChunk, n_we - w0);
         if (tid < nrec) {
           const int j = welist[w0 + tid];
-          const Tok tk = lds_tok_load(sv, j);
+          const Tok tk = sv.load(j);
           const int sword = tk.pad0;
           const bool tr = lx.is_transparent(sword) != 0;
           const int last_word = tr ? tk.last_cword : sword;
@@ -1124,7 +1193,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       if (sh.we_best != 0ull) {                       // beam_inter_word_factoring() :2549-2637
         const unsigned long long kb = sh.we_best;
         const float best_score = unord((unsigned)(kb >> 32));
-        const Tok tk = lds_tok_load(sv, (int)(~(unsigned)kb));
+        const Tok tk = sv.load((int)(~(unsigned)kb));
         const int sword = tk.pad0;
         const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
         for (int r = tid; r < lx.nshared; r += NT) {
@@ -1226,14 +1295,14 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           if (dfa && t == 0) {                                 // an initial token of the grammar
             l_ls[k] = lx.init_lscore(sub);
           } else if (j < n_surv && sub < XW) {                 // intra-word
-            const Tok tk = lds_tok_load(sv, j);
+            const Tok tk = sv.load(j);
             l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
             if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
             else l_ls[k] = tk.last_lscore;
           } else {
             const bool iso = j < n_surv;
             if (!iso) j = (int)(~(unsigned)sh.we_best);        // the factoring pass: from the best word end
-            const Tok tk = lds_tok_load(sv, j);
+            const Tok tk = sv.load(j);
             const int sword = tk.pad0;
             const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
             l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
@@ -1378,8 +1447,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
-    for (int j = tid; j < n_keep; j += NT) lds_tok_store(sv, j, CUR(welist[j]));
+    const int n_keep = exact_prune<WIDE>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
+    for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(welist[j]));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
     for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
@@ -1389,9 +1458,11 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   __syncthreads();
 
   if (smode == 1) {
-    if (!stopped) {
-      u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
-      for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = sv[i];
+    if constexpr (!WIDE) {
+      if (!stopped) {
+        u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
+        for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = sv.p[i];
+      }
     }
     if (tid == 0) {
       ss->started = 1; ss->active = stopped ? 0 : 1; ss->frames_done = T; ss->n_surv = sh.n_surv; ss->thr = thr;
@@ -1445,7 +1516,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     res->natom = natom; res->ties = 0; res->max_tokens = max_tokens;
     res->ties_node = 0; res->ties_wordend = 0; res->ties_cut = 0;
     if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+#ifdef JAMD_DEV
     if (TIMED && JAMD_XBEAM_PROBE == 4) res->phase_us[7] = (int)((clock64() - cyc0) * 100ull / (wall_clock64() - wall0));   // MHz
+#endif
     res->frames = T;
     if (sh.n_atom > wk.atom_cap) res->status = JAMD_PASS1_OVERFLOW;
     if (res->status == JAMD_PASS1_OK) {
@@ -1465,14 +1538,16 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 
 // diagnostic: the pruning step alone on given score bits (tests/test_prune_order.py fuzzes it against the
 // sequential heap)
+template <bool WIDE>
 __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigned *keys, int n, int k, int *out, int *nout,
-                                                         unsigned long long *hglob) {
+                                                         unsigned long long *hglob, u32x4 *gcol) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   PruneMem pm;
   pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
   pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
   pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
+  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);
   pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
   pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
   pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
@@ -1486,8 +1561,8 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
-  const int nk = exact_prune(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
-                             xw.prune_mode);
+  const int nk = exact_prune<WIDE>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
+                                   xw.prune_mode, gcol);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
   if (threadIdx.x == 0) *nout = nk;
 }
@@ -1495,6 +1570,113 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
 }  // namespace
 
 namespace jamdb {
+
+// The fixed part of the image for one of the two layouts.
+//   narrow: [survivors Tok[beam]] [atom] [welist] [dbase] [tpre] [bitmap] | cells / pruning overlay | score row
+//   wide:   [welist] | [atom] [dbase] [tpre] [bitmap] cells | score row     -- the survivors live in the utterance's
+//           slice (o_sv: steps 0 and A read them in order, only the winner look-ups of step C are gathers), and the
+//           pruning step overlays everything behind welist[] (all of it is dead between step C and the next step 0;
+//           welist[] carries the pruning step's result).
+static int xbeam_fixed(XWork *xw, bool wide, int maxfan, int nroot, int ninit, int nshared) {
+  const int beam = xw->w.beam;
+  int at = 0;
+  auto place = [&](int *off, int bytes) { *off = at; at = (at + bytes + 15) & ~15; };
+  xw->wide = wide ? 1 : 0;
+  if (!wide) {
+    at = beam * (int)sizeof(Tok);
+    place(&xw->off_atom, 4 * beam);
+    place(&xw->off_we, 4 * beam);
+    place(&xw->off_dbase, 4 * (beam + 2));
+    xw->w.sv_bytes = at;                             // what a streaming session parks between launches
+    place(&xw->off_tpre, 4 * NT);
+  } else {
+    place(&xw->off_we, 4 * beam);
+    xw->off_dov = at;
+    place(&xw->off_atom, 4 * beam);
+    place(&xw->off_dbase, 4 * (beam + 2));
+    xw->w.sv_bytes = (beam * (int)sizeof(Tok) + 15) & ~15;   // the survivors' home in the slice; nothing to park
+    place(&xw->off_tpre, 4 * NT);
+  }
+  if (at + 8 * 1024 > kMaxDynLds) return -2;
+  // creation-order bitmap: XW bits per source plus a few word ends' worth of roots (a frame that needs more
+  // uses the copy in global memory); at most an eighth of what is left
+  int bm_words = (beam * maxfan + 8 * nroot + nshared + ninit + 31) / 32 + 64;
+  if (bm_words > 4096) bm_words = 4096;
+  if (4 * bm_words > (kMaxDynLds - at) / 8) bm_words = (kMaxDynLds - at) / 32;
+  xw->bm_words = bm_words;
+  place(&xw->off_bm, 4 * bm_words);
+  xw->cells_at = at;
+  if (!wide) xw->off_dov = at;
+  return 0;
+}
+
+static int xbeam_tail_bytes(int beam) {
+  return (4 * ((beam + 31) / 32 + 2 + 4 * kMaxCand + 4 + (kMaxCand + 1) * (kTakers + 1)) + 15) & ~15;
+}
+
+// The per-launch part with `want` bytes set aside for the score row.  The frame's Viterbi cells take what is left
+// (16 bytes a slot); the pruning step overlays them (narrow) or everything behind welist[] (wide):
+//   narrow: [compR|compT 16 b_cap] [vposR 4] [idR 4] [hist] [tail] [heap: the rest]
+//   wide:   [compA|compB 16 b_cap] [idA 4] [idB 4] ... [hist] [tail]   with the heap laid over the lists (it is dead
+//           once the top elements are collected into o_collect) and vposR over compA (dead once the list is sorted)
+// b_cap = 0: no room for the closed-form extraction (the sequential extraction runs on one lane).
+static void xbeam_place_with(XWork *xw, int want) {
+  const int beam = xw->w.beam;
+  const int cells_at = xw->cells_at;
+  int region = ((kMaxDynLds - cells_at) & ~1023) - want;
+  if (region < 0) region = 0;
+  int nslot = (region / 16) & ~63;
+  if (nslot < 1024) nslot = 0;                       // too few to be worth probing: every cell in nodekey[]
+  xw->nslot = nslot;
+  xw->off_cells = cells_at;
+  xw->off_lnode = cells_at + 8 * nslot;
+  xw->off_lfirst = cells_at + 12 * nslot;
+  const int end = cells_at + region;
+  const int tail_bytes = xbeam_tail_bytes(beam);
+  int at = xw->off_dov;
+  auto place = [&](int *off, int bytes) { *off = at; at = (at + bytes + 15) & ~15; };
+  xw->b_cap = beam + 256;
+  if (!xw->wide) {
+    if (16 * xw->b_cap + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) xw->b_cap = 0;
+    place(&xw->off_compr, 16 * xw->b_cap);
+    place(&xw->off_vpos, 4 * xw->b_cap);
+    place(&xw->off_id, 4 * xw->b_cap);
+    xw->off_idt = xw->off_id;
+    place(&xw->off_hist, xw->b_cap ? 4 * 2048 : 0);
+    place(&xw->off_tail, tail_bytes);
+    place(&xw->off_heap, 0);
+    xw->heap_cap = (end - xw->off_heap) / 8 - 2;
+  } else {
+    const int dreg = end - xw->off_dov;
+    if (24 * xw->b_cap + 4 * 2048 + tail_bytes + 64 > dreg) xw->b_cap = 0;
+    xw->off_tail = end - tail_bytes;
+    xw->off_hist = xw->off_tail - 4 * 2048;
+    xw->off_heap = xw->off_dov;
+    place(&xw->off_compr, 16 * xw->b_cap);
+    place(&xw->off_idt, 4 * xw->b_cap);
+    place(&xw->off_id, 4 * xw->b_cap);
+    xw->off_vpos = xw->off_compr;
+    xw->heap_cap = (xw->off_hist - xw->off_heap) / 8 - 2;
+  }
+  if (xw->heap_cap < 0) xw->heap_cap = 0;
+  xw->off_row = end;
+  xw->lds_bytes = end;
+}
+
+void xbeam_place(XWork *xw, int nstate) {
+  xbeam_place_with(xw, 0);
+  xw->w.row_cache = 0;
+  if (nstate <= 0) return;
+  // make room for the frame's score row when the cell table, the LDS heap and the top lists can spare it
+  XWork t = *xw;
+  xbeam_place_with(&t, (4 * nstate + 1023) & ~1023);
+  const int beam = xw->w.beam;
+  const bool ok = t.b_cap == xw->b_cap && t.off_row + 4 * nstate <= kMaxDynLds &&
+                  (xw->wide ? 2 * t.heap_cap >= 5 * beam : (t.nslot >= 6 * beam && t.heap_cap >= 5 * beam));
+  if (!ok) return;                                   // the row stays in global memory
+  *xw = t;
+  xw->w.row_cache = 1;
+}
 
 int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared) {
   xw->w = w;
@@ -1507,89 +1689,51 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   int jb = 1; while ((1 << jb) < beam + 2) jb++;
   if (s1 + jb > 32) return -1;
   xw->s1 = s1;
-  // LDS image
-  int at = beam * (int)sizeof(Tok);
-  auto place = [&](int *off, int bytes) { *off = at; at = (at + bytes + 15) & ~15; };
-  place(&xw->off_atom, 4 * beam);
-  place(&xw->off_we, 4 * beam);
-  place(&xw->off_dbase, 4 * (beam + 2));
-  xw->w.sv_bytes = at;                               // what a streaming session parks between launches
-  place(&xw->off_tpre, 4 * NT);
-  if (at + 8 * 1024 > kMaxDynLds) return -2;         // the survivors do not fit: wider beams use the strict-order kernel
-  // creation-order bitmap: XW bits per source plus a few word ends' worth of roots (a frame that needs more
-  // uses the copy in global memory); at most an eighth of what is left
-  int bm_words = (beam * maxfan + 8 * nroot + nshared + ninit + 31) / 32 + 64;
-  if (bm_words > 4096) bm_words = 4096;
-  if (4 * bm_words > (kMaxDynLds - at) / 8) bm_words = (kMaxDynLds - at) / 32;
-  xw->bm_words = bm_words;
-  place(&xw->off_bm, 4 * bm_words);
-  // the rest: the frame's Viterbi cells (16 bytes a slot); the pruning step overlays them
-  const int cells_at = at;
-  const int region = (kMaxDynLds - cells_at) & ~1023;
-  int nslot = (region / 16) & ~63;
-  if (nslot < 1024) nslot = 0;                       // too few to be worth probing: every cell in nodekey[]
-  xw->nslot = nslot;
-  xw->off_cells = cells_at;
-  xw->off_lnode = cells_at + 8 * nslot;
-  xw->off_lfirst = cells_at + 12 * nslot;
-  // overlay: top-k lists of the closed-form extraction when they leave room for a heap of at least 2 beam + 64
-  // entries, then the heap (a frame with more tokens than it holds builds its heap in global memory)
-  at = cells_at;
-  xw->b_cap = beam + 256;
-  const int tail_bytes = 4 * ((beam + 31) / 32 + 2 + 4 * kMaxCand + 4 + (kMaxCand + 1) * (kTakers + 1));
-  if (16 * xw->b_cap + 8 * xw->b_cap + 4 * 2048 + tail_bytes + 128 + 8 * (2 * beam + 64) > region) xw->b_cap = 0;
-  place(&xw->off_compr, 16 * xw->b_cap);
-  place(&xw->off_vpos, 4 * xw->b_cap);
-  place(&xw->off_id, 4 * xw->b_cap);
-  place(&xw->off_hist, xw->b_cap ? 4 * 2048 : 0);
-  place(&xw->off_tail, tail_bytes);
-  place(&xw->off_heap, 0);
-  xw->heap_cap = (cells_at + region - xw->off_heap) / 8 - 2;
-  if (xw->heap_cap < 0) xw->heap_cap = 0;
-  xw->off_row = cells_at + region;
-  xw->lds_bytes = xw->off_row;
+  if ((long long)w.tok_cap + 2 >= (1ll << (kMaxL + 1))) return -3;   // prekey() numbers heap positions below 2^(kMaxL+1)
+  // the narrow layout (survivors in LDS) while it leaves room for the closed-form extraction and for the heap of a
+  // typical frame (three to six tokens per survivor) beside the top lists, else the wide one
+  int rc = xbeam_fixed(xw, false, maxfan, nroot, ninit, nshared);
+  if (rc == 0) { xbeam_place_with(xw, 0); if (xw->b_cap == 0 || xw->heap_cap < 8 * beam) rc = -2; }
+  if (rc != 0) {
+    rc = xbeam_fixed(xw, true, maxfan, nroot, ninit, nshared);
+    if (rc != 0) return rc;
+    xbeam_place_with(xw, 0);
+  }
+  xw->w.row_cache = 0;
   xw->prune_mode = 0;
   return 0;
 }
 
-void xbeam_shrink_for_row(XWork *xw, int nstate) {
-  // make room for the frame's score row when the cell table and the LDS heap can spare it
-  const int want = (4 * nstate + 1023) & ~1023;
-  const int cells_at = xw->off_cells;
-  const int region = xw->off_row - cells_at - want;
-  const int nslot = (region / 16) & ~63;
-  const int heap_cap = (cells_at + region - xw->off_heap) / 8 - 2;
-  if (region <= 0 || nslot < 6 * xw->w.beam || heap_cap < 5 * xw->w.beam) return;   // the row stays in global memory
-  xw->nslot = nslot;
-  xw->off_lnode = cells_at + 8 * nslot;
-  xw->off_lfirst = cells_at + 12 * nslot;
-  xw->heap_cap = heap_cap;
-  xw->off_row = cells_at + region;
-  xw->lds_bytes = xw->off_row;
-}
-
 hipError_t xbeam_prepare() {
-  hipError_t e = hipFuncSetAttribute((const void *)beam_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)beam_exact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prune_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-  return e;
+  const void *fn[] = {(const void *)beam_exact_kernel<false, false>, (const void *)beam_exact_kernel<true, false>,
+                      (const void *)beam_exact_kernel<false, true>, (const void *)beam_exact_kernel<true, true>,
+                      (const void *)prune_order_kernel<false>, (const void *)prune_order_kernel<true>};
+  for (const void *f : fn) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int nstate, const int *d_utt_off, int nutt,
                   int smode, bool timed, hipStream_t st) {
   XWork xw = xw0;
-  xbeam_shrink_for_row(&xw, nstate);
-  xw.w.row_cache = xw.lds_bytes + 4 * nstate <= kMaxDynLds ? 1 : 0;
+  xbeam_place(&xw, nstate);
   const int lds = xw.lds_bytes + (xw.w.row_cache ? 4 * nstate : 0);
-  if (timed)
-    hipLaunchKernelGGL(beam_exact_kernel<true>, dim3(nutt), dim3(NT), lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-  else
-    hipLaunchKernelGGL(beam_exact_kernel<false>, dim3(nutt), dim3(NT), lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+  const dim3 grid(nutt), block(NT);
+  if (xw.wide) {
+    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, true>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+    else hipLaunchKernelGGL((beam_exact_kernel<false, true>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+  } else {
+    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, false>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+    else hipLaunchKernelGGL((beam_exact_kernel<false, false>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+  }
 }
 
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, hipStream_t st) {
-  hipLaunchKernelGGL(prune_order_kernel, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob);
+                              unsigned long long *d_hglob, u32x4 *d_collect, hipStream_t st) {
+  if (xw.wide) hipLaunchKernelGGL(prune_order_kernel<true>, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
+  else hipLaunchKernelGGL(prune_order_kernel<false>, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
 }
 
 }  // namespace jamdb

@@ -49,11 +49,10 @@ __device__ __forceinline__ bool decode_block(int nfb, int nstb, int &fb, int &sb
 // broadcast through op_sel from an SGPR pair.  Measured on MI355X
 // (tools/ubench_valu.hip): a plain VOP2 with an SGPR operand issues at ~0.6x
 // the VGPR-only rate, the packed forms do not pay that penalty.
-// ABL selects the mixture log-sum form: 0 = software-pipelined table gather
-// (the gather for entry e is issued after its D-loop and consumed after the
-// D-loop of entry e-1, so its latency hides behind ~160 packed VALU ops),
-// 1 = gather and wait in place, 2/3 = timing-only ablations (wrong results).
-template <int D, int FPL, int NS, int ABL>
+// The mixture log-sum is software-pipelined: the table gather for entry e is
+// issued after its D-loop and consumed after the D-loop of entry e-1, so its
+// latency hides behind ~160 packed VALU ops.
+template <int D, int FPL, int NS>
 __global__ void __launch_bounds__(64 * kWaves)
 gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
                 const float *__restrict__ frames, const float *__restrict__ tbl,
@@ -89,10 +88,7 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
     const int ns = min(NS, s_end - sg);
     for (int si = 0; si < ns; si++) {
       const int e0 = st_off[sg + si], e1 = st_off[sg + si + 1];
-      float y[FPL];
-      f2 y2[NP], tv2[NP];            // ABL == 0: running log-sum and pending table term, packed per frame pair
-#pragma unroll
-      for (int k = 0; k < FPL; k++) y[k] = JAMD_LOG_ZERO;
+      f2 y2[NP], tv2[NP];            // running log-sum and pending table term, packed per frame pair
 #pragma unroll
       for (int p = 0; p < NP; p++) { y2[p] = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO}; tv2[p] = f2{0.0f, 0.0f}; }
       for (int e = e1 - 1; e >= e0; e--) {
@@ -116,51 +112,28 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
         const bool nulld = (gc != gc);  // NULL density marker (gprune_none.c:67)
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-          if (ABL == 0) {
-            // Packed form of the step below for the two frames of a lane.  The table term of the
-            // previous entry arrives in tv2 (0.0f from the extra table entry when none was due), so
-            // finishing that step (addlog.c:119: y += tbl[idx]) is one packed add without a select.
-            f2 s2 = acc[p] * f2{-0.5f, -0.5f};
-            if (nulld) s2 = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO};
-            s2 = s2 + f2{lw, lw};
-            __builtin_amdgcn_sched_barrier(0);     // keep the wait for the gathered term behind the D-loop
-            const f2 yy = y2[p] + tv2[p];
-            const bool g0 = s2.x > yy.x, g1 = s2.y > yy.y;
-            const f2 hi = {g0 ? s2.x : yy.x, g1 ? s2.y : yy.y};
-            const f2 lo = {g0 ? yy.x : s2.x, g1 ? yy.y : s2.y};
-            const f2 dd = lo - hi;
-            const unsigned i0 = !(dd.x < addmin_f) ? (unsigned)((double)(-dd.x) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
-            const unsigned i1 = !(dd.y < addmin_f) ? (unsigned)((double)(-dd.y) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
-            tv2[p] = f2{tbl[i0], tbl[i1]};
-            y2[p] = hi;
-            continue;
-          }
-          float s0 = acc[p].x * -0.5f, s1 = acc[p].y * -0.5f;
-          if (nulld) { s0 = JAMD_LOG_ZERO; s1 = JAMD_LOG_ZERO; }
-          s0 = s0 + lw; s1 = s1 + lw;
-          const float sc2[2] = {s0, s1};
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int k = 2 * p + h;
-            if (ABL == 1) {
-              y[k] = addlog_step(y[k], sc2[h], tbl, addmin_f);
-            } else if (ABL == 2) {  // timing only: index math but no gather
-              const bool gt = sc2[h] > y[k];
-              const float hi = gt ? sc2[h] : y[k], lo = gt ? y[k] : sc2[h];
-              const float dd = lo - hi;
-              float rr = hi;
-              if (!(dd < addmin_f)) rr = hi + (float)(unsigned)((double)(-dd) * JAMD_TMAG + 0.5);
-              y[k] = rr;
-            } else {                // timing only: running max
-              y[k] = sc2[h] > y[k] ? sc2[h] : y[k];
-            }
-          }
+          // Packed form of addlog_step() for the two frames of a lane.  The table term of the
+          // previous entry arrives in tv2 (0.0f from the extra table entry when none was due), so
+          // finishing that step (addlog.c:119: y += tbl[idx]) is one packed add without a select.
+          f2 s2 = acc[p] * f2{-0.5f, -0.5f};
+          if (nulld) s2 = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO};
+          s2 = s2 + f2{lw, lw};
+          __builtin_amdgcn_sched_barrier(0);     // keep the wait for the gathered term behind the D-loop
+          const f2 yy = y2[p] + tv2[p];
+          const bool g0 = s2.x > yy.x, g1 = s2.y > yy.y;
+          const f2 hi = {g0 ? s2.x : yy.x, g1 ? s2.y : yy.y};
+          const f2 lo = {g0 ? yy.x : s2.x, g1 ? yy.y : s2.y};
+          const f2 dd = lo - hi;
+          const unsigned i0 = !(dd.x < addmin_f) ? (unsigned)((double)(-dd.x) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
+          const unsigned i1 = !(dd.y < addmin_f) ? (unsigned)((double)(-dd.y) * JAMD_TMAG + 0.5) : (unsigned)JAMD_TBLSIZE;
+          tv2[p] = f2{tbl[i0], tbl[i1]};
+          y2[p] = hi;
         }
       }
 #pragma unroll
       for (int k = 0; k < FPL; k++) {
-        if (ABL == 0) { const f2 fin = y2[k / 2] + tv2[k / 2]; y[k] = (k & 1) ? fin.y : fin.x; }
-        tile[wave][k * 64 + lane][si] = finish_state(y[k]);
+        const f2 fin = y2[k / 2] + tv2[k / 2];
+        tile[wave][k * 64 + lane][si] = finish_state((k & 1) ? fin.y : fin.x);
       }
     }
     // wave-private tile: make the LDS writes visible to the other lanes
@@ -168,152 +141,6 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int RPI = 64 / NS;  // rows per store instruction
-    const int col = lane % NS, rsub = lane / NS;
-#pragma unroll 4
-    for (int it = 0; it < FPW / RPI; it++) {
-      const int rr = it * RPI + rsub;
-      const int t = t0 + rr;
-      if (t < T && col < ns) out[(size_t)t * S + sg + col] = tile[wave][rr][col];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// Persistent form of the tile kernel: the grid is sized to the chip (waves are
-// independent, there is no block-level barrier) and every WAVE pulls
-// (16-state x 128-frame) tiles from a global ticket counter, state-group major,
-// so that (a) there is no tail quantisation of a fixed 2-3 round grid and (b)
-// waves running at the same time mostly stream the same Gaussian records
-// through the scalar cache.  SPLIT=1 additionally software-pipelines the
-// scalar loads: the record is consumed in two halves and the next half is
-// requested before the current half's ~80 packed VALU ops.
-template <int D, int NS, int SPLIT>
-__global__ void __launch_bounds__(64 * kWaves)
-gmm_ptile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
-                 const float *__restrict__ frames, const float *__restrict__ tbl,
-                 float *__restrict__ out, int T, int S, int nfg, int ntile,
-                 unsigned *__restrict__ ticket, float addmin_f) {
-  constexpr int REC = ((2 * D + 2) + 3) & ~3;
-  constexpr int FPW = 128;
-  constexpr int DA = (D + 1) / 2, DB = D - DA;   // dims in first / second half
-  __shared__ float tile[kWaves][FPW][NS + 1];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-
-  for (;;) {
-    unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(ticket, 1u);
-    tk = __builtin_amdgcn_readfirstlane(tk);
-    if (tk >= (unsigned)ntile) break;
-    const int sgi = tk / nfg, fg = tk - sgi * nfg;
-    const int sg = sgi * NS;
-    const int t0 = fg * FPW;
-    const int ns = min(NS, S - sg);
-
-    f2 v[D];
-    {
-      int ta = t0 + lane, tb = ta + 64;
-      if (ta > T - 1) ta = T - 1;
-      if (tb > T - 1) tb = T - 1;
-      const float *fa = frames + (size_t)ta * D, *fb_ = frames + (size_t)tb * D;
-#pragma unroll
-      for (int d = 0; d < D; d++) { v[d].x = fa[d]; v[d].y = fb_[d]; }
-    }
-
-    for (int si = 0; si < ns; si++) {
-      const int e0 = st_off[sg + si], e1 = st_off[sg + si + 1];
-      float y[2] = {JAMD_LOG_ZERO, JAMD_LOG_ZERO}, tv[2] = {0.0f, 0.0f};
-      bool need[2] = {false, false};
-      if (SPLIT == 0) {
-        for (int e = e1 - 1; e >= e0; e--) {
-          const float *__restrict__ r = rec + (size_t)e * REC;
-          const float gc = r[2 * D], lw = r[2 * D + 1];
-          f2 acc = {gc, gc};
-#pragma unroll
-          for (int d = 0; d < D; d++) {
-            const float mu = r[d], iv = r[D + d];
-            f2 x = v[d] - f2{mu, mu};
-            x = x * x;
-            x = x * f2{iv, iv};
-            acc = acc + x;
-          }
-          const bool nulld = (gc != gc);
-          float sc2[2] = {acc.x * -0.5f, acc.y * -0.5f};
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            float sc = nulld ? JAMD_LOG_ZERO : sc2[h];
-            sc = sc + lw;
-            const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
-            const bool gt = sc > yy;
-            const float hi = gt ? sc : yy, lo = gt ? yy : sc;
-            const float dd = lo - hi;
-            need[h] = !(dd < addmin_f);
-            const unsigned idx = need[h] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
-            tv[h] = tbl[idx];
-            y[h] = hi;
-          }
-        }
-      } else {
-        // record layout for SPLIT: [muA(DA) ivA(DA) | muB(DB) ivB(DB) gc lw]
-        float a_mu[DA], a_iv[DA];
-        if (e1 > e0) {
-          const float *__restrict__ r = rec + (size_t)(e1 - 1) * REC;
-#pragma unroll
-          for (int d = 0; d < DA; d++) { a_mu[d] = r[d]; a_iv[d] = r[DA + d]; }
-        }
-        for (int e = e1 - 1; e >= e0; e--) {
-          const float *__restrict__ r = rec + (size_t)e * REC;
-          float b_mu[DB], b_iv[DB];
-#pragma unroll
-          for (int d = 0; d < DB; d++) { b_mu[d] = r[2 * DA + d]; b_iv[d] = r[2 * DA + DB + d]; }
-          const float gc = r[2 * D], lw = r[2 * D + 1];
-          f2 acc = {gc, gc};
-#pragma unroll
-          for (int d = 0; d < DA; d++) {
-            f2 x = v[d] - f2{a_mu[d], a_mu[d]};
-            x = x * x;
-            x = x * f2{a_iv[d], a_iv[d]};
-            acc = acc + x;
-          }
-          // request the next entry's first half while the second half computes
-          const float *__restrict__ rn = rec + (size_t)(e > e0 ? e - 1 : e) * REC;
-#pragma unroll
-          for (int d = 0; d < DA; d++) { a_mu[d] = rn[d]; a_iv[d] = rn[DA + d]; }
-#pragma unroll
-          for (int d = 0; d < DB; d++) {
-            f2 x = v[DA + d] - f2{b_mu[d], b_mu[d]};
-            x = x * x;
-            x = x * f2{b_iv[d], b_iv[d]};
-            acc = acc + x;
-          }
-          const bool nulld = (gc != gc);
-          float sc2[2] = {acc.x * -0.5f, acc.y * -0.5f};
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            float sc = nulld ? JAMD_LOG_ZERO : sc2[h];
-            sc = sc + lw;
-            const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
-            const bool gt = sc > yy;
-            const float hi = gt ? sc : yy, lo = gt ? yy : sc;
-            const float dd = lo - hi;
-            need[h] = !(dd < addmin_f);
-            const unsigned idx = need[h] ? (unsigned)((double)(-dd) * JAMD_TMAG + 0.5) : 0u;
-            tv[h] = tbl[idx];
-            y[h] = hi;
-          }
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const float yy = y[h] + (need[h] ? tv[h] : 0.0f);
-        tile[wave][h * 64 + lane][si] = finish_state(yy);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    constexpr int RPI = 64 / NS;
     const int col = lane % NS, rsub = lane / NS;
 #pragma unroll 4
     for (int it = 0; it < FPW / RPI; it++) {
@@ -407,7 +234,7 @@ gmm_tile_generic_kernel(const float *__restrict__ rec, const int *__restrict__ s
   }
 }
 
-template <int D, int FPL, int NS, int ABL = 0>
+template <int D, int FPL, int NS>
 int launch_tile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
   constexpr int FPB = kWaves * 64 * FPL;
   const int nfb = (T + FPB - 1) / FPB;
@@ -421,29 +248,10 @@ int launch_tile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t
   const int nsb = NS;
   const int nstb = (g->S + nsb - 1) / nsb;
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
-  hipLaunchKernelGGL((gmm_tile_kernel<D, FPL, NS, ABL>), dim3(grid), dim3(64 * kWaves), 0, st,
+  hipLaunchKernelGGL((gmm_tile_kernel<D, FPL, NS>), dim3(grid), dim3(64 * kWaves), 0, st,
                      g->d_rec, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, nsb, nfb,
                      nstb, g->eng->addmin_f);
-  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_tile<D=%d,FPL=%d,NS=%d,ABL=%d> grid=%d nsb=%d",
-           D, FPL, NS, ABL, grid, nsb);
-  return JAMD_OK;
-}
-
-template <int D, int NS, int SPLIT>
-int launch_ptile(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st, int bpc) {
-  const int nfg = (T + 127) / 128;
-  const int nsg = (g->S + NS - 1) / NS;
-  const int ntile = nfg * nsg;
-  int grid = g->eng->num_cu * bpc;
-  const int need = (ntile + kWaves - 1) / kWaves;
-  if (grid > need) grid = need;
-  JAMD_HIP(hipMemsetAsync(g->d_ticket, 0, sizeof(unsigned), st));
-  const float *recp = SPLIT ? g->d_rec_split : g->d_rec;
-  hipLaunchKernelGGL((gmm_ptile_kernel<D, NS, SPLIT>), dim3(grid), dim3(64 * kWaves), 0, st,
-                     recp, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, nfg, ntile,
-                     g->d_ticket, g->eng->addmin_f);
-  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_ptile<D=%d,NS=%d,SPLIT=%d> grid=%d tiles=%d",
-           D, NS, SPLIT, grid, ntile);
+  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_tile<D=%d,FPL=%d,NS=%d> grid=%d nsb=%d", D, FPL, NS, grid, nsb);
   return JAMD_OK;
 }
 
@@ -455,6 +263,8 @@ int launch_tile_generic(jamd_gmm *g, const float *frames, int T, float *out, hip
   const int nstb = (g->S + nsb - 1) / nsb;
   const int grid = 8 * ((nstb + 7) / 8) * nfb;
   const size_t dyn = sizeof(float) * kWaves * g->D * 64 * FPL;
+  const int rc = jamd_reserve_dyn_lds((const void *)gmm_tile_generic_kernel<FPL, NS>, dyn, "GMM outprob");
+  if (rc != JAMD_OK) return rc;
   hipLaunchKernelGGL((gmm_tile_generic_kernel<FPL, NS>), dim3(grid), dim3(64 * kWaves), dyn, st,
                      g->d_rec, g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec,
                      nsb, nfb, nstb, g->eng->addmin_f);
@@ -631,24 +441,6 @@ static int gmm_create_impl(jamd_engine *e, const jamd_gmm_desc *d, int gprune, i
   }
   JAMD_HIP(hipMalloc(&g->d_rec, sizeof(float) * (rec.size() ? rec.size() : 4)));
   JAMD_HIP(hipMemcpy(g->d_rec, rec.data(), sizeof(float) * rec.size(), hipMemcpyHostToDevice));
-  {
-    // same records re-ordered for the split-prefetch kernel:
-    // [muA ivA | muB ivB gc lw], A = first ceil(D/2) dims
-    const int DA = (D + 1) / 2, DB = D - DA;
-    std::vector<float> rs(rec.size(), 0.0f);
-    for (int en = 0; en < g->E_plain; en++) {
-      const float *r = rec.data() + (size_t)en * g->rec;
-      float *q = rs.data() + (size_t)en * g->rec;
-      memcpy(q, r, sizeof(float) * DA);
-      memcpy(q + DA, r + D, sizeof(float) * DA);
-      memcpy(q + 2 * DA, r + DA, sizeof(float) * DB);
-      memcpy(q + 2 * DA + DB, r + D + DA, sizeof(float) * DB);
-      q[2 * D] = r[2 * D]; q[2 * D + 1] = r[2 * D + 1];
-    }
-    JAMD_HIP(hipMalloc(&g->d_rec_split, sizeof(float) * (rs.size() ? rs.size() : 4)));
-    JAMD_HIP(hipMemcpy(g->d_rec_split, rs.data(), sizeof(float) * rs.size(), hipMemcpyHostToDevice));
-  }
-  JAMD_HIP(hipMalloc(&g->d_ticket, sizeof(unsigned)));
   JAMD_HIP(hipMalloc(&g->d_st_off, sizeof(int) * (g->S + 1)));
   JAMD_HIP(hipMemcpy(g->d_st_off, d->st_off, sizeof(int) * (g->S + 1), hipMemcpyHostToDevice));
   JAMD_HIP(hipMalloc(&g->d_st_off_plain, sizeof(int) * (g->S + 1)));
@@ -703,7 +495,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
 void jamd_gmm_destroy(jamd_gmm *g) {
   if (!g) return;
   (void)hipSetDevice(g->eng->device);
-  void *ptrs[] = { g->d_rec, g->d_rec_split, g->d_ticket, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
+  void *ptrs[] = { g->d_rec, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
                    g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete g;
@@ -780,14 +572,6 @@ int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev
   JAMD_HIP(hipSetDevice(g->eng->device));
   hipStream_t st = jamd_stream(g->eng, stream);
   int rc = JAMD_OK;
-  // JAMD_GMM_VARIANT: experiment switch for the D=39 kernel.  Several variants are ABLATIONS that return wrong
-  // scores, so the switch only exists in a -DJAMD_DEV build (tools/prof_gmm.sh); the shipped library always
-  // runs variant 0.
-#ifdef JAMD_DEV
-  static const int var = getenv("JAMD_GMM_VARIANT") ? atoi(getenv("JAMD_GMM_VARIANT")) : 0;
-#else
-  constexpr int var = 0;
-#endif
   if (g->E_plain == 0 && g->ntied == g->S) {
     // all states tied-mixture: nothing for the plain-state kernels to do
   } else if (g->gprune == JAMD_GPRUNE_SAFE && g->gprune_num < g->maxmix) {
@@ -800,20 +584,7 @@ int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev
     rc = jamd_gmm_launch_safe(g, dev_frames, T, dev_out, st);
   } else
   switch (g->D) {
-    case 39:
-      switch (var) {
-        default: rc = launch_tile<39, 2, 16, 0>(g, dev_frames, T, dev_out, st); break;
-        case 1: rc = launch_tile<39, 2, 16, 1>(g, dev_frames, T, dev_out, st); break;
-        case 2: rc = launch_tile<39, 2, 16, 2>(g, dev_frames, T, dev_out, st); break;
-        case 3: rc = launch_tile<39, 2, 16, 3>(g, dev_frames, T, dev_out, st); break;
-        case 4: rc = launch_tile<39, 4, 16, 0>(g, dev_frames, T, dev_out, st); break;
-        case 5: rc = launch_tile<39, 4, 16, 3>(g, dev_frames, T, dev_out, st); break;
-        case 6: rc = launch_ptile<39, 16, 0>(g, dev_frames, T, dev_out, st, 4); break;
-        case 7: rc = launch_ptile<39, 16, 1>(g, dev_frames, T, dev_out, st, 4); break;
-        case 8: rc = launch_ptile<39, 16, 0>(g, dev_frames, T, dev_out, st, 5); break;
-        case 9: rc = launch_ptile<39, 16, 1>(g, dev_frames, T, dev_out, st, 5); break;
-      }
-      break;
+    case 39: rc = launch_tile<39, 2, 16>(g, dev_frames, T, dev_out, st); break;
     case 38: rc = launch_tile<38, 2, 16>(g, dev_frames, T, dev_out, st); break;
     case 26: rc = launch_tile<26, 2, 16>(g, dev_frames, T, dev_out, st); break;
     case 25: rc = launch_tile<25, 2, 16>(g, dev_frames, T, dev_out, st); break;

@@ -187,9 +187,13 @@ int launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t
   const size_t dyn = DT > 0 ? 0 : sizeof(float) * kWaves * g->D * 128;
   const int cap = g->gprune_num < g->maxmix ? g->gprune_num : g->maxmix;
 #define JAMD_SAFE(N)                                                                         \
-  hipLaunchKernelGGL((gmm_safe_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_rec,   \
-                     g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec, \
-                     cap, nsb, g->eng->addmin_f)
+  do {                                                                                       \
+    const int rc_ = jamd_reserve_dyn_lds((const void *)gmm_safe_kernel<DT, N>, dyn, "gprune safe"); \
+    if (rc_ != JAMD_OK) return rc_;                                                          \
+    hipLaunchKernelGGL((gmm_safe_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_rec, \
+                       g->d_st_off_plain, frames, g->eng->d_addlog, out, T, g->S, g->D, g->rec, \
+                       cap, nsb, g->eng->addmin_f);                                          \
+  } while (0)
   if (cap <= 2) JAMD_SAFE(2);
   else if (cap <= 4) JAMD_SAFE(4);
   else if (cap <= 8) JAMD_SAFE(8);
@@ -209,8 +213,12 @@ int launch_book(jamd_gmm *g, const float *frames, int T, float *c_score, int *c_
   const size_t dyn = DT > 0 ? 0 : sizeof(float) * kWaves * g->D * 128;
   const int cap = g->tm_cap;
 #define JAMD_BOOK(N)                                                                          \
-  hipLaunchKernelGGL((tmix_book_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_book_rec, \
-                     g->d_book_off, frames, c_score, c_id, c_num, T, g->nbook, g->D, g->rec, cap)
+  do {                                                                                        \
+    const int rc_ = jamd_reserve_dyn_lds((const void *)tmix_book_kernel<DT, N>, dyn, "tied-mixture codebooks"); \
+    if (rc_ != JAMD_OK) return rc_;                                                           \
+    hipLaunchKernelGGL((tmix_book_kernel<DT, N>), grid, dim3(64 * kWaves), dyn, st, g->d_book_rec, \
+                       g->d_book_off, frames, c_score, c_id, c_num, T, g->nbook, g->D, g->rec, cap); \
+  } while (0)
   if (g->gprune == JAMD_GPRUNE_NONE) JAMD_BOOK(0);
   else if (cap <= 2) JAMD_BOOK(2);
   else if (cap <= 4) JAMD_BOOK(4);

@@ -49,8 +49,6 @@ struct jamd_gmm {
   bool uniform_mix = false;       // every state has the same entry count
   // device model
   float *d_rec = nullptr;         // [E][rec]: mean[D], ivar[D], gconst, logw
-  float *d_rec_split = nullptr;   // [E][rec]: muA ivA | muB ivB gconst logw (split-prefetch kernel)
-  unsigned *d_ticket = nullptr;   // tile ticket counter of the persistent kernel
   int *d_st_off = nullptr;        // [S+1] original entry offsets (index d_ent_logw)
   int *d_st_off_plain = nullptr;  // [S+1] offsets into d_rec; a tied-mixture state has an empty range
   int E_plain = 0;
@@ -75,6 +73,21 @@ struct jamd_gmm {
 int jamd_gmm_launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st);
 int jamd_gmm_launch_tmix(jamd_gmm *g, const float *frames, int T, float *out, float *c_score,
                          int *c_id, int *c_num, hipStream_t st);
+
+// A kernel whose static + dynamic LDS passes the default 64 KB window needs the attribute raised, and the sum
+// must fit the 160 KB of a CU (the generic-D kernels keep 2 KB of frame data per vector component in LDS).
+static inline int jamd_reserve_dyn_lds(const void *kernel, size_t dyn, const char *what) {
+  if (dyn == 0) return JAMD_OK;
+  hipFuncAttributes fa;
+  JAMD_HIP(hipFuncGetAttributes(&fa, kernel));
+  if (fa.sharedSizeBytes + dyn > 160u * 1024u) {
+    jamd_set_error("%s: the vector length needs %zu bytes of LDS per workgroup (%zu static + %zu), the CU has 163840",
+                   what, fa.sharedSizeBytes + dyn, (size_t)fa.sharedSizeBytes, dyn);
+    return JAMD_EINVAL;
+  }
+  JAMD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  return JAMD_OK;
+}
 
 static inline hipStream_t jamd_stream(jamd_engine *e, void *s) {
   return s ? (hipStream_t)s : e->stream;

@@ -218,6 +218,32 @@ def write_npy(path, a):
     np.save(path, np.ascontiguousarray(a, dtype="<f4"))
 
 
+def write_dnnconf(workdir, dnn, feature_len=None, context_len=1, num_threads=1):
+    """The network in the reference's own files: W<l>.npy / b<l>.npy, the state prior list and the dnnconf that
+    `-dnnconf` reads (libjulius/src/m_jconf.c:600-660, libsent/src/phmm/calc_dnn.c:528 dnn_setup).  All hidden
+    layers share one width (reference limitation).  Returns the dnnconf path."""
+    workdir = Path(workdir)
+    dims = [int(x) for x in dnn["dims"]]
+    nl = len(dims) - 1
+    assert len(set(dims[1:-1])) == 1, "reference needs equal hidden widths"
+    feature_len = feature_len or dims[0] // context_len
+    assert feature_len * context_len == dims[0]
+    for l in range(nl):
+        write_npy(workdir / f"W{l}.npy", dnn["w"][l])
+        write_npy(workdir / f"b{l}.npy", np.asarray(dnn["b"][l]).reshape(-1, 1))
+    with open(workdir / "prior", "w") as f:
+        for i, v in enumerate(dnn["prior_lin"]):
+            f.write(f"{i} {float(v):.9e}\n")
+    nh = nl - 1
+    lines = [f"feature_type USER", f"feature_len {feature_len}", f"context_len {context_len}", f"input_nodes {dims[0]}",
+             f"output_nodes {dims[-1]}", f"hidden_nodes {dims[1]}", f"hidden_layers {nh}"]
+    lines += [f"W{l + 1} W{l}.npy" for l in range(nh)] + [f"B{l + 1} b{l}.npy" for l in range(nh)]
+    lines += [f"output_W W{nh}.npy", f"output_B b{nh}.npy", "state_prior prior", "state_prior_factor 1.0",
+              "state_prior_log10nize yes", f"num_threads {num_threads}"]
+    (workdir / "dnn.conf").write_text("\n".join(lines) + "\n")
+    return workdir / "dnn.conf"
+
+
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
                        maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None):

@@ -370,6 +370,11 @@ static void inter_word_factoring(beam *b)
  * died at frame *died_at (the reference would segment the input there), -1 =
  * atom buffer too small.
  */
+/* statistics of the last jo_beam_pass1() call (test sizing: how many tokens a frame creates) */
+static int jo_stat_max_tokens = 0; static double jo_stat_sum_tokens = 0.0; static int jo_stat_frames = 0;
+int jo_beam_last_max_tokens(void) { return jo_stat_max_tokens; }
+double jo_beam_last_mean_tokens(void) { return jo_stat_frames ? jo_stat_sum_tokens / jo_stat_frames : 0.0; }
+
 int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
                   int beam_width, float score_pruning_width,
                   jamd_trellis_atom *atoms, int atom_cap, int *natom,
@@ -381,6 +386,7 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
   b->lx = lx; b->sc = sc; b->S = S; b->atoms = atoms; b->atom_cap = atom_cap;
   b->lmt = lx->lm_type & 0xff; b->mp = (lx->lm_type & JAMD_LM_MULTIPATH) != 0;
   *natom = 0; *wnum = 0; *pass1_score = JO_LOG_ZERO; *died_at = -1;
+  jo_stat_max_tokens = 0; jo_stat_sum_tokens = 0.0; jo_stat_frames = 0;
   if (T <= 0) return 1;
 
   /* get_back_trellis_init */
@@ -475,6 +481,8 @@ int jo_beam_pass1(const jamd_lexicon_desc *lx, const float *sc, int T, int S,
     if (score_pruning_width >= 0.0f) b->score_pruning_threshold = b->score_pruning_max - score_pruning_width;
     else b->score_pruning_threshold = JO_LOG_ZERO;
     b->tnum[tl] = 0;                                                           /* clear_tlist */
+    if (b->tnum[tn] > jo_stat_max_tokens) jo_stat_max_tokens = b->tnum[tn];
+    jo_stat_sum_tokens += b->tnum[tn]; jo_stat_frames++;
     sort_token_no_order(b, beam_width);
     if (b->tnum[tn] == 0) { if (!final) { *died_at = t; rc = 2; } break; }
   }

@@ -385,6 +385,7 @@ int jref_engine_recognize(void *h, const char *mfcfile)
   jref_eng *e = (jref_eng *)h;
   RecogProcess *r = e->recog->process_list;
   int t, n = 0;
+  r->pass1_wnum = 0;              /* find_1pass_result() leaves the previous input's sequence behind when it fails (beam.c:427-431) */
   if (j_open_stream(e->recog, (char *)mfcfile) != 0) return -1;
   if (j_recognize_stream(e->recog) == -1) return -1;
   if (r->backtrellis->num == NULL) return 0;

@@ -39,16 +39,22 @@ def test_vs_oracle_shapes(engine, oracle, dims, T):
     assert np.array_equal(got, want), f"max |d| = {np.abs(got - want).max()}"
 
 
-def test_full_size_envr_shape(engine, oracle):
-    """BASELINE configs[3] shape: 528 -> 6 x 2048 sigmoid -> 4000 senones."""
+def test_full_size_envr_shape(engine, oracle, ref, tmp_path):
+    """BASELINE configs[3] shape: 528 -> 6 x 2048 sigmoid -> 4000 senones, against the COMPILED REFERENCE's
+    dnn_calc_outprob() (libsent/src/phmm/calc_dnn.c:774, its FMA kernel calc_dnn_fma.c:19, loaded from the same
+    .npy files by dnn_setup()), and against the C restatement."""
     dnn = synth.make_dnn(seed=3)
-    T = 40
+    T = 96
     fr = np.random.default_rng(5).normal(0, 1.0, (T, 528)).astype(np.float32)
     net = lib.Dnn(engine, dnn)
     got = net.outprob_host(fr)
-    want = oracle.dnn_outprob(dnn, fr, po.DNN_FMA)
-    assert close(got, want)
-    assert np.array_equal(got, want), f"max |d| = {np.abs(got - want).max()}"
+    if b"FMA" in ref.lib.jref_simd_string():       # the reference picks the best SIMD kernel of the host CPU
+        want_ref = ref.dnn_load(dnn, tmp_path, num_threads=1).outprob(fr)
+        assert close(got, want_ref)
+        assert np.array_equal(got, want_ref), f"vs compiled reference: max |d| = {np.abs(got - want_ref).max()}"
+    want = oracle.dnn_outprob(dnn, fr[:40], po.DNN_FMA)
+    assert close(got[:40], want)
+    assert np.array_equal(got[:40], want), f"max |d| = {np.abs(got[:40] - want).max()}"
     # batch == frame-by-frame (the reference's mode), and softmax normalisation
     big = np.random.default_rng(6).normal(0, 1.0, (300, 528)).astype(np.float32)
     out = net.outprob_host(big)

@@ -1,6 +1,6 @@
 """CPU: julius_amd/shim/jamd_export.c -- the exporter a Julius maintainer runs once per
 configuration: Julius' own loaders -> "JAMDGMM1" / "JAMDLEX1" files for workers that never link
-Julius.  Built against the unmodified reference by oracle/Makefile (oracle/_ref/jamd_export);
+Julius.  Built against the unmodified reference by oracle/Makefile (julius_amd/jamd_export);
 its files must equal what the tap driver's in-process flattening produces."""
 import subprocess
 
@@ -10,13 +10,13 @@ import pytest
 from julius_amd import lexblob, synth
 from oracle import pyoracle
 
-EXPORT = pyoracle.REF_SO.parent / "jamd_export"
+EXPORT = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
 
 
 @pytest.mark.parametrize("lm", ["ngram", "grammar"])
 def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
     if not EXPORT.exists():
-        pytest.skip("oracle/_ref/jamd_export not built")
+        pytest.skip("julius_amd/jamd_export not built")
     task = synth.make_triphone_task(tmp_path, seed=91, nword=60)
     if lm == "ngram":
         args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
@@ -44,7 +44,7 @@ def test_export_selection_model(ref, tmp_path):
     """-gshmm: PREFIX.gms holds the flattened selection model, the state map and -gsnum, equal to what
     gms_init() (gms.c:275-317) built inside the reference."""
     if not EXPORT.exists():
-        pytest.skip("oracle/_ref/jamd_export not built")
+        pytest.skip("julius_amd/jamd_export not built")
     task = synth.make_triphone_task(tmp_path, seed=92, nword=60)
     gpath, _ = synth.make_gs_model(task, seed=92)
     args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
@@ -63,7 +63,7 @@ def test_export_verification_gmms(ref, tmp_path):
     """-gmm / -gmmnum / -gmmreject: PREFIX.rej holds the flattened GMM definitions, the output state of
     every model in recog->gmm->start order, -gmmnum, the names and gc->is_voice[]."""
     if not EXPORT.exists():
-        pytest.skip("oracle/_ref/jamd_export not built")
+        pytest.skip("julius_amd/jamd_export not built")
     task = synth.make_triphone_task(tmp_path, seed=94, nword=60)
     gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=94, null_frac=0.1)
     args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],

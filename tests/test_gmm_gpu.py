@@ -197,6 +197,27 @@ def test_safe_vs_oracle(engine, oracle, S, M, D, T, n):
     assert np.array_equal(gm.outprob_host(fr), oracle.gmm_outprob(m, fr, po.GPRUNE_SAFE, n))
 
 
+@pytest.mark.parametrize("D", [16, 24, 32, 48, 60])
+def test_generic_veclen_needs_more_than_64k_of_lds(engine, oracle, D):
+    """Vector lengths without a specialised kernel keep their frames in dynamic LDS (2 KB per component) next to the
+    34 KB output tile: from D = 16 on that passes the default 64 KB window (hipFuncAttributeMaxDynamicSharedMemorySize
+    must be raised), safe pruning and plain scoring alike; beyond the CU's 160 KB the library refuses with a message."""
+    m = synth.make_gmm(S=20, M=6, D=D, seed=D, ragged=True)
+    fr = synth.make_frames(m, T=300, seed=D)
+    assert np.array_equal(lib.Gmm(engine, m).outprob_host(fr), oracle.gmm_outprob(m, fr))
+    gm = lib.Gmm(engine, m, gprune=lib.GPRUNE_SAFE, gprune_num=3)
+    assert np.array_equal(gm.outprob_host(fr), oracle.gmm_outprob(m, fr, po.GPRUNE_SAFE, 3))
+    t = synth.make_tied_gmm(S=12, nbook=2, K=24, D=D, seed=D)
+    tm = lib.Gmm(engine, t, gprune=lib.GPRUNE_SAFE, gprune_num=4)
+    assert np.array_equal(tm.outprob_host(fr), oracle.gmm_outprob(t, fr, po.GPRUNE_SAFE, 4))
+
+
+def test_vector_length_beyond_the_lds_is_refused(engine):
+    m = synth.make_gmm(S=4, M=2, D=96, seed=1)
+    with pytest.raises(lib.JamdError, match="LDS"):
+        lib.Gmm(engine, m).outprob_host(synth.make_frames(m, T=8, seed=1))
+
+
 @pytest.mark.parametrize("nbook,K,D,T,gp,n", [(3, 64, 39, 260, "safe", 2), (1, 256, 39, 100, "safe", 4),
                                               (5, 33, 25, 140, "safe", 8), (2, 40, 13, 70, "safe", 3),
                                               (3, 64, 39, 130, "none", 64)])

@@ -124,10 +124,10 @@ def test_export_then_standalone_batch(ref, tmp_path, gms):
     also with Gaussian mixture selection (-gshmm -> PREFIX.gms -> jamd_batch -gms)."""
     import subprocess
     from oracle import pyoracle
-    export = pyoracle.REF_SO.parent / "jamd_export"
+    export = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
     exe = lib._PKG / "jamd_batch"
     if not export.exists():
-        pytest.skip("oracle/_ref/jamd_export not built")
+        pytest.skip("julius_amd/jamd_export not built")
     task = synth.make_triphone_task(tmp_path, seed=93, nword=120, nphone=10, S=160)
     args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
                              "-input", "htkparam", "-gprune", "safe", "-tmix", "3", "-b", "150", "-sepnum", "5", "-1pass"]]
@@ -161,10 +161,10 @@ def test_export_then_standalone_batch_with_verification(ref, tmp_path):
     as the plain reference decides (gc->gmm_score[], gmm_max_cm, gmm_valid_input())."""
     import subprocess
     from oracle import pyoracle
-    export = pyoracle.REF_SO.parent / "jamd_export"
+    export = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
     exe = lib._PKG / "jamd_batch"
     if not export.exists():
-        pytest.skip("oracle/_ref/jamd_export not built")
+        pytest.skip("julius_amd/jamd_export not built")
     task = synth.make_triphone_task(tmp_path, seed=95, nword=120, nphone=10, S=160)
     gpath, _, names = synth.make_rejection_gmm(tmp_path, task["model"]["centre"], seed=95, M=24, null_frac=0.05)
     base = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],

@@ -12,7 +12,7 @@ import pytest
 from julius_amd import lexblob, lib, synth
 from oracle import pyoracle
 
-EXPORT = pyoracle.REF_SO.parent / "jamd_export"
+EXPORT = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
 
 
 def _ref():

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build/variants
 CS=julius_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Wall -Wno-unused-function \
-  "$@" -I$CS -c ${SRC:-$CS/beam_exact.hip} -o build/variants/beam_exact_$name.o
+  -DJAMD_DEV "$@" -I$CS -c ${SRC:-$CS/beam_exact.hip} -o build/variants/beam_exact_$name.o
 objs=$(ls $CS/*.o | grep -v beam_exact.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/$name.so $objs build/variants/beam_exact_$name.o
 echo built build/variants/$name.so
