@@ -41,19 +41,18 @@ extern "C" {
 
 #define JAMD_LOG_ZERO (-1000000.0f)
 
-/* Gaussian pruning selector (GPRUNE_SEL_*, libsent/include/sent/hmm_calc.h:38-45).
- * none and safe are served for every model.  heu and beam prune with thresholds taken from
- * the N best Gaussians of the PREVIOUS frame's codebook cache (last_id), which exists only
- * for tied-mixture codebooks (calc_tied_mix.c:203-215) and depends on which frames the lazy
- * CPU search happened to score.  For plain mixture states calc_mix() passes last_id == NULL
- * (calc_mix.c:63), where both functions ARE safe pruning (gprune_heu.c:337-350,
- * gprune_beam.c:337-350): a model without tied-mixture states is therefore served with
- * heu/beam too, bit for bit; a tied-mixture model with heu/beam is refused (it stays on the
- * reference's CPU code). */
+/* Gaussian pruning selector (GPRUNE_SEL_*, libsent/include/sent/hmm_calc.h:38-45).  All four are served for
+ * every model.  heu and beam prune with thresholds taken from the N best Gaussians of the PREVIOUS frame's
+ * codebook cache (last_id), which exists only for tied-mixture codebooks (calc_tied_mix.c:203-215).  For plain
+ * mixture states calc_mix() passes last_id == NULL (calc_mix.c:63), where both functions ARE safe pruning
+ * (gprune_heu.c:337-350, gprune_beam.c:337-350).  For tied-mixture codebooks the previous frame's cache depends, in
+ * the reference, on which frames its lazy search happened to score; the device scores every state of every frame,
+ * so its results are the reference's under eager scoring (outprob_set_batch_computation(), outprob.c:230-242) --
+ * bit for bit, cache contents included -- and an utterance's first frame takes the no-history branch. */
 #define JAMD_GPRUNE_NONE 0  /* gprune_none()  libsent/src/phmm/gprune_none.c:133 */
 #define JAMD_GPRUNE_SAFE 1  /* gprune_safe()  libsent/src/phmm/gprune_safe.c:160 */
-#define JAMD_GPRUNE_HEU  2  /* gprune_heu()   gprune_heu.c:295  (plain mixture states only) */
-#define JAMD_GPRUNE_BEAM 3  /* gprune_beam()  gprune_beam.c:291 (plain mixture states only) */
+#define JAMD_GPRUNE_HEU  2  /* gprune_heu()   gprune_heu.c:295  (tied-mixture codebooks: parity under eager scoring) */
+#define JAMD_GPRUNE_BEAM 3  /* gprune_beam()  gprune_beam.c:291 (ditto) */
 
 /* pseudo-phone set reduction (hmminfo->cdset_method, htk_hmm.h:388) */
 #define JAMD_IWCD_MAX   0   /* outprob_cd_max   libsent/src/phmm/outprob.c:332 */
@@ -134,6 +133,13 @@ int  jamd_gmm_veclen(const jamd_gmm *g);
  * outprob_cache layout, outprob.c:127-129). */
 int  jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out,
                           void *stream);
+/* The same for a BATCH of utterances laid back to back: utterance u owns frames utt_off[u]..utt_off[u+1]) (utt_off is
+ * a HOST array of nutt+1 ints, utt_off[0] = 0).  The boundaries matter to one configuration only: gprune heu / beam
+ * over tied-mixture codebooks, whose thresholds at frame t come from the codebook's winners at frame t-1 of the SAME
+ * input (calc_tied_mix.c:203-215; outprob_prepare() clears the cache per input, outprob.c:138-166);
+ * jamd_gmm_outprob_dev() treats its T frames as one utterance. */
+int  jamd_gmm_outprob_utts_dev(jamd_gmm *g, const float *dev_frames, const int *utt_off, int nutt, float *dev_out,
+                               void *stream);
 /* Same with host buffers (packs HTK_Param rows, uploads, scores, downloads). */
 int  jamd_gmm_outprob_host(jamd_gmm *g, const float *host_frames, int T, float *host_out);
 /* Tied-mixture codebook cache of calc_tied_mix.c:189-227 for inspection: top-N

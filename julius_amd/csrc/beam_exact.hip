@@ -330,6 +330,59 @@ __device__ __forceinline__ void heap_extract_serial(HP H, int n, int cnt) {
   }
 }
 
+// The same loop PIPELINED on one wave (heap in LDS).  Extraction e takes the tail element s = H[n - e + 1], puts the
+// root there and lets s run down from the root; its step at depth d reads the two children at depth d + 1 and writes
+// depth d.  Extraction e + 1 may therefore start two steps behind extraction e: every value it reads has received all
+// earlier extractions' writes one step before at the latest (a step's reads come before its writes, and a step sees
+// the writes of the step before -- the lanes of one wave).  One more dependency: the tail position n - e + 1 itself
+// lies inside the heaps of the earlier extractions, which may still read it, move it up or end there; that is
+// possible only for an extraction whose hole is an ancestor (or the position itself), and e waits until no such
+// extraction is in flight.  Lane (e - 1) & 63 runs extraction e; about depth / 2 extractions are in flight, so the
+// loop costs ~2 steps an extraction instead of one per level: 7x at 4000 extractions from 8000 tokens -- the form
+// sort_token_downward() and the fall-backs of the closed-form extraction run in.  Reads and writes are the
+// sequential loop's, so is the result.
+template <bool UP>
+__device__ __noinline__ void heap_extract_pipelined(lds_u64 *H, int n, int cnt) {
+  H = uni(H); n = uni(n); cnt = uni(cnt);
+  const int lane = threadIdx.x & 63;
+  bool active = false;
+  int p = 0, m = 0;
+  unsigned long long s = 0ull;
+  int next_e = 1, since = 2;                                     // steps since the last start
+  for (;;) {
+    // may extraction next_e start in this step?
+    bool start = false;
+    if (next_e <= cnt && since >= 2) {
+      const unsigned q = (unsigned)(n - next_e + 1);
+      start = __ballot(active && insub(q, (unsigned)p)) == 0ull;
+    }
+    const bool mine = start && lane == ((next_e - 1) & 63);
+    if (mine) { active = true; p = 1; m = n - next_e; }
+    // reads of this step: the starting lane also takes the tail element and the root
+    unsigned long long tail = 0ull, root = 0ull;
+    u32x4 ch = u32x4{0u, 0u, 0u, 0u};
+    const bool inner = active && 2 * p <= m;
+    if (mine) { tail = H[n - next_e + 1]; root = H[1]; }
+    if (inner) ch = *(const lds_v4 *)&H[2 * p];
+    wave_sync();
+    if (mine) { s = tail; H[n - next_e + 1] = root; }
+    if (active) {
+      const int child = 2 * p;
+      const unsigned a = ch.y, b = ch.w, sv = (unsigned)(s >> 32);
+      const bool right = inner && child < m && (UP ? (a < b) : (a > b));
+      const unsigned cv = right ? b : a;
+      if (!inner || (UP ? (sv >= cv) : (sv <= cv))) { H[p] = s; active = false; }
+      else {
+        H[p] = right ? (((unsigned long long)ch.w << 32) | ch.z) : (((unsigned long long)ch.y << 32) | ch.x);
+        p = child + (right ? 1 : 0);
+      }
+    }
+    wave_sync();
+    if (start) { next_e++; since = 1; } else since++;
+    if (next_e > cnt && __ballot(active) == 0ull) break;
+  }
+}
+
 // k-th largest of the score bits in H[1..n] (radix select, 11 bits a pass over the bits in which the
 // frame's max and min differ).  Returns the value; all threads.
 template <typename HP>
@@ -539,13 +592,21 @@ __device__ __noinline__ unsigned long long apply_event(lds_u64 *compR_, lds_u32 
 }
 
 // one tail candidate handled start to finish by one wave (the serial form: more than kMaxCand candidates)
-__device__ __noinline__ void replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
+// Returns the turn at which the re-inserted element sits on a tail position again IF it is tied with an element still
+// in the heap (the replay must then reach that turn), else 0.
+__device__ __noinline__ int replay_tail(const PruneMem &pm, int nB, int n, int k, int i) {
   const int occ = uni((int)(chain_scan(pm.vposR, nB, n, i, pm.takers + kMaxCand * (kTakers + 1)) >> 32));
-  if (occ < 0) return;
-  const unsigned hole = uni((unsigned)(apply_event(pm.compR, pm.vposR, pm.idR, nB, n, k, i, occ) >> 32));
-  if (hole >= (unsigned)(n - k + 1) && (threadIdx.x & 63) == 0)     // it sits on a tail position again: its turn comes later
-    atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
+  if (occ < 0) return 0;
+  const unsigned long long ev = apply_event(pm.compR, pm.vposR, pm.idR, nB, n, k, i, occ);
+  const unsigned hole = uni((unsigned)(ev >> 32));
+  const bool tied = (uni((unsigned)ev) & 0x80000000u) != 0u;
+  int again = 0;
+  if (hole >= (unsigned)(n - k + 1)) {                               // it sits on a tail position again: its turn comes later
+    if ((threadIdx.x & 63) == 0) atomicOr((unsigned *)&pm.tailmask[(n - (int)hole) >> 5], 1u << ((n - (int)hole) & 31));
+    if (tied) again = n - (int)hole + 1;
+  }
   __builtin_amdgcn_wave_barrier();
+  return again;
 }
 
 // sort_token_no_order() (:1492): the visiting order of the next frame.  keys[i] = score bits of token i in
@@ -577,12 +638,16 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
   const bool upward = k < n - k;
   const bool in_lds = n <= heap_cap;
   auto run = [&](auto Hh) -> void {
-    for (int i = tid; i < n; i += NT) Hh[i + 1] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
-    __syncthreads();
-    PTICK5(4);
-    bool heaped = false;
-    if constexpr (std::is_same<decltype(Hh), lds_u64 *>::value) heaped = upward ? heapify_overlapped<true>(Hh, n) : heapify_overlapped<false>(Hh, n);
-    if (!heaped) { if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n); }
+    constexpr bool kLdsHeap = std::is_same<decltype(Hh), lds_u64 *>::value;
+    auto build_heap = [&]() {                                      // first loop of sort_token_upward / _downward (:1354-1367)
+      for (int i = tid; i < n; i += NT) Hh[i + 1] = ((unsigned long long)keys[i] << 32) | (unsigned)i;
+      __syncthreads();
+      PTICK5(4);
+      bool heaped = false;
+      if constexpr (kLdsHeap) heaped = upward ? heapify_overlapped<true>(Hh, n) : heapify_overlapped<false>(Hh, n);
+      if (!heaped) { if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n); }
+    };
+    build_heap();
     PTICK5(5);
     PTICK(4);
     bool done = false;
@@ -694,14 +759,37 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           if (tid == 0) { ctl[0] = nc; ctl[1] = 0; ctl[2] = 0; ctl[3] = sh.i_last; }
         }
         __syncthreads();
+        // More live candidates (turn <= the last turn that matters) than the parallel replay holds: an event costs a
+        // scan of the whole top list on one wave, hundreds of them cost more than the extraction loop itself run
+        // pipelined -- give the closed form up for this frame.  (Wide beams over flat scores: a third of the top
+        // elements sit on tail positions.)  The heap was overlaid by the lists in the wide layout: it is built again.
+        bool give_up = false;
+        if constexpr (kLdsHeap) {
+          if (uni(ctl[0]) > kMaxCand) {
+            const int il = uni(ctl[3]);
+            int live = 0;
+            for (int w = tid; w * 32 < il; w += NT) {
+              unsigned bits = pm.tailmask[w];
+              const int rem = il - w * 32;
+              if (rem < 32) bits &= (1u << rem) - 1u;
+              live += __popc(bits);
+            }
+            live = block_excl_scan(sh, live); live = uni(sh.scan_total);
+            give_up = live > kMaxCand / 2;
+          }
+        }
+        if (give_up) {
+          if constexpr (WIDE) { build_heap(); }
+        } else {
 #ifdef JAMD_DEV
         if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tc3_ = wall_clock64();   // slot 7 - (4 + 5 + 6) = everything before the replay
 #endif
         const int ncand0 = uni(ctl[0]);
         if (ncand0 > kMaxCand) {
-          if (tid < 64) {                                     // serial form, straight off the mask
+          if (tid < 64) {                                     // serial form, straight off the mask, up to the last turn that matters
             const int nw = (k + 31) / 32;
-            for (int w = 0; w < nw; w++) {
+            int ilast = uni(ctl[3]);
+            for (int w = 0; w < nw && w * 32 + 1 <= ilast; w++) {
               unsigned donebits = 0u;
               for (;;) {
                 const unsigned bits = ((volatile lds_u32 *)pm.tailmask)[w] & ~donebits;
@@ -709,7 +797,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
                 const int b = __ffs((int)bits) - 1;
                 donebits |= (b == 31) ? 0xffffffffu : ((2u << b) - 1u);
                 const int i = w * 32 + b + 1;
-                if (i <= k) replay_tail(pm, nB, n, k, i);
+                if (i > ilast) break;
+                if (i <= k) { const int again = uni(replay_tail(pm, nB, n, k, i)); if (again > ilast) ilast = again; }
               }
             }
           }
@@ -800,10 +889,11 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
             if (uni(ctl[2])) break;
           }
           if (ctl[0] > kMaxCand && tid < 64) {                // candidate table overflowed mid-way: the rest serially
-            for (int i = pm.cand[pm.ordv[ctl[1]]]; i <= k; i++) {
+            int ilast = uni(ctl[3]);
+            for (int i = pm.cand[pm.ordv[ctl[1]]]; i <= k && i <= ilast; i++) {
               bool any = false;
               for (int r0 = 0; r0 < nB; r0 += 64) { const int r = r0 + (tid & 63); if (__ballot(r < nB && pm.vposR[r] == (unsigned)(n - i + 1))) { any = true; break; } }
-              if (any) replay_tail(pm, nB, n, k, i);
+              if (any) { const int again = uni(replay_tail(pm, nB, n, k, i)); if (again > ilast) ilast = again; }
             }
           }
         }
@@ -811,10 +901,20 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         PTICK(7);
         for (int j = tid; j < k; j += NT) svid[j] = (int)pm.idR[k - 1 - j];    // tindex[n-k+j]: ascending
         done = true;
-      }
+        }                                                        // (!give_up)
+      }                                                          // (more ties on the cut than the lists hold: the heap is untouched)
     }
     if (!done) {
-      if (tid == 0) { if (upward) heap_extract_serial<true>(Hh, n, k); else heap_extract_serial<false>(Hh, n, n - k); }
+      // the extraction loop itself: pipelined on one wave when the heap is in LDS, else (and in the cross-check
+      // mode JAMD_ORDER_EXACT_SERIAL) sequentially on one lane
+      bool piped = false;
+      if constexpr (std::is_same<decltype(Hh), lds_u64 *>::value) {
+        if (mode != 1) {
+          if (tid < 64) { if (upward) heap_extract_pipelined<true>(Hh, n, k); else heap_extract_pipelined<false>(Hh, n, n - k); }
+          piped = true;
+        }
+      }
+      if (!piped && tid == 0) { if (upward) heap_extract_serial<true>(Hh, n, k); else heap_extract_serial<false>(Hh, n, n - k); }
       __syncthreads();
       for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)(upward ? Hh[n - k + 1 + j] : Hh[1 + j]);
     }

@@ -359,6 +359,7 @@ static int gmm_create_impl(jamd_engine *e, const jamd_gmm_desc *d, int gprune, i
     return JAMD_EINVAL;
   }
   const bool history_pruning = gprune == JAMD_GPRUNE_HEU || gprune == JAMD_GPRUNE_BEAM;
+  const int requested_gprune = gprune;
   // heu / beam on plain mixture states: calc_mix() passes last_id == NULL, the branch that is safe pruning
   // (gprune_heu.c:337-350, gprune_beam.c:337-350) -- same kernel, same numbers.  Checked below once the
   // states are classified.
@@ -400,12 +401,11 @@ static int gmm_create_impl(jamd_engine *e, const jamd_gmm_desc *d, int gprune, i
   }
   g->E_plain = st_off_plain[g->S];
   g->ntied = (int)tied.size();
-  if (history_pruning && g->ntied > 0) {
-    jamd_set_error("jamd_gmm_create: gprune heu/beam with tied-mixture states depends on the previous frame's codebook "
-                   "cache and on which frames were scored (calc_tied_mix.c:203-215): not served on the device; use "
-                   "none or safe, or leave scoring to the reference's CPU code");
-    return JAMD_EINVAL;
-  }
+  // heu / beam over tied-mixture codebooks: frame t's thresholds come from the codebook's cached winners of frame
+  // t - 1 (calc_tied_mix.c:203-215).  The device scores every state of every frame, so that history is the previous
+  // frame of the same utterance: parity is defined against the reference under eager scoring
+  // (outprob_set_batch_computation, outprob.c:230-242); see tmix_book_hist_kernel.
+  if (history_pruning && g->ntied > 0) g->hist_method = requested_gprune;
   g->nbook = g->ntied ? d->nbook : 0;
   if (gprune == JAMD_GPRUNE_SAFE && gprune_num < 1) {
     jamd_set_error("jamd_gmm_create: gprune safe needs gprune_num >= 1"); return JAMD_EINVAL;
@@ -495,7 +495,7 @@ int jamd_gmm_create(jamd_engine *e, const jamd_gmm_desc *d, int gprune, int gpru
 void jamd_gmm_destroy(jamd_gmm *g) {
   if (!g) return;
   (void)hipSetDevice(g->eng->device);
-  void *ptrs[] = { g->d_rec, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
+  void *ptrs[] = { g->d_rec, g->d_cur_utt_off, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
                    g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete g;
@@ -563,15 +563,40 @@ int jamd_gmm_dens_host(jamd_gmm *g, const float *host_frames, int T, float *host
   return rc;
 }
 
+// utterance boundaries of the running call, for the one scoring path that cares where an input begins
+static int set_utterances(jamd_gmm *g, const int *utt_off, int nutt, hipStream_t st) {
+  if (g->hist_method == 0) return JAMD_OK;
+  if ((size_t)(nutt + 1) > g->utt_off_cap) {
+    if (g->d_cur_utt_off) JAMD_HIP(hipFree(g->d_cur_utt_off));
+    g->d_cur_utt_off = nullptr; g->utt_off_cap = 0;
+    JAMD_HIP(hipMalloc(&g->d_cur_utt_off, sizeof(int) * ((size_t)nutt + 1)));
+    g->utt_off_cap = (size_t)nutt + 1;
+  }
+  JAMD_HIP(hipMemcpyAsync(g->d_cur_utt_off, utt_off, sizeof(int) * ((size_t)nutt + 1), hipMemcpyHostToDevice, st));
+  JAMD_HIP(hipStreamSynchronize(st));   // utt_off is the caller's memory
+  g->cur_nutt = nutt;
+  return JAMD_OK;
+}
+
 int jamd_gmm_outprob_dev(jamd_gmm *g, const float *dev_frames, int T, float *dev_out, void *stream) {
-  if (!g || !dev_frames || !dev_out || T < 0) {
-    jamd_set_error("jamd_gmm_outprob_dev: bad argument");
+  const int off[2] = {0, T};
+  if (T < 0) { jamd_set_error("jamd_gmm_outprob_dev: bad argument"); return JAMD_EINVAL; }
+  return jamd_gmm_outprob_utts_dev(g, dev_frames, off, 1, dev_out, stream);
+}
+
+int jamd_gmm_outprob_utts_dev(jamd_gmm *g, const float *dev_frames, const int *utt_off, int nutt, float *dev_out, void *stream) {
+  if (!g || !dev_frames || !dev_out || !utt_off || nutt < 1 || utt_off[0] != 0) {
+    jamd_set_error("jamd_gmm_outprob_utts_dev: bad argument");
     return JAMD_EINVAL;
   }
+  for (int u = 0; u < nutt; u++)
+    if (utt_off[u + 1] < utt_off[u]) { jamd_set_error("jamd_gmm_outprob_utts_dev: utt_off must be non-decreasing"); return JAMD_EINVAL; }
+  const int T = utt_off[nutt];
   if (T == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(g->eng->device));
   hipStream_t st = jamd_stream(g->eng, stream);
   int rc = JAMD_OK;
+  if ((rc = set_utterances(g, utt_off, nutt, st)) != JAMD_OK) return rc;
   if (g->E_plain == 0 && g->ntied == g->S) {
     // all states tied-mixture: nothing for the plain-state kernels to do
   } else if (g->gprune == JAMD_GPRUNE_SAFE && g->gprune_num < g->maxmix) {
@@ -643,8 +668,9 @@ int jamd_gmm_tmix_cache_dev(jamd_gmm *g, const float *dev_frames, int T, float *
   if (!g->ntied) { jamd_set_error("jamd_gmm_tmix_cache_dev: model has no tied-mixture states"); return JAMD_ESTATE; }
   if (T == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(g->eng->device));
-  int rc = jamd_gmm_launch_tmix(g, dev_frames, T, nullptr, dev_score, dev_id, dev_num,
-                                jamd_stream(g->eng, stream));
+  const int off[2] = {0, T};
+  int rc = set_utterances(g, off, 1, jamd_stream(g->eng, stream));
+  if (rc == JAMD_OK) rc = jamd_gmm_launch_tmix(g, dev_frames, T, nullptr, dev_score, dev_id, dev_num, jamd_stream(g->eng, stream));
   if (rc != JAMD_OK) return rc;
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) {

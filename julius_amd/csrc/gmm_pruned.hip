@@ -154,6 +154,166 @@ tmix_book_kernel(const float *__restrict__ brec, const int *__restrict__ book_of
   }
 }
 
+// ---- tied-mixture codebooks, gprune heu / beam WITH HISTORY --------------------------------
+// gprune_heu() (gprune_heu.c:295-352) and gprune_beam() (gprune_beam.c:291-352) called from calc_tied_mix() with
+// last_id = the codebook's cached winners of frame t - 1 (calc_tied_mix.c:203-215).  Under eager scoring (every
+// state of every frame, outprob.c:230-242) that history is the previous frame's result, so a codebook is a chain over
+// the frames of ONE utterance: one wave per (codebook, utterance) walks the frames, the lanes share the codebook's
+// Gaussians.  Per frame:
+//   1. last frame's winners (lane j = winner j) are computed in full -- the sum starts at 0 and gconst is added at
+//      the end (compute_g_beam_updating :153-177, compute_g_heu_updating :138-162: NOT compute_g_base's order) --
+//      and their per-dimension partial sums (beam) / terms (heu) go to LDS; the lanes then take one dimension each:
+//      beam  th[d] = max(0, partial sums) + TMBEAMWIDTH (added in double, :142);
+//      heu   backmax[d] = max(0, terms), summed from the last dimension backwards (make_backmax :107-121);
+//   2. every other Gaussian (lane = Gaussian): beam -- dropped if ANY partial sum exceeds th[d] (the reference returns
+//      at the first one); heu -- its largest (partial sum + backmax[d + 1]) is kept, because the threshold it is
+//      compared with (-2 x the list's last score) moves while the list fills (:334-345);
+//   3. the survivors enter the top-N list in index order with cache_push()'s rule; the list lives in registers, one
+//      entry per lane.
+// Frame 0 of an utterance (and a frame whose predecessor cached nothing) takes the safe-pruning branch (:337-350) =
+// compute_g_base() scores pushed in index order.  Same MIXCACHE layout as tmix_book_kernel.
+struct TopList {                 // lane p holds entry p of the descending list (cap <= 64)
+  float sc; int id; int len, cap;
+  __device__ __forceinline__ void push(float score, int gid, int lane) {      // cache_push(), gprune_common.c:88-126
+    const float last = __shfl(sc, len > 0 ? len - 1 : 0, 64);
+    if (len > 0 && last >= score) {                                            // bottom: append if there is room
+      if (len < cap) { if (lane == len) { sc = score; id = gid; } len++; }
+      return;
+    }
+    const int p = __popcll(__ballot(lane < len && sc > score));                // entries strictly greater stay in front
+    const float usc = __shfl_up(sc, 1, 64); const int uid = __shfl_up(id, 1, 64);
+    if (lane > p && lane <= len && lane < cap) { sc = usc; id = uid; }
+    if (lane == p) { sc = score; id = gid; }
+    if (len < cap) len++;
+  }
+};
+
+template <int METHOD>
+__global__ void __launch_bounds__(64)
+tmix_book_hist_kernel(const float *__restrict__ brec, const int *__restrict__ book_off, const float *__restrict__ frames,
+                      const int *__restrict__ utt_off, float *__restrict__ c_score, int *__restrict__ c_id,
+                      int *__restrict__ c_num, int nbook, int D, int REC, int cap, int kmax) {
+  extern __shared__ __align__(16) float dyn[];
+  float *x = dyn;                         // [D]     the frame
+  float *th = x + D;                      // [D + 1] beam: thresholds; heu: backmax
+  float *part = th + D + 1;               // [cap][D] per-dimension values of last frame's winners
+  int *calced = reinterpret_cast<int *>(part + (size_t)cap * D);   // [kmax] mixcalced
+  const int lane = threadIdx.x, b = blockIdx.x, u = blockIdx.y;
+  const int k0 = book_off[b], K = book_off[b + 1] - k0;
+  const int t_begin = utt_off[u], t_end = utt_off[u + 1];
+  for (int i = lane; i < K; i += 64) calced[i] = 0;
+  TopList L; L.sc = JAMD_LOG_ZERO; L.id = 0; L.len = 0; L.cap = cap;
+  int last_id = 0, lnum = 0;              // lane j: winner j of the previous frame
+  auto sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int t = t_begin; t < t_end; t++) {
+    for (int d = lane; d < D; d += 64) x[d] = frames[(size_t)t * D + d];
+    sync();
+    L.len = 0;
+    if (t == t_begin || lnum == 0) {
+      // no history: safe pruning = the N best compute_g_base() scores, pushed in index order
+      for (int i0 = 0; i0 < K; i0 += 64) {
+        const int i = i0 + lane;
+        float sc = JAMD_LOG_ZERO;
+        if (i < K) {
+          const float *__restrict__ r = brec + (size_t)(k0 + i) * REC;
+          const float gc = r[2 * D];
+          float acc = gc;
+          for (int d = 0; d < D; d++) { float v = x[d] - r[d]; v = v * v; v = v * r[D + d]; acc = acc + v; }
+          sc = (gc != gc) ? JAMD_LOG_ZERO : acc * -0.5f;
+        }
+        // (a NULL density scores LOG_ZERO and is pushed like any other, gprune_safe.c:185-196)
+        unsigned long long m = __ballot(i < K);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          L.push(__shfl(sc, l, 64), i0 + l, lane);
+        }
+      }
+    } else {
+      // 1. last frame's winners
+      float psc = JAMD_LOG_ZERO;
+      if (lane < lnum) {
+        const float *__restrict__ r = brec + (size_t)(k0 + last_id) * REC;
+        const float gc = r[2 * D];
+        const bool nulld = gc != gc;
+        float tmp = 0.0f;
+        for (int d = 0; d < D; d++) {
+          float v = x[d] - r[d]; v = v * v; v = v * r[D + d];
+          if (METHOD == JAMD_GPRUNE_BEAM) { tmp = tmp + v; part[lane * D + d] = nulld ? 0.0f : tmp; }
+          else { tmp = tmp + v; part[lane * D + d] = nulld ? 0.0f : v; }
+        }
+        psc = nulld ? JAMD_LOG_ZERO : (tmp + gc) * -0.5f;
+        calced[last_id] = 1;
+      }
+      sync();
+      for (int d = lane; d < D; d += 64) {
+        float m = 0.0f;
+        for (int j = 0; j < lnum; j++) { const float v = part[j * D + d]; if (m < v) m = v; }
+        th[d] = (METHOD == JAMD_GPRUNE_BEAM) ? (float)((double)m + 5.0) : m;         // TMBEAMWIDTH, hmm_calc.h:54
+      }
+      for (int j = 0; j < lnum; j++) L.push(__shfl(psc, j, 64), __shfl(last_id, j, 64), lane);
+      sync();
+      if (METHOD == JAMD_GPRUNE_HEU) {
+        if (lane == 0) {
+          th[D] = 0.0f;
+          for (int d = D - 1; d >= 0; d--) th[d] = th[d] + th[d + 1];
+        }
+        sync();
+      }
+      // 2. the rest, 3. pushed in index order
+      float thres = __shfl(L.sc, L.len - 1, 64);
+      for (int i0 = 0; i0 < K; i0 += 64) {
+        const int i = i0 + lane;
+        float sc = JAMD_LOG_ZERO, mx = 0.0f;
+        bool cand = false;
+        if (i < K) {
+          if (calced[i]) calced[i] = 0;
+          else {
+            const float *__restrict__ r = brec + (size_t)(k0 + i) * REC;
+            const float gc = r[2 * D];
+            float tmp = 0.0f;
+            bool pruned = false;
+            mx = -3.0e38f;
+            for (int d = 0; d < D; d++) {
+              float v = x[d] - r[d]; v = v * v; v = v * r[D + d];
+              tmp = tmp + v;
+              if (METHOD == JAMD_GPRUNE_BEAM) pruned |= tmp > th[d];
+              else { const float w = tmp + th[d + 1]; if (mx < w) mx = w; }
+            }
+            sc = (gc != gc || pruned) ? JAMD_LOG_ZERO : (tmp + gc) * -0.5f;
+            cand = sc > JAMD_LOG_ZERO;
+          }
+        }
+        // heu: once the list is full its last score only rises, so a Gaussian over the CURRENT threshold is out for good
+        // (while the list still grows an appended entry LOWERS it: no shortcut then)
+        if (METHOD == JAMD_GPRUNE_HEU && L.len == L.cap) cand = cand && !(mx > thres * -2.0f);
+        unsigned long long m = __ballot(cand);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          const float s_l = __shfl(sc, l, 64);
+          if (METHOD == JAMD_GPRUNE_HEU) {
+            if (__shfl(mx, l, 64) > thres * -2.0f) continue;
+            L.push(s_l, i0 + l, lane);
+            thres = __shfl(L.sc, L.len - 1, 64);
+          } else {
+            L.push(s_l, i0 + l, lane);
+          }
+        }
+      }
+    }
+    const size_t o = ((size_t)t * nbook + b) * cap;
+    if (lane < L.len) { c_score[o + lane] = L.sc; c_id[o + lane] = L.id; }
+    if (lane == 0) c_num[(size_t)t * nbook + b] = L.len;
+    last_id = L.id; lnum = L.len;
+    sync();
+  }
+}
+
 // ---- tied-mixture states: weights of the cached winners + log-sum -----------
 __global__ void __launch_bounds__(256)
 tmix_state_kernel(const int *__restrict__ tied_states, int ntied, const int *__restrict__ st_off,
@@ -205,6 +365,22 @@ int launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t
   return JAMD_OK;
 }
 
+int launch_book_hist(jamd_gmm *g, const float *frames, float *c_score, int *c_id, int *c_num, hipStream_t st) {
+  const dim3 grid(g->nbook, g->cur_nutt);
+  const size_t dyn = sizeof(float) * ((size_t)g->D + (size_t)g->D + 1 + (size_t)g->tm_cap * g->D) + sizeof(int) * (size_t)g->maxbook;
+  const void *fn = g->hist_method == JAMD_GPRUNE_BEAM ? (const void *)tmix_book_hist_kernel<JAMD_GPRUNE_BEAM>
+                                                       : (const void *)tmix_book_hist_kernel<JAMD_GPRUNE_HEU>;
+  const int rc = jamd_reserve_dyn_lds(fn, dyn, "gprune heu/beam over tied-mixture codebooks");
+  if (rc != JAMD_OK) return rc;
+  if (g->hist_method == JAMD_GPRUNE_BEAM)
+    hipLaunchKernelGGL(tmix_book_hist_kernel<JAMD_GPRUNE_BEAM>, grid, dim3(64), dyn, st, g->d_book_rec, g->d_book_off, frames,
+                       g->d_cur_utt_off, c_score, c_id, c_num, g->nbook, g->D, g->rec, g->tm_cap, g->maxbook);
+  else
+    hipLaunchKernelGGL(tmix_book_hist_kernel<JAMD_GPRUNE_HEU>, grid, dim3(64), dyn, st, g->d_book_rec, g->d_book_off, frames,
+                       g->d_cur_utt_off, c_score, c_id, c_num, g->nbook, g->D, g->rec, g->tm_cap, g->maxbook);
+  return JAMD_OK;
+}
+
 template <int DT>
 int launch_book(jamd_gmm *g, const float *frames, int T, float *c_score, int *c_id, int *c_num,
                 hipStream_t st) {
@@ -246,7 +422,8 @@ int jamd_gmm_launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hi
 int jamd_gmm_launch_tmix(jamd_gmm *g, const float *frames, int T, float *out, float *c_score,
                          int *c_id, int *c_num, hipStream_t st) {
   int rc;
-  switch (g->D) {
+  if (g->hist_method != 0) rc = launch_book_hist(g, frames, c_score, c_id, c_num, st);
+  else switch (g->D) {
     case 39: rc = launch_book<39>(g, frames, T, c_score, c_id, c_num, st); break;
     case 38: rc = launch_book<38>(g, frames, T, c_score, c_id, c_num, st); break;
     case 26: rc = launch_book<26>(g, frames, T, c_score, c_id, c_num, st); break;

@@ -146,7 +146,7 @@ int main(int argc, char **argv)
     if (jamd_malloc(e, sizeof(float) * used, (void **)&d_frames) != JAMD_OK ||
         jamd_malloc(e, sizeof(float) * (size_t)off[n] * nstate, (void **)&d_scores) != JAMD_OK ||
         jamd_memcpy_h2d(e, d_frames, frames, sizeof(float) * used) != JAMD_OK) die("device buffers");
-    if ((gm ? jamd_gmm_outprob_dev(gm, d_frames, off[n], d_scores, NULL)
+    if ((gm ? jamd_gmm_outprob_utts_dev(gm, d_frames, off, n, d_scores, NULL)
             : jamd_dnn_outprob_dev(dn, d_frames, off[n], d_scores, NULL)) != JAMD_OK) die("scoring");
     if (gs != NULL && jamd_gms_apply_dev(gs, d_frames, off[n], off, n, d_scores, NULL) != JAMD_OK) die("Gaussian mixture selection");
     if (jamd_beam_pass1_dev(bm, d_scores, nstate, off, n, NULL) != JAMD_OK || jamd_engine_sync(e) != JAMD_OK ||

@@ -14,6 +14,8 @@ import numpy as np
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libjulius_amd.so"
+if os.environ.get("JAMD_LIB"):          # development: a library variant built by tools/build_variant.sh
+    LIB_PATH = Path(os.environ["JAMD_LIB"]).resolve()
 
 LOG_ZERO = -1000000.0
 GPRUNE_NONE, GPRUNE_SAFE, GPRUNE_HEU, GPRUNE_BEAM = 0, 1, 2, 3
@@ -100,6 +102,7 @@ def load():
         "jamd_gmm_nstate": (ci, [vp]),
         "jamd_gmm_veclen": (ci, [vp]),
         "jamd_gmm_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
+        "jamd_gmm_outprob_utts_dev": (ci, [vp, vp, vp, ci, vp, vp]),
         "jamd_gmm_outprob_host": (ci, [vp, vp, ci, vp]),
         "jamd_gmm_tmix_cache_dev": (ci, [vp, vp, ci, vp, vp, vp, vp]),
         "jamd_gmm_last_kernel": (C.c_char_p, [vp]),
@@ -283,6 +286,12 @@ class Gmm:
     def outprob_dev(self, dev_frames: int, T: int, dev_out: int, stream: int = 0):
         _check(load().jamd_gmm_outprob_dev(self.h, dev_frames, T, dev_out, stream or None),
                "jamd_gmm_outprob_dev")
+
+    def outprob_utts_dev(self, dev_frames: int, utt_off, dev_out: int, stream: int = 0):
+        """A batch of utterances back to back (the boundaries matter to gprune heu / beam over tied-mixture codebooks)."""
+        off = _i32(utt_off)
+        _check(load().jamd_gmm_outprob_utts_dev(self.h, dev_frames, off.ctypes.data, len(off) - 1, dev_out, stream or None),
+               "jamd_gmm_outprob_utts_dev")
 
     def dens_host(self, frames: np.ndarray) -> np.ndarray:
         """Per-Gaussian scores [T][nentry] (the plugin slot's compute_gaussset values)."""

@@ -18,8 +18,8 @@
  * all unchanged, all consuming device scores that are bit-identical to calc_mix() /
  * calc_tied_mix().
  *
- * Supported: GMM acoustic models (plain or tied-mixture), single stream, -gprune none
- * or -gprune safe, with or without Gaussian mixture selection (-gshmm: the selection stage of
+ * Supported: GMM acoustic models (plain or tied-mixture), single stream, -gprune none,
+ * safe, heu or beam (the last two over tied-mixture codebooks: eager-scoring values), with or without Gaussian mixture selection (-gshmm: the selection stage of
  * gms.c runs on the device after the scoring, jamd_gms_apply_host); DNN acoustic models
  * (-dnnconf).  Anything else (heu/beam pruning,
  * multi-stream, -input outprob) is left to libsent's CPU code with one log line -- those paths are outside
@@ -102,12 +102,15 @@ static void examine(wrap_ctx *c)
   }
   if (wrk->compute_gaussset == gprune_none) gprune = JAMD_GPRUNE_NONE;
   else if (wrk->compute_gaussset == gprune_safe) gprune = JAMD_GPRUNE_SAFE;
-  else if (wrk->compute_gaussset == gprune_heu && !wrk->OP_hmminfo->is_tied_mixture) gprune = JAMD_GPRUNE_HEU;
-  else if (wrk->compute_gaussset == gprune_beam && !wrk->OP_hmminfo->is_tied_mixture) gprune = JAMD_GPRUNE_BEAM;
+  else if (wrk->compute_gaussset == gprune_heu) gprune = JAMD_GPRUNE_HEU;
+  else if (wrk->compute_gaussset == gprune_beam) gprune = JAMD_GPRUNE_BEAM;
   else {
-    jlog("Stat: jamd: this -gprune method depends on the previous frame; scoring stays on libsent's CPU code\n");
+    jlog("Stat: jamd: unknown Gaussian pruning function (a plugin?); scoring stays on libsent's CPU code\n");
     return;
   }
+  if (gprune >= JAMD_GPRUNE_HEU && wrk->OP_hmminfo->is_tied_mixture)
+    jlog("Stat: jamd: -gprune heu/beam over tied-mixture codebooks: the thresholds of frame t come from frame t-1 of the same input "
+         "(every frame is scored on the device), i.e. the reference's values under eager scoring\n");
   if (jamd_flatten_hmminfo(wrk->OP_hmminfo, &fg) != 0) die("cannot flatten the acoustic model");
   if (jamd_gmm_create(g_eng, &fg.desc, gprune, wrk->OP_gprune_num, &c->gmm) != JAMD_OK) die("jamd_gmm_create");
   c->nstate = fg.desc.nstate;

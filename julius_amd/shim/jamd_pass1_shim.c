@@ -22,7 +22,7 @@
  * indexes it with bt_relocate_rw / bt_sort_rw exactly as the reference does.
  *
  * Supported configuration (anything else is refused loudly at _init()): N-gram
- * LM, non-multipath acoustic model -- GMM with -gprune none|safe, or DNN (-dnnconf) --
+ * LM, non-multipath acoustic model -- GMM with any -gprune method, or DNN (-dnnconf) --
  * no short-pause segmentation, buffered input.  The "no nodes left in beam" condition is
  * reported by failing the utterance (J_RESULT_STATUS_FAIL) instead of segmenting.
  */
@@ -46,6 +46,8 @@ typedef struct {
   float cfg_key[10];           /* scalar configuration baked into the device lexicon / scorer (cfg_key_of()) */
   /* streaming state of the current utterance */
   int chunk;                   /* JAMD_STREAM_CHUNK: push every this many frames from _proceed(); 0 = all at _end() */
+  int whole_input;             /* the scoring carries state from frame to frame (-gshmm selection, -gprune heu/beam over
+                                * tied-mixture codebooks): the input is scored in one piece, no interim results */
   int pushed;                  /* frames already handed to the device */
   int failed;
   float *host_scores; int host_cap;   /* [pushed][nstate] rows kept for the 2nd pass's cache */
@@ -164,8 +166,8 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     switch (r->am->config->gprune_method) {      /* jconf.h:94, values hmm_calc.h:38-45 */
     case GPRUNE_SEL_NONE: gprune = JAMD_GPRUNE_NONE; break;
     case GPRUNE_SEL_SAFE: gprune = JAMD_GPRUNE_SAFE; break;
-    case GPRUNE_SEL_HEURISTIC: gprune = JAMD_GPRUNE_HEU; break;     /* plain mixture states only: jamd_gmm_create() */
-    case GPRUNE_SEL_BEAM: gprune = JAMD_GPRUNE_BEAM; break;         /* refuses tied-mixture models with these two   */
+    case GPRUNE_SEL_HEURISTIC: gprune = JAMD_GPRUNE_HEU; break;     /* tied-mixture codebooks: the reference's values under */
+    case GPRUNE_SEL_BEAM: gprune = JAMD_GPRUNE_BEAM; break;         /* eager scoring (history = frame t-1 of the input)     */
     default:
       jlog("ERROR: jamd: unknown -gprune method\n");
       return FALSE;
@@ -220,8 +222,9 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     jlog("Stat: jamd: first pass on HIP device %d, beam %d, tie order: %s\n", jamd_engine_device(g_eng), r->trellis_beam_width,
          (m >= 0 && m < 4) ? names[m] : "?");
     if (m == JAMD_ORDER_FAST && c->order_mode != JAMD_ORDER_FAST)
-      jlog("Warning: jamd: beam %d is too wide for the exact-order kernel's LDS image; exactly tied hypotheses are resolved canonically, not in the "
-           "reference's visiting order (JAMD_ORDER_MODE=strict gives the reference's order, slowly)\n", r->trellis_beam_width);
+      jlog("Warning: jamd: beam %d is too wide for the exact-order kernel's LDS image (it serves beams up to about 12 000); exactly tied "
+           "hypotheses are resolved canonically, not in the reference's visiting order (JAMD_ORDER_MODE=strict gives the reference's "
+           "order, slowly)\n", r->trellis_beam_width);
   }
   c->wchmm = r->wchmm; c->hmminfo = r->am->hmminfo;
   c->nnode = r->wchmm->n; c->nword = r->wchmm->winfo->num; c->dfa = (void *)r->wchmm->dfa;
@@ -288,7 +291,7 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
       jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores) != JAMD_OK ||
       jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||
       (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, (int)total, d_scores, NULL)
-              : jamd_gmm_outprob_dev(c->gmm, d_frames, (int)total, d_scores, NULL)) != JAMD_OK ||
+              : jamd_gmm_outprob_utts_dev(c->gmm, d_frames, off, n, d_scores, NULL)) != JAMD_OK ||
       (c->gms && jamd_gms_apply_dev(c->gms, d_frames, (int)total, off, n, d_scores, NULL) != JAMD_OK) ||
       jamd_beam_pass1_dev(bb, d_scores, c->nstate, off, n, NULL) != JAMD_OK ||
       jamd_engine_sync(g_eng) != JAMD_OK || jamd_beam_results(bb, res, n) != JAMD_OK) goto out;
@@ -369,7 +372,10 @@ boolean get_back_trellis_init(HTK_Param *param, RecogProcess *r)
   if (r->config->output.progout_interval_frame < 1) r->config->output.progout_interval_frame = 1;
   c->chunk = getenv("JAMD_STREAM_CHUNK") ? atoi(getenv("JAMD_STREAM_CHUNK")) : 0;
   if (c->strict) c->chunk = 0;                        /* one final push */
-  if (c->gms != NULL) c->chunk = 0;                   /* the selection carries state from frame to frame */
+  c->whole_input = c->gms != NULL ||
+                   (c->gmm != NULL && r->am->hmminfo->is_tied_mixture &&
+                    (r->am->config->gprune_method == GPRUNE_SEL_HEURISTIC || r->am->config->gprune_method == GPRUNE_SEL_BEAM));
+  if (c->whole_input) c->chunk = 0;
   c->pushed = 0; c->failed = 0; c->hit = -1;
   if (c->npre > 0 && param->samplenum > 0) {          /* decoded ahead in a batch? */
     float *fr = jamd_pack_param(param, 0, param->samplenum);
@@ -493,7 +499,7 @@ boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boole
    * (the atoms ending at t-1 are emitted while frame t is processed) and the trellis so far is read back.  The
    * strict-order kernel and the selection stage need the whole input in one piece: no interim results there. */
   if (r->config->output.progout_flag && t > 0 && ((t - 1) % r->config->output.progout_interval_frame) == 0 &&
-      (c->hit >= 0 || (!c->strict && c->gms == NULL))) {
+      (c->hit >= 0 || (!c->strict && !c->whole_input))) {
     if (c->hit >= 0) {
       interim_result(r, c->pre[c->hit].atoms, c->pre[c->hit].natom, t - 1);
       r->have_interim = TRUE;
@@ -507,10 +513,12 @@ boolean get_back_trellis_proceed(int t, HTK_Param *param, RecogProcess *r, boole
         return FALSE;
       }
       if (c->iatoms == NULL || res.natom > c->iatom_cap) {
-        c->iatom_cap = res.natom + 65536;
-        c->iatoms = (jamd_trellis_atom *)realloc(c->iatoms, sizeof(jamd_trellis_atom) * (size_t)c->iatom_cap);
+        const int ncap = res.natom + 65536;
+        jamd_trellis_atom *na = (jamd_trellis_atom *)realloc(c->iatoms, sizeof(jamd_trellis_atom) * (size_t)ncap);
+        if (na == NULL) jlog("Warning: jamd: out of memory for the interim trellis (%d atoms): no interim result at frame %d\n", ncap, t - 1);
+        else { c->iatoms = na; c->iatom_cap = ncap; }
       }
-      if (c->iatoms != NULL && jamd_beam_trellis(c->beam, 0, c->iatoms, res.natom, &natom) == JAMD_OK) {
+      if (c->iatoms != NULL && res.natom <= c->iatom_cap && jamd_beam_trellis(c->beam, 0, c->iatoms, res.natom, &natom) == JAMD_OK) {
         interim_result(r, c->iatoms, natom < res.natom ? natom : res.natom, t - 1);
         r->have_interim = TRUE;
       }

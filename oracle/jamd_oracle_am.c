@@ -193,6 +193,125 @@ static int gset_safe(const gctx *c, const int *dens, int n, int cap,
   return num;
 }
 
+/* gprune_beam.c:291-352 with history (tied-mixture codebooks, frame t >= 1): last frame's winners are computed in
+ * full while the largest partial sum of every dimension is recorded (compute_g_beam_updating :153-177: the sum
+ * starts at 0 and gconst is added at the END), TMBEAMWIDTH (5.0, hmm_calc.h:54) is added to those maxima, and every
+ * other Gaussian is dropped at the first dimension where its partial sum exceeds the threshold
+ * (compute_g_beam_pruning :192-215).  Without history: the safe-pruning branch (:337-350). */
+#define JO_TMBEAMWIDTH 5.0
+static int gset_beam(const gctx *c, const int *dens, int n, int cap, const int *last_id, int lnum,
+                     unsigned char *mark, float *th, float *sc, int *id)
+{
+  int num = 0, D = c->D;
+  if (last_id == NULL) return gset_safe(c, dens, n, cap, NULL, 0, mark, sc, id);
+  for (int d = 0; d < D; d++) th[d] = 0.0f;                       /* clear_dimthres */
+  for (int j = 0; j < lnum; j++) {
+    int i = last_id[j];
+    float score = JO_LOG_ZERO;
+    if (dens[i] >= 0) {
+      const float *mean = c->mean + (size_t)dens[i] * D, *var = c->ivar + (size_t)dens[i] * D;
+      float tmp = 0.0f;
+      for (int d = 0; d < D; d++) {
+        float x = c->vec[d] - mean[d];
+        float xx = x * x;
+        float t = xx * var[d];
+        tmp = tmp + t;
+        if (th[d] < tmp) th[d] = tmp;
+      }
+      score = (float)((tmp + c->gconst[dens[i]]) * -0.5);
+    }
+    num = topn_push(sc, id, cap, i, score, num);
+    mark[i] = 1;
+  }
+  for (int d = 0; d < D; d++) th[d] = (float)(th[d] + JO_TMBEAMWIDTH);   /* set_dimthres: float += double */
+  for (int i = 0; i < n; i++) {
+    if (mark[i]) { mark[i] = 0; continue; }
+    float score = JO_LOG_ZERO;
+    if (dens[i] >= 0) {
+      const float *mean = c->mean + (size_t)dens[i] * D, *var = c->ivar + (size_t)dens[i] * D;
+      float tmp = 0.0f;
+      int d;
+      for (d = 0; d < D; d++) {
+        float x = c->vec[d] - mean[d];
+        float xx = x * x;
+        float t = xx * var[d];
+        tmp = tmp + t;
+        if (tmp > th[d]) break;
+      }
+      if (d == D) score = (float)((tmp + c->gconst[dens[i]]) * -0.5);
+    }
+    if (score > JO_LOG_ZERO) num = topn_push(sc, id, cap, i, score, num);
+  }
+  return num;
+}
+
+/* gprune_heu.c:295-352 with history: last frame's winners are computed in full while the largest TERM of every
+ * dimension is recorded (compute_g_heu_updating :138-162), the maxima are summed from the last dimension backwards
+ * (make_backmax :107-121: backmax[D] = 0), and every other Gaussian is dropped as soon as its partial sum plus the
+ * recorded maximum of the dimensions still to come exceeds -2 x the current N-th best score
+ * (compute_g_heu_pruning :180-206; the threshold follows the list, :334-345). */
+static int gset_heu(const gctx *c, const int *dens, int n, int cap, const int *last_id, int lnum,
+                    unsigned char *mark, float *bm, float *sc, int *id)
+{
+  int num = 0, D = c->D;
+  float thres;
+  if (last_id == NULL) return gset_safe(c, dens, n, cap, NULL, 0, mark, sc, id);
+  for (int d = 0; d <= D; d++) bm[d] = 0.0f;                      /* init_backmax */
+  for (int j = 0; j < lnum; j++) {
+    int i = last_id[j];
+    float score = JO_LOG_ZERO;
+    if (dens[i] >= 0) {
+      const float *mean = c->mean + (size_t)dens[i] * D, *var = c->ivar + (size_t)dens[i] * D;
+      float sum = 0.0f;
+      for (int d = 0; d < D; d++) {
+        float x = c->vec[d] - mean[d];
+        float xx = x * x;
+        float tmp = xx * var[d];
+        sum = sum + tmp;
+        if (bm[d] < tmp) bm[d] = tmp;
+      }
+      score = (float)((sum + c->gconst[dens[i]]) * -0.5);
+    }
+    num = topn_push(sc, id, cap, i, score, num);
+    mark[i] = 1;
+  }
+  bm[D] = 0.0f;                                                   /* make_backmax */
+  for (int d = D - 1; d >= 0; d--) bm[d] = bm[d] + bm[d + 1];
+  thres = sc[num - 1];
+  for (int i = 0; i < n; i++) {
+    if (mark[i]) { mark[i] = 0; continue; }
+    float score = JO_LOG_ZERO;
+    if (dens[i] >= 0) {
+      const float *mean = c->mean + (size_t)dens[i] * D, *var = c->ivar + (size_t)dens[i] * D;
+      float fthres = (float)(thres * (-2.0));
+      float tmp = 0.0f;
+      int d;
+      for (d = 0; d < D; d++) {
+        float x = c->vec[d] - mean[d];
+        float xx = x * x;
+        float t = xx * var[d];
+        tmp = tmp + t;
+        if (tmp + bm[d + 1] > fthres) break;
+      }
+      if (d == D) score = (float)((tmp + c->gconst[dens[i]]) * -0.5);
+    }
+    if (score > JO_LOG_ZERO) {
+      num = topn_push(sc, id, cap, i, score, num);
+      thres = sc[num - 1];
+    }
+  }
+  return num;
+}
+
+/* compute_gaussset as outprob_init.c:99-147 selects it */
+static int gset_pruned(int gprune, const gctx *c, const int *dens, int n, int cap, const int *last_id, int lnum,
+                       unsigned char *mark, float *dimwork, float *sc, int *id)
+{
+  if (gprune == JO_GPRUNE_BEAM) return gset_beam(c, dens, n, cap, last_id, lnum, mark, dimwork, sc, id);
+  if (gprune == JO_GPRUNE_HEU) return gset_heu(c, dens, n, cap, last_id, lnum, mark, dimwork, sc, id);
+  return gset_safe(c, dens, n, cap, last_id, lnum, mark, sc, id);
+}
+
 /* calc_mix.c:75-80 / calc_tied_mix.c:231-236 for a single stream with stream
  * weight 1: logprobsum = 0 + logprob*1; LOG_ZERO if 0 or <= LOG_ZERO; result is
  * the double product with INV_LOG_TEN rounded to float. */
@@ -215,19 +334,20 @@ int jo_tmix_topn(int D, const float *mean, const float *ivar, const float *gcons
   float *sc = malloc(sizeof(float) * (book_num + 1));
   int *id = malloc(sizeof(int) * (book_num + 1));
   gctx c = { D, mean, ivar, gconst, NULL };
+  float *dimwork = malloc(sizeof(float) * (D + 1));
   int lastn = 0; const int *last = NULL;
   for (int t = 0; t < T; t++) {
     c.vec = frames + (size_t)t * D;
     int num;
     if (gprune == JO_GPRUNE_NONE) num = gset_none(&c, book_dens, book_num, sc, id);
-    else num = gset_safe(&c, book_dens, book_num, cap, (t >= 1 && lastn > 0) ? last : NULL,
-                         lastn, mark, sc, id);
+    else num = gset_pruned(gprune, &c, book_dens, book_num, cap, (t >= 1 && lastn > 0) ? last : NULL,
+                           lastn, mark, dimwork, sc, id);
     out_num[t] = num;
     memcpy(out_score + (size_t)t * cap, sc, sizeof(float) * num);
     memcpy(out_id + (size_t)t * cap, id, sizeof(int) * num);
     last = out_id + (size_t)t * cap; lastn = num;
   }
-  free(mark); free(sc); free(id);
+  free(mark); free(sc); free(id); free(dimwork);
   return 0;
 }
 
@@ -250,6 +370,7 @@ int jo_gmm_outprob(int S, int D,
   float *sc = malloc(sizeof(float) * (maxn + 1));
   int *id = malloc(sizeof(int) * (maxn + 1));
   unsigned char *mark = calloc(maxn + 1, 1);
+  float *dimwork = malloc(sizeof(float) * (D + 1));
   /* per-codebook cache for the current and the previous frame */
   float *bsc[2] = { NULL, NULL }; int *bid[2] = { NULL, NULL }; int *bnum[2] = { NULL, NULL };
   if (nbook > 0) {
@@ -279,19 +400,19 @@ int jo_gmm_outprob(int S, int D,
           const int *last = NULL; int lnum = 0;
           if (t >= 1 && bnum[prv][b] > 0) { last = bid[prv] + (size_t)b * cap; lnum = bnum[prv][b]; }
           if (gprune == JO_GPRUNE_NONE) num = gset_none(&c, dens, n, sc, id);
-          else num = gset_safe(&c, dens, n, cap, last, lnum, mark, sc, id);
+          else num = gset_pruned(gprune, &c, dens, n, cap, last, lnum, mark, dimwork, sc, id);
           bnum[cur][b] = num;
           for (int i = 0; i < num; i++) { cid[i] = id[i]; csc[i] = sc[i]; sc[i] += logw[id[i]]; }
         }
       } else {                                       /* calc_mix.c:63-70 */
         if (gprune == JO_GPRUNE_NONE) num = gset_none(&c, dens, n, sc, id);
-        else num = gset_safe(&c, dens, n, cap, NULL, 0, mark, sc, id);
+        else num = gset_pruned(gprune, &c, dens, n, cap, NULL, 0, mark, dimwork, sc, id);   /* calc_mix(): last_id == NULL */
         for (int i = 0; i < num; i++) sc[i] += logw[id[i]];
       }
       out[(size_t)t * S + s] = finish_state(jo_addlog_array(sc, num));
     }
   }
-  free(sc); free(id); free(mark);
+  free(sc); free(id); free(mark); free(dimwork);
   for (int k = 0; k < 2; k++) { free(bsc[k]); free(bid[k]); free(bnum[k]); }
   return 0;
 }

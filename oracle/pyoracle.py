@@ -21,7 +21,7 @@ REF_AMD_SO = HERE / "_ref" / "libjref_amd.so"   # same reference, first pass ser
 PLUGIN_DIR = HERE / "_ref" / "plugin"
 REF_O_SO = HERE / "_ref" / "libjref_o.so"       # same reference (own beam), scoring entry points wrapped (boundary O)
 
-GPRUNE_NONE, GPRUNE_SAFE = 0, 1
+GPRUNE_NONE, GPRUNE_SAFE, GPRUNE_HEU, GPRUNE_BEAM = 0, 1, 2, 3
 # reference enum (libsent/include/sent/hmm_calc.h:45)
 REF_GPRUNE = {"none": 1, "safe": 2, "heu": 3, "beam": 4}
 IWCD_MAX, IWCD_AVG, IWCD_NBEST = 0, 1, 2
@@ -434,6 +434,12 @@ class RefEngine:
         lib.jref_engine_info(self.h, _p(info))
         (self.nnode, self.nword, self.startnum, self.isolatenum, self.beam_width, self.nstate,
          self.lmtype, self.multipath, self.ccd) = [int(x) for x in info[:9]]
+
+    def set_eager(self, on=True):
+        """Every state of a frame is scored at the first request (outprob.c:230-242) instead of lazily."""
+        self.ref.lib.jref_engine_set_eager.argtypes = [C.c_void_p, C.c_int]
+        self.ref.lib.jref_engine_set_eager(self.h, 1 if on else 0)
+        return self
 
     def save_lexicon(self, path):
         rc = self.ref.lib.jref_engine_save_lexicon(self.h, str(path).encode())

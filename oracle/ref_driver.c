@@ -377,6 +377,16 @@ void *jref_engine_create(int argc, char **argv)
   return e;
 }
 
+/* Eager scoring for the engine's acoustic models (outprob_set_batch_computation(), outprob_init.c:196: every state of
+ * a frame is scored at the first request, outprob.c:230-242).  Values are those of the default lazy mode except
+ * where the scoring carries history from frame to frame: -gprune heu / beam over tied-mixture codebooks. */
+void jref_engine_set_eager(void *h, int on)
+{
+  jref_eng *e = (jref_eng *)h;
+  PROCESS_AM *am;
+  for (am = e->recog->amlist; am; am = am->next) outprob_set_batch_computation(&am->hmmwrk, on ? TRUE : FALSE);
+}
+
 /* Recognise one HTK parameter file (-input htkparam).  Returns the number of
  * trellis atoms, or -1.  With -1pass the word trellis is left exactly as
  * finalize_1st_pass() built it. */

@@ -109,15 +109,51 @@ def test_gprune_heu_beam_on_plain_states_vs_compiled_reference(engine, ref, meth
     """SURVEY 8a A7, the plain-mixture half: calc_mix() calls the pruning function with last_id == NULL
     (`calc_mix.c:63`), where gprune_heu() / gprune_beam() are safe pruning (`gprune_heu.c:337-350`,
     `gprune_beam.c:337-350`).  The device serves such models with these methods, bit for bit with the compiled
-    reference running the real gprune_heu / gprune_beam.  A tied-mixture model is still refused."""
+    reference running the real gprune_heu / gprune_beam."""
     m = synth.make_gmm(S=90, M=12, D=39, seed=21, ragged=True, null_frac=0.05)
     fr = synth.make_frames(m, T=300, seed=22)
     want = ref.am_from_flat(m, gprune=method, gprune_num=num).outprob(fr, want_out=True)
     got = lib.Gmm(engine, m, code, num).outprob_host(fr)
     assert np.array_equal(got, want)
-    tied = synth.make_tied_gmm(S=30, nbook=2, K=16, D=39, seed=3)
-    with pytest.raises(lib.JamdError):
-        lib.Gmm(engine, tied, code, num)
+
+
+@pytest.mark.parametrize("method,code", [("heu", lib.GPRUNE_HEU), ("beam", lib.GPRUNE_BEAM)])
+@pytest.mark.parametrize("n,nbook,K,D,noise", [(1, 3, 64, 39, 2.0), (2, 4, 64, 39, 2.0), (4, 2, 129, 39, 1.0),
+                                               (10, 1, 40, 25, 3.0), (64, 2, 24, 13, 2.0), (2, 129, 16, 39, 2.0)])
+def test_gprune_heu_beam_on_tied_mixture_vs_compiled_reference(engine, ref, tmp_path, method, code, n, nbook, K, D, noise):
+    """SURVEY 8a A7, the tied-mixture half -- the case where these functions do something of their own, and the fast
+    build's default for C1-type models: thresholds from the codebook's winners of frame t-1 (`gprune_heu.c:305-335`,
+    `gprune_beam.c:301-336`, hand-over `calc_tied_mix.c:203-215`).  Parity is defined against the compiled reference
+    under EAGER scoring (`outprob_set_batch_computation`, `outprob.c:230-242`: every state of every frame, so frame t-1's
+    cache always exists): state scores and the MIXCACHE contents, bit for bit; a batch call restarts the history at
+    every utterance boundary."""
+    m = synth.make_tied_gmm(S=max(21, nbook), nbook=nbook, K=K, D=D, seed=K + n)
+    synth.write_hmmdefs(tmp_path / "h", m, kind="MFCC_E_D_A" if D == 39 else "USER")
+    am = ref.am_load(tmp_path / "h", gprune=method, gprune_num=n)
+    assert am.is_tied and am.nbook == nbook
+    ex = am.export()
+    fr = synth.make_frames(m, T=75, seed=9 + n, noise=noise)
+    gm = lib.Gmm(engine, ex, code, n)
+    want = am.outprob(fr)
+    got = gm.outprob_host(fr)
+    assert np.array_equal(got, want), f"max |d| = {np.abs(got - want).max()}"
+    sc, ids, num = gm.tmix_cache_host(fr)
+    for b in range(min(nbook, 4)):
+        rsc, rids, rnum = am.tmix_cache(fr, b, n)
+        assert np.array_equal(num[:, b], rnum)
+        for t in range(len(fr)):
+            k = rnum[t]
+            assert np.array_equal(ids[t, b, :k], rids[t, :k]) and np.array_equal(sc[t, b, :k], rsc[t, :k]), (b, t)
+    # two utterances in one call: the second one starts without history, as outprob_prepare() leaves it
+    fr2 = synth.make_frames(m, T=40, seed=77, noise=noise)
+    both = np.concatenate([fr, fr2])
+    d_fr = lib.DevBuf(engine, both.nbytes).upload(both)
+    d_out = lib.DevBuf(engine, 4 * len(both) * gm.S)
+    gm.outprob_utts_dev(d_fr.ptr, [0, len(fr), len(both)], d_out.ptr)
+    engine.sync()
+    out = d_out.download((len(both), gm.S), np.float32)
+    assert np.array_equal(out[:len(fr)], want) and np.array_equal(out[len(fr):], am.outprob(fr2))
+    am.close()
 
 
 def test_tied_mixture_more_than_65535_frames(engine):

@@ -43,6 +43,35 @@ def test_tied_gmm(ref, oracle, tmp_path, gprune, n):
     am.close()
 
 
+@pytest.mark.parametrize("gprune", ["heu", "beam"])
+@pytest.mark.parametrize("n,nbook,K,noise", [(1, 3, 64, 2.0), (2, 4, 64, 2.0), (4, 2, 129, 1.0), (10, 1, 40, 3.0), (64, 2, 24, 2.0)])
+def test_tied_gmm_history_pruning(ref, oracle, tmp_path, gprune, n, nbook, K, noise):
+    """SURVEY 8a A7, the tied-mixture half: gprune_heu() / gprune_beam() with a live last_id (`gprune_heu.c:305-335`,
+    `gprune_beam.c:301-336`): the thresholds of frame t come from the codebook's cached winners of frame t-1
+    (`calc_tied_mix.c:203-215`).  Under eager scoring (the batch loop `outprob.c:230-242`: every state of every frame)
+    that history is deterministic, and the restatement must give the compiled reference's numbers and cache."""
+    m = synth.make_tied_gmm(S=21, nbook=nbook, K=K, D=39, seed=K + n)
+    synth.write_hmmdefs(tmp_path / "h", m)
+    am = ref.am_load(tmp_path / "h", gprune=gprune, gprune_num=n)
+    assert am.is_tied and am.nbook == nbook
+    ex = am.export()
+    fr = synth.make_frames(m, T=60, seed=9 + n, noise=noise)
+    code = po.GPRUNE_HEU if gprune == "heu" else po.GPRUNE_BEAM
+    want = am.outprob(fr)
+    assert np.array_equal(oracle.gmm_outprob(ex, fr, code, n), want)
+    safe = oracle.gmm_outprob(ex, fr, po.GPRUNE_SAFE, n)
+    if n < 10:
+        assert not np.array_equal(safe, want)              # these methods really prune differently from safe
+    cap = n                                                 # the reference's cache rows are OP_gprune_num wide
+    for b in range(nbook):
+        sc, ids, num = am.tmix_cache(fr, b, cap)
+        osc, oids, onum = oracle.tmix_topn(ex, b, fr, code, n)
+        assert np.array_equal(num, onum)
+        for t in range(len(fr)):
+            assert np.array_equal(ids[t, :num[t]], oids[t, :num[t]]) and np.array_equal(sc[t, :num[t]], osc[t, :num[t]])
+    am.close()
+
+
 def test_lazy_equals_eager(ref, tmp_path):
     """outprob.c:245-247 (lazy cache fill) and :230-242 (batch) give the same values."""
     m = synth.make_gmm(S=15, M=4, D=39, seed=2)

@@ -151,6 +151,40 @@ def test_c1_tied_mixture_grammar_over_device_scores(ref, tmp_path):
         _compare_exact(plain, wrapped, tmp_path / "u.mfc")
 
 
+@pytest.mark.parametrize("so", ["o", "amd"])
+@pytest.mark.parametrize("gprune", ["beam", "heuristic"])
+def test_c1_history_pruning_over_device_scores(ref, tmp_path, monkeypatch, so, gprune):
+    """BASELINE configs[0] shape with the pruning the reference's fast build defaults to for tied-mixture models
+    (`-gprune beam`, and `heu`): thresholds from the codebook's winners of frame t-1 (`calc_tied_mix.c:203-215`).  The
+    device scores every frame, so parity is defined against the reference under EAGER scoring
+    (`outprob_set_batch_computation`): through boundary O (reference search over device scores) and boundary B (device
+    first pass, exact order) the trellis, pass-1 and final results are the eager reference's, bit for bit."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
+    monkeypatch.delenv("JAMD_ORDER_MODE", raising=False)
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "25")           # ignored: this scoring needs the input in one piece
+    lib_so = pyoracle.REF_O_SO if so == "o" else pyoracle.REF_AMD_SO
+    if not lib_so.exists():
+        pytest.skip(f"{lib_so} not built")
+    task = synth.make_grammar_task(tmp_path, seed=11)
+    args = ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam",
+            "-gprune", gprune, "-tmix", "2", "-b", "200"]
+    eager = pyoracle.RefEngine(ref, args).set_eager()
+    wrapped = pyoracle.RefEngine(pyoracle.Ref(so=lib_so), args)
+    for u in range(3):
+        fr, _ = synth.make_grammar_utterance(task, nwords=3 + u, seed=20 + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, (w0, s0) = eager.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = eager.final_result()
+        tr1, (w1, s1) = wrapped.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = wrapped.final_result()
+        d1, n1 = wrapped.cache_fill()
+        assert d1 == n1                                      # every (t, s) came from the device
+        assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0
+        assert np.array_equal(f1, f0) and fs1 == fs0
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k
+
+
 @pytest.mark.parametrize("so,strict", [("o", False), ("amd", True)])
 def test_c4_dnn_over_device_scores(ref, tmp_path, monkeypatch, so, strict):
     """DNN-HMM (-dnnconf) through the scoring wrapper: dnn_calc_outprob()'s work is done by the
