@@ -110,7 +110,7 @@ def timed_steps(dd: Dist, stream, step, steps, warmup, nevents=2):
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nevents)] for _ in range(steps)]
     t0 = time.perf_counter()
     for e in ev:
-        step(lambda i, e=e: e[i].record(stream))
+        step((lambda i, e=e: e[i].record(stream)) if stream is not None else e)   # stream None: the step records e[i] itself
     dd.fence()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0)
     return elapsed, ev
@@ -381,7 +381,12 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     if args.order:
         bm.set_order_mode(args.order)
     mode = bm.order_mode()
-    stream = torch.cuda.Stream()
+    # Two HIP streams, two score buffers: the scoring kernels of step k+1 run on `s_score` while the first pass of step
+    # k runs on `s_beam` (it waits for its own step's scores, and a score buffer is rewritten only when the first pass
+    # that read it is done).  With fewer utterances than CUs (configs[4] at N = 8: 64 per GPU, one workgroup each) the
+    # scoring fills the idle CUs; with a full batch the two compete and the gain is a few percent.
+    s_score, s_beam = torch.cuda.Stream(), torch.cuda.Stream()
+    pipelined = not args.no_pipeline
     out = {}
     for ri, (key, nutt, steps, warmup, scaling) in enumerate(runs):
         # the batch is a global list (utterance g = distinct utterance g % nuniq) dealt round-robin: rank r holds g = r + u * world
@@ -391,22 +396,39 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
         frames = np.concatenate(utts)
         T = len(frames)
         d_fr = torch.from_numpy(frames).cuda()
-        d_sc = torch.empty((T, NS), dtype=torch.float32, device="cuda")
+        nbuf = 2 if pipelined else 1
+        d_scs = [torch.empty((T, NS), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        d_sc = d_scs[0]
+        scored = [torch.cuda.Event() for _ in range(nbuf)]       # buffer b holds this step's scores
+        consumed = [torch.cuda.Event() for _ in range(nbuf)]     # the first pass that read buffer b is done
+        for e in consumed:
+            e.record(s_beam)
         torch.cuda.synchronize()
+        count = [0]
+        sb = s_beam if pipelined else s_score
 
         def step(mark):
+            b = count[0] % nbuf
+            count[0] += 1
+            s_score.wait_event(consumed[b])
             if mark:
-                mark(0)
-            scorer.outprob_dev(d_fr.data_ptr(), T, d_sc.data_ptr(), stream.cuda_stream)
+                mark[0].record(s_score)
+            scorer.outprob_dev(d_fr.data_ptr(), T, d_scs[b].data_ptr(), s_score.cuda_stream)
             if mark:
-                mark(1)
-            bm.pass1_dev(d_sc.data_ptr(), NS, off, stream.cuda_stream)
+                mark[1].record(s_score)
+            scored[b].record(s_score)
+            sb.wait_event(scored[b])
             if mark:
-                mark(2)
+                mark[2].record(sb)
+            bm.pass1_dev(d_scs[b].data_ptr(), NS, off, sb.cuda_stream)
+            if mark:
+                mark[3].record(sb)
+            consumed[b].record(sb)
 
-        elapsed, ev = timed_steps(dd, stream, step, steps, warmup, nevents=3)
+        elapsed, ev = timed_steps(dd, None, step, steps, warmup, nevents=4)
+        d_sc = d_scs[(count[0] - 1) % nbuf]                      # the scores of the last step (parity leg)
         sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        beam_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        beam_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         res_local = bm.results()
         # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
         nutt_all = nutt * dd.world
@@ -428,7 +450,8 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
                  "config": {"workload": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {beam}, "
                                         f"{nutt} utterances ({T} frames, {nuniq} distinct) per GPU per step",
                             "lexicon_built_by_reference": ref_built, "order_mode": mode, "beam": beam,
-                            "utts_per_gpu": nutt, "utts_total": nutt_all},
+                            "utts_per_gpu": nutt, "utts_total": nutt_all,
+                            "pipelined": "scoring of step k+1 on a second stream under the first pass of step k" if pipelined else "no"},
                  "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                               "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
                                       "is frames/s of the first pass over the batch",
@@ -443,7 +466,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
                 if cpu is not None:
                     r["cpu_baseline"] = cpu
             out[key] = r
-        del d_fr, d_sc
+        del d_fr, d_sc, d_scs
     bm.close()
     tmp.cleanup()
     return out
@@ -540,6 +563,9 @@ def main():
                     help="utterances per GPU per step (gmm/dnn: x1000 frames, default 64 = one GPU's share of the "
                          "512-utterance batch of configs[4]; e2e: default 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="e2e: scoring and first pass of every step on ONE stream (default: two streams, the scoring of step k+1 "
+                         "overlaps the first pass of step k)")
     ap.add_argument("--workload", default="all", choices=["all", "gmm", "dnn", "e2e", "e2e-dnn"],
                     help="all (default) = gmm at top level with e2e (C3), e2e_strong (C5 batch), e2e_dnn (C4) and dnn (C4 scoring "
                          "half) nested; gmm = BASELINE configs[1] alone; dnn = configs[3] scoring half; e2e = configs[2] "

@@ -398,14 +398,11 @@ int  jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *d, jamd_lexico
  *   jamd_gmm_load_binhmm()   the binary HMM definition of mkbinhmm (libsent/src/hmminfo/read_binhmm.c:756): the
  *                            same device model as jamd_export's PREFIX.am made from that file;
  *   jamd_binhmm_to_blob()    the same conversion to a "JAMDGMM1" file (byte for byte jamd_export's; no device);
- *   jamd_bingram_to_blob()   the binary N-gram of mkbingram (v5, libsent/src/ngram/ngram_read_bin.c): 1-gram and
- *                            forward 2-gram tables as the first pass reads them (ngram_access.c:449-466) in a
- *                            "JAMDNGR1" file: records ints {mode, nword, nbigram, N, dir}, ng_uni_prob, ng_uni_bo,
- *                            ng_bi_bgn, ng_bi_num, ng_bi_wid, ng_bi_prob, wname -- the ng_* records of PREFIX.lex.
- * The tree lexicon is the output of libjulius/src/wchmm.c, not a file format: PREFIX.lex comes from jamd_export. */
+ * The tree lexicon is the output of libjulius/src/wchmm.c over dictionary + HMMList + LM (its factoring values and
+ * the words kept out of the tree are functions of the LM), not a file format: PREFIX.lex -- tree and N-gram tables
+ * together -- comes from jamd_export, which links Julius' own loaders. */
 int  jamd_gmm_load_binhmm(jamd_engine *e, const char *binhmm_path, int gprune, int gprune_num, jamd_gmm **out);
 int  jamd_binhmm_to_blob(const char *binhmm_path, const char *blob_path);
-int  jamd_bingram_to_blob(const char *bingram_path, const char *blob_path);
 
 /* The same from a "JAMDLEX1" file written by jamd_lexicon_save()
  * (julius_amd/shim/jamd_flatten_lex.c) in a process that loaded the dictionary and LM

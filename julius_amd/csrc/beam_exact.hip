@@ -343,43 +343,43 @@ __device__ __forceinline__ void heap_extract_serial(HP H, int n, int cnt) {
 // sequential loop's, so is the result.
 template <bool UP>
 __device__ __noinline__ void heap_extract_pipelined(lds_u64 *H, int n, int cnt) {
+  // Branch-free body: idle lanes (p == 0) read H[0..1] and write H[0] (the unused slot in front of the heap), every lane
+  // reads the starting extraction's tail element and the root (a broadcast), so no execution-mask juggling is left --
+  // a single wave pays ~8 cycles per instruction, the count is what matters.
   H = uni(H); n = uni(n); cnt = uni(cnt);
   const int lane = threadIdx.x & 63;
-  bool active = false;
-  int p = 0, m = 0;
-  unsigned long long s = 0ull;
-  int next_e = 1, since = 2;                                     // steps since the last start
+  lds_u32 *H32 = (lds_u32 *)H;
+  int p = 0, m = 0;                                              // p == 0: the lane is idle
+  unsigned shi = 0u, slo = 0u;                                   // the element on its way down
+  int e = 1;
+  bool rest = false;                                             // a start in the previous step: this step starts nothing
   for (;;) {
-    // may extraction next_e start in this step?
-    bool start = false;
-    if (next_e <= cnt && since >= 2) {
-      const unsigned q = (unsigned)(n - next_e + 1);
-      start = __ballot(active && insub(q, (unsigned)p)) == 0ull;
-    }
-    const bool mine = start && lane == ((next_e - 1) & 63);
-    if (mine) { active = true; p = 1; m = n - next_e; }
-    // reads of this step: the starting lane also takes the tail element and the root
-    unsigned long long tail = 0ull, root = 0ull;
-    u32x4 ch = u32x4{0u, 0u, 0u, 0u};
-    const bool inner = active && 2 * p <= m;
-    if (mine) { tail = H[n - next_e + 1]; root = H[1]; }
-    if (inner) ch = *(const lds_v4 *)&H[2 * p];
+    // may extraction e start in this step?
+    bool st = false;
+    const int q = n - e + 1;
+    if (!rest && e <= cnt) st = __ballot(p != 0 && insub((unsigned)q, (unsigned)p)) == 0ull;
+    rest = st;
+    const bool mine = st && lane == ((e - 1) & 63);
+    if (mine) { p = 1; m = n - e; }
+    const int qe = st ? q : 0;
+    // reads
+    const unsigned long long tail = H[qe], root = H[1];
+    const u32x4 ch = *(const lds_v4 *)&H[2 * p];
     wave_sync();
-    if (mine) { s = tail; H[n - next_e + 1] = root; }
-    if (active) {
-      const int child = 2 * p;
-      const unsigned a = ch.y, b = ch.w, sv = (unsigned)(s >> 32);
-      const bool right = inner && child < m && (UP ? (a < b) : (a > b));
-      const unsigned cv = right ? b : a;
-      if (!inner || (UP ? (sv >= cv) : (sv <= cv))) { H[p] = s; active = false; }
-      else {
-        H[p] = right ? (((unsigned long long)ch.w << 32) | ch.z) : (((unsigned long long)ch.y << 32) | ch.x);
-        p = child + (right ? 1 : 0);
-      }
-    }
+    // decisions and writes
+    if (mine) { shi = (unsigned)(tail >> 32); slo = (unsigned)tail; }
+    H[qe] = root;                                                // (no start: slot 0)
+    const int child = 2 * p;
+    const bool inner = p != 0 && child <= m;
+    const bool right = inner && child < m && (UP ? (ch.y < ch.w) : (ch.y > ch.w));
+    const unsigned cv = right ? ch.w : ch.y, cl = right ? ch.z : ch.x;
+    const bool stop = !inner || (UP ? (shi >= cv) : (shi <= cv));
+    H32[2 * p] = stop ? slo : cl;
+    H32[2 * p + 1] = stop ? shi : cv;
+    p = stop ? 0 : child + (right ? 1 : 0);
     wave_sync();
-    if (start) { next_e++; since = 1; } else since++;
-    if (next_e > cnt && __ballot(active) == 0ull) break;
+    e += st ? 1 : 0;
+    if (e > cnt && __ballot(p != 0) == 0ull) break;
   }
 }
 
@@ -775,7 +775,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
               live += __popc(bits);
             }
             live = block_excl_scan(sh, live); live = uni(sh.scan_total);
-            give_up = live > kMaxCand / 2;
+            give_up = live > kMaxCand;
           }
         }
         if (give_up) {

@@ -4,14 +4,11 @@
 //       (libsent/src/hmminfo/write_binhmm.c, read back by read_binhmm.c:756-903) -> the flat model of
 //       jamd_gmm_desc / the "JAMDGMM1" blob, byte for byte what jamd_export produces from the same file
 //       through Julius' own reader + julius_amd/shim/jamd_flatten.c (tests/test_readers.py compares the files).
-//   jamd_bingram_to_blob()                           the binary N-gram mkbingram writes
-//       (libsent/src/ngram/ngram_write_bin.c, read back by ngram_read_bin.c) -> the 1-gram / 2-gram tables the
-//       first pass uses (forward 2-gram as bi_prob_func_set() selects it, ngram_access.c:449-466), in the
-//       records of a "JAMDNGR1" blob; they equal the ng_* records inside jamd_export's lexicon blob.
-// Not covered: the tree lexicon itself.  It is not a file format but the output of libjulius/src/wchmm.c
-// (build_wchmm2(): 2 000 lines of tree building, cross-word context handling and factoring set-up over the
-// dictionary, the HMMList and the LM); PREFIX.lex therefore still comes from jamd_export.  Old bingram
-// versions (v3/v4, converted on load by the reference) and gzip-compressed files are refused with a message.
+// Not covered: the tree lexicon and its LM tables.  The lexicon is not a file format but the output of
+// libjulius/src/wchmm.c (build_wchmm2(): 2 000 lines of tree building, cross-word context handling and factoring
+// set-up over the dictionary, the HMMList AND the LM -- the factoring values and the words kept out of the tree are
+// functions of the 1-gram); PREFIX.lex, tree and N-gram tables together, therefore comes from jamd_export, which links
+// Julius' own loaders.  gzip-compressed files are refused with a message.
 #include "jamd_internal.h"
 
 #include <cstdint>
@@ -233,72 +230,6 @@ bool put(FILE *f, const char *name, int dtype, int count, const void *data) {
   return count <= 0 || fwrite(data, 4, (size_t)count, f) == (size_t)count;
 }
 
-// ---- binary N-gram ---------------------------------------------------------------------------------------
-struct Tuple {                            // NGRAM_TUPLE_INFO, libsent/include/sent/ngram2.h:137-156
-  unsigned totalnum = 0, bgnlistlen = 0, context_num = 0;
-  bool is24bit = false, ct_compaction = false;
-  std::vector<unsigned> bgn; std::vector<unsigned> num; std::vector<unsigned> nnid2wid;
-  std::vector<float> prob, bo_wt;
-};
-
-bool read_bingram(const char *path, int &n_out, int &dir_out, bool &reversed, std::vector<std::string> &wname,
-                  std::vector<Tuple> &t, std::vector<float> &bo_wt_1, std::vector<float> &p_2) {
-  Reader r;
-  if (!r.open(path)) return false;
-  char hd[512];
-  r.swap = false;
-  r.raw(hd, 1, 512);
-  if (!r.ok) return false;
-  hd[511] = 0;
-  if (strncmp(hd, "julius_bingram_v5", 17) != 0) {
-    jamd_set_error("%s: not a julius_bingram_v5 file (older versions are converted by mkbingram)", path); return false;
-  }
-  // second header line: "word=<size> byteorder=LE|BE" (ngram_read_bin.c check_header())
-  const char *l2 = strchr(hd, '\n');
-  if (!l2 || !strstr(l2, "word=4byte(int)")) { jamd_set_error("%s: 2-byte word ids (WORDS_INT build expected)", path); return false; }
-  const char *bo = strstr(l2, "byteorder=");
-  r.swap = bo != nullptr && strncmp(bo + 10, "BE", 2) == 0;          // files of this version carry their writer's order
-  if (!bo) r.swap = true;                                            // no tag: big-endian (older writers)
-  const int n = r.get<int>(), dir = r.get<int>();
-  const unsigned char rev = r.get<unsigned char>();
-  if (!r.ok || n < 2 || n > 10) { jamd_set_error("%s: N=%d", path, n); return false; }
-  n_out = n; dir_out = dir; reversed = rev != 0;
-  t.assign((size_t)n, Tuple());
-  for (int m = 0; m < n; m++) t[(size_t)m].totalnum = r.get<unsigned>();
-  const int wlen = r.get<int>();
-  if (!r.ok || wlen < 0) { jamd_set_error("%s: bad word list", path); return false; }
-  std::vector<char> names((size_t)wlen + 1, 0);
-  r.raw(names.data(), 1, (size_t)wlen);
-  for (int p = 0; p < wlen;) { wname.emplace_back(names.data() + p); p += (int)wname.back().size() + 1; }
-  if (!r.ok || wname.size() != t[0].totalnum) { jamd_set_error("%s: %zu names for %u words", path, wname.size(), t[0].totalnum); return false; }
-  for (int m = 0; m < n && r.ok; m++) {
-    Tuple &x = t[(size_t)m];
-    x.is24bit = r.get<unsigned char>() != 0; x.ct_compaction = r.get<unsigned char>() != 0;
-    x.bgnlistlen = r.get<unsigned>(); x.context_num = r.get<unsigned>();
-    if (!r.ok || x.totalnum > (1u << 30) || x.bgnlistlen > (1u << 30) || x.context_num > (1u << 30)) { r.ok = false; break; }
-    if (m > 0) {
-      x.bgn.resize(x.bgnlistlen);
-      if (x.is24bit) {
-        std::vector<unsigned char> up(x.bgnlistlen); std::vector<unsigned short> lo(x.bgnlistlen);
-        r.raw(up.data(), 1, up.size()); r.raw(lo.data(), 2, lo.size());
-        for (size_t i = 0; i < up.size(); i++) x.bgn[i] = up[i] == 255 ? 0xffffffffu : ((unsigned)up[i] << 16) | lo[i];   // NNID_INVALID_UPPER
-      } else r.raw(x.bgn.data(), 4, x.bgn.size());
-      x.num.resize(x.bgnlistlen);
-      r.raw(x.num.data(), 4, x.num.size());                          // WORD_ID = int in the WORDS_INT build
-      x.nnid2wid.resize(x.totalnum);
-      r.raw(x.nnid2wid.data(), 4, x.nnid2wid.size());
-    }
-    x.prob.resize(x.totalnum);
-    r.raw(x.prob.data(), 4, x.prob.size());
-    if (r.get<int>() != 0) { x.bo_wt.resize(x.context_num); r.raw(x.bo_wt.data(), 4, x.bo_wt.size()); }
-    if (r.get<int>() != 0) r.skip((size_t)x.totalnum * 3);           // nnid2ctid (only for N >= 3 lookups)
-  }
-  if (r.ok && r.get<int>() != 0) { bo_wt_1.resize(t[0].context_num); r.raw(bo_wt_1.data(), 4, bo_wt_1.size()); }
-  if (r.ok && r.get<int>() != 0) { p_2.resize(t[1].totalnum); r.raw(p_2.data(), 4, p_2.size()); }
-  if (!r.ok) { jamd_set_error("%s: truncated or malformed", path); return false; }
-  return true;
-}
-
 }  // namespace
 
 extern "C" {
@@ -331,39 +262,6 @@ int jamd_gmm_load_binhmm(jamd_engine *e, const char *binhmm_path, int gprune, in
   d.mean = g.mean.data(); d.ivar = g.ivar.data(); d.gconst = g.gconst.data(); d.st_off = g.st_off.data();
   d.ent_dens = g.ent_dens.data(); d.ent_logw = g.ent_logw.data(); d.st_book = g.st_book.data();
   return jamd_gmm_create(e, &d, gprune, gprune_num, out);
-}
-
-int jamd_bingram_to_blob(const char *bingram_path, const char *blob_path) {
-  if (!bingram_path || !blob_path) { jamd_set_error("jamd_bingram_to_blob: NULL argument"); return JAMD_EINVAL; }
-  int n = 0, dir = 0; bool reversed = false;
-  std::vector<std::string> wname; std::vector<Tuple> t; std::vector<float> bo_wt_1, p_2;
-  if (!read_bingram(bingram_path, n, dir, reversed, wname, t, bo_wt_1, p_2)) return JAMD_EINVAL;
-  const Tuple &t1 = t[0], &t2 = t[1];
-  const int V = (int)t1.totalnum;
-  // which 2-gram the first pass reads: bi_prob_func_set(), ngram_access.c:449-466 (DIR_LR = 0, DIR_RL = 1)
-  int mode; const std::vector<float> *bo, *bp;
-  if (reversed) { mode = JAMD_NG_ADDITIONAL_OLD; bo = &bo_wt_1; bp = &p_2; }
-  else if (dir == 0) { mode = JAMD_NG_NORMAL; bo = &t1.bo_wt; bp = &t2.prob; }
-  else if (!bo_wt_1.empty()) { mode = JAMD_NG_ADDITIONAL; bo = &bo_wt_1; bp = &p_2; }
-  else { mode = JAMD_NG_COMPUTE; bo = &t1.bo_wt; bp = &t2.prob; }
-  if ((int)bo->size() < V || bp->size() < t2.totalnum || (int)t2.bgn.size() < V || (int)t2.num.size() < V || (int)t1.prob.size() < V) {
-    jamd_set_error("%s: 2-gram tables shorter than the vocabulary", bingram_path); return JAMD_EINVAL;
-  }
-  std::vector<int> bgn((size_t)V), num((size_t)V), wid(t2.totalnum);
-  for (int i = 0; i < V; i++) { bgn[(size_t)i] = t2.bgn[(size_t)i] == 0xffffffffu ? -1 : (int)t2.bgn[(size_t)i]; num[(size_t)i] = (int)t2.num[(size_t)i]; }
-  for (size_t i = 0; i < wid.size(); i++) wid[i] = (int)t2.nnid2wid[i];
-  std::string names;
-  for (const std::string &w : wname) { names += w; names.push_back('\0'); }
-  FILE *f = fopen(blob_path, "wb");
-  if (!f) { jamd_set_error("cannot write %s", blob_path); return JAMD_EINVAL; }
-  const int nrec = 8, ints[5] = {mode, V, (int)t2.totalnum, n, dir};
-  bool ok = fwrite("JAMDNGR1", 1, 8, f) == 8 && fwrite(&nrec, 4, 1, f) == 1;
-  ok = ok && put(f, "ints", 0, 5, ints) && put(f, "ng_uni_prob", 1, V, t1.prob.data()) && put(f, "ng_uni_bo", 1, V, bo->data()) &&
-       put(f, "ng_bi_bgn", 0, V, bgn.data()) && put(f, "ng_bi_num", 0, V, num.data()) && put(f, "ng_bi_wid", 0, (int)wid.size(), wid.data()) &&
-       put(f, "ng_bi_prob", 1, (int)t2.totalnum, bp->data()) && put(f, "wname", 2, (int)names.size(), names.data());
-  if (fclose(f) != 0) ok = false;
-  if (!ok) { jamd_set_error("write error on %s", blob_path); return JAMD_EINVAL; }
-  return JAMD_OK;
 }
 
 }  // extern "C"

@@ -96,7 +96,6 @@ def load():
         "jamd_dnn_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_load_binhmm": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
         "jamd_binhmm_to_blob": (ci, [C.c_char_p, C.c_char_p]),
-        "jamd_bingram_to_blob": (ci, [C.c_char_p, C.c_char_p]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),

@@ -609,10 +609,8 @@ int jref_am_save(void *h, const char *path)
   return jamd_gmm_save(&a->flat.desc, path);
 }
 
-/* ---- binary model files, written by the reference's own writers (what mkbinhmm / mkbingram do:
- * mkbinhmm/mkbinhmm.c:65-119, mkbingram/mkbingram.c:198-250), so that the product's direct readers
- * (julius_amd/csrc/readers.hip) can be checked against Julius' own reader on the same file. */
-#include <sent/ngram2.h>
+/* ---- binary HMM file, written by the reference's own writer (what mkbinhmm does, mkbinhmm/mkbinhmm.c:65-119), so
+ * that the product's direct reader (julius_amd/csrc/readers.hip) can be checked against Julius' own on the same file. */
 int jref_write_binhmm(const char *hmmdefs, const char *outfile)
 {
   HTK_HMM_INFO *h = hmminfo_new();
@@ -625,18 +623,3 @@ int jref_write_binhmm(const char *hmmdefs, const char *outfile)
   return ok ? 0 : -3;
 }
 
-int jref_write_bingram(const char *arpa_lr, const char *arpa_rl, const char *outfile)
-{
-  NGRAM_INFO *ng = ngram_info_new();
-  FILE *fp;
-  int ok;
-  char header[64] = "written by oracle/ref_driver.c\n";
-  if (arpa_rl != NULL) {
-    if (!init_ngram_arpa(ng, (char *)arpa_rl, DIR_RL)) return -1;
-    if (arpa_lr != NULL && !init_ngram_arpa_additional(ng, (char *)arpa_lr)) return -1;
-  } else if (!init_ngram_arpa(ng, (char *)arpa_lr, DIR_LR)) return -1;
-  if ((fp = fopen_writefile((char *)outfile)) == NULL) return -2;
-  ok = ngram_write_bin(fp, ng, header);
-  fclose_writefile(fp);
-  return ok ? 0 : -3;
-}

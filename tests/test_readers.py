@@ -1,8 +1,7 @@
-"""Julius' BINARY model files read directly (julius_amd/csrc/readers.hip), without a Julius
-process -- checked against the reference's own readers: the binary files are written by the reference's
-write_binhmm() / ngram_write_bin() (what mkbinhmm / mkbingram do), loaded by Julius' read_binhmm() /
-ngram_read_bin() inside jamd_export, flattened by the shim, and the direct conversion must give the same
-bytes.  Host code only: runs without a GPU."""
+"""Julius' BINARY HMM definition read directly (julius_amd/csrc/readers.hip), without a Julius
+process -- checked against the reference's own reader: the file is written by the reference's write_binhmm()
+(what mkbinhmm does), loaded by Julius' read_binhmm() inside jamd_export, flattened by the shim, and the direct
+conversion must give the same bytes.  Host code only: runs without a GPU."""
 import ctypes as C
 import subprocess
 
@@ -20,7 +19,6 @@ def _ref():
         pytest.skip("oracle/_ref not built")
     r = pyoracle.Ref()
     r.lib.jref_write_binhmm.argtypes = [C.c_char_p, C.c_char_p]
-    r.lib.jref_write_bingram.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     return r
 
 
@@ -67,33 +65,6 @@ def test_binhmm_direct_equals_export(tmp_path, kind):
     assert L.jamd_binhmm_to_blob(str(tmp_path / "junk").encode(), str(tmp_path / "x").encode()) != 0
     (tmp_path / "trunc").write_bytes(open(binhmm, "rb").read()[:3000])
     assert L.jamd_binhmm_to_blob(str(tmp_path / "trunc").encode(), str(tmp_path / "x").encode()) != 0
-
-
-@pytest.mark.parametrize("with_rl", [False, True])
-def test_bingram_direct_equals_export(tmp_path, with_rl):
-    """Forward 2-gram alone (DIR_LR) and backward 3-gram + additional forward 2-gram (the -nlr/-nrl pair):
-    the 1-gram / 2-gram tables of the direct reader equal the ng_* records of jamd_export's lexicon blob."""
-    ref = _ref()
-    task = synth.make_triphone_task(tmp_path, seed=73, nword=80, nphone=8, S=120, M=2, with_rl3=with_rl)
-    bingram = tmp_path / "lm.bingram"
-    rc = ref.lib.jref_write_bingram(str(task["arpa"]).encode(), str(task["arpa_rl"]).encode() if with_rl else None,
-                                    str(bingram).encode())
-    assert rc == 0
-    subprocess.run([str(EXPORT), "-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-d", str(bingram),
-                    "-input", "htkparam", "-jamdout", str(tmp_path / "exp")], check=True, capture_output=True)
-    L = lib.load()
-    rc = L.jamd_bingram_to_blob(str(bingram).encode(), str(tmp_path / "direct.ngr").encode())
-    assert rc == 0, L.jamd_last_error()
-    got = _blob_records(tmp_path / "direct.ngr", b"JAMDNGR1")
-    want = _blob_records(tmp_path / "exp.lex", b"JAMDLEX1")
-    for k in ("ng_uni_prob", "ng_uni_bo", "ng_bi_bgn", "ng_bi_num", "ng_bi_wid", "ng_bi_prob"):
-        assert got[k] == want[k], k
-    ints = np.frombuffer(got["ints"][1], np.int32)
-    lex = lexblob.load(tmp_path / "exp.lex")
-    assert int(ints[0]) == int(lex["ng_mode"]) and int(ints[1]) == int(lex["ng_nword"]) and int(ints[2]) == int(lex["ng_nbigram"])
-    assert ints[3] == (3 if with_rl else 2)
-    names = got["wname"][1].split(b"\0")
-    assert b"<s>" in names and b"</s>" in names
 
 
 @pytest.mark.gpu
