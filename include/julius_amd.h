@@ -87,6 +87,16 @@ int  jamd_host_alloc(jamd_engine *e, size_t bytes, void **host);
 int  jamd_host_free(jamd_engine *e, void *host);
 int  jamd_memcpy_h2d(jamd_engine *e, void *dev, const void *host, size_t bytes);
 int  jamd_memcpy_d2h(jamd_engine *e, void *host, const void *dev, size_t bytes);
+/* Streams for callers without their own HIP runtime (the `stream` arguments below take any hipStream_t): a batch
+ * driver scores input k+1 on one stream while the first pass of input k runs on another -- the first pass keeps
+ * one workgroup per utterance busy, the scoring kernels fill whatever CUs that leaves (host/jamd_batch.c).
+ * jamd_stream_wait(): everything submitted to `waiter` after the call starts only when everything submitted to
+ * `signaler` before the call is done (an event record + wait; NULL = the engine's own stream). */
+int  jamd_stream_create(jamd_engine *e, void **stream);
+int  jamd_stream_destroy(jamd_engine *e, void *stream);
+int  jamd_stream_wait(jamd_engine *e, void *waiter, void *signaler);
+int  jamd_stream_sync(jamd_engine *e, void *stream);
+int  jamd_memcpy_h2d_async(jamd_engine *e, void *dev, const void *host, size_t bytes, void *stream);
 
 /* --------------------------------------------------------------- GMM model */
 /* Flattened HTK_HMM_INFO (libsent/include/sent/htk_hmm.h:330-420) after

@@ -244,6 +244,9 @@ dnn_layer_rs_kernel(const float *__restrict__ Xr, const float *__restrict__ Wr, 
 // (A wave per frame that runs the scan only over the terms within -LOG_ADDMIN of the maximum to their right --
 // the others provably leave the sum unchanged -- is bit-exact too, but 4x slower on a network whose outputs lie
 // close together, as the random-init benchmark network's do: every term then takes the serial step.)
+// (Round 3: the kernel is bound by the THROUGHPUT of the scattered table gathers -- 2.56e8 of them, each its own
+// cache line, 190 G gathers/s -- not by their latency: spreading the frames over 2x..16x more waves, 32 down to 4
+// frames a wave, changes nothing or loses: 34.85 / 34.97 / 35.38 / 37.09 ms for the whole network against 34.99.)
 __global__ void __launch_bounds__(64)
 dnn_lse_kernel(const float *__restrict__ x, const float *__restrict__ tbl, float *__restrict__ lse,
                int T, int S, float addmin_f) {

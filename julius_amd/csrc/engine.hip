@@ -133,6 +133,43 @@ int jamd_memcpy_h2d(jamd_engine *e, void *dev, const void *host, size_t bytes) {
   JAMD_HIP(hipStreamSynchronize(e->stream));
   return JAMD_OK;
 }
+int jamd_stream_create(jamd_engine *e, void **stream) {
+  if (!e || !stream) { jamd_set_error("jamd_stream_create: NULL argument"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  hipStream_t st = nullptr;
+  JAMD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = (void *)st;
+  return JAMD_OK;
+}
+int jamd_stream_destroy(jamd_engine *e, void *stream) {
+  if (!e) { jamd_set_error("jamd_stream_destroy: NULL engine"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  if (stream) JAMD_HIP(hipStreamDestroy((hipStream_t)stream));
+  return JAMD_OK;
+}
+int jamd_stream_wait(jamd_engine *e, void *waiter, void *signaler) {
+  if (!e) { jamd_set_error("jamd_stream_wait: NULL engine"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  hipEvent_t ev = nullptr;
+  JAMD_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t rc = hipEventRecord(ev, jamd_stream(e, signaler));
+  if (rc == hipSuccess) rc = hipStreamWaitEvent(jamd_stream(e, waiter), ev, 0);
+  (void)hipEventDestroy(ev);                       // released once the recorded work has completed
+  if (rc != hipSuccess) { jamd_set_error("jamd_stream_wait: %s", hipGetErrorString(rc)); return JAMD_ENODEV; }
+  return JAMD_OK;
+}
+int jamd_stream_sync(jamd_engine *e, void *stream) {
+  if (!e) { jamd_set_error("jamd_stream_sync: NULL engine"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  JAMD_HIP(hipStreamSynchronize(jamd_stream(e, stream)));
+  return JAMD_OK;
+}
+int jamd_memcpy_h2d_async(jamd_engine *e, void *dev, const void *host, size_t bytes, void *stream) {
+  if (!e) { jamd_set_error("jamd_memcpy_h2d_async: NULL engine"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(e->device));
+  JAMD_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, jamd_stream(e, stream)));
+  return JAMD_OK;
+}
 int jamd_memcpy_d2h(jamd_engine *e, void *host, const void *dev, size_t bytes) {
   if (!e) { jamd_set_error("jamd_memcpy_d2h: NULL engine"); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(e->device));

@@ -14,7 +14,8 @@
  * Every line of the file list names an HTK parameter file (what Julius reads with
  * `-input htkparam`: 12-byte big-endian header nSamples, sampPeriod, sampSize, parmKind, then
  * big-endian float vectors -- libsent/src/anlz/rdparam.c).  All utterances are scored and
- * decoded in device launches of up to 256 utterances; one result line per utterance:
+ * decoded in device launches of up to 256 utterances (reading + scoring of launch k+1 overlap the
+ * first pass of launch k on a second stream); one result line per utterance:
  *   <file> status=<0 ok|1 no result|2 beam died|3 trellis overflow> score=<pass-1 score> words=<id id ...>
  * which is what get_back_trellis_end() leaves in r->pass1_wseq / pass1_score.
  */
@@ -59,13 +60,40 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
   return n;
 }
 
+/* one launch: up to 256 utterances, their frames on the host and on the device, their score rows */
+typedef struct { float *frames, *d_frames, *d_scores; int off[257], n; } chunk;
+
+/* reads the files of the launch that starts at files[first], uploads the frames and queues the scoring kernels on
+ * `stream` (nothing is waited for) */
+static void load_and_score(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate,
+                           jamd_gmm *gm, jamd_dnn *dn, jamd_gms *gs, void *stream)
+{
+  size_t used = 0, cap = 0;
+  int u;
+  c->n = nfile - first < 256 ? nfile - first : 256;
+  c->frames = NULL; c->off[0] = 0;
+  for (u = 0; u < c->n; u++) {
+    const int t = read_htk(files[first + u], veclen, &c->frames, &used, &cap);
+    if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first + u], veclen); exit(1); }
+    c->off[u + 1] = c->off[u] + t;
+  }
+  if (jamd_malloc(e, sizeof(float) * used, (void **)&c->d_frames) != JAMD_OK ||
+      jamd_malloc(e, sizeof(float) * (size_t)c->off[c->n] * nstate, (void **)&c->d_scores) != JAMD_OK ||
+      jamd_memcpy_h2d_async(e, c->d_frames, c->frames, sizeof(float) * used, stream) != JAMD_OK) die("device buffers");
+  if ((gm ? jamd_gmm_outprob_utts_dev(gm, c->d_frames, c->off, c->n, c->d_scores, stream)
+          : jamd_dnn_outprob_dev(dn, c->d_frames, c->off[c->n], c->d_scores, stream)) != JAMD_OK) die("scoring");
+  if (gs != NULL && jamd_gms_apply_dev(gs, c->d_frames, c->off[c->n], c->off, c->n, c->d_scores, stream) != JAMD_OK) die("Gaussian mixture selection");
+}
+
 int main(int argc, char **argv)
 {
   const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL, *rejp = NULL;
   int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, order = -1, shard_r = 0, shard_n = 1, i;
   float bs = -1.0f;
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
-  char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first;
+  char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first, k;
+  chunk ck[2];
+  void *s_score = NULL, *s_beam = NULL;
   char line[4096];
   FILE *fl;
 
@@ -131,41 +159,37 @@ int main(int argc, char **argv)
   }
   fclose(fl);
 
-  for (first = 0; first < nfile; first += 256) {                 /* launches of up to 256 utterances */
-    const int n = nfile - first < 256 ? nfile - first : 256;
-    float *frames = NULL, *d_frames = NULL, *d_scores = NULL; size_t used = 0, cap = 0;
-    int off[257], u;
+  /* Launches of up to 256 utterances, pipelined over two streams: while the first pass of launch k runs on
+   * `s_beam` (one workgroup per utterance), the host reads the files of launch k+1 and `s_score` uploads and
+   * scores them -- the scoring kernels fill the CUs the first pass leaves idle. */
+  if (jamd_stream_create(e, &s_score) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
+  if (nfile > 0) load_and_score(e, &ck[0], files, 0, nfile, veclen, nstate, gm, dn, gs, s_score);
+  for (first = 0, k = 0; first < nfile; first += 256, k++) {
+    chunk *c = &ck[k & 1];
+    const int n = c->n;
+    const int *off = c->off;
+    int u;
     float *us = NULL;
     jamd_pass1_result res[256];
-    off[0] = 0;
-    for (u = 0; u < n; u++) {
-      const int t = read_htk(files[first + u], veclen, &frames, &used, &cap);
-      if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first + u], veclen); return 1; }
-      off[u + 1] = off[u] + t;
-    }
-    if (jamd_malloc(e, sizeof(float) * used, (void **)&d_frames) != JAMD_OK ||
-        jamd_malloc(e, sizeof(float) * (size_t)off[n] * nstate, (void **)&d_scores) != JAMD_OK ||
-        jamd_memcpy_h2d(e, d_frames, frames, sizeof(float) * used) != JAMD_OK) die("device buffers");
-    if ((gm ? jamd_gmm_outprob_utts_dev(gm, d_frames, off, n, d_scores, NULL)
-            : jamd_dnn_outprob_dev(dn, d_frames, off[n], d_scores, NULL)) != JAMD_OK) die("scoring");
-    if (gs != NULL && jamd_gms_apply_dev(gs, d_frames, off[n], off, n, d_scores, NULL) != JAMD_OK) die("Gaussian mixture selection");
-    if (jamd_beam_pass1_dev(bm, d_scores, nstate, off, n, NULL) != JAMD_OK || jamd_engine_sync(e) != JAMD_OK ||
-        jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+    if (jamd_stream_wait(e, s_beam, s_score) != JAMD_OK) die("stream order");                  /* the scores of launch k */
+    if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
+    if (first + 256 < nfile) load_and_score(e, &ck[(k + 1) & 1], files, first + 256, nfile, veclen, nstate, gm, dn, gs, s_score);
+    if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
     if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
       const int nm = jamd_rejgmm_nmodel(rj);
       float *d_fs = NULL, *d_us = NULL;
       us = (float *)malloc(sizeof(float) * (size_t)n * nm);
       if (us == NULL || jamd_malloc(e, sizeof(float) * (size_t)off[n] * nm, (void **)&d_fs) != JAMD_OK ||
           jamd_malloc(e, sizeof(float) * (size_t)n * nm, (void **)&d_us) != JAMD_OK ||
-          jamd_rejgmm_frame_scores_dev(rj, d_frames, off[n], d_fs, NULL) != JAMD_OK ||
-          jamd_rejgmm_utt_scores_dev(rj, d_fs, off[n], off, n, d_us, NULL) != JAMD_OK ||
-          jamd_engine_sync(e) != JAMD_OK || jamd_memcpy_d2h(e, us, d_us, sizeof(float) * (size_t)n * nm) != JAMD_OK) die("input verification");
+          jamd_rejgmm_frame_scores_dev(rj, c->d_frames, off[n], d_fs, s_beam) != JAMD_OK ||
+          jamd_rejgmm_utt_scores_dev(rj, d_fs, off[n], off, n, d_us, s_beam) != JAMD_OK ||
+          jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_memcpy_d2h(e, us, d_us, sizeof(float) * (size_t)n * nm) != JAMD_OK) die("input verification");
       jamd_free(e, d_fs); jamd_free(e, d_us);
     }
     for (u = 0; u < n; u++) {
-      int k;
+      int w;
       printf("%s status=%d score=%.9g words=", files[first + u], res[u].status, (double)res[u].score);
-      for (k = 0; k < res[u].wnum; k++) printf("%s%d", k ? " " : "", res[u].wseq[k]);
+      for (w = 0; w < res[u].wnum; w++) printf("%s%d", w ? " " : "", res[u].wseq[w]);
       if (rj != NULL) {
         int win, acc; float cm;
         if (jamd_rejgmm_verdict(rj, us + (size_t)u * jamd_rejgmm_nmodel(rj), &win, &cm, &acc) != JAMD_OK) die("verdict");
@@ -175,8 +199,10 @@ int main(int argc, char **argv)
       printf("\n");
     }
     free(us);
-    jamd_free(e, d_frames); jamd_free(e, d_scores); free(frames);
+    jamd_free(e, c->d_frames); jamd_free(e, c->d_scores); free(c->frames);
+    c->d_frames = c->d_scores = NULL; c->frames = NULL;
   }
+  jamd_stream_destroy(e, s_score); jamd_stream_destroy(e, s_beam);
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
   if (rj) jamd_rejgmm_destroy(rj);
   if (gs) jamd_gms_destroy(gs);

@@ -100,6 +100,11 @@ def load():
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),
         "jamd_gmm_veclen": (ci, [vp]),
+        "jamd_stream_create": (ci, [vp, vp]),
+        "jamd_stream_destroy": (ci, [vp, vp]),
+        "jamd_stream_wait": (ci, [vp, vp, vp]),
+        "jamd_stream_sync": (ci, [vp, vp]),
+        "jamd_memcpy_h2d_async": (ci, [vp, vp, vp, C.c_size_t, vp]),
         "jamd_gmm_outprob_dev": (ci, [vp, vp, ci, vp, vp]),
         "jamd_gmm_outprob_utts_dev": (ci, [vp, vp, vp, ci, vp, vp]),
         "jamd_gmm_outprob_host": (ci, [vp, vp, ci, vp]),
