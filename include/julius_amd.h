@@ -490,14 +490,17 @@ int  jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate
 int  jamd_beam_set_strict_order(jamd_beam *b, int on);
 /* How exact score ties are resolved (they are the only freedom a parallel schedule has; every
  * float is the reference's float in all modes):
- *   JAMD_ORDER_EXACT   (default where the beam fits the LDS image, about beam <= 2500, non-multipath):
+ *   JAMD_ORDER_EXACT   (default for non-multipath lexicons and beams up to about 12 000: up to ~950 the survivors live
+ *       in LDS; wider beams keep them in the utterance's slice of HBM and the pruning step overlays the whole LDS
+ *       image; the closed-form extraction serves beams up to 4 400, beyond that the heap's extraction loop itself
+ *       runs pipelined on one wave):
  *       frame-parallel kernel with the reference's own semantics -- candidates keyed by their position
  *       in the reference's visiting order (first writer wins, propagate_token() beam.c:1945-1980,
  *       wordend_best :2308), token creation order, and the partial heap sort of
  *       sort_token_no_order() (beam.c:1342-1516) reproduced exactly.  The word trellis equals the
  *       reference's bit for bit, ties included.
  *   JAMD_ORDER_EXACT_SERIAL  the same kernel with the heap's extraction loop run sequentially on one
- *       lane instead of in closed form (cross-check and timing).
+ *       lane instead of in closed form / pipelined (cross-check and timing).
  *   JAMD_ORDER_FAST    frame-parallel kernel with canonical tie breaks (larger source id, smaller node
  *       on the rank cut): identical to the reference whenever jamd_pass1_result.ties == 0.
  *   JAMD_ORDER_STRICT  = jamd_beam_set_strict_order(b, 1): the sequential algorithm, one lane per utterance.

@@ -1726,6 +1726,7 @@ int jamd_beam_set_strict_order(jamd_beam *b, int on) {
     JAMD_HIP(hipMalloc(&p, U * b->w.nnode * sizeof(int))); b->owned.push_back(p); b->sw.token = (int *)p;
   }
   b->strict = on != 0;
+  if (!on) b->exact = b->exact_status == 0;          // back to the work area's default order (jamd_beam_create())
   return JAMD_OK;
 }
 
@@ -1733,7 +1734,7 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
   if (!b) { jamd_set_error("jamd_beam_set_order_mode: NULL"); return JAMD_EINVAL; }
   if (b->streaming > 0) { jamd_set_error("jamd_beam_set_order_mode: a streaming session is open"); return JAMD_ESTATE; }
   switch (mode) {
-    case JAMD_ORDER_FAST: b->exact = false; return jamd_beam_set_strict_order(b, 0);
+    case JAMD_ORDER_FAST: { const int rc = jamd_beam_set_strict_order(b, 0); b->exact = false; return rc; }
     case JAMD_ORDER_STRICT: b->exact = false; return jamd_beam_set_strict_order(b, 1);
     case JAMD_ORDER_EXACT:
     case JAMD_ORDER_EXACT_SERIAL:
@@ -1745,8 +1746,9 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
         return JAMD_ESTATE;
       }
       b->xw.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;
+      b->strict = false;
       b->exact = true;
-      return jamd_beam_set_strict_order(b, 0);
+      return JAMD_OK;
     default: jamd_set_error("jamd_beam_set_order_mode: mode=%d", mode); return JAMD_EINVAL;
   }
 }

@@ -1581,6 +1581,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   if (tid == 0) sh.best_atom = -1;
   __syncthreads();
   if (res->status == JAMD_PASS1_OK && dfa) {
+    // grammar / word list (:433-455): the best word on the latest frame that has one.  The reference walks rw[t], which
+    // bt_sort_rw() has sorted by word id, with a strict <: of equally good words the smaller id wins -- the key below.
     if (tid == 0) { sh.n_arc = -1; sh.we_best = 0ull; }
     __syncthreads();
     int lt = -1;
