@@ -1283,7 +1283,8 @@ struct jamd_beam {
   jamd_lexicon *lex = nullptr;
   Work w{};
   int max_utts = 0;
-  int *d_utt_off = nullptr;
+  int *d_utt_off = nullptr;        // [nutt + 1] row offsets, then [nutt] the launch order (see upload_utt_off())
+  std::vector<int> h_utt_off;      // host image of the same (the copy is asynchronous)
   bool strict = false;             // order mode JAMD_ORDER_STRICT
   bool exact = false;              // order mode JAMD_ORDER_EXACT (beam_exact.hip)
   int exact_status = -3;           // 0 = the exact-order kernel can serve this work area (xbeam_layout())
@@ -1308,6 +1309,21 @@ static void launch_pass1(jamd_beam *b, const Work &w, int lds, int nutt, const f
     if (b->timed) hipLaunchKernelGGL((beam_pass1_kernel<true, false>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
     else hipLaunchKernelGGL((beam_pass1_kernel<false, false>), grid, block, lds, st, b->lex->d, w, dev_scores, nstate, b->d_utt_off, smode);
   }
+}
+
+// Row offsets of the launch, followed by the ORDER in which the workgroups take the utterances: longest first.  With
+// more utterances than CUs the dispatcher hands the next workgroup to the first CU that frees up, so longest-first is
+// the classic greedy balance (a 512-utterance batch of 1 200-1 600-frame utterances: the slowest CU carries two average
+// utterances instead of the two longest; 274 -> 245 ms).  The exact-order kernel reads it; the others ignore it.
+static int upload_utt_off(jamd_beam *b, const int *utt_off, int nutt, hipStream_t st) {
+  std::vector<int> &h = b->h_utt_off;
+  h.assign((size_t)2 * nutt + 1, 0);
+  for (int u = 0; u <= nutt; u++) h[(size_t)u] = utt_off[u];
+  int *order = h.data() + nutt + 1;
+  for (int u = 0; u < nutt; u++) order[u] = u;
+  std::stable_sort(order, order + nutt, [&](int a, int c) { return utt_off[a + 1] - utt_off[a] > utt_off[c + 1] - utt_off[c]; });
+  JAMD_HIP(hipMemcpyAsync(b->d_utt_off, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
+  return JAMD_OK;
 }
 
 extern "C" {
@@ -1581,7 +1597,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     if (ae != hipSuccess) { jamd_set_error("jamd_beam_create: cannot reserve %d bytes of LDS: %s", w.sv_bytes,
                                            hipGetErrorString(ae)); rc = JAMD_ENODEV; }
   }
-  if (rc == JAMD_OK) rc = alloc((void **)&b->d_utt_off, (U + 1) * sizeof(int), true);
+  if (rc == JAMD_OK) rc = alloc((void **)&b->d_utt_off, (2 * U + 1) * sizeof(int), true);
   if (rc == JAMD_OK && b->exact_status == 0) {
     // same slices, same offsets; only the LDS image differs
     const int svb = b->xw.w.sv_bytes;
@@ -1619,7 +1635,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   if (nutt == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
-  JAMD_HIP(hipMemcpyAsync(b->d_utt_off, utt_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
+  { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
   if (b->lex->multipath && !b->strict) {
     jamd_set_error("jamd_beam_pass1_dev: a multipath lexicon is decoded by the strict-order kernel only: "
                    "jamd_beam_set_strict_order(b, 1)");
@@ -1692,7 +1708,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   b->stream_pushes++;
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
-  JAMD_HIP(hipMemcpyAsync(b->d_utt_off, chunk_off, sizeof(int) * (nutt + 1), hipMemcpyHostToDevice, st));
+  { const int rc = upload_utt_off(b, chunk_off, nutt, st); if (rc != JAMD_OK) return rc; }
   if (b->exact) {
     b->xw.w.stream = b->w.stream;
     xbeam_launch(b->lex->d, b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);

@@ -994,7 +994,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   const Work &wk = xw.w;
-  const int u = blockIdx.x, tid = threadIdx.x;
+  const int u = utt_off[gridDim.x + 1 + blockIdx.x], tid = threadIdx.x;      // longest utterance first (upload_utt_off())
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
   StreamState *ss = smode ? wk.stream + u : nullptr;
   const bool resume = smode && ss->started;

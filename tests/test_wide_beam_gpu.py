@@ -68,6 +68,47 @@ def test_wide_beam_exact_vs_compiled_reference(engine, oracle, ref, big_task, tm
     bm.close()
 
 
+def test_wide_beam_streaming_equals_one_shot(engine, ref, big_task, tmp_path):
+    """The wide layout keeps its survivors in the utterance's slice between launches: input pushed in ragged chunks
+    (jamd_beam_stream_*) gives the one-shot call's trellis, at a beam where rank pruning is live on the big lexicon."""
+    wd, task = big_task
+    beam = 2500
+    eng = pyoracle.RefEngine(ref, ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
+                                   "-input", "outprob", "-1pass", "-b", str(beam)])
+    eng.save_lexicon(tmp_path / "lex.blob")
+    lex = lexblob.load(tmp_path / "lex.blob")
+    rng = np.random.default_rng(3)
+    flat = rng.normal(-8.0, 0.33, (70, S)).astype(np.float32)
+    scores = [flat, (np.round(flat[:55] * 4.0) / 4.0).astype(np.float32)]
+    lx = lib.Lexicon(engine, lex)
+    one = lib.Beam(engine, lx, beam, -1.0, max_utts=2, atoms_per_utt=1 << 18)
+    res1, tre1 = one.pass1_host(scores)
+    bm = lib.Beam(engine, lx, beam, -1.0, max_utts=2, atoms_per_utt=1 << 18)
+    bm.stream_begin(2)
+    pos = [0, 0]
+    chunks = [1, 16, 0, 9, 23, 10000]
+    for ci, c in enumerate(chunks):
+        part, off = [], [0]
+        for u, sc in enumerate(scores):
+            n = min(len(sc) - pos[u], c + 2 * u if c else 0)
+            part.append(sc[pos[u]:pos[u] + n]); pos[u] += n; off.append(off[-1] + n)
+        rows = np.concatenate(part) if off[-1] else np.zeros((1, S), np.float32)
+        d = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(d.ptr, S, np.array(off, np.int32), final=ci == len(chunks) - 1)
+        bm.results(2)
+        d.free()
+    for u, r in enumerate(bm.results(2)):
+        assert (r.status, r.natom, r.score, r.max_tokens) == (res1[u].status, res1[u].natom, res1[u].score, res1[u].max_tokens)
+        assert r.max_tokens > beam
+        a, b = lexblob.canonical_trellis(bm.trellis(u)), lexblob.canonical_trellis(tre1[u])
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+    # and the one-shot result is the reference's
+    synth.write_htk_param(tmp_path / "u.prob", scores[0], parmkind=synth.PARM_USER)
+    rtr, _ = eng.recognize(tmp_path / "u.prob")
+    assert_trellis_equal(tre1[0], rtr)
+    one.close(); bm.close()
+
+
 @pytest.mark.parametrize("mode", ["exact", "exact_serial"])
 @pytest.mark.parametrize("beam", [2000, 3000, 4000, 4400, 5000])
 def test_prune_order_wide(engine, oracle, beam, mode):
