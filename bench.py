@@ -456,6 +456,8 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
                               "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
                                       "is frames/s of the first pass over the batch",
                               "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
+                              "timing_note": ("HIP events on each stream; under the two-stream pipeline the scoring events include the wait "
+                                              "for CUs that the first pass of the previous step still holds") if pipelined else "HIP events, one stream",
                               "beam_frames_per_s": T / (beam_ms * 1e-3),
                               "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
                  "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,

@@ -1321,7 +1321,8 @@ static int upload_utt_off(jamd_beam *b, const int *utt_off, int nutt, hipStream_
   for (int u = 0; u <= nutt; u++) h[(size_t)u] = utt_off[u];
   int *order = h.data() + nutt + 1;
   for (int u = 0; u < nutt; u++) order[u] = u;
-  std::stable_sort(order, order + nutt, [&](int a, int c) { return utt_off[a + 1] - utt_off[a] > utt_off[c + 1] - utt_off[c]; });
+  if (nutt > b->eng->num_cu)       // (one round: every workgroup starts at once, the order is irrelevant)
+    std::stable_sort(order, order + nutt, [&](int a, int c) { return utt_off[a + 1] - utt_off[a] > utt_off[c + 1] - utt_off[c]; });
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
   return JAMD_OK;
 }
