@@ -69,7 +69,7 @@ struct XShared {
   unsigned maxbits, minbits;
   unsigned sel_digit, sel_need, sel_count;
   unsigned wsum[NT / 64], wsum2[NT / 64];
-
+  int scan_total, scan_total2;
 };
 
 struct XCells {
@@ -79,10 +79,8 @@ struct XCells {
 };
 constexpr int kXProbes = 24;
 
-// block-wide exclusive scan of one int per thread.  ONE barrier: every thread adds up all the wave totals itself
-// (sixteen broadcast LDS reads) instead of waiting for one thread to publish the sum.  The caller's next barrier
-// separates the reads of wsum[] from its next use (every call site has one before any other scan or select).
-__device__ __forceinline__ int block_excl_scan(XShared &sh, int v, int &total) {
+// block-wide exclusive scan of one int per thread (two barriers); total in sh.scan_total
+__device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int incl = v;
 #pragma unroll
@@ -92,15 +90,15 @@ __device__ __forceinline__ int block_excl_scan(XShared &sh, int v, int &total) {
   }
   if (lane == 63) sh.wsum[wv] = (unsigned)incl;
   __syncthreads();
-  int base = 0, all = 0;
-#pragma unroll
-  for (int w = 0; w < NT / 64; w++) { const int x = (int)sh.wsum[w]; all += x; base += w < wv ? x : 0; }
-  total = all;
+  int base = 0;
+  for (int w = 0; w < wv; w++) base += (int)sh.wsum[w];
+  if (threadIdx.x == NT - 1) sh.scan_total = base + incl;
+  __syncthreads();
   return base + incl - v;
 }
 
-// the same for two ints per thread
-__device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int &ea, int &eb, int &ta, int &tb) {
+// the same for two ints per thread (totals in sh.scan_total / sh.scan_total2)
+__device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int &ea, int &eb) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int ia = a, ib = b;
 #pragma unroll
@@ -110,13 +108,10 @@ __device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int 
   }
   if (lane == 63) { sh.wsum[wv] = (unsigned)ia; sh.wsum2[wv] = (unsigned)ib; }
   __syncthreads();
-  int ba = 0, bb = 0, alla = 0, allb = 0;
-#pragma unroll
-  for (int w = 0; w < NT / 64; w++) {
-    const int x = (int)sh.wsum[w], y = (int)sh.wsum2[w];
-    alla += x; allb += y; ba += w < wv ? x : 0; bb += w < wv ? y : 0;
-  }
-  ta = alla; tb = allb;
+  int ba = 0, bb = 0;
+  for (int w = 0; w < wv; w++) { ba += (int)sh.wsum[w]; bb += (int)sh.wsum2[w]; }
+  if (threadIdx.x == NT - 1) { sh.scan_total = ba + ia; sh.scan_total2 = bb + ib; }
+  __syncthreads();
   ea = ba + ia - a; eb = bb + ib - b;
 }
 
@@ -690,8 +685,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         {
           // exclusive prefix from the top bin down: thread t owns bins 2047 - 2t and 2046 - 2t (NT == 1024, as above)
           const unsigned c1 = pm.hist[2047 - 2 * tid], c0 = pm.hist[2046 - 2 * tid];
-          int tot_;
-          const int ex = block_excl_scan(sh, (int)(c1 + c0), tot_);
+          const int ex = block_excl_scan(sh, (int)(c1 + c0));
           pm.hist[2047 - 2 * tid] = (unsigned)ex; pm.hist[2046 - 2 * tid] = (unsigned)ex + c1;
           __syncthreads();
           for (int e = tid; e < nB; e += NT) {                  // by bin, any order inside; hist[b] ends as the END of bin b
@@ -780,8 +774,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
               if (rem < 32) bits &= (1u << rem) - 1u;
               live += __popc(bits);
             }
-            { int tot_; (void)block_excl_scan(sh, live, tot_); live = uni(tot_); }
-            __syncthreads();                                     // (wsum[] is read above and written again by the next scan)
+            live = block_excl_scan(sh, live); live = uni(sh.scan_total);
             give_up = (long long)live * nB > 80ll * k + 6400;       // events: ~0.36 us per 64 list entries each; the loop: ~0.45 us an extraction
           }
         }
@@ -1032,20 +1025,6 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);
   cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);
   lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);
-  // The two work queues of a frame -- (survivor, extra arc) pairs of step A, (token, state set) pairs of step C -- keep
-  // their first entries in LDS areas that are idle at that moment (the prefix table + bitmap before step C0; the
-  // word-end list during step C) and only the overflow in the slice: a queue written and read back through global
-  // memory costs a round trip on the critical path of its step.
-  lds_u64 *qa = (lds_u64 *)(dyn_lds + xw.off_tpre), *qc = (lds_u64 *)(dyn_lds + xw.off_we);
-  const int qa_cap = (xw.off_bm + 4 * xw.bm_words - xw.off_tpre) / 8, qc_cap = (4 * wk.beam) / 8;
-  auto qput = [&](lds_u64 *q, int cap, int i, int x, int y) {
-    if (i < cap) q[i] = (unsigned long long)(unsigned)x | ((unsigned long long)(unsigned)y << 32);
-    else ARCQ(i) = make_int2(x, y);
-  };
-  auto qget = [&](const lds_u64 *q, int cap, int i) -> int2 {
-    if (i < cap) { const unsigned long long v = q[i]; return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32)); }
-    return ARCQ(i);
-  };
   PruneMem pm;
   pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
   pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
@@ -1155,10 +1134,10 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           if (alive && !last) cnt = XW + ((sw >= 0 && !wordmode && sw != lx.tail_silwid) ? nroot_x : 0);
           isend = (alive && sw >= 0) ? 1 : 0;
         }
-        int ex, ea, tcnt, tend;
-        block_excl_scan2(sh, cnt, isend, ex, ea, tcnt, tend);
+        int ex, ea;
+        block_excl_scan2(sh, cnt, isend, ex, ea);
         if (j < n_surv) { dbase[j] = carry + ex; sv_atom[j] = isend ? acarry + ea : -1; }
-        carry += tcnt; acarry += tend;
+        carry += sh.scan_total; acarry += sh.scan_total2;
         __syncthreads();
       }
       if (tid == 0) { dbase[n_surv] = carry; sh.n_atom = acarry; }
@@ -1196,7 +1175,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
         const int e0 = na.z, e1 = na.w;
         if (e1 > e0) {
           const int b0 = atomicAdd(&sh.n_arc, e1 - e0);
-          for (int e = e0; e < e1; e++) qput(qa, qa_cap, b0 + e - e0, j | ((2 + e - e0) << 16), e);   // (source | transition number, arc)
+          for (int e = e0; e < e1; e++) ARCQ(b0 + e - e0) = make_int2(j | ((2 + e - e0) << 16), e);   // (source | transition number, arc)
         }
         { const float a = __int_as_float(na.x); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node, a, 0, 0); }
         { const float a = __int_as_float(na.y); if (a != JAMD_LOG_ZERO) intra_candidate(tk, j, node + 1, a, 1, nscid1); }
@@ -1223,7 +1202,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     if (!last) {
       const int n_arc = uni(sh.n_arc);
       for (int q = tid; q < n_arc; q += NT) {
-        const int2 it = qget(qa, qa_cap, q);
+        const int2 it = ARCQ(q);
         const int j = it.x & 0xffff;
         const int to = lx.ac_to(it.y);
         const Tok tk = sv.load(j);
@@ -1357,8 +1336,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       PROBE(2, 4);
       int cnt = 0;
       for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm_get(w)); }
-      int tot_;
-      const int ex = block_excl_scan(sh, cnt, tot_);
+      const int ex = block_excl_scan(sh, cnt);
       tpre[tid] = (unsigned)ex;
       __syncthreads();
       PROBE(2, 5);
@@ -1499,7 +1477,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
             if (b < mymin) mymin = b;
           } else {
             nw.score = score;
-            qput(qc, qc_cap, atomicAdd(&sh.n_arc, 1), s, ~ent[k]);
+            ARCQ(atomicAdd(&sh.n_arc, 1)) = make_int2(s, ~ent[k]);
           }
           CUR(s) = nw;
         }
@@ -1514,7 +1492,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       for (int q0 = 0; q0 < n_set; q0 += NT >> lsh) {
         const int q = q0 + (tid >> lsh);
         const bool act = q < n_set;
-        const int2 it = act ? qget(qc, qc_cap, q) : make_int2(0, 0);
+        const int2 it = act ? ARCQ(q) : make_int2(0, 0);
         const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
         const float sc0 = (act && sub == 0) ? CUR(it.x).score : 0.0f;      // in flight beside the member loads
         float r;

@@ -100,7 +100,12 @@ dnn_pack_rm_kernel(const float *__restrict__ X, float *__restrict__ Xr, int T, i
 
 // OUT: 0 = output layer (raw values, natural order, row stride ldy), 1 = hidden layer (table logistic, written as
 // residue-major rows of 8 * kmp_out entries, zero padded)
-template <int OUT>
+// STRADDLE: the residue segments are not a whole number of slabs long (kmp % 32 != 0: the 528-wide first layer has
+// 72-entry segments).  The chains then do not get slabs of their own -- three per chain, the third a quarter full:
+// 24 slabs of staging, barriers and pipeline fill for 18 slabs of data -- but the operand rows are streamed as they
+// lie (the eight segments are contiguous) in 8 * kmp / 32 slabs, and a chain is folded into the running sum in the
+// middle of a slab, after its last group of eight entries.  Same multiplications in the same chains.
+template <int OUT, bool STRADDLE>
 __global__ void __launch_bounds__(256, 2)
 dnn_layer_rs_kernel(const float *__restrict__ Xr, const float *__restrict__ Wr, const float *__restrict__ bias,
                     const float *__restrict__ sig, float *__restrict__ Y, int T, int kmp, int N, int ncover,
@@ -138,14 +143,15 @@ dnn_layer_rs_kernel(const float *__restrict__ Xr, const float *__restrict__ Wr, 
       src[j] = live[j] ? Wr + (size_t)orow * L + 4 * c : zero16;
     }
   }
-  auto stage = [&](int buf, int l, int m0) {
-    const bool full = m0 + MS <= kmp;
+  auto stage = [&](int buf, int l, int m0) {                // STRADDLE: l = 0, m0 = offset in the whole row of L entries
+    const int lim = STRADDLE ? L : kmp;
+    const bool full = m0 + MS <= lim;
     const int off = l * kmp + m0;
 #pragma unroll
     for (int j = 0; j < NI; j++) {
       const int id = 8 * wave + j;
       const float *g = live[j] ? src[j] + off : zero16;
-      if (!full && !(m0 + cq[j] < kmp)) g = zero16;
+      if (!full && !(m0 + cq[j] < lim)) g = zero16;
       float *dst = (id < 16) ? &Xs[buf][256 * (id & 15)] : &Ws[buf][256 * (id & 15)];
       __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)dst, 16, 0, 0);
     }
@@ -171,6 +177,43 @@ dnn_layer_rs_kernel(const float *__restrict__ Xr, const float *__restrict__ Wr, 
   stage(0, 0, 0);
   __syncthreads();          // carries the vmcnt(0) that lands the DMA
   int cur = 0;
+  if constexpr (STRADDLE) {
+    const int gpc = kmp >> 3, ngroup = 8 * gpc, nslab_row = (L + MS - 1) / MS;   // groups per chain, in the row; slabs of the row
+    int left = gpc;                                       // groups of the running chain still to come
+    bool first = true;
+    for (int s = 0; s < nslab_row; s++) {
+      if (s + 1 < nslab_row) stage(cur ^ 1, 0, (s + 1) * MS);
+#pragma unroll
+      for (int g = 0; g < MS / 8; g++) {
+        if (4 * s + g >= ngroup) break;
+        const int c = 2 * g + half;
+        f4v a[2], bq[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          a[i] = *(const f4v *)&Xs[cur][arow[i] * MS + 4 * (c ^ asw[i])];
+          bq[i] = *(const f4v *)&Ws[cur][brow[i] * MS + 4 * (c ^ bsw[i])];
+        }
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][st], bq[j][st], acc[i][j], 0, 0, 0);
+        if (--left == 0) {                                // the chain is complete (calc_dnn_fma.c:53-60: lanes added left to right)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+              for (int r = 0; r < 16; r++) { S[i][j][r] = first ? acc[i][j][r] : S[i][j][r] + acc[i][j][r]; acc[i][j][r] = 0.0f; }
+          first = false; left = gpc;
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else
   for (int l = 0; l < 8; l++) {
     for (int s = 0; s < nslab; s++) {
       {                                                   // the next slab: of this chain, or the first of the next one
@@ -437,12 +480,13 @@ int jamd_dnn_outprob_dev(jamd_dnn *n, const float *dev_frames, int T, float *dev
         float *dst = last ? dev_out + (size_t)t0 * S : n->d_act[l & 1];
         const int nnb = (ncover + RB - 1) / RB;
         const int grid = 8 * ((nnb + 7) / 8) * nmb;
-        if (last)
-          hipLaunchKernelGGL((dnn_layer_rs_kernel<0>), dim3(grid), dim3(256), 0, st, src, n->d_wr[l], n->d_b[l],
-                             n->eng->d_logistic, dst, Tc, n->kmp[l], N, ncover, N, 0, nmb, n->d_zero);
-        else
-          hipLaunchKernelGGL((dnn_layer_rs_kernel<1>), dim3(grid), dim3(256), 0, st, src, n->d_wr[l], n->d_b[l],
-                             n->eng->d_logistic, dst, Tc, n->kmp[l], N, ncover, 8 * kout, kout, nmb, n->d_zero);
+        const bool straddle = (n->kmp[l] % MS) != 0;     // segments that are not whole slabs: stream the row (see the kernel)
+#define JAMD_DNN_LAYER(OUT_, STR_, LDY_, KOUT_)                                                                          \
+        hipLaunchKernelGGL((dnn_layer_rs_kernel<OUT_, STR_>), dim3(grid), dim3(256), 0, st, src, n->d_wr[l], n->d_b[l], \
+                           n->eng->d_logistic, dst, Tc, n->kmp[l], N, ncover, LDY_, KOUT_, nmb, n->d_zero)
+        if (last) { if (straddle) JAMD_DNN_LAYER(0, true, N, 0); else JAMD_DNN_LAYER(0, false, N, 0); }
+        else { if (straddle) JAMD_DNN_LAYER(1, true, 8 * kout, kout); else JAMD_DNN_LAYER(1, false, 8 * kout, kout); }
+#undef JAMD_DNN_LAYER
         src = dst;
       }
     }
