@@ -79,9 +79,20 @@ struct XCells {
 };
 constexpr int kXProbes = 24;
 
+// The thread index as a value the optimiser cannot carry from one frame to the next.  Everything derived from it (lane
+// and wave numbers, per-thread addresses into a dozen arrays) is loop-invariant over the frame loop; hoisted, those
+// values cost more registers than the kernel has and come back from scratch memory in the middle of serial sections.
+// Recomputing them where they are used is a few VALU instructions.
+__device__ __forceinline__ int tid_now() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < NT);
+  return t;
+}
+
 // block-wide exclusive scan of one int per thread (two barriers); total in sh.scan_total
 __device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   int incl = v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -92,14 +103,14 @@ __device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
   __syncthreads();
   int base = 0;
   for (int w = 0; w < wv; w++) base += (int)sh.wsum[w];
-  if (threadIdx.x == NT - 1) sh.scan_total = base + incl;
+  if (tx == NT - 1) sh.scan_total = base + incl;
   __syncthreads();
   return base + incl - v;
 }
 
 // the same for two ints per thread (totals in sh.scan_total / sh.scan_total2)
 __device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int &ea, int &eb) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   int ia = a, ib = b;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -110,7 +121,7 @@ __device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int 
   __syncthreads();
   int ba = 0, bb = 0;
   for (int w = 0; w < wv; w++) { ba += (int)sh.wsum[w]; bb += (int)sh.wsum2[w]; }
-  if (threadIdx.x == NT - 1) { sh.scan_total = ba + ia; sh.scan_total2 = bb + ib; }
+  if (tx == NT - 1) { sh.scan_total = ba + ia; sh.scan_total2 = bb + ib; }
   __syncthreads();
   ea = ba + ia - a; eb = bb + ib - b;
 }
@@ -224,7 +235,7 @@ __device__ __forceinline__ void heapify_levels(HP H, int n) {
   if (top >= 1) {
     for (int L = 31 - __clz(top); L >= 0; L--) {
       const int lo = 1 << L, hi = min((2 << L) - 1, top);
-      for (int root = lo + (int)threadIdx.x; root <= hi; root += NT) heap_sift<UP>(H, n, root, H[root]);
+      for (int root = lo + tid_now(); root <= hi; root += NT) heap_sift<UP>(H, n, root, H[root]);
       __syncthreads();
     }
   }
@@ -275,7 +286,7 @@ __device__ __forceinline__ void sift_overlapped(lds_u64 *H, int n, SiftSlot (&sl
 constexpr int kSplitLevel = 6;           // depths >= 6: 64 subtrees, four per wave; depths < 6: wave 0
 template <bool UP, int R>
 __device__ __forceinline__ void heapify_subtrees(lds_u64 *H, int n, int Ltop, int Lmax) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   const int D = Ltop - kSplitLevel + 1, top = n / 2;       // a subtree has 2^D - 1 roots: index 1 .. 2^D - 1 inside it
   SiftSlot sl[R];
 #pragma unroll
@@ -305,8 +316,9 @@ __device__ __forceinline__ bool heapify_overlapped(lds_u64 *H, int n) {
     else return false;
     __syncthreads();
   }
-  if (threadIdx.x < 64) {
-    const int r = (int)threadIdx.x + 1, L = 31 - __clz(r);
+  const int tx = tid_now();
+  if (tx < 64) {
+    const int r = tx + 1, L = 31 - __clz(r);
     const int Lt = Ltop < kSplitLevel ? Ltop : kSplitLevel - 1;
     SiftSlot sl[1];
     sl[0].live = r <= top && L <= Lt;
@@ -391,7 +403,7 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
   const unsigned maxb = uni(sh.maxbits), diff = maxb ^ uni(sh.minbits);
   int remaining = diff ? 32 - __clz(diff) : 0;
   unsigned prefix = remaining < 32 ? (maxb >> remaining) : 0u;
-  const int tid = threadIdx.x;
+  const int tid = tid_now();
   for (int i = tid; i < 2048; i += NT) hist[i] = 0;      // every pass leaves the histogram cleared (three barriers a pass)
   __syncthreads();
   while (remaining > 0) {
@@ -619,7 +631,7 @@ template <bool WIDE>
 __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
                            unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode, u32x4 *G,
                            unsigned long long *tp = nullptr) {
-  const int tid = threadIdx.x;
+  const int tid = tid_now();
   unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
   (void)tc3_;
 #define PTICK(i) do { if (tp && tid == 0 && ((JAMD_XBEAM_PROBE != 3 && JAMD_XBEAM_PROBE != 5) || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
@@ -994,7 +1006,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   const Work &wk = xw.w;
-  const int u = utt_off[gridDim.x + 1 + blockIdx.x], tid = threadIdx.x;      // longest utterance first (upload_utt_off())
+  const int u = utt_off[gridDim.x + 1 + blockIdx.x];                         // longest utterance first (upload_utt_off())
+  int tid = threadIdx.x;                                                     // refreshed every frame: see tid_now()
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
   StreamState *ss = smode ? wk.stream + u : nullptr;
   const bool resume = smode && ss->started;
@@ -1112,6 +1125,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   };
   row_request(resume ? base : (dfa ? 0 : 1));
   for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
+    tid = tid_now();
     const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
