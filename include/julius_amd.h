@@ -511,6 +511,21 @@ int  jamd_beam_set_strict_order(jamd_beam *b, int on);
 #define JAMD_ORDER_EXACT_SERIAL 3
 int  jamd_beam_set_order_mode(jamd_beam *b, int mode);
 int  jamd_beam_order_mode(const jamd_beam *b);
+/* Workgroup shape of the exact-order kernel (a scheduling choice: the results are the same bit for bit).
+ *   JAMD_SHAPE_FULL  one utterance per CU: 1024 threads and the CU's whole LDS -- the lowest latency per utterance.
+ *   JAMD_SHAPE_HALF  512 threads and half the LDS, so two utterances share a CU and the barriers and wave-serial
+ *       sections of one overlap the work of the other: more frames per second once a launch carries more
+ *       utterances than the device can hold in the full shape.  Available while half a CU's LDS still holds a
+ *       typical frame (beams up to about 1 000, a little more with few word-initial nodes); JAMD_ESTATE otherwise.
+ *   JAMD_SHAPE_AUTO  (default) HALF for launches (and streaming sessions) of more than 1.5 x the CU count
+ *       utterances when available, else FULL.
+ * jamd_beam_workgroup_shape() tells which one a launch of nutt utterances would use.  A streaming session keeps
+ * the shape it was opened with. */
+#define JAMD_SHAPE_AUTO 0
+#define JAMD_SHAPE_FULL 1
+#define JAMD_SHAPE_HALF 2
+int  jamd_beam_set_workgroup_shape(jamd_beam *b, int shape);
+int  jamd_beam_workgroup_shape(const jamd_beam *b, int nutt);
 /* The rank-pruning step alone (sort_token_no_order(), beam.c:1492): given the scores of the n tokens of
  * a frame in creation order (host array), writes the token indices the next frame visits, in visiting
  * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the

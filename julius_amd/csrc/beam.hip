@@ -1289,6 +1289,10 @@ struct jamd_beam {
   bool exact = false;              // order mode JAMD_ORDER_EXACT (beam_exact.hip)
   int exact_status = -3;           // 0 = the exact-order kernel can serve this work area (xbeam_layout())
   XWork xw{};
+  XWork xw_half{};                 // the same work area for the half shape (two workgroups per CU), when it fits
+  int half_status = -2;            // 0 = xw_half is usable
+  int shape_mode = JAMD_SHAPE_AUTO;
+  bool stream_half = false;        // the shape of the open streaming session (the parked state is the layout's)
   unsigned *d_pkeys = nullptr; int *d_pout = nullptr; size_t pcap = 0;   // jamd_beam_prune_order() scratch
   bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
@@ -1297,6 +1301,15 @@ struct jamd_beam {
   StrictWork sw{};
   std::vector<void *> owned;
 };
+
+// The exact-order kernel's workgroup shape for a launch of nutt utterances.  The full shape (1024 threads, a CU's whole
+// LDS) is the faster one per utterance; the half shape lets two utterances share a CU, which pays once the batch has
+// clearly more utterances than the device has CUs (one's barriers and wave-serial sections hide behind the other's work).
+static bool use_half_shape(const jamd_beam *b, int nutt) {
+  if (b->half_status != 0 || b->shape_mode == JAMD_SHAPE_FULL) return false;
+  if (b->shape_mode == JAMD_SHAPE_HALF) return true;
+  return nutt > b->eng->num_cu + b->eng->num_cu / 2;
+}
 
 // the frame-parallel (canonical tie) kernel: instantiation by where the survivor image lives and by instrumentation
 static void launch_pass1(jamd_beam *b, const Work &w, int lds, int nutt, const float *dev_scores, int nstate, int smode,
@@ -1568,9 +1581,11 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     place(&w.o_lmcache, (size_t)w.nscword * sizeof(unsigned long long));
     // exact-order kernel (beam_exact.hip): its LDS layout, and its three extra per-utterance arrays
     XWork &xw = b->xw;
-    b->exact_status = l->multipath ? -4 : xbeam_layout(&xw, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared);
+    b->exact_status = l->multipath ? -4 : xbeam_layout(&xw, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, false);
+    b->half_status = b->exact_status != 0 ? -2 : xbeam_layout(&b->xw_half, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, true);
     size_t sv_max = (size_t)w.sv_bytes;
     if (b->exact_status == 0 && (size_t)xw.w.sv_bytes > sv_max) sv_max = (size_t)xw.w.sv_bytes;
+    if (b->half_status == 0 && (size_t)b->xw_half.w.sv_bytes > sv_max) sv_max = (size_t)b->xw_half.w.sv_bytes;
     place(&w.o_sv, sv_max);
     if (b->exact_status == 0) {
       // the bitmap holds one bit per visiting index: maxfan per survivor plus startnum per word end
@@ -1603,6 +1618,12 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     // same slices, same offsets; only the LDS image differs
     const int svb = b->xw.w.sv_bytes;
     b->xw.w = w; b->xw.w.sv_bytes = svb;
+    if (b->half_status == 0) {
+      XWork &xh = b->xw_half;
+      const int svh = xh.w.sv_bytes;
+      xh.w = w; xh.w.sv_bytes = svh;
+      xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect;
+    }
     if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
   }
   // default order mode: the exact-order kernel where it can serve the work area, else the frame-parallel one
@@ -1649,7 +1670,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
     hipLaunchKernelGGL(beam_strict_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
   else if (b->exact)
-    xbeam_launch(b->lex->d, b->xw, dev_scores, nstate, b->d_utt_off, nutt, 0, b->timed, st);
+    xbeam_launch(b->lex->d, use_half_shape(b, nutt) ? b->xw_half : b->xw, dev_scores, nstate, b->d_utt_off, nutt, 0, b->timed, st);
   else {
     Work w = b->w;                                     // the score row joins the LDS image when it still fits
     w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds;
@@ -1674,6 +1695,7 @@ int jamd_beam_stream_begin(jamd_beam *b, int nutt) {
   JAMD_HIP(hipMemsetAsync(b->w.stream, 0, sizeof(StreamState) * (size_t)nutt, b->eng->stream));
   JAMD_HIP(hipStreamSynchronize(b->eng->stream));
   b->streaming = nutt; b->stream_pushes = 0;
+  b->stream_half = use_half_shape(b, nutt);           // one shape for the whole session: the parked state is the layout's
   b->stream_frames.assign((size_t)nutt, 0);
   return JAMD_OK;
 }
@@ -1711,8 +1733,8 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, chunk_off, nutt, st); if (rc != JAMD_OK) return rc; }
   if (b->exact) {
-    b->xw.w.stream = b->w.stream;
-    xbeam_launch(b->lex->d, b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
+    b->xw.w.stream = b->w.stream; b->xw_half.w.stream = b->w.stream;
+    xbeam_launch(b->lex->d, b->stream_half ? b->xw_half : b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
   } else {
     Work w = b->w;
     w.row_cache = w.lds_bytes + 4 * nstate <= kMaxDynLds;
@@ -1762,12 +1784,32 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
                        : b->exact_status == -4 ? "multipath lexicon" : "no LDS");
         return JAMD_ESTATE;
       }
-      b->xw.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;
+      b->xw.prune_mode = b->xw_half.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;
       b->strict = false;
       b->exact = true;
       return JAMD_OK;
     default: jamd_set_error("jamd_beam_set_order_mode: mode=%d", mode); return JAMD_EINVAL;
   }
+}
+
+int jamd_beam_set_workgroup_shape(jamd_beam *b, int shape) {
+  if (!b) { jamd_set_error("jamd_beam_set_workgroup_shape: NULL"); return JAMD_EINVAL; }
+  if (b->streaming > 0) { jamd_set_error("jamd_beam_set_workgroup_shape: a streaming session is open"); return JAMD_ESTATE; }
+  if (shape != JAMD_SHAPE_AUTO && shape != JAMD_SHAPE_FULL && shape != JAMD_SHAPE_HALF) {
+    jamd_set_error("jamd_beam_set_workgroup_shape: shape=%d", shape); return JAMD_EINVAL;
+  }
+  if (shape == JAMD_SHAPE_HALF && b->half_status != 0) {
+    jamd_set_error("jamd_beam_set_workgroup_shape: beam %d does not fit the half shape (%s)", b->w.beam,
+                   b->exact_status != 0 ? "the exact-order kernel cannot serve this work area" : "half a CU's LDS holds no typical frame");
+    return JAMD_ESTATE;
+  }
+  b->shape_mode = shape;
+  return JAMD_OK;
+}
+
+int jamd_beam_workgroup_shape(const jamd_beam *b, int nutt) {
+  if (!b) return -1;
+  return use_half_shape(b, nutt) ? JAMD_SHAPE_HALF : JAMD_SHAPE_FULL;
 }
 
 int jamd_beam_order_mode(const jamd_beam *b) {
@@ -1798,7 +1840,7 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   int *d_nout = b->d_pout + b->pcap;
   unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 4);
   u32x4 *d_collect = reinterpret_cast<u32x4 *>(d_heap + b->pcap + 2);
-  xbeam_prune_order_launch(b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, st);
+  xbeam_prune_order_launch(use_half_shape(b, 1) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, st);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_prune_order: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpyAsync(nkeep, d_nout, 4, hipMemcpyDeviceToHost, st));

@@ -11,6 +11,8 @@ using namespace jamd;
 constexpr int NT = 1024;                // threads per utterance workgroup
 constexpr int MAXSEQ = 150;             // MAXSEQNUM, libsent/include/sent/speech.h:50
 constexpr int kMaxDynLds = 159 * 1024;  // dynamic LDS budget of the one workgroup a CU holds (160 KB LDS per CU, < 1 KB static)
+constexpr int kHalfNT = 512;              // the exact-order kernel's half shape: two workgroups per CU (beam_exact.h)
+constexpr int kHalfDynLds = 79 * 1024;
 constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its space with the first cells (free during step D)
 
 // All lexicon / LM arrays live in ONE device allocation and are addressed as base + 32-bit byte

@@ -11,6 +11,7 @@ struct XWork {
   unsigned o_bitmap;           // u32 [gbm_words] creation-order bitmap when it outgrows LDS
   unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
   unsigned o_collect;          // u32x4 [beam + 256] wide layout: the top list on its way from the heap to the sorted lists
+  int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())
   int cells_at, fixed_end;     // start of the per-launch part of the image (cells / pruning overlay / score row)
@@ -29,7 +30,9 @@ struct XWork {
 // Fills the LDS layout for beam width w.beam.  maxfan = 2 + most extra arcs of a node, nroot = startnum.
 // 0 = ok, -1 = the visiting index does not fit 32 bits, -2 = the per-survivor arrays do not fit LDS (beam too wide
 // even for the wide layout), -3 = more tokens per frame than the heap's position keys can number.
-int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared);
+// half = the half shape: 512 threads and half a CU's LDS, so that two utterances share a CU and one's barriers and
+// wave-serial sections overlap the other's work (-2 when a typical frame would not fit that image).
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half);
 // places the per-launch part of the image (cells, pruning overlay, score row of nstate floats or none)
 void xbeam_place(XWork *xw, int nstate);
 hipError_t xbeam_prepare();

@@ -86,11 +86,12 @@ constexpr int kXProbes = 24;
 __device__ __forceinline__ int tid_now() {
   int t = (int)threadIdx.x;
   asm volatile("" : "+v"(t));
-  __builtin_assume(t >= 0 && t < NT);
+  __builtin_assume(t >= 0 && t < 1024);
   return t;
 }
 
 // block-wide exclusive scan of one int per thread (two barriers); total in sh.scan_total
+template <int NT>
 __device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
   const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   int incl = v;
@@ -109,6 +110,7 @@ __device__ __forceinline__ int block_excl_scan(XShared &sh, int v) {
 }
 
 // the same for two ints per thread (totals in sh.scan_total / sh.scan_total2)
+template <int NT>
 __device__ __forceinline__ void block_excl_scan2(XShared &sh, int a, int b, int &ea, int &eb) {
   const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   int ia = a, ib = b;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void heap_sift(HP H, int n, int parent, unsigned long
 }
 
 // first loop of sort_token_upward/_downward (:1354-1367): level-parallel
-template <bool UP, typename HP>
+template <bool UP, int NT, typename HP>
 __device__ __forceinline__ void heapify_levels(HP H, int n) {
   const int top = n / 2;
   if (top >= 1) {
@@ -283,19 +285,20 @@ __device__ __forceinline__ void sift_overlapped(lds_u64 *H, int n, SiftSlot (&sl
   }
 }
 
-constexpr int kSplitLevel = 6;           // depths >= 6: 64 subtrees, four per wave; depths < 6: wave 0
-template <bool UP, int R>
+constexpr int kSplitLevel = 6;           // depths >= 6: 64 subtrees, 64 / (waves of the workgroup) per wave; depths < 6: wave 0
+template <bool UP, int R, int NT>
 __device__ __forceinline__ void heapify_subtrees(lds_u64 *H, int n, int Ltop, int Lmax) {
+  constexpr int kSubPerWave = 64 / (NT / 64);
   const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
   const int D = Ltop - kSplitLevel + 1, top = n / 2;       // a subtree has 2^D - 1 roots: index 1 .. 2^D - 1 inside it
   SiftSlot sl[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const int idx = r * 64 + lane;                          // R * 64 = 4 << D
+    const int idx = r * 64 + lane;                          // R * 64 = kSubPerWave << D
     const int sub = idx >> D, within = idx & ((1 << D) - 1);
     const int d = within ? 31 - __clz(within) : 0;
-    const int pos = (((1 << kSplitLevel) + 4 * wv + sub) << d) + (within - (1 << d));
-    sl[r].live = within != 0 && sub < 4 && pos <= top;
+    const int pos = (((1 << kSplitLevel) + kSubPerWave * wv + sub) << d) + (within - (1 << d));
+    sl[r].live = within != 0 && sub < kSubPerWave && pos <= top;
     sl[r].parent = pos; sl[r].t0 = Ltop - (kSplitLevel + d);
     sl[r].s = sl[r].live ? H[pos] : 0ull;
   }
@@ -303,16 +306,17 @@ __device__ __forceinline__ void heapify_subtrees(lds_u64 *H, int n, int Ltop, in
 }
 
 // returns false when the heap is too deep for the register slots (the caller runs heapify_levels)
-template <bool UP>
+template <bool UP, int NT>
 __device__ __forceinline__ bool heapify_overlapped(lds_u64 *H, int n) {
   const int top = n / 2;
   if (top < 1) return true;
   const int Ltop = 31 - __clz(top), Lmax = 31 - __clz(n);
   if (Ltop >= kSplitLevel) {
     const int D = Ltop - kSplitLevel + 1;
-    if (D <= 5) heapify_subtrees<UP, 2>(H, n, Ltop, Lmax);
-    else if (D == 6) heapify_subtrees<UP, 4>(H, n, Ltop, Lmax);
-    else if (D == 7) heapify_subtrees<UP, 8>(H, n, Ltop, Lmax);
+    constexpr int R5 = ((64 / (NT / 64)) << 5) / 64;      // register slots a lane needs at D = 5
+    if (D <= 5) heapify_subtrees<UP, R5, NT>(H, n, Ltop, Lmax);
+    else if (D == 6) heapify_subtrees<UP, 2 * R5, NT>(H, n, Ltop, Lmax);
+    else if (D == 7 && R5 <= 2) heapify_subtrees<UP, (R5 <= 2 ? 4 * R5 : 1), NT>(H, n, Ltop, Lmax);
     else return false;
     __syncthreads();
   }
@@ -397,7 +401,7 @@ __device__ __noinline__ void heap_extract_pipelined(lds_u64 *H, int n, int cnt) 
 
 // k-th largest of the score bits in H[1..n] (radix select, 11 bits a pass over the bits in which the
 // frame's max and min differ).  Returns the value; all threads.
-template <typename HP>
+template <int NT, typename HP>
 __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k, lds_u32 *hist) {
   unsigned need = (unsigned)k;
   const unsigned maxb = uni(sh.maxbits), diff = maxb ^ uni(sh.minbits);
@@ -417,10 +421,11 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
     }
     __syncthreads();
     {
-      static_assert(NT == 1024, "the 2048 radix bins are scanned two per thread");
-      const unsigned h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
-      hist[2 * tid] = 0u; hist[2 * tid + 1] = 0u;
-      const unsigned pair = h0 + h1;
+      constexpr int BPT = 2048 / NT;                   // radix bins per thread
+      static_assert(BPT * NT == 2048 && BPT >= 1, "the 2048 radix bins are scanned BPT per thread");
+      unsigned h[BPT], pair = 0u;
+#pragma unroll
+      for (int x = 0; x < BPT; x++) { h[x] = hist[BPT * tid + x]; hist[BPT * tid + x] = 0u; pair += h[x]; }
       unsigned incl = pair;
       const int ln = tid & 63;
 #pragma unroll
@@ -432,9 +437,11 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
       __syncthreads();
       unsigned above = incl - pair;
       for (int wv = (tid >> 6) + 1; wv < NT / 64; wv++) above += sh.wsum[wv];
-      if (above < need && need <= above + h1) { sh.sel_digit = 2u * tid + 1u; sh.sel_need = need - above; sh.sel_count = h1; }
-      above += h1;
-      if (above < need && need <= above + h0) { sh.sel_digit = 2u * tid; sh.sel_need = need - above; sh.sel_count = h0; }
+#pragma unroll
+      for (int x = BPT - 1; x >= 0; x--) {
+        if (above < need && need <= above + h[x]) { sh.sel_digit = (unsigned)(BPT * tid + x); sh.sel_need = need - above; sh.sel_count = h[x]; }
+        above += h[x];
+      }
     }
     __syncthreads();
     prefix = (prefix << w) | uni(sh.sel_digit);      // (written again only behind two more barriers)
@@ -627,7 +634,7 @@ __device__ __noinline__ int replay_tail(const PruneMem &pm, int nB, int n, int k
 // WIDE (the wide-beam layout): the heap is laid over the list areas -- it is dead once the top elements are
 // collected, so they travel through `G` (a scratch array in the utterance's slice) with their token ids, and the
 // sorted list is built where the heap was; vposR lies over the sorting scratch.
-template <bool WIDE>
+template <bool WIDE, int NT>
 __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
                            unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode, u32x4 *G,
                            unsigned long long *tp = nullptr) {
@@ -656,8 +663,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       __syncthreads();
       PTICK5(4);
       bool heaped = false;
-      if constexpr (kLdsHeap) heaped = upward ? heapify_overlapped<true>(Hh, n) : heapify_overlapped<false>(Hh, n);
-      if (!heaped) { if (upward) heapify_levels<true>(Hh, n); else heapify_levels<false>(Hh, n); }
+      if constexpr (kLdsHeap) heaped = upward ? heapify_overlapped<true, NT>(Hh, n) : heapify_overlapped<false, NT>(Hh, n);
+      if (!heaped) { if (upward) heapify_levels<true, NT>(Hh, n); else heapify_levels<false, NT>(Hh, n); }
     };
     build_heap();
     PTICK5(5);
@@ -665,7 +672,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     bool done = false;
     if (upward && mode != 1 && pm.b_cap > 0) {
       // closed form of the extraction loop
-      const unsigned vk = kth_largest(sh, Hh, n, k, pm.hist);
+      const unsigned vk = kth_largest<NT>(sh, Hh, n, k, pm.hist);
       // The top list sorted by (score descending, pre-order of the heap position ascending).  A bitonic network is 55
       // dependent steps at this size; the scores are spread well over their range, so the list is sorted by counting
       // instead: 2048 score bins between the k-th largest score and the maximum (monotone in the score, equal scores
@@ -695,10 +702,14 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       PTICK(5);
       if (nB <= pm.b_cap) {
         {
-          // exclusive prefix from the top bin down: thread t owns bins 2047 - 2t and 2046 - 2t (NT == 1024, as above)
-          const unsigned c1 = pm.hist[2047 - 2 * tid], c0 = pm.hist[2046 - 2 * tid];
-          const int ex = block_excl_scan(sh, (int)(c1 + c0));
-          pm.hist[2047 - 2 * tid] = (unsigned)ex; pm.hist[2046 - 2 * tid] = (unsigned)ex + c1;
+          // exclusive prefix from the top bin down: thread t owns bins 2047 - BPT t ... 2048 - BPT (t + 1)
+          constexpr int BPT = 2048 / NT;
+          unsigned cb[BPT]; int tot = 0;
+#pragma unroll
+          for (int x = 0; x < BPT; x++) { cb[x] = pm.hist[2047 - BPT * tid - x]; tot += (int)cb[x]; }
+          unsigned ex = (unsigned)block_excl_scan<NT>(sh, tot);
+#pragma unroll
+          for (int x = 0; x < BPT; x++) { pm.hist[2047 - BPT * tid - x] = ex; ex += cb[x]; }
           __syncthreads();
           for (int e = tid; e < nB; e += NT) {                  // by bin, any order inside; hist[b] ends as the END of bin b
             if constexpr (WIDE) {                               // (the heap is dead: every thread is past the barrier behind the collection)
@@ -786,7 +797,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
               if (rem < 32) bits &= (1u << rem) - 1u;
               live += __popc(bits);
             }
-            live = block_excl_scan(sh, live); live = uni(sh.scan_total);
+            live = block_excl_scan<NT>(sh, live); live = uni(sh.scan_total);
             give_up = (long long)live * nB > 80ll * k + 6400;       // events: ~0.36 us per 64 list entries each; the loop: ~0.45 us an extraction
           }
         }
@@ -1000,7 +1011,7 @@ template <> struct XSv<true> {
   }
 };
 
-template <bool TIMED, bool WIDE>
+template <bool TIMED, bool WIDE, int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
   __shared__ XShared sh;
@@ -1149,7 +1160,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           isend = (alive && sw >= 0) ? 1 : 0;
         }
         int ex, ea;
-        block_excl_scan2(sh, cnt, isend, ex, ea);
+        block_excl_scan2<NT>(sh, cnt, isend, ex, ea);
         if (j < n_surv) { dbase[j] = carry + ex; sv_atom[j] = isend ? acarry + ea : -1; }
         carry += sh.scan_total; acarry += sh.scan_total2;
         __syncthreads();
@@ -1283,21 +1294,34 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
           const int part = x / niso, i = x - part * niso;
           const int2 ir = lx.iso_root(i);
           unsigned long long best = 0ull; unsigned nfirst = 0u;
-          for (int w = part; w < nrec; w += parts) {
-            const u32x4 rec = werec[w];
-            const int ctx = (int)rec.y;
-            const float p = (ctx < 0) ? 0.0f
-                            : lx.iwtab ? lx.iwtab[(size_t)ctx * niso + i]
-                            : bigram_prob(lx, ctx, lx.wton(ir.y)) + lx.cprob(ir.y);
-            float tmpsum = __uint_as_float(rec.x);
-            const float ng = p * lmw + pen;
-            tmpsum += ng;
-            if (rec.z & 0x80000000u) tmpsum += lx.lm_penalty_trans;
-            if (tmpsum <= JAMD_LOG_ZERO) continue;
-            const unsigned nv = ~(((rec.z & 0x7fffffffu) << s1) | (unsigned)(XW + i));
-            const unsigned long long key = ((unsigned long long)ordz(tmpsum) << 32) | nv;
-            if (key > best) best = key;
-            if (nv > nfirst) nfirst = nv;
+          // four word ends at a time: the table reads of a group go out together (one memory latency per group, not
+          // per word end; a maximum and a minimum do not care about the order)
+          constexpr int G = 4;
+          for (int w0g = part; w0g < nrec; w0g += G * parts) {
+            u32x4 rec[G]; float p[G]; bool live[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+              const int w = w0g + g * parts;
+              live[g] = w < nrec;
+              rec[g] = werec[live[g] ? w : part];
+              const int ctx = (int)rec[g].y;
+              p[g] = (!live[g] || ctx < 0) ? 0.0f
+                     : lx.iwtab ? lx.iwtab[(size_t)ctx * niso + i]
+                     : bigram_prob(lx, ctx, lx.wton(ir.y)) + lx.cprob(ir.y);
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+              if (!live[g]) continue;
+              float tmpsum = __uint_as_float(rec[g].x);
+              const float ng = p[g] * lmw + pen;
+              tmpsum += ng;
+              if (rec[g].z & 0x80000000u) tmpsum += lx.lm_penalty_trans;
+              if (tmpsum <= JAMD_LOG_ZERO) continue;
+              const unsigned nv = ~(((rec[g].z & 0x7fffffffu) << s1) | (unsigned)(XW + i));
+              const unsigned long long key = ((unsigned long long)ordz(tmpsum) << 32) | nv;
+              if (key > best) best = key;
+              if (nv > nfirst) nfirst = nv;
+            }
           }
           if (best != 0ull) xpush_key(sh, cl, ir.x, best, nfirst);
         }
@@ -1350,7 +1374,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       PROBE(2, 4);
       int cnt = 0;
       for (int x = 0; x < W; x++) { const int w = tid * W + x; if (w < nwords) cnt += __popc(bm_get(w)); }
-      const int ex = block_excl_scan(sh, cnt);
+      const int ex = block_excl_scan<NT>(sh, cnt);
       tpre[tid] = (unsigned)ex;
       __syncthreads();
       PROBE(2, 5);
@@ -1561,7 +1585,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune<WIDE>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
+    const int n_keep = exact_prune<WIDE, NT>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
     for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(welist[j]));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
@@ -1654,7 +1678,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 
 // diagnostic: the pruning step alone on given score bits (tests/test_prune_order.py fuzzes it against the
 // sequential heap)
-template <bool WIDE>
+template <bool WIDE, int NT>
 __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigned *keys, int n, int k, int *out, int *nout,
                                                          unsigned long long *hglob, u32x4 *gcol) {
   __shared__ XShared sh;
@@ -1677,7 +1701,7 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
-  const int nk = exact_prune<WIDE>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
+  const int nk = exact_prune<WIDE, NT>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
                                    xw.prune_mode, gcol);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
   if (threadIdx.x == 0) *nout = nk;
@@ -1704,21 +1728,21 @@ static int xbeam_fixed(XWork *xw, bool wide, int maxfan, int nroot, int ninit, i
     place(&xw->off_we, 4 * beam);
     place(&xw->off_dbase, 4 * (beam + 2));
     xw->w.sv_bytes = at;                             // what a streaming session parks between launches
-    place(&xw->off_tpre, 4 * NT);
+    place(&xw->off_tpre, 4 * xw->nt);
   } else {
     place(&xw->off_we, 4 * beam);
     xw->off_dov = at;
     place(&xw->off_atom, 4 * beam);
     place(&xw->off_dbase, 4 * (beam + 2));
     xw->w.sv_bytes = (beam * (int)sizeof(Tok) + 15) & ~15;   // the survivors' home in the slice; nothing to park
-    place(&xw->off_tpre, 4 * NT);
+    place(&xw->off_tpre, 4 * xw->nt);
   }
-  if (at + 8 * 1024 > kMaxDynLds) return -2;
+  if (at + 8 * 1024 > xw->lds_budget) return -2;
   // creation-order bitmap: XW bits per source plus a few word ends' worth of roots (a frame that needs more
   // uses the copy in global memory); at most an eighth of what is left
   int bm_words = (beam * maxfan + 8 * nroot + nshared + ninit + 31) / 32 + 64;
   if (bm_words > 4096) bm_words = 4096;
-  if (4 * bm_words > (kMaxDynLds - at) / 8) bm_words = (kMaxDynLds - at) / 32;
+  if (4 * bm_words > (xw->lds_budget - at) / 8) bm_words = (xw->lds_budget - at) / 32;
   xw->bm_words = bm_words;
   place(&xw->off_bm, 4 * bm_words);
   xw->cells_at = at;
@@ -1739,7 +1763,7 @@ static int xbeam_tail_bytes(int beam) {
 static void xbeam_place_with(XWork *xw, int want) {
   const int beam = xw->w.beam;
   const int cells_at = xw->cells_at;
-  int region = ((kMaxDynLds - cells_at) & ~1023) - want;
+  int region = ((xw->lds_budget - cells_at) & ~1023) - want;
   if (region < 0) region = 0;
   int nslot = (region / 16) & ~63;
   if (nslot < 1024) nslot = 0;                       // too few to be worth probing: every cell in nodekey[]
@@ -1783,19 +1807,22 @@ void xbeam_place(XWork *xw, int nstate) {
   xbeam_place_with(xw, 0);
   xw->w.row_cache = 0;
   if (nstate <= 0) return;
-  // make room for the frame's score row when the cell table, the LDS heap and the top lists can spare it
+  // make room for the frame's score row when the cell table, the LDS heap and the top lists can spare it (the half
+  // shape asks for the narrow layout's cell count: with half the LDS, cells lost to the row cost more than the row saves)
   XWork t = *xw;
   xbeam_place_with(&t, (4 * nstate + 1023) & ~1023);
   const int beam = xw->w.beam;
-  const bool ok = t.b_cap == xw->b_cap && t.off_row + 4 * nstate <= kMaxDynLds &&
-                  (xw->wide ? 2 * t.heap_cap >= 5 * beam : (t.nslot >= 6 * beam && t.heap_cap >= 5 * beam));
+  const bool ok = t.b_cap == xw->b_cap && t.off_row + 4 * nstate <= xw->lds_budget &&
+                  (xw->wide && xw->nt == NT ? 2 * t.heap_cap >= 5 * beam : (t.nslot >= 6 * beam && t.heap_cap >= 5 * beam));
   if (!ok) return;                                   // the row stays in global memory
   *xw = t;
   xw->w.row_cache = 1;
 }
 
-int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared) {
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half) {
   xw->w = w;
+  xw->nt = half ? kHalfNT : NT;
+  xw->lds_budget = half ? kHalfDynLds : kMaxDynLds;
   const int beam = w.beam;
   xw->xw = maxfan;                                   // self, next, extra arcs
   int need = maxfan + nroot;                         // transition numbers of one source
@@ -1808,24 +1835,33 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   if ((long long)w.tok_cap + 2 >= (1ll << (kMaxL + 1))) return -3;   // prekey() numbers heap positions below 2^(kMaxL+1)
   // the narrow layout (survivors in LDS) while it leaves room for the closed-form extraction and for the heap of a
   // typical frame (three to six tokens per survivor) beside the top lists, else the wide one
-  int rc = xbeam_fixed(xw, false, maxfan, nroot, ninit, nshared);
+  int rc = half ? -2 : xbeam_fixed(xw, false, maxfan, nroot, ninit, nshared);   // (the half shape: always the wide layout)
   if (rc == 0) { xbeam_place_with(xw, 0); if (xw->b_cap == 0 || xw->heap_cap < 8 * beam) rc = -2; }
   if (rc != 0) {
     rc = xbeam_fixed(xw, true, maxfan, nroot, ninit, nshared);
     if (rc != 0) return rc;
     xbeam_place_with(xw, 0);
   }
+  // the half shape is there for throughput: only where a typical frame still runs out of LDS
+  if (half && (xw->b_cap == 0 || xw->heap_cap < 5 * beam || xw->nslot < 3 * beam)) return -2;
   xw->w.row_cache = 0;
   xw->prune_mode = 0;
   return 0;
 }
 
 hipError_t xbeam_prepare() {
-  const void *fn[] = {(const void *)beam_exact_kernel<false, false>, (const void *)beam_exact_kernel<true, false>,
-                      (const void *)beam_exact_kernel<false, true>, (const void *)beam_exact_kernel<true, true>,
-                      (const void *)prune_order_kernel<false>, (const void *)prune_order_kernel<true>};
+  const void *fn[] = {(const void *)beam_exact_kernel<false, false, NT>, (const void *)beam_exact_kernel<true, false, NT>,
+                      (const void *)beam_exact_kernel<false, true, NT>, (const void *)beam_exact_kernel<true, true, NT>,
+                      (const void *)prune_order_kernel<false, NT>, (const void *)prune_order_kernel<true, NT>};
   for (const void *f : fn) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if (e != hipSuccess) return e;
+  }
+  // the half shape is always the wide layout (xbeam_layout())
+  const void *fh[] = {(const void *)beam_exact_kernel<false, true, kHalfNT>, (const void *)beam_exact_kernel<true, true, kHalfNT>,
+                      (const void *)prune_order_kernel<true, kHalfNT>};
+  for (const void *f : fh) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfDynLds);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -1836,20 +1872,23 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
   XWork xw = xw0;
   xbeam_place(&xw, nstate);
   const int lds = xw.lds_bytes + (xw.w.row_cache ? 4 * nstate : 0);
-  const dim3 grid(nutt), block(NT);
-  if (xw.wide) {
-    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, true>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-    else hipLaunchKernelGGL((beam_exact_kernel<false, true>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-  } else {
-    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, false>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-    else hipLaunchKernelGGL((beam_exact_kernel<false, false>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-  }
+  const dim3 grid(nutt), block(xw.nt);
+#define JAMD_XLAUNCH(W, N)                                                                                                   \
+  do {                                                                                                                       \
+    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode); \
+    else hipLaunchKernelGGL((beam_exact_kernel<false, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);      \
+  } while (0)
+  if (xw.nt == kHalfNT) JAMD_XLAUNCH(true, kHalfNT);
+  else if (xw.wide) JAMD_XLAUNCH(true, NT);
+  else JAMD_XLAUNCH(false, NT);
+#undef JAMD_XLAUNCH
 }
 
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
                               unsigned long long *d_hglob, u32x4 *d_collect, hipStream_t st) {
-  if (xw.wide) hipLaunchKernelGGL(prune_order_kernel<true>, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
-  else hipLaunchKernelGGL(prune_order_kernel<false>, dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
+  if (xw.nt == kHalfNT) hipLaunchKernelGGL((prune_order_kernel<true, kHalfNT>), dim3(1), dim3(kHalfNT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
+  else if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
+  else hipLaunchKernelGGL((prune_order_kernel<false, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
 }
 
 }  // namespace jamdb

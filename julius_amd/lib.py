@@ -131,6 +131,8 @@ def load():
         "jamd_beam_set_strict_order": (ci, [vp, ci]),
         "jamd_beam_set_order_mode": (ci, [vp, ci]),
         "jamd_beam_order_mode": (ci, [vp]),
+        "jamd_beam_set_workgroup_shape": (ci, [vp, ci]),
+        "jamd_beam_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
@@ -618,6 +620,18 @@ class Beam:
     def order_mode(self) -> str:
         m = load().jamd_beam_order_mode(self.h)
         return {v: k for k, v in self.ORDER_MODES.items()}[m]
+
+    SHAPES = {"auto": 0, "full": 1, "half": 2}
+
+    def set_workgroup_shape(self, shape):
+        """'auto' (default), 'full' (one utterance per CU) or 'half' (two per CU) -- see julius_amd.h."""
+        m = self.SHAPES[shape] if isinstance(shape, str) else int(shape)
+        _check(load().jamd_beam_set_workgroup_shape(self.h, m), "jamd_beam_set_workgroup_shape")
+        return self
+
+    def workgroup_shape(self, nutt: int = 1) -> str:
+        m = load().jamd_beam_workgroup_shape(self.h, nutt)
+        return {v: k for k, v in self.SHAPES.items()}[m]
 
     def prune_order(self, scores):
         """sort_token_no_order() alone: the visiting order the exact-order kernel derives for tokens with

@@ -56,6 +56,8 @@ def run(d: Path, args):
         bm = lib.Beam(eng, lx, beam, -1.0, max_utts=nutt, atoms_per_utt=1 << (18 if beam > 1600 else 17))
         if args.order:
             bm.set_order_mode(args.order)
+        if args.shape:
+            bm.set_workgroup_shape(args.shape)
         d_sc, off, maxlen = scores_of(nutt)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         best = 1e30
@@ -68,7 +70,7 @@ def run(d: Path, args):
                 best = min(best, ev[0].elapsed_time(ev[1]))
         res = bm.results()
         r = {"beam_ms": round(best, 3), "us_per_frame": round(best * 1e3 / maxlen, 2), "frames_per_s": round(int(off[-1]) / (best * 1e-3)),
-             "ok": int(sum(x.status == 0 for x in res)), "peak_tokens": int(res[0].max_tokens)}
+             "ok": int(sum(x.status == 0 for x in res)), "peak_tokens": int(res[0].max_tokens), "shape": bm.workgroup_shape(nutt)}
         if timed:
             r["phase_us_per_frame"] = [round(x / maxlen, 2) for x in res[0].phase_us]
         bm.close()
@@ -98,6 +100,8 @@ def run(d: Path, args):
         out["c3b"] = bench_case(800, 256, gmm_scores, False)
     if "c3c" in what:
         out["c3c"] = bench_case(800, 512, gmm_scores, False, reps=2)
+    if "c3d" in what:
+        out["c3d"] = bench_case(800, 1024, gmm_scores, False, reps=2)
     if "wide" in what:
         out["wide"] = bench_case(4000, 1, flat_scores, True, reps=2)
     if "wideb" in what:
@@ -113,6 +117,7 @@ if __name__ == "__main__":
     ap.add_argument("--tag", default=None)
     ap.add_argument("--what", default="c3,c3b,wide,wideb")
     ap.add_argument("--order", default=None)
+    ap.add_argument("--shape", default=None, help="auto | full | half (jamd_beam_set_workgroup_shape)")
     a = ap.parse_args()
     if a.cmd == "prepare":
         prepare(Path(a.dir))
