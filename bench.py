@@ -385,10 +385,15 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     # k runs on `s_beam` (it waits for its own step's scores, and a score buffer is rewritten only when the first pass
     # that read it is done).  With fewer utterances than CUs (configs[4] at N = 8: 64 per GPU, one workgroup each) the
     # scoring fills the idle CUs; with a full batch the two compete and the gain is a few percent.
+    # A batch that fills the device (one workgroup per CU in the full shape, two in the half shape) leaves the scoring
+    # kernels nothing to hide behind -- co-scheduled, their workgroups only take LDS the first pass wants for its second
+    # utterance per CU (measured: 512 utterances, first pass 200 ms alone, 413 ms under the pipeline) -- so such a step
+    # runs scoring and first pass back to back on one stream.
     s_score, s_beam = torch.cuda.Stream(), torch.cuda.Stream()
-    pipelined = not args.no_pipeline
+    num_cu = torch.cuda.get_device_properties(dd.local_rank).multi_processor_count
     out = {}
     for ri, (key, nutt, steps, warmup, scaling) in enumerate(runs):
+        pipelined = not args.no_pipeline and nutt < num_cu
         # the batch is a global list (utterance g = distinct utterance g % nuniq) dealt round-robin: rank r holds g = r + u * world
         utts = [uniq[(dd.rank + u * dd.world) % nuniq] for u in range(nutt)]
         off = np.zeros(nutt + 1, np.int32)
@@ -451,6 +456,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
                                         f"{nutt} utterances ({T} frames, {nuniq} distinct) per GPU per step",
                             "lexicon_built_by_reference": ref_built, "order_mode": mode, "beam": beam,
                             "utts_per_gpu": nutt, "utts_total": nutt_all,
+                            "workgroup_shape": bm.workgroup_shape(nutt) + (" (two utterances per CU)" if bm.workgroup_shape(nutt) == "half" else " (one utterance per CU)"),
                             "pipelined": "scoring of step k+1 on a second stream under the first pass of step k" if pipelined else "no"},
                  "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                               "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
@@ -563,7 +569,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--utts", type=int, default=None,
                     help="utterances per GPU per step (gmm/dnn: x1000 frames, default 64 = one GPU's share of the "
-                         "512-utterance batch of configs[4]; e2e: default 256)")
+                         "512-utterance batch of configs[4]; e2e: default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="e2e: scoring and first pass of every step on ONE stream (default: two streams, the scoring of step k+1 "
@@ -612,13 +618,17 @@ def main():
     if wl in ("all", "e2e"):
         # configs[2] weak (fixed utterances per GPU) and configs[4] strong (the fixed 512-utterance batch sharded over the
         # GPUs: 64 per GPU at N = 8, all 512 on one GPU at N = 1), same models, lexicon and utterances
-        per_gpu = pick(args.utts, 256)
+        # weak: 512 utterances per GPU per step -- two per CU, the exact-order kernel's half shape (throughput); the
+        # 256-utterance step of rounds 2-3 (one per CU, full shape: the latency-optimal launch) rides along as e2e_256
+        per_gpu = pick(args.utts, 512)
         strong_total = args.batch_total or C5_TOTAL_UTTS
         runs = []
         if wl == "all" or not args.strong:
-            runs.append(("e2e", per_gpu, pick(args.steps, 8), pick(args.warmup, 1), "weak"))
+            runs.append(("e2e", per_gpu, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
         if wl == "all" or args.strong:
             runs.append(("e2e_strong", max(1, strong_total // dd.world), pick(args.steps, 4), pick(args.warmup, 1), "strong"))
+        if not args.strong and args.utts is None:
+            runs.append(("e2e_256", 256, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
         r = run_e2e(args, dd, runs, use_dnn=False)
         if dd.rank == 0:
             if nested:

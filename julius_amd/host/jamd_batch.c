@@ -14,8 +14,8 @@
  * Every line of the file list names an HTK parameter file (what Julius reads with
  * `-input htkparam`: 12-byte big-endian header nSamples, sampPeriod, sampSize, parmKind, then
  * big-endian float vectors -- libsent/src/anlz/rdparam.c).  All utterances are scored and
- * decoded in device launches of up to 256 utterances (reading + scoring of launch k+1 overlap the
- * first pass of launch k on a second stream); one result line per utterance:
+ * decoded in device launches of up to 512 utterances (reading and uploading launch k+1 overlap the
+ * kernels of launch k); one result line per utterance:
  *   <file> status=<0 ok|1 no result|2 beam died|3 trellis overflow> score=<pass-1 score> words=<id id ...>
  * which is what get_back_trellis_end() leaves in r->pass1_wseq / pass1_score.
  */
@@ -60,17 +60,19 @@ static int read_htk(const char *path, int veclen, float **buf, size_t *used, siz
   return n;
 }
 
-/* one launch: up to 256 utterances, their frames on the host and on the device, their score rows */
-typedef struct { float *frames, *d_frames, *d_scores; int off[257], n; } chunk;
+/* One launch: up to LAUNCH utterances, their frames on the host and on the device, their score rows.  512 = two per CU
+ * of an MI355X: the exact-order first pass then runs in its half shape (jamd_beam_set_workgroup_shape(), automatic),
+ * the one with the most frames per second; beams too wide for it run the same launch one utterance per CU. */
+#define LAUNCH 512
+typedef struct { float *frames, *d_frames, *d_scores; int off[LAUNCH + 1], n; } chunk;
 
-/* reads the files of the launch that starts at files[first], uploads the frames and queues the scoring kernels on
- * `stream` (nothing is waited for) */
-static void load_and_score(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate,
-                           jamd_gmm *gm, jamd_dnn *dn, jamd_gms *gs, void *stream)
+/* reads the files of the launch that starts at files[first] and queues the upload of the frames on `stream` (nothing
+ * is waited for) */
+static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream)
 {
   size_t used = 0, cap = 0;
   int u;
-  c->n = nfile - first < 256 ? nfile - first : 256;
+  c->n = nfile - first < LAUNCH ? nfile - first : LAUNCH;
   c->frames = NULL; c->off[0] = 0;
   for (u = 0; u < c->n; u++) {
     const int t = read_htk(files[first + u], veclen, &c->frames, &used, &cap);
@@ -80,6 +82,12 @@ static void load_and_score(jamd_engine *e, chunk *c, char **files, int first, in
   if (jamd_malloc(e, sizeof(float) * used, (void **)&c->d_frames) != JAMD_OK ||
       jamd_malloc(e, sizeof(float) * (size_t)c->off[c->n] * nstate, (void **)&c->d_scores) != JAMD_OK ||
       jamd_memcpy_h2d_async(e, c->d_frames, c->frames, sizeof(float) * used, stream) != JAMD_OK) die("device buffers");
+}
+
+/* queues the scoring kernels of a loaded launch on `stream` */
+static void score(chunk *c, int nstate, jamd_gmm *gm, jamd_dnn *dn, jamd_gms *gs, void *stream)
+{
+  (void)nstate;
   if ((gm ? jamd_gmm_outprob_utts_dev(gm, c->d_frames, c->off, c->n, c->d_scores, stream)
           : jamd_dnn_outprob_dev(dn, c->d_frames, c->off[c->n], c->d_scores, stream)) != JAMD_OK) die("scoring");
   if (gs != NULL && jamd_gms_apply_dev(gs, c->d_frames, c->off[c->n], c->off, c->n, c->d_scores, stream) != JAMD_OK) die("Gaussian mixture selection");
@@ -93,7 +101,7 @@ int main(int argc, char **argv)
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first, k;
   chunk ck[2];
-  void *s_score = NULL, *s_beam = NULL;
+  void *s_copy = NULL, *s_beam = NULL;
   char line[4096];
   FILE *fl;
 
@@ -144,7 +152,7 @@ int main(int argc, char **argv)
     if (jamd_rejgmm_veclen(rj) != veclen) { fprintf(stderr, "jamd_batch: %s is for %d-dim input\n", rejp, jamd_rejgmm_veclen(rj)); return 1; }
   }
   if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
-  if (jamd_beam_create(e, lx, beam, bs, 256, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
+  if (jamd_beam_create(e, lx, beam, bs, LAUNCH, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
   if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
   if (!strict && order >= 0 && jamd_beam_set_order_mode(bm, order) != JAMD_OK) die("order mode");
 
@@ -159,21 +167,23 @@ int main(int argc, char **argv)
   }
   fclose(fl);
 
-  /* Launches of up to 256 utterances, pipelined over two streams: while the first pass of launch k runs on
-   * `s_beam` (one workgroup per utterance), the host reads the files of launch k+1 and `s_score` uploads and
-   * scores them -- the scoring kernels fill the CUs the first pass leaves idle. */
-  if (jamd_stream_create(e, &s_score) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
-  if (nfile > 0) load_and_score(e, &ck[0], files, 0, nfile, veclen, nstate, gm, dn, gs, s_score);
-  for (first = 0, k = 0; first < nfile; first += 256, k++) {
+  /* Launches of up to LAUNCH utterances over two streams: while launch k is scored and searched on `s_beam`, the host
+   * reads the files of launch k+1 and `s_copy` uploads them.  The kernels of consecutive launches stay in one stream:
+   * a launch fills the device, and scoring kernels co-scheduled with the first pass only take the LDS it wants for
+   * its second utterance per CU (measured: the first pass of 512 utterances takes twice as long under them). */
+  if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
+  if (nfile > 0) load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy);
+  for (first = 0, k = 0; first < nfile; first += LAUNCH, k++) {
     chunk *c = &ck[k & 1];
     const int n = c->n;
     const int *off = c->off;
     int u;
     float *us = NULL;
-    jamd_pass1_result res[256];
-    if (jamd_stream_wait(e, s_beam, s_score) != JAMD_OK) die("stream order");                  /* the scores of launch k */
+    static jamd_pass1_result res[LAUNCH];
+    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the frames of launch k */
+    score(c, nstate, gm, dn, gs, s_beam);
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
-    if (first + 256 < nfile) load_and_score(e, &ck[(k + 1) & 1], files, first + 256, nfile, veclen, nstate, gm, dn, gs, s_score);
+    if (first + LAUNCH < nfile) load(e, &ck[(k + 1) & 1], files, first + LAUNCH, nfile, veclen, nstate, s_copy);
     if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
     if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
       const int nm = jamd_rejgmm_nmodel(rj);
@@ -202,7 +212,7 @@ int main(int argc, char **argv)
     jamd_free(e, c->d_frames); jamd_free(e, c->d_scores); free(c->frames);
     c->d_frames = c->d_scores = NULL; c->frames = NULL;
   }
-  jamd_stream_destroy(e, s_score); jamd_stream_destroy(e, s_beam);
+  jamd_stream_destroy(e, s_copy); jamd_stream_destroy(e, s_beam);
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
   if (rj) jamd_rejgmm_destroy(rj);
   if (gs) jamd_gms_destroy(gs);
