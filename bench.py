@@ -388,12 +388,12 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     # A batch that fills the device (one workgroup per CU in the full shape, two in the half shape) leaves the scoring
     # kernels nothing to hide behind -- co-scheduled, their workgroups only take LDS the first pass wants for its second
     # utterance per CU (measured: 512 utterances, first pass 200 ms alone, 413 ms under the pipeline) -- so such a step
-    # runs scoring and first pass back to back on one stream.
+    # runs scoring and first pass back to back on one stream (stream priorities do not change the picture: 431 ms).
     s_score, s_beam = torch.cuda.Stream(), torch.cuda.Stream()
     num_cu = torch.cuda.get_device_properties(dd.local_rank).multi_processor_count
     out = {}
     for ri, (key, nutt, steps, warmup, scaling) in enumerate(runs):
-        pipelined = not args.no_pipeline and nutt < num_cu
+        pipelined = not args.no_pipeline and nutt <= num_cu
         # the batch is a global list (utterance g = distinct utterance g % nuniq) dealt round-robin: rank r holds g = r + u * world
         utts = [uniq[(dd.rank + u * dd.world) % nuniq] for u in range(nutt)]
         off = np.zeros(nutt + 1, np.int32)
