@@ -68,11 +68,13 @@ typedef struct { float *frames, *d_frames, *d_scores; int off[LAUNCH + 1], n; } 
 
 /* reads the files of the launch that starts at files[first] and queues the upload of the frames on `stream` (nothing
  * is waited for) */
+static int launch = LAUNCH;      /* -launch N: utterances per device launch (1 .. LAUNCH) */
+
 static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream)
 {
   size_t used = 0, cap = 0;
   int u;
-  c->n = nfile - first < LAUNCH ? nfile - first : LAUNCH;
+  c->n = nfile - first < launch ? nfile - first : launch;
   c->frames = NULL; c->off[0] = 0;
   for (u = 0; u < c->n; u++) {
     const int t = read_htk(files[first + u], veclen, &c->frames, &used, &cap);
@@ -123,6 +125,7 @@ int main(int argc, char **argv)
       else die("-order exact|fast|strict");
     }
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
+    else if (!strcmp(argv[i], "-launch") && i + 1 < argc) launch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
     else if (!strcmp(argv[i], "-gms") && i + 1 < argc) gmsp = argv[++i];
     else if (!strcmp(argv[i], "-rej") && i + 1 < argc) rejp = argv[++i];
@@ -131,9 +134,9 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
     else { fprintf(stderr, "jamd_batch: unknown option %s\n", argv[i]); return 2; }
   }
-  if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n) {
+  if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n || launch < 1 || launch > LAUNCH) {
     fprintf(stderr, "usage: jamd_batch (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
-                    "[-d dev] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N]\n");
+                    "[-d dev] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512]\n");
     return 2;
   }
   if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
@@ -173,7 +176,7 @@ int main(int argc, char **argv)
    * its second utterance per CU (measured: the first pass of 512 utterances takes twice as long under them). */
   if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
   if (nfile > 0) load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy);
-  for (first = 0, k = 0; first < nfile; first += LAUNCH, k++) {
+  for (first = 0, k = 0; first < nfile; first += launch, k++) {
     chunk *c = &ck[k & 1];
     const int n = c->n;
     const int *off = c->off;
@@ -183,7 +186,7 @@ int main(int argc, char **argv)
     if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the frames of launch k */
     score(c, nstate, gm, dn, gs, s_beam);
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
-    if (first + LAUNCH < nfile) load(e, &ck[(k + 1) & 1], files, first + LAUNCH, nfile, veclen, nstate, s_copy);
+    if (first + launch < nfile) load(e, &ck[(k + 1) & 1], files, first + launch, nfile, veclen, nstate, s_copy);
     if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
     if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
       const int nm = jamd_rejgmm_nmodel(rj);

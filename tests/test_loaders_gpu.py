@@ -115,6 +115,13 @@ def test_standalone_c_driver(oracle, tmp_path):
         assert f[0] == name and f[1] == "status=0"
         assert np.float32(float(f[2].split("=")[1])) == np.float32(utt["score"])
         assert [int(x) for x in f[3].split("=", 1)[1].split()] == list(utt["wseq"])
+    # several launches (reading + upload of launch k+1 under the kernels of launch k, two chunk buffers in turn), default
+    # order mode: the same lines
+    for per_launch in ("1", "2"):
+        again = subprocess.run([str(exe), "-am", str(tmp_path / "am.blob"), "-lex", str(tmp_path / "lex.blob"), "-filelist",
+                                str(tmp_path / "list"), "-b", str(g["beam_width"]), "-launch", per_launch],
+                               check=True, capture_output=True, text=True).stdout.strip().splitlines()
+        assert again == out
 
 
 @pytest.mark.parametrize("gms", [False, True])

@@ -1,13 +1,10 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r03r; mkdir -p $O
-for mode in serial pipe pipe_prio; do
-  case $mode in serial) E="";; pipe) E="JAMD_BENCH_FORCE_PIPE=1";; pipe_prio) E="JAMD_BENCH_FORCE_PIPE=1 JAMD_BENCH_PRIO=1";; esac
-  env $E timeout 600 python bench.py --workload e2e --utts 512 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/$mode.json
-  env $E timeout 600 python bench.py --workload e2e --utts 256 --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${mode}_256.json
-  python - <<PY
-import json
-for f in ("$mode","${mode}_256"):
-    r=json.load(open("gpurun_out/r03r/%s.json"%f)); print(f, round(r['ms_per_step'],1), 'score', round(r['roofline']['score_kernels_ms'],1), 'beam', round(r['roofline']['beam_kernel_ms'],1), r['config']['pipelined'][:8])
-PY
+O=gpurun_out/r03s; mkdir -p $O
+python tools/xbeam_lab.py prepare /tmp/xlab > /dev/null 2>&1
+for v in product uprobe product uprobe; do
+  if [ $v = product ]; then L=""; else L="--lib build/variants/$v.so"; fi
+  python tools/xbeam_lab.py run /tmp/xlab $L --tag $v --what c3,c3b,c3c 2>$O/err_$v.txt | tail -1 | tee -a $O/lab.json
 done
+JAMD_LIB=build/variants/uprobe.so timeout 600 python -m pytest tests/test_beam_gpu.py tests/test_half_shape_gpu.py tests/test_exact_fuzz_gpu.py -q -m gpu --maxfail=5 > $O/pytest_uprobe.txt 2>&1; echo "rc=$?" >> $O/pytest_uprobe.txt; tail -3 $O/pytest_uprobe.txt
+timeout 300 python -m pytest tests/test_loaders_gpu.py -q -m gpu > $O/pytest_loaders.txt 2>&1; tail -2 $O/pytest_loaders.txt
