@@ -605,6 +605,10 @@ class Beam:
         _check(load().jamd_beam_create(eng.h, lexicon.h, beam_width, score_pruning_width, max_utts,
                                        atoms_per_utt, C.byref(h)), "jamd_beam_create")
         self.h = h
+        # test knob: JAMD_TEST_SHAPE=half runs every work area that can in the half workgroup shape (the results must
+        # not depend on it), so the whole GPU suite can be replayed over that shape
+        if os.environ.get("JAMD_TEST_SHAPE") == "half":
+            load().jamd_beam_set_workgroup_shape(self.h, 2)
 
     def set_strict_order(self, on: bool = True):
         _check(load().jamd_beam_set_strict_order(self.h, 1 if on else 0), "jamd_beam_set_strict_order")

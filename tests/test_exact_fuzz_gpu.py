@@ -2,7 +2,8 @@
 tests/test_beam_oracle.py) on a sweep of small random tasks chosen to be FULL of exact score ties: few tied states
 (many lexicon branches score identically), quantised acoustic scores, beams from 1 to a few hundred so that the
 rank-pruning step goes through all of its forms (nothing pruned, sort_token_downward, sort_token_upward with the
-closed-form extraction, serial fallback), with and without a score beam.  The word trellis must be identical."""
+closed-form extraction, serial fallback), with and without a score beam, in both workgroup shapes.  The word trellis
+must be identical."""
 import numpy as np
 import pytest
 
@@ -12,8 +13,9 @@ from julius_amd import lexblob, lib, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("shape", ["full", "half"])
 @pytest.mark.parametrize("seed", range(12))
-def test_exact_kernel_vs_oracle_on_tie_heavy_tasks(engine, oracle, seed):
+def test_exact_kernel_vs_oracle_on_tie_heavy_tasks(engine, oracle, seed, shape):
     rng = np.random.default_rng(1000 + seed)
     nphone = int(rng.choice([4, 6, 10]))
     S = nphone * int(rng.choice([3, 6, 9]))
@@ -29,6 +31,8 @@ def test_exact_kernel_vs_oracle_on_tie_heavy_tasks(engine, oracle, seed):
         for width in (-1.0, float(rng.choice([30.0, 80.0]))):
             bm = lib.Beam(engine, lx, beam, width, max_utts=len(scores))
             assert bm.order_mode() == "exact"
+            bm.set_workgroup_shape(shape)              # both workgroup shapes of the kernel (julius_amd.h, JAMD_SHAPE_*)
+            assert bm.workgroup_shape(len(scores)) == shape
             res, tre = bm.pass1_host(scores)
             for sc, r, atoms in zip(scores, res, tre):
                 oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, width)

@@ -113,11 +113,11 @@ def test_full_size_half_vs_compiled_reference_and_auto_choice(engine, ref, tmp_p
     gm = lib.Gmm(engine, am)
     scores = [gm.outprob_host(fr) for fr in utts]
     lx = lib.Lexicon(engine, lex)
-    probe = lib.Beam(engine, lx, 800, -1.0, max_utts=1)
+    probe = lib.Beam(engine, lx, 800, -1.0, max_utts=1).set_workgroup_shape("auto")
     nbig = next(n for n in range(1, 1 << 14) if probe.workgroup_shape(n) == "half")   # 1.5 x CU count + 1
     probe.close()
     assert nbig > 64
-    bm = lib.Beam(engine, lx, 800, -1.0, max_utts=nbig, atoms_per_utt=1 << 16)
+    bm = lib.Beam(engine, lx, 800, -1.0, max_utts=nbig, atoms_per_utt=1 << 16).set_workgroup_shape("auto")
     assert bm.order_mode() == "exact"
     assert bm.workgroup_shape(nbig - 1) == "full" and bm.workgroup_shape(nbig) == "half"
     _half(bm)
