@@ -519,8 +519,9 @@ int  jamd_beam_order_mode(const jamd_beam *b);
  *       typical frame (beams up to about 1 000, a little more with few word-initial nodes); JAMD_ESTATE otherwise.
  *   JAMD_SHAPE_AUTO  (default) HALF for launches (and streaming sessions) of more than 1.5 x the CU count
  *       utterances when available, else FULL.
- * jamd_beam_workgroup_shape() tells which one a launch of nutt utterances would use.  A streaming session keeps
- * the shape it was opened with. */
+ * jamd_beam_workgroup_shape() tells which one a launch of nutt utterances would use in the exact order modes (the
+ * canonical-tie and strict-order kernels have one shape each and ignore the setting).  A streaming session keeps the
+ * shape it was opened with. */
 #define JAMD_SHAPE_AUTO 0
 #define JAMD_SHAPE_FULL 1
 #define JAMD_SHAPE_HALF 2
