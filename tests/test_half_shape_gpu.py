@@ -140,3 +140,41 @@ def test_full_size_half_vs_compiled_reference_and_auto_choice(engine, ref, tmp_p
         if u % 16 == 0:
             ca, cf = lexblob.canonical_trellis(tre_a[u]), lexblob.canonical_trellis(tre_f[u])
             assert all(np.array_equal(ca[k], cf[k]) for k in ca)
+
+
+def test_streaming_session_chooses_its_shape_once(engine, oracle):
+    """A streaming session of more utterances than 1.5 x the CU count opens in the half shape and keeps it for every
+    push (the parked state is the layout's); the results equal the one-shot call in the full shape."""
+    g = load_beam_golden("beam_score.npz")
+    base = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    S = base[0].shape[1]
+    lx = lib.Lexicon(engine, g["lex"])
+    probe = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=1).set_workgroup_shape("auto")
+    nbig = next(n for n in range(1, 1 << 14) if probe.workgroup_shape(n) == "half")
+    probe.close()
+    scores = [base[u % len(base)][:len(base[u % len(base)]) - (u * 3) % 17] for u in range(nbig)]
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=nbig).set_workgroup_shape("auto")
+    assert bm.workgroup_shape(nbig) == "half"
+    bm.stream_begin(nbig)
+    pos = [0] * nbig
+    while True:
+        take = [min(23 + u % 5, len(sc) - p) for u, (sc, p) in enumerate(zip(scores, pos))]
+        final = all(p + k >= len(sc) for sc, p, k in zip(scores, pos, take))
+        rows = np.concatenate([sc[p:p + k] for sc, p, k in zip(scores, pos, take)])
+        off = np.zeros(nbig + 1, np.int32)
+        off[1:] = np.cumsum(take)
+        pos = [p + k for p, k in zip(pos, take)]
+        d = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(d.ptr, S, off, final=final)
+        d.free()
+        if final:
+            break
+    res_s = bm.results(nbig)
+    tre_s = [bm.trellis(u) for u in range(0, nbig, 37)]
+    bm.set_workgroup_shape("full")
+    res_f, tre_f = bm.pass1_host(scores)
+    for u in range(nbig):
+        a, f = res_s[u], res_f[u]
+        assert (a.status, a.natom, a.wnum, a.score, a.frames) == (f.status, f.natom, f.wnum, f.score, f.frames)
+    for i, u in enumerate(range(0, nbig, 37)):
+        assert_trellis_equal(tre_s[i], lexblob.canonical_trellis(tre_f[u]))
