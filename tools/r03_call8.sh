@@ -1,4 +1,5 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r03ab; mkdir -p $O
-timeout 600 python -m pytest tests/test_half_shape_gpu.py tests/test_exact_fuzz_gpu.py -q -m gpu > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -12 $O/pytest.txt
+O=gpurun_out/r03ad; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; echo "rc=$?" >> $O/gpu_tests.txt; tail -3 $O/gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
