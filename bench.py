@@ -385,15 +385,17 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     # k runs on `s_beam` (it waits for its own step's scores, and a score buffer is rewritten only when the first pass
     # that read it is done).  With fewer utterances than CUs (configs[4] at N = 8: 64 per GPU, one workgroup each) the
     # scoring fills the idle CUs; with a full batch the two compete and the gain is a few percent.
-    # A batch that fills the device (one workgroup per CU in the full shape, two in the half shape) leaves the scoring
-    # kernels nothing to hide behind -- co-scheduled, their workgroups only take LDS the first pass wants for its second
-    # utterance per CU (measured: 512 utterances, first pass 200 ms alone, 413 ms under the pipeline) -- so such a step
-    # runs scoring and first pass back to back on one stream (stream priorities do not change the picture: 431 ms).
+    # The first pass wants whole CUs (full shape) or half CUs (half shape: two workgroups per CU, all of the LDS).  Queued
+    # next to it, the scoring workgroups of step k+1 take LDS its workgroups are waiting for (measured: 512 utterances,
+    # first pass 200 ms alone, 413 ms; 64 utterances 128 vs 137 ms; stream priorities do not change the picture).  So the
+    # host releases the scoring of step k+1 only once the first pass of step k is running (jamd_beam_wait_started() + 1 ms
+    # for its workgroups to be placed): the scoring then fills the CUs the first pass does not use or that its shorter
+    # utterances leave -- 512 utterances: 304 ms per step against 321 ms with both kernels in one stream.
     s_score, s_beam = torch.cuda.Stream(), torch.cuda.Stream()
-    num_cu = torch.cuda.get_device_properties(dd.local_rank).multi_processor_count
     out = {}
     for ri, (key, nutt, steps, warmup, scaling) in enumerate(runs):
-        pipelined = not args.no_pipeline and nutt <= num_cu
+        pipelined = not args.no_pipeline
+        tailfill = pipelined
         # the batch is a global list (utterance g = distinct utterance g % nuniq) dealt round-robin: rank r holds g = r + u * world
         utts = [uniq[(dd.rank + u * dd.world) % nuniq] for u in range(nutt)]
         off = np.zeros(nutt + 1, np.int32)
@@ -416,6 +418,9 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
             b = count[0] % nbuf
             count[0] += 1
             s_score.wait_event(consumed[b])
+            if tailfill:
+                bm.wait_started()                               # the previous step's first pass is next to run ...
+                time.sleep(1e-3)                                # ... and has its workgroups on the CUs
             if mark:
                 mark[0].record(s_score)
             scorer.outprob_dev(d_fr.data_ptr(), T, d_scs[b].data_ptr(), s_score.cuda_stream)
@@ -457,7 +462,8 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
                             "lexicon_built_by_reference": ref_built, "order_mode": mode, "beam": beam,
                             "utts_per_gpu": nutt, "utts_total": nutt_all,
                             "workgroup_shape": bm.workgroup_shape(nutt) + (" (two utterances per CU)" if bm.workgroup_shape(nutt) == "half" else " (one utterance per CU)"),
-                            "pipelined": "scoring of step k+1 on a second stream under the first pass of step k" if pipelined else "no"},
+                            "pipelined": ("scoring of step k+1 on a second stream, released once the first pass of step k is running (it fills the CUs "
+                                          "the first pass leaves)" if pipelined else "no")},
                  "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                               "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
                                       "is frames/s of the first pass over the batch",

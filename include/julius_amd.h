@@ -527,6 +527,13 @@ int  jamd_beam_order_mode(const jamd_beam *b);
 #define JAMD_SHAPE_HALF 2
 int  jamd_beam_set_workgroup_shape(jamd_beam *b, int shape);
 int  jamd_beam_workgroup_shape(const jamd_beam *b, int nutt);
+/* Blocks the host until everything queued ahead of the latest first-pass launch of this work area has completed, i.e.
+ * until that kernel is next to run (returns at once when nothing was launched).  For hosts that pipeline batches: a
+ * first pass that fills the device (one or two workgroups per CU, all of a CU's LDS) must get its workgroups placed
+ * before the scoring kernels of the NEXT batch are queued on another stream -- queued earlier they take the LDS the
+ * first pass wants, and the first pass of 512 utterances takes twice as long; queued once it runs they only fill the
+ * CUs its shorter utterances leave (julius_amd/host/jamd_batch.c, bench.py: -5 % per step). */
+int  jamd_beam_wait_started(jamd_beam *b);
 /* The rank-pruning step alone (sort_token_no_order(), beam.c:1492): given the scores of the n tokens of
  * a frame in creation order (host array), writes the token indices the next frame visits, in visiting
  * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the

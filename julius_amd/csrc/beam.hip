@@ -1293,6 +1293,7 @@ struct jamd_beam {
   int half_status = -2;            // 0 = xw_half is usable
   int shape_mode = JAMD_SHAPE_AUTO;
   bool stream_half = false;        // the shape of the open streaming session (the parked state is the layout's)
+  hipEvent_t ev_started = nullptr; // recorded right before the latest first-pass launch (jamd_beam_wait_started())
   unsigned *d_pkeys = nullptr; int *d_pout = nullptr; size_t pcap = 0;   // jamd_beam_prune_order() scratch
   bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
@@ -1337,6 +1338,14 @@ static int upload_utt_off(jamd_beam *b, const int *utt_off, int nutt, hipStream_
   if (nutt > b->eng->num_cu)       // (one round: every workgroup starts at once, the order is irrelevant)
     std::stable_sort(order, order + nutt, [&](int a, int c) { return utt_off[a + 1] - utt_off[a] > utt_off[c + 1] - utt_off[c]; });
   JAMD_HIP(hipMemcpyAsync(b->d_utt_off, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
+  return JAMD_OK;
+}
+
+// An event behind everything the launch stream holds before the first-pass kernel: it completes when that kernel is
+// next to run (jamd_beam_wait_started()).
+static int mark_started(jamd_beam *b, hipStream_t st) {
+  if (!b->ev_started) JAMD_HIP(hipEventCreateWithFlags(&b->ev_started, hipEventDisableTiming));
+  JAMD_HIP(hipEventRecord(b->ev_started, st));
   return JAMD_OK;
 }
 
@@ -1637,6 +1646,7 @@ void jamd_beam_destroy(jamd_beam *b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
   for (void *p : b->owned) (void)hipFree(p);
+  if (b->ev_started) (void)hipEventDestroy(b->ev_started);
   delete b;
 }
 
@@ -1658,6 +1668,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
   if (b->lex->multipath && !b->strict) {
     jamd_set_error("jamd_beam_pass1_dev: a multipath lexicon is decoded by the strict-order kernel only: "
                    "jamd_beam_set_strict_order(b, 1)");
@@ -1732,6 +1743,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, chunk_off, nutt, st); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
   if (b->exact) {
     b->xw.w.stream = b->w.stream; b->xw_half.w.stream = b->w.stream;
     xbeam_launch(b->lex->d, b->stream_half ? b->xw_half : b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
@@ -1804,6 +1816,14 @@ int jamd_beam_set_workgroup_shape(jamd_beam *b, int shape) {
     return JAMD_ESTATE;
   }
   b->shape_mode = shape;
+  return JAMD_OK;
+}
+
+int jamd_beam_wait_started(jamd_beam *b) {
+  if (!b) { jamd_set_error("jamd_beam_wait_started: NULL"); return JAMD_EINVAL; }
+  if (!b->ev_started) return JAMD_OK;                  // nothing launched yet
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  JAMD_HIP(hipEventSynchronize(b->ev_started));
   return JAMD_OK;
 }
 

@@ -14,8 +14,8 @@
  * Every line of the file list names an HTK parameter file (what Julius reads with
  * `-input htkparam`: 12-byte big-endian header nSamples, sampPeriod, sampSize, parmKind, then
  * big-endian float vectors -- libsent/src/anlz/rdparam.c).  All utterances are scored and
- * decoded in device launches of up to 512 utterances (reading and uploading launch k+1 overlap the
- * kernels of launch k); one result line per utterance:
+ * decoded in device launches of up to 512 utterances (reading, uploading and -- in the CUs its shorter
+ * utterances leave -- scoring launch k+1 overlap the first pass of launch k); one result line per utterance:
  *   <file> status=<0 ok|1 no result|2 beam died|3 trellis overflow> score=<pass-1 score> words=<id id ...>
  * which is what get_back_trellis_end() leaves in r->pass1_wseq / pass1_score.
  */
@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "julius_amd.h"
 
 static void die(const char *what)
@@ -170,12 +171,13 @@ int main(int argc, char **argv)
   }
   fclose(fl);
 
-  /* Launches of up to LAUNCH utterances over two streams: while launch k is scored and searched on `s_beam`, the host
-   * reads the files of launch k+1 and `s_copy` uploads them.  The kernels of consecutive launches stay in one stream:
-   * a launch fills the device, and scoring kernels co-scheduled with the first pass only take the LDS it wants for
-   * its second utterance per CU (measured: the first pass of 512 utterances takes twice as long under them). */
+  /* Launches of up to LAUNCH utterances over two streams: `s_copy` uploads and scores, `s_beam` searches.  While the
+   * first pass of launch k runs, the host reads the files of launch k+1, uploads them and -- once that first pass is
+   * on the device (jamd_beam_wait_started(): queued any earlier, the scoring workgroups take the LDS the first pass
+   * wants for its second utterance per CU and it takes twice as long) -- queues their scoring, which fills the CUs
+   * that the shorter utterances of launch k leave. */
   if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
-  if (nfile > 0) load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy);
+  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy); score(&ck[0], nstate, gm, dn, gs, s_copy); }
   for (first = 0, k = 0; first < nfile; first += launch, k++) {
     chunk *c = &ck[k & 1];
     const int n = c->n;
@@ -183,10 +185,15 @@ int main(int argc, char **argv)
     int u;
     float *us = NULL;
     static jamd_pass1_result res[LAUNCH];
-    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the frames of launch k */
-    score(c, nstate, gm, dn, gs, s_beam);
+    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch k */
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
-    if (first + launch < nfile) load(e, &ck[(k + 1) & 1], files, first + launch, nfile, veclen, nstate, s_copy);
+    if (first + launch < nfile) {
+      chunk *nx = &ck[(k + 1) & 1];
+      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy);
+      if (jamd_beam_wait_started(bm) != JAMD_OK) die("first pass");
+      { struct timespec ms = {0, 1000000}; nanosleep(&ms, NULL); }            /* its workgroups are on the CUs by now */
+      score(nx, nstate, gm, dn, gs, s_copy);
+    }
     if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
     if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
       const int nm = jamd_rejgmm_nmodel(rj);

@@ -133,6 +133,7 @@ def load():
         "jamd_beam_order_mode": (ci, [vp]),
         "jamd_beam_set_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_workgroup_shape": (ci, [vp, ci]),
+        "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
@@ -636,6 +637,10 @@ class Beam:
     def workgroup_shape(self, nutt: int = 1) -> str:
         m = load().jamd_beam_workgroup_shape(self.h, nutt)
         return {v: k for k, v in self.SHAPES.items()}[m]
+
+    def wait_started(self):
+        """Host waits until the latest first-pass launch is next to run (jamd_beam_wait_started)."""
+        _check(load().jamd_beam_wait_started(self.h), "jamd_beam_wait_started")
 
     def prune_order(self, scores):
         """sort_token_no_order() alone: the visiting order the exact-order kernel derives for tokens with

@@ -178,3 +178,25 @@ def test_streaming_session_chooses_its_shape_once(engine, oracle):
         assert (a.status, a.natom, a.wnum, a.score, a.frames) == (f.status, f.natom, f.wnum, f.score, f.frames)
     for i, u in enumerate(range(0, nbig, 37)):
         assert_trellis_equal(tre_s[i], lexblob.canonical_trellis(tre_f[u]))
+
+
+def test_wait_started(engine, oracle):
+    """jamd_beam_wait_started(): returns at once before any launch, and after a launch once the kernel is next to run;
+    the results are untouched by it."""
+    g = load_beam_golden("beam_rank.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    bm.wait_started()
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    S = scores[0].shape[1]
+    off = np.zeros(len(scores) + 1, np.int32)
+    off[1:] = np.cumsum([len(x) for x in scores])
+    allsc = np.ascontiguousarray(np.concatenate(scores), np.float32)
+    d = lib.DevBuf(engine, allsc.nbytes).upload(allsc)
+    bm.pass1_dev(d.ptr, S, off)
+    bm.wait_started()
+    res = bm.results()
+    for u, r in enumerate(res):
+        assert r.status == 0 and r.score == g["utts"][u]["score"]
+        assert_trellis_equal(bm.trellis(u), g["utts"][u]["trellis"])
+    d.free()
