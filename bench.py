@@ -50,6 +50,13 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), round robin in creation
+# order; two streams that land on the same queue run their kernels one after the other.  The end-to-end steps rely on the
+# scoring stream and the first-pass stream being concurrent, and this process creates more than four streams by then
+# (measured: nested in the default run the two kernels serialised, 317 ms per step against 304 ms stand-alone).  Read
+# when the runtime initialises, so it is set before anything touches HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 S, M, D = 3000, 16, 39
 FRAMES_PER_UTT = 1000
 LAUNCHES_PER_STEP = 12         # C2: one step = 12 sub-batches of --utts utterances (>= 100 ms of kernel time per step)

@@ -140,6 +140,7 @@ int main(int argc, char **argv)
                     "[-d dev] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512]\n");
     return 2;
   }
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* the upload/scoring stream and the first-pass stream must not share a hardware queue */
   if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
   if (jamd_engine_create(device, &e) != JAMD_OK) die("engine");
   if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }

@@ -1,10 +1,11 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r03ag; mkdir -p $O
-for n in 256 64; do for m in 1 100000; do
-  JAMD_BENCH_TF_MIN=$m timeout 600 python bench.py --workload e2e --utts $n --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/u${n}_m$m.json
-  python - <<PY
+O=gpurun_out/r03ah; mkdir -p $O
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+python - <<'PY'
 import json
-r=json.load(open("gpurun_out/r03ag/u${n}_m$m.json")); print("utts $n tf_min $m", round(r['ms_per_step'],1), 'score', round(r['roofline']['score_kernels_ms'],1), 'beam', round(r['roofline']['beam_kernel_ms'],1))
+j=json.load(open("gpurun_out/r03ah/bench_default.json"))
+print("C2", round(j["ms_per_step"],1), j["roofline"]["frac"])
+for k in ("e2e","e2e_strong","e2e_256","e2e_dnn","dnn"):
+    v=j[k]; print(k, "ms/step", round(v["ms_per_step"],1), "rtf_inv", round(v["rtf_inv"]), 'score', v["roofline"].get("score_kernels_ms"), 'beam', v["roofline"].get("beam_kernel_ms"), v["roofline"].get("frac"), v.get("parity",{}).get("device_vs_compiled_reference",{}).get("trellis_identical"))
 PY
-done; done
