@@ -91,7 +91,12 @@ int  jamd_memcpy_d2h(jamd_engine *e, void *host, const void *dev, size_t bytes);
  * driver scores input k+1 on one stream while the first pass of input k runs on another -- the first pass keeps
  * one workgroup per utterance busy, the scoring kernels fill whatever CUs that leaves (host/jamd_batch.c).
  * jamd_stream_wait(): everything submitted to `waiter` after the call starts only when everything submitted to
- * `signaler` before the call is done (an event record + wait; NULL = the engine's own stream). */
+ * `signaler` before the call is done (an event record + wait; NULL = the engine's own stream).
+ * Two things such a driver has to know: (1) the first pass must be ON the device before the next input's scoring is
+ * queued (jamd_beam_wait_started() below), or the scoring workgroups take the LDS it is waiting for; (2) the ROCm
+ * runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams
+ * on one queue run one after the other -- a process that creates many streams raises that limit before its first HIP
+ * call (jamd_batch and bench.py set 16). */
 int  jamd_stream_create(jamd_engine *e, void **stream);
 int  jamd_stream_destroy(jamd_engine *e, void *stream);
 int  jamd_stream_wait(jamd_engine *e, void *waiter, void *signaler);
