@@ -328,12 +328,13 @@ int jamd_pass1_prefetch_run(RecogProcess *r)
   const int keep = !r->config->compute_only_1pass && getenv("JAMD_NO_CACHE_FILL") == NULL;
   int first = 0, rc = JAMD_OK, nrun = 0;
   if (c == NULL || c->beam == NULL) return JAMD_EINVAL;
-  while (first < c->npre) {                           /* launches of <= 256 utterances / 2^18 frames */
+  while (first < c->npre) {                           /* launches of <= 512 utterances (two per CU: the exact-order kernel's
+                                                       * half shape, jamd_beam_set_workgroup_shape()) / 2^20 frames */
     int n = 0; size_t fr = 0;
     if (c->pre[first].done != 0) { first++; continue; }
-    while (first + n < c->npre && c->pre[first + n].done == 0 && n < 256 &&
+    while (first + n < c->npre && c->pre[first + n].done == 0 && n < 512 &&
            c->pre[first + n].veclen == c->pre[first].veclen &&
-           (n == 0 || fr + (size_t)c->pre[first + n].T <= ((size_t)1 << 18))) { fr += (size_t)c->pre[first + n].T; n++; }
+           (n == 0 || fr + (size_t)c->pre[first + n].T <= ((size_t)1 << 20))) { fr += (size_t)c->pre[first + n].T; n++; }
     if (prefetch_chunk(c, r, first, n, keep) != JAMD_OK) rc = JAMD_EINVAL;
     first += n; nrun += n;
   }
