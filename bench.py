@@ -348,7 +348,7 @@ def trellis_diff(a, b):
     return int(diff + (~same).sum())
 
 
-def run_e2e(args, dd: Dist, runs, use_dnn=False):
+def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
     """configs[2] (GMM) / configs[3] (DNN) end to end on the device: acoustic scores -> exact-order first pass.
     `runs` = list of (key, utterances per GPU, steps, warmup, scaling): every run shares the models, the lexicon and the
     distinct utterances; the FIRST run carries the parity block and the CPU baseline.  Returns {key: result}."""
@@ -358,7 +358,9 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     tmp = tempfile.TemporaryDirectory(prefix="jamd_e2e_")
     wd = Path(tmp.name)
     beam = args.beam if args.beam else (4000 if use_dnn else 800)
-    dnn = synth.make_dnn(seed=0) if use_dnn else None
+    # C4: a network whose posteriors are peaked on the state a frame was drawn from (synth.make_decodable_dnn: the first
+    # pass ends in a sentence), or -- flat=True, the worst case for the rank pruning step -- random-init weights over noise
+    dnn = (synth.make_dnn(seed=0) if flat else synth.make_decodable_dnn(seed=0)) if use_dnn else None
     NS = int(dnn["dims"][-1]) if use_dnn else S
     task, jargs, prefix = build_reference_task(wd, args.nword, beam, dnn)
     ref_built = prefix is not None
@@ -374,11 +376,15 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False):
     maxu = max(r[1] for r in runs)
     ndist = max(1, min(maxu, args.distinct))
     if use_dnn:
-        # random-init weights (there are no trained ones offline): the scores carry no sentence, the beam is saturated
         scorer = lib.Dnn.from_dnnconf(eng, task["dnnconf"]) if ref_built else lib.Dnn(eng, dnn)
-        rng = np.random.default_rng(1000)
-        uniq = [rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32) for _ in range(min(ndist, 16))]
-        what = f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob"
+        if flat:    # random-init weights over noise: the scores carry no sentence, every frame saturates the beam
+            rng = np.random.default_rng(1000)
+            uniq = [rng.normal(0, 1, (FRAMES_PER_UTT, int(dnn["dims"][0]))).astype(np.float32) for _ in range(min(ndist, 16))]
+        else:
+            uniq = [synth.make_dnn_utterance(task, dnn, nwords=30, seed=u)[0] for u in range(min(ndist, 16))]
+        what = (f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob, "
+                + ("random-init weights over noise frames (flat scores: no sentence, worst case of the rank pruning step)" if flat
+                   else "nearest-centroid output layer over random hidden layers (peaked posteriors), frames drawn along word sequences"))
     else:
         scorer = lib.Gmm.from_file(eng, str(prefix) + ".am") if ref_built else lib.Gmm(eng, task["model"])
         uniq = [synth.make_utterance(task, nwords=30, seed=u)[0] for u in range(ndist)]
@@ -597,6 +603,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="e2e: run configs[4] as specified -- the FIXED batch of --batch-total utterances sharded over the GPUs "
                          "(strong scaling) -- instead of --utts utterances per GPU")
+    ap.add_argument("--flat", action="store_true",
+                    help="e2e-dnn: the flat-score stream (random-init weights over noise frames: nothing decodes, every frame "
+                         "saturates the beam) instead of the input that decodes")
     ap.add_argument("--batch-total", type=int, default=None, help="e2e --strong: utterances in the fixed batch (default 512)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
     ap.add_argument("--distinct", type=int, default=32, help="e2e: distinct utterances in the batch")
@@ -651,14 +660,27 @@ def main():
                 for k in list(r)[1:]:
                     line[k] = r[k]
     if wl in ("all", "e2e-dnn"):
-        # configs[3] end to end at the reference recipe's beam (-b 4000), reference-built lexicon, parity vs julius -1pass
-        runs = [("e2e_dnn", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")]
-        r = run_e2e(args, dd, runs, use_dnn=True)
+        # configs[3] end to end at the reference recipe's beam (-b 4000), reference-built lexicon, parity vs julius -1pass:
+        # the input that decodes (weak line + the configs[4] strong line), then the flat-score stream of round 3 as the
+        # labelled worst case of the rank pruning step
+        strong_total = args.batch_total or C5_TOTAL_UTTS
+        runs = []
+        if wl == "all" or not (args.strong or args.flat):
+            runs.append(("e2e_dnn", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak"))
+        if wl == "all" or (args.strong and not args.flat):
+            runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 2), pick(args.warmup, 1), "strong"))
+        r = run_e2e(args, dd, runs, use_dnn=True) if runs else {}
+        if wl == "all" or args.flat:
+            r.update(run_e2e(args, dd, [("e2e_dnn_flat", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
+                             use_dnn=True, flat=True))
         if dd.rank == 0:
             if nested:
                 line.update(r)
             else:
-                line = top(r["e2e_dnn"])
+                ks = list(r)
+                line = top(r[ks[0]])
+                for k in ks[1:]:
+                    line[k] = r[k]
     if wl in ("all", "dnn"):
         a = argparse.Namespace(**vars(args))
         a.utts = pick(args.utts, 64)

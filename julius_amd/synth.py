@@ -213,6 +213,80 @@ def make_dnn(dims=(528, 2048, 2048, 2048, 2048, 2048, 2048, 4000), seed=0):
     return dict(dims=np.asarray(dims, dtype=np.int32), w=w, b=b, prior=prior, prior_lin=p)
 
 
+def _dnn_hidden(dnn, x):
+    """The hidden layers of dnn_calc_outprob() (calc_dnn.c:837-845) in numpy: h = logistic(W h + b)."""
+    h = np.asarray(x, dtype=np.float32)
+    for w, b in zip(dnn["w"][:-1], dnn["b"][:-1]):
+        h = h @ w.T + b
+        h = (1.0 / (1.0 + np.exp(-np.clip(h, -8.0, 8.0)))).astype(np.float32)
+    return h
+
+
+def make_decodable_dnn(dims=(528, 2048, 2048, 2048, 2048, 2048, 2048, 4000), seed=0, gain=2.5, sharp=20.0):
+    """A DNN of the ENVR-v5.4 shape whose posteriors are PEAKED on the state a frame was drawn from, without a
+    training loop (there are no trained weights offline): random hidden layers, and an output layer that is the
+    nearest-centroid classifier over the last hidden layer's activations of one centre input per state --
+    logit_c(h) = a (z_c . (h - mu) - |z_c|^2 / 2) with z_c = h(centre_c) - mu, i.e. -a/2 |h - h(centre_c)|^2 + const(h),
+    `a` chosen so that the mean squared distance between two centres is worth `sharp` log10 units.  A frame
+    centre[c] + noise then scores state c near 0 and the other states tens of log10 units below, the way a trained
+    acoustic model does: the first pass over these scores ends in a sentence (configs[3] with an input that decodes;
+    README.md:104-127 of the reference shows the recipe on a real model).  `gain` scales the hidden weights
+    (N(0, gain / sqrt(in))): at gain 1 six logistic layers contract every input onto nearly one point.
+    Returns make_dnn()'s dict plus `centre[S][dims[0]]`."""
+    rng = np.random.default_rng(seed)
+    dims = [int(d) for d in dims]
+    w, b = [], []
+    for l in range(len(dims) - 2):
+        w.append((gain * rng.standard_normal((dims[l + 1], dims[l])) / np.sqrt(dims[l])).astype(np.float32))
+        b.append((0.1 * rng.standard_normal(dims[l + 1])).astype(np.float32))
+    # hidden layers l >= 1 see logistic outputs (mean 1/2): centre their pre-activations so they stay in the steep part
+    for l in range(1, len(w)):
+        b[l] = (b[l] - 0.5 * w[l].sum(axis=1)).astype(np.float32)
+    S = dims[-1]
+    centre = rng.standard_normal((S, dims[0])).astype(np.float32)
+    dnn = dict(dims=np.asarray(dims, dtype=np.int32), w=w + [None], b=b + [None])
+    H = _dnn_hidden(dnn, centre).astype(np.float64)
+    mu = H.mean(axis=0)
+    Z = H - mu
+    # mean squared distance between two centres in the last hidden layer = 2 * mean |z|^2 (the z are centred)
+    msd = 2.0 * float((Z * Z).sum(axis=1).mean())
+    a = sharp * np.log(10.0) * 2.0 / msd
+    dnn["w"][-1] = (a * Z).astype(np.float32)
+    dnn["b"][-1] = (-a * ((Z * Z).sum(axis=1) * 0.5 + Z @ mu)).astype(np.float32)
+    p = rng.dirichlet(np.full(S, 5.0)).astype(np.float32)
+    dnn.update(prior=np.log10(p.astype(np.float64)).astype(np.float32), prior_lin=p, centre=centre)
+    return dnn
+
+
+def word_state_path(task, ws, rng):
+    """The emitting states of silB + words `ws` + silE through the task's own models: every phone becomes the logical
+    triphone l-c+r of its neighbours (across word boundaries, silB / silE at the ends), mapped by the HMMList to its
+    physical model's three states; a triphone the HMMList leaves out (make_triphone_task's defined_frac: the
+    pseudo-phone sets of libsent/src/hmminfo/cdset.c serve it) takes some variant of its centre phone."""
+    phys, logical = task["phys"], task["logical"]
+    ph = ["silB"] + [p for _, pp in ws for p in pp] + ["silE"]
+    seq = list(phys["silB"])
+    for i in range(1, len(ph) - 1):
+        name = logical.get(f"{ph[i - 1]}-{ph[i]}+{ph[i + 1]}")
+        if name is None:
+            var = sorted(k for k in phys if k.startswith(ph[i] + "_v"))
+            name = var[int(rng.integers(0, len(var)))]
+        seq += list(phys[name])
+    return seq + list(phys["silE"])
+
+
+def make_dnn_utterance(task, dnn, nwords=30, seed=0, frames_per_state=3, noise=0.5):
+    """An utterance for the DNN-HMM task: frames in the network's INPUT space (one dims[0]-vector per frame, the
+    form `-input htkparam` hands to dnn_calc_outprob(): parvec[t] is the spliced vector already, calc_dnn.c:800-803)
+    drawn around the centres of the states of a random word sequence taken through the task's own triphone models
+    (word_state_path), `frames_per_state` frames each.  Returns (frames, words)."""
+    rng = np.random.default_rng(seed)
+    ws = [task["words"][int(i)] for i in rng.integers(0, len(task["words"]), size=nwords)]
+    st = np.repeat(np.array(word_state_path(task, ws, rng)), frames_per_state)
+    fr = dnn["centre"][st] + rng.normal(0, noise, size=(len(st), dnn["centre"].shape[1]))
+    return fr.astype(np.float32), [w for w, _ in ws]
+
+
 def write_npy(path, a):
     """NPY v1 '<f4' C-order, the only form load_npy() accepts (calc_dnn.c:225-335)."""
     np.save(path, np.ascontiguousarray(a, dtype="<f4"))
@@ -357,7 +431,8 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
                 f.write(f"{-rng.uniform(0.2, 2.0):.6f}\t{vocab[j]} {vocab[i]} {vocab[k]}\n")
             f.write("\n\\end\\\n")
     return dict(dir=workdir, hmmdefs=workdir / "hmmdefs", hmmlist=workdir / "hmmlist", dict=workdir / "dict",
-                arpa=workdir / "lm.arpa", arpa_rl=rl, model=model, words=words, vocab=vocab, phones=phones)
+                arpa=workdir / "lm.arpa", arpa_rl=rl, model=model, words=words, vocab=vocab, phones=phones,
+                phys=dict(phys), logical=dict(ln.split() for ln in lines))
 
 
 def make_utterance(task, nwords=6, seed=0, frames_per_state=3, noise=0.7):
