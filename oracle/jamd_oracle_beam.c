@@ -16,6 +16,7 @@
  * Parity status: PINNED against the compiled reference (oracle/_ref) by
  * tests/test_beam_oracle.py and the fixtures under tests/golden/.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "jamd_oracle.h"
@@ -186,9 +187,26 @@ static void sort_token_downward(beam *b, int neednum, int totalnum)
     SD(parent) = s;
   }
 }
+/* Test tooling: with JAMD_ORACLE_DUMP_SORT=<file> every call appends (n, neednum, n scores in tindex order) -- real
+ * inputs of the rank pruning step for tools/prune_lab.py and the device fuzz tests. */
+static void dump_sort_input(beam *b, int neednum, int totalnum)
+{
+  static const char *path = NULL; static int asked = 0;
+  if (!asked) { path = getenv("JAMD_ORACLE_DUMP_SORT"); asked = 1; }
+  if (path && totalnum > neednum) {
+    FILE *f = fopen(path, "ab");
+    if (f) {
+      int i, hdr[2]; hdr[0] = totalnum; hdr[1] = neednum;
+      fwrite(hdr, sizeof(int), 2, f);
+      for (i = 0; i < totalnum; i++) fwrite(&b->tlist[b->tn][b->tindex[b->tn][i]].score, sizeof(float), 1, f);
+      fclose(f);
+    }
+  }
+}
 static void sort_token_no_order(beam *b, int neednum)   /* :1492 */
 {
   int totalnum = b->tnum[b->tn], restnum = totalnum - neednum;
+  dump_sort_input(b, neednum, totalnum);
   if (neednum >= totalnum) { b->n_start = 0; b->n_end = totalnum - 1; }
   else if (neednum < restnum) { sort_token_upward(b, neednum, totalnum); b->n_start = totalnum - neednum; b->n_end = totalnum - 1; }
   else { sort_token_downward(b, restnum, totalnum); b->n_start = 0; b->n_end = neednum - 1; }
