@@ -1603,6 +1603,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       place(&xw.o_bitmap, (bits + 31) / 32 * 4);
       place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
       place(&xw.o_collect, ((size_t)beam_width + 256) * 16);
+      place(&xw.o_sweep, xbeam_sweep_bytes(beam_width));
     }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
@@ -1631,7 +1632,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       XWork &xh = b->xw_half;
       const int svh = xh.w.sv_bytes;
       xh.w = w; xh.w.sv_bytes = svh;
-      xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect;
+      xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect; xh.o_sweep = b->xw.o_sweep;
     }
     if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
   }
@@ -1846,8 +1847,8 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
     void *p = nullptr;
     const size_t cap = ((size_t)n + 1024 + 3) & ~(size_t)3;     // multiple of 4: the heap and the top-list scratch stay aligned
     JAMD_HIP(hipMalloc(&p, cap * 4)); b->owned.push_back(p); b->d_pkeys = (unsigned *)p;
-    // out[cap] + nout (+ pad) | heap u64[cap + 2] | top-list scratch u32x4[beam + 256] (wide layout)
-    JAMD_HIP(hipMalloc(&p, 4 * (cap + 4) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256))); b->owned.push_back(p); b->d_pout = (int *)p;
+    // out[cap] + nout (+ pad) | heap u64[cap + 2] | top-list scratch u32x4[beam + 256] (wide layout) | sweep replay scratch
+    JAMD_HIP(hipMalloc(&p, 4 * (cap + 4) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256) + xbeam_sweep_bytes(b->w.beam))); b->owned.push_back(p); b->d_pout = (int *)p;
     b->pcap = cap;
   }
   std::vector<unsigned> keys((size_t)n);
@@ -1860,13 +1861,21 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   int *d_nout = b->d_pout + b->pcap;
   unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 4);
   u32x4 *d_collect = reinterpret_cast<u32x4 *>(d_heap + b->pcap + 2);
-  xbeam_prune_order_launch(use_half_shape(b, 1) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, st);
+  unsigned char *d_sweep = reinterpret_cast<unsigned char *>(d_collect + (size_t)b->w.beam + 256);
+  xbeam_prune_order_launch(use_half_shape(b, 1) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, d_sweep, st);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_prune_order: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpyAsync(nkeep, d_nout, 4, hipMemcpyDeviceToHost, st));
   JAMD_HIP(hipStreamSynchronize(st));
   if (*nkeep < 0 || *nkeep > n) { jamd_set_error("jamd_beam_prune_order: the kernel reported %d of %d tokens kept", *nkeep, n); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpy(order, b->d_pout, 4 * (size_t)*nkeep, hipMemcpyDeviceToHost));
+  return JAMD_OK;
+}
+
+int jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds) {
+  if (!b || !sweep_rounds || !b->d_pout) { jamd_set_error("jamd_beam_prune_info: bad argument (or no jamd_beam_prune_order() call yet)"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  JAMD_HIP(hipMemcpy(sweep_rounds, b->d_pout + b->pcap + 1, 4, hipMemcpyDeviceToHost));
   return JAMD_OK;
 }
 

@@ -11,6 +11,7 @@ struct XWork {
   unsigned o_bitmap;           // u32 [gbm_words] creation-order bitmap when it outgrows LDS
   unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
   unsigned o_collect;          // u32x4 [beam + 256] wide layout: the top list on its way from the heap to the sorted lists
+  unsigned o_sweep;            // xbeam_sweep_bytes(beam): scratch of the sweep replay (beam_sweep.h), 0 = none
   int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())
@@ -39,6 +40,7 @@ hipError_t xbeam_prepare();
 void xbeam_launch(const LexDev &lx, const XWork &xw, const float *scores, int nstate, const int *d_utt_off, int nutt,
                   int smode, bool timed, hipStream_t st);
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, u32x4 *d_collect, hipStream_t st);
+                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, hipStream_t st);
+size_t xbeam_sweep_bytes(int beam);   // global scratch of the sweep replay per utterance
 
 }  // namespace jamdb

@@ -70,6 +70,8 @@ struct XShared {
   unsigned sel_digit, sel_need, sel_count;
   unsigned wsum[NT / 64], wsum2[NT / 64];
   int scan_total, scan_total2;
+  int sw_nev, sw_limit, sw_fail, sw_changed;     // the sweep replay (beam_sweep.h)
+  int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
 };
 
 struct XCells {
@@ -209,6 +211,9 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   lds_i32 *takers;               // [kMaxCand + 1][kTakers + 1] chain occupants per candidate (+ their count); last row: serial form
   lds_i32 *ordv;                 // [kMaxCand] candidate slots in the order of their turns
   int b_cap;
+  unsigned char JAMD_LDS *sw_region;   // the sweep replay (beam_sweep.h): all of the pruning step's overlay, laid out afresh
+  int sw_bytes;
+  unsigned char *sw_glob;        // its global scratch (sweep_global_bytes()), nullptr = no sweep
 };
 
 template <bool UP, typename HP>
@@ -450,6 +455,8 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
   }
   return prefix;
 }
+
+#include "beam_sweep.h"
 
 // ---- the events of the extraction loop, replayed by ONE wave (see the file header) -------------------
 // Replays extraction i (1-based) when the tail position q = n - i + 1 may hold one of the top elements.
@@ -786,24 +793,27 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         // scan of the whole top list on one wave, hundreds of them cost more than the extraction loop itself run
         // pipelined -- give the closed form up for this frame.  (Wide beams over flat scores: a third of the top
         // elements sit on tail positions.)  The heap was overlaid by the lists in the wide layout: it is built again.
+        // More candidates than the wave-serial replay below holds (wide beams: a tenth of the top elements sit on tail
+        // positions, hundreds of candidates): the sweep replay resolves them together (beam_sweep.h).  What it cannot
+        // hold -- or a work area without its scratch -- goes to the extraction loop itself: the heap is built again (the
+        // sweep lays its own image over the whole overlay).
         bool give_up = false;
-        if constexpr (kLdsHeap) {
-          if (uni(ctl[0]) > kMaxCand) {
-            const int il = uni(ctl[3]);
-            int live = 0;
-            for (int w = tid; w * 32 < il; w += NT) {
-              unsigned bits = pm.tailmask[w];
-              const int rem = il - w * 32;
-              if (rem < 32) bits &= (1u << rem) - 1u;
-              live += __popc(bits);
-            }
-            live = block_excl_scan<NT>(sh, live); live = uni(sh.scan_total);
-            give_up = (long long)live * nB > 80ll * k + 6400;       // events: ~0.36 us per 64 list entries each; the loop: ~0.45 us an extraction
+        if (uni(ctl[0]) > kMaxCand && uni(ctl[3]) > 0) {
+          bool swept = false;
+          if constexpr (NT == jamdb::NT) {         // (the half shape serves narrow beams: a handful of candidates)
+           if (pm.sw_glob) {
+            swept = sweep_replay<NT>(sh, pm.sw_region, pm.sw_bytes, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, k,
+                                     uni(ctl[3]), svid);
+            if (!swept && tid == 0) sh.sw_info = -1;
+            __syncthreads();
+           }
           }
+          if (swept) { done = true; PTICK(7); }
+          else give_up = true;
         }
         if (give_up) {
-          if constexpr (WIDE) { build_heap(); }
-        } else {
+          build_heap();
+        } else if (!done) {
 #ifdef JAMD_DEV
         if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tc3_ = wall_clock64();   // slot 7 - (4 + 5 + 6) = everything before the replay
 #endif
@@ -1060,6 +1070,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
   pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
   pm.b_cap = xw.b_cap;
+  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
+  pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
   u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
@@ -1680,7 +1692,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 // sequential heap)
 template <bool WIDE, int NT>
 __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigned *keys, int n, int k, int *out, int *nout,
-                                                         unsigned long long *hglob, u32x4 *gcol) {
+                                                         unsigned long long *hglob, u32x4 *gcol, unsigned char *gsweep) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   PruneMem pm;
@@ -1694,17 +1706,19 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
   pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
   pm.b_cap = xw.b_cap;
+  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
+  pm.sw_glob = gsweep;
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
   for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }
-  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; }
+  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; sh.sw_info = 0; }
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
   const int nk = exact_prune<WIDE, NT>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
                                    xw.prune_mode, gcol);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
-  if (threadIdx.x == 0) *nout = nk;
+  if (threadIdx.x == 0) { nout[0] = nk; nout[1] = sh.sw_info; }
 }
 
 }  // namespace
@@ -1885,10 +1899,12 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
 }
 
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, u32x4 *d_collect, hipStream_t st) {
-  if (xw.nt == kHalfNT) hipLaunchKernelGGL((prune_order_kernel<true, kHalfNT>), dim3(1), dim3(kHalfNT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
-  else if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
-  else hipLaunchKernelGGL((prune_order_kernel<false, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect);
+                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, hipStream_t st) {
+  if (xw.nt == kHalfNT) hipLaunchKernelGGL((prune_order_kernel<true, kHalfNT>), dim3(1), dim3(kHalfNT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
+  else if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
+  else hipLaunchKernelGGL((prune_order_kernel<false, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
 }
+
+size_t xbeam_sweep_bytes(int beam) { return sweep_global_bytes(beam + 256); }
 
 }  // namespace jamdb

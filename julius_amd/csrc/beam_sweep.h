@@ -1,0 +1,458 @@
+// beam_sweep.h -- the events of the extraction loop of sort_token_upward() (libjulius/src/beam.c:1368-1383), ALL AT ONCE.
+// Included by beam_exact.hip behind its helpers (block scans, prekey(), tid_now()).
+//
+// beam_exact.hip replaces the extraction loop by its closed form: the top elements come out sorted by (score, pre-order
+// of their heap position), except for "events" -- a turn i whose tail position n - i + 1 still holds a top element x:
+// x is taken off its leaf and re-inserted from the root (it sinks past strictly greater elements along the path of
+// larger children and stops at `h`).  The wave-serial replay in beam_exact.hip handles a few dozen tail candidates; a
+// wide beam over a 20k-word lexicon has hundreds per frame (a tenth of the top 4000 sit on tail leaves), and replaying
+// them one after the other costs more than the loop itself.  This file resolves them together.
+//
+// THE STATIC MODEL.  Give every top element a chain of incarnations: its heap position after heapify, and one more
+// position per event (the landing h).  With the last incarnation of every element in place FROM THE START and the
+// earlier ones taken out, the event-free closed form describes the real loop at all times that matter:
+//   * the element picked off its leaf never moved before its turn, so nothing ever waited for it (taking it out
+//     changes nobody's moves), and
+//   * the landed element x at h is worse than everything that passes through h before it lands, so it delays nobody
+//     before its turn (putting it there early changes nobody's moves before that turn).
+// In the closed form the moves are a table: T_d(e) = the turn in which e leaves the depth-d ancestor of its position,
+// T_0(e) = its own extraction turn = 1 + number of elements before it in the order, and
+//      T_{d+1}(e) = T_d(the element just before e among those below the same depth-d ancestor)
+// (a position passes its subtree's elements up in order, one each time its own occupant leaves).  So ONE SWEEP over the
+// list in extraction order gives every move: level by level the elements that lie deeper than d are partitioned
+// stably by their next path bit -- all left-goers first, as in a wavelet matrix: the groups (one per depth-d ancestor)
+// stay contiguous and sorted -- and take the T of the entry in front of them.  From the table:
+//   * an element on the tail position of turn i (depth D) is an event iff T_D >= i (it has not left its leaf), and
+//   * its landing: the elements that move in turn i from depth 1, 2, ... are the hole's path; x sinks past them while
+//     they are strictly better and takes the position the last of them left.
+// An event changes the model (x moves to h), which can change later candidates' answers -- in the real frames of the
+// C4 task a quarter of the events see an earlier one.  So the sweep is ITERATED: the incarnations that were picked
+// ride along as PROBES (entries that learn when they would have left their leaf but delay nobody: whoever stands
+// behind a probe looks through it), every round re-derives every chain from the table, and the rounds stop when no
+// chain changes.  A landed entry born in turn b is looked through while the value behind it is < b, which keeps a
+// tentative landing from disturbing earlier turns; with that, a self-consistent state is the real loop's (induction
+// over the turns: the earliest wrong belief would be re-derived from correct earlier ones).  Real frames converge in 3-6
+// rounds.  Inside a group of EQUAL scores the members come out by pre-order among those present; a member that lands
+// in turn b is present from turn b + 1 (the schedule in sweep_order_group()).
+// tools/prune_lab2.py restates all of this in numpy and checks it against the sequential loop (3 600 tie-heavy random
+// arrays, frames of the C4 task); tests/test_prune_order.py does it for this code through jamd_beam_prune_order().
+//
+// Cost: a round is ~14 level passes over <= 5 000 entries by the whole workgroup; whatever the sweep cannot hold
+// (more than kSwEvMax events, a tie group with events and more than kSwGroup entries, no convergence) falls back to the
+// pipelined extraction loop.
+#pragma once
+
+constexpr int kSwEvMax = 1024;           // events (probe entries) held
+constexpr int kSwCandMax = 1024;         // candidate turns with a path row
+constexpr int kSwDepth = kMaxL + 2;      // path row: one slot per depth
+constexpr int kSwChain = 3;              // events per element
+constexpr int kSwGroup = 48;             // entries of a tie group that holds events (ordered by one thread)
+constexpr int kSwRounds = 24;
+constexpr int kSwPerThread = 8;          // list entries per thread in a pass
+
+typedef JAMD_LDS unsigned short lds_u16;
+constexpr unsigned kSwPos = 0x3fffffu;   // heap position (< 2^(kMaxL+1))
+constexpr unsigned kSwProbe = 0x80000000u, kSwLanded = 0x40000000u;
+
+struct SweepMem {
+  lds_u32 *evp;                  // [M] position | flags, per entry (x < nB: the element's current incarnation; nB + c: the probe of event c)
+  lds_u16 *ebirth;               // [nB] turn of the element's last event (landed entries)
+  lds_u16 *gid;                  // [nB] tie group: 0x8000 | length at the group's first rank, else that rank
+  lds_u16 *ep;                   // [nB + 1] events of the elements in front (the event table is sorted by element)
+  lds_u32 *ent[2];               // [M] the list of a level, ping-pong: entry | T << 16
+  lds_u32 *evq[2], *evh[2];      // [kSwEvMax] event table, double buffered: tail position left, landing
+  lds_u16 *evel[2];              // [kSwEvMax] element
+  lds_u16 *tpre;                 // [words + 1] prefix popcount of the tail mask
+  lds_u32 *tailmask;
+  unsigned short *TDx;           // global [M] T at the entry's own depth
+  unsigned short *path;          // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
+  unsigned *ids;                 // global [nB] token ids
+  u32x4 *chain;                  // global [nB] new chain of an element: landings (x, y, z), count (w)
+};
+
+// LDS and global scratch the sweep needs for a top list of nB entries
+__host__ __device__ inline int sweep_lds_bytes(int nB, int k) {
+  const int M = nB + kSwEvMax;
+  return 4 * M + 2 * nB + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * kSwEvMax + 2 * ((k + 31) / 32 + 4) + 64;
+}
+__host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
+  return 2 * (size_t)(b_cap + kSwEvMax) + 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 16 * (size_t)b_cap + 64;
+}
+
+__device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
+
+// block-wide exclusive scan with max (one unsigned per thread, identity 0)
+template <int NT>
+__device__ __forceinline__ unsigned block_excl_scan_max(XShared &sh, unsigned v) {
+  const int tx = tid_now(), lane = tx & 63, wv = tx >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl = incl > o ? incl : o;
+  }
+  if (lane == 63) sh.wsum[wv] = incl;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wv; w++) base = base > sh.wsum[w] ? base : sh.wsum[w];
+  unsigned ex = __shfl_up(incl, 1, 64);
+  if (lane == 0) ex = 0;
+  __syncthreads();
+  return base > ex ? base : ex;
+}
+
+// order key of an entry inside its tie group: pre-order of its position, then the entry number
+__device__ __forceinline__ unsigned long long sw_key(const SweepMem &m, unsigned x) {
+  return ((unsigned long long)prekey(m.evp[x] & kSwPos) << 16) | x;
+}
+
+// A tie group that holds events, ordered by ONE thread: its nm members' current incarnations and the probes of their
+// events [c0, c1), into dst[0 .. cnt) as entry | T_0 << 16.  Pre-order among the entries; the members come out in that
+// order among those PRESENT (a member landed in turn b is present from turn b + 1), a probe stays in front of the member
+// that follows it in pre-order.  `tmp` = cnt words of scratch.  Returns false when the group is too large.
+__device__ __forceinline__ bool sweep_order_group(const SweepMem &m, int nB, int g0, int nm, int c0, int c1, lds_u32 *dst, lds_u32 *tmp, int k, lds_i32 *svid) {
+  const int cnt = nm + (c1 - c0);
+  if (cnt > kSwGroup) return false;
+  for (int i = 0; i < cnt; i++) {                                      // insertion sort by (pre-order, entry)
+    const unsigned x = i < nm ? (unsigned)(g0 + i) : (unsigned)(nB + c0 + (i - nm));
+    const unsigned long long kx = sw_key(m, x);
+    int j = i;
+    while (j > 0 && sw_key(m, dst[j - 1]) > kx) { dst[j] = dst[j - 1]; j--; }
+    dst[j] = x;
+  }
+  const int tstart = g0 + 1;                                           // turn of the group's first member
+  bool sched = false;
+  for (int i = 0; i < cnt; i++) {
+    const unsigned x = dst[i];
+    if (x < (unsigned)nB && (m.evp[x] & kSwLanded) && (int)m.ebirth[x] >= tstart) sched = true;
+  }
+  if (sched) {
+    // turn by turn: the first member in pre-order that is present and not out yet
+    unsigned long long out = 0ull;
+    for (int i = 0; i < cnt; i++) tmp[i] = 0u;                         // tmp[i] = turn of dst[i] (members)
+    int t = tstart;
+    for (int r = 0; r < nm; r++, t++) {
+      int pick = -1, early = -1;
+      for (int i = 0; i < cnt; i++) {
+        const unsigned x = dst[i];
+        if (x >= (unsigned)nB || ((out >> i) & 1ull)) continue;
+        const int b = (m.evp[x] & kSwLanded) ? (int)m.ebirth[x] : 0;
+        if (b < t) { pick = i; break; }
+        if (early < 0 || b < ((m.evp[dst[early]] & kSwLanded) ? (int)m.ebirth[dst[early]] : 0)) early = i;
+      }
+      if (pick < 0) pick = early;                                       // (not in a consistent state)
+      out |= 1ull << pick;
+      tmp[pick] = (unsigned)t;
+    }
+    // new order: members by turn, every probe in front of the member that followed it in pre-order
+    unsigned follow = 0u;                                              // turn of the next member in pre-order, 0 = none
+    for (int i = cnt - 1; i >= 0; i--) {
+      if (dst[i] < (unsigned)nB) follow = tmp[i]; else tmp[i] = follow ? follow : 0xffffu;   // probe: the turn it precedes
+    }
+    // stable insertion sort by (turn, probes first, pre-order): cnt <= kSwGroup
+    for (int i = 0; i < cnt; i++) {
+      const unsigned turn = tmp[i] == 0xffffu ? (unsigned)(tstart + nm) : tmp[i];
+      tmp[i] = (turn << 16) | (dst[i] >= (unsigned)nB ? 0u : 0x8000u) | (unsigned)i;
+    }
+    for (int i = 1; i < cnt; i++) {
+      const unsigned kx = tmp[i], x = dst[i];
+      int j = i;
+      while (j > 0 && tmp[j - 1] > kx) { tmp[j] = tmp[j - 1]; dst[j] = dst[j - 1]; j--; }
+      tmp[j] = kx; dst[j] = x;
+    }
+    for (int i = 0; i < cnt; i++) dst[i] |= tmp[i] & 0xffff0000u;
+  } else {
+    int t = tstart;
+    for (int i = 0; i < cnt; i++) {
+      const unsigned x = dst[i];
+      dst[i] = x | ((unsigned)t << 16);
+      if (x < (unsigned)nB) t++;
+    }
+  }
+  for (int i = 0; i < cnt; i++) {                                      // the order of the next frame (last round's values stand)
+    const unsigned w = dst[i];
+    const int t = (int)(w >> 16);
+    if ((w & 0xffffu) < (unsigned)nB && t <= k) svid[k - t] = (int)m.ids[w & 0xffffu];
+  }
+  return true;
+}
+
+// The replay itself.  In: the top list sorted by (score, pre-order) -- pm.compR / vposR / idR of nB entries --, the tail
+// mask of the tail positions that hold one (bit b <-> turn b + 1), ilast = the last turn at which a TIED element can sit
+// on the tail position.  `region` = LDS the sweep may lay out afresh (the lists are read into registers first), gs =
+// global scratch of sweep_global_bytes().  Out: svid[0..k) = token ids in the visiting order of the next frame.
+// Returns false when it gives up (the caller runs the extraction loop).  Whole workgroup.
+template <int NT>
+__device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *region, int region_bytes, unsigned char *gs,
+                                          const lds_u64 *compR, const lds_u32 *vposR, const lds_u32 *idR, lds_u32 *tailmask,
+                                          int nB, int n, int k, int ilast, lds_i32 *svid) {
+  const int tid = tid_now();
+  const int M = nB + kSwEvMax;
+  const int nwords = (k + 31) / 32 + 1;
+  if (nB > kSwPerThread * NT || M > 0xffff || nB >= 0x8000 || sweep_lds_bytes(nB, k) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
+  // ---- the lists leave the region through the global scratch, then it is laid out afresh
+  SweepMem m;
+  m.TDx = reinterpret_cast<unsigned short *>(gs);
+  m.path = m.TDx + ((M + 7) & ~7);
+  m.ids = reinterpret_cast<unsigned *>(m.path + (size_t)kSwCandMax * kSwDepth);
+  m.chain = reinterpret_cast<u32x4 *>(m.ids + ((nB + 3) & ~3));
+  unsigned *const stage = reinterpret_cast<unsigned *>(m.chain);      // [nB] positions, [nB] score bits, the tail mask
+  for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
+  for (int w = tid; w < nwords; w += NT) stage[2 * nB + w] = tailmask[w];
+  __syncthreads();
+  {
+    unsigned char JAMD_LDS *at = region;
+    auto take = [&](int bytes) { unsigned char JAMD_LDS *p = at; at += (bytes + 15) & ~15; return p; };
+    m.evp = (lds_u32 *)take(4 * M);
+    m.ent[0] = (lds_u32 *)take(4 * M);
+    m.ent[1] = (lds_u32 *)take(4 * M);
+    m.ebirth = (lds_u16 *)take(2 * nB);
+    m.gid = (lds_u16 *)take(2 * nB);
+    m.ep = (lds_u16 *)take(2 * (nB + 2));
+    for (int b = 0; b < 2; b++) { m.evq[b] = (lds_u32 *)take(4 * kSwEvMax); m.evh[b] = (lds_u32 *)take(4 * kSwEvMax); m.evel[b] = (lds_u16 *)take(2 * kSwEvMax); }
+    m.tailmask = (lds_u32 *)take(4 * (nwords + 1));
+    m.tpre = (lds_u16 *)take(2 * (nwords + 2));
+  }
+  lds_u32 *score = m.ent[1];                                           // (until the groups are known)
+  for (int r = tid; r < nB; r += NT) { m.evp[r] = stage[r]; score[r] = stage[nB + r]; m.ebirth[r] = 0; }
+  for (int w = tid; w < nwords; w += NT) m.tailmask[w] = stage[2 * nB + w];
+  if (tid == 0) m.tailmask[nwords] = 0u;
+  __syncthreads();
+  // ---- tie groups: gid[r] = first rank of r's group; the first rank carries 0x8000 | length
+  {
+    const int C = (nB + NT - 1) / NT;
+    const int lo = tid * C, hi = min(nB, lo + C);
+    unsigned last = 0u;                                                // (first rank + 1) of the latest group start in the chunk
+    for (int r = lo; r < hi; r++) if (r == 0 || score[r - 1] != score[r]) last = (unsigned)r + 1u;
+    const unsigned before = block_excl_scan_max<NT>(sh, last);
+    unsigned cur = before;
+    for (int r = lo; r < hi; r++) {
+      if (r == 0 || score[r - 1] != score[r]) cur = (unsigned)r + 1u;
+      m.gid[r] = (unsigned short)(cur - 1u);
+    }
+    __syncthreads();
+    lds_u32 *glen = m.ent[0];
+    for (int r = tid; r < nB; r += NT) glen[r] = 0u;
+    __syncthreads();
+    for (int r = tid; r < nB; r += NT) atomicMax((unsigned *)&glen[m.gid[r]], (unsigned)(r - (int)m.gid[r] + 1));
+    __syncthreads();
+    for (int r = tid; r < nB; r += NT) if ((int)m.gid[r] == r) m.gid[r] = (unsigned short)(0x8000u | glen[r]);
+    __syncthreads();
+  }
+  auto group_of = [&](int r, int &g0, int &len) {
+    const unsigned g = m.gid[r];
+    g0 = (g & 0x8000u) ? r : (int)g;
+    len = (int)(m.gid[g0] & 0x7fffu);
+  };
+  if (tid == 0) { sh.sw_nev = 0; sh.sw_limit = ilast; sh.sw_fail = 0; }
+  __syncthreads();
+  int cur = 0;                                                         // event table in use
+  int round = 0;
+  for (;;) {
+    round++;
+    if (round > kSwRounds) return false;
+    const int nev = uni(sh.sw_nev), limit = uni(sh.sw_limit);
+    const int L0 = nB + nev;
+    lds_u32 *const evq = m.evq[cur], *const evh = m.evh[cur];
+    lds_u16 *const evel = m.evel[cur];
+    // ---- ep[r] = events of the elements in front of r; prefix popcount of the tail mask; path rows cleared
+    {
+      lds_u32 *cntv = m.ent[1];
+      for (int r = tid; r <= nB; r += NT) cntv[r] = 0u;
+      __syncthreads();
+      for (int c = tid; c < nev; c += NT) atomicAdd((unsigned *)&cntv[evel[c]], 1u);
+      __syncthreads();
+      const int C = (nB + 1 + NT - 1) / NT;
+      const int lo = tid * C, hi = min(nB + 1, lo + C);
+      int tot = 0;
+      for (int r = lo; r < hi; r++) tot += (int)cntv[r];
+      int ex = block_excl_scan<NT>(sh, tot);
+      for (int r = lo; r < hi; r++) { const int c = (int)cntv[r]; m.ep[r] = (unsigned short)ex; ex += c; }
+      if (tid < 64) {
+        int run = 0;
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+          const int w = w0 + tid;
+          const int c = w < nwords ? __popc(m.tailmask[w]) : 0;
+          int incl = c;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (tid >= off) incl += o; }
+          if (w < nwords) m.tpre[w] = (unsigned short)(run + incl - c);
+          run += __shfl(incl, 63, 64);
+        }
+        if (tid == 0) m.tpre[nwords] = (unsigned short)run;
+      }
+      __syncthreads();
+    }
+    const int nrows = min((int)m.tpre[nwords], kSwCandMax);
+    {
+      unsigned *p32 = reinterpret_cast<unsigned *>(m.path);
+      for (int i = tid; i < (nrows * kSwDepth + 1) / 2; i += NT) p32[i] = 0xffffffffu;
+    }
+    // ---- level 0: the entries in extraction order.  A group without events keeps the order of the sorted list.
+    {
+      lds_u32 *A = m.ent[0];
+      for (int r = tid; r < nB; r += NT) {
+        int g0, len;
+        group_of(r, g0, len);
+        const int c0 = m.ep[g0], c1 = m.ep[g0 + len];
+        if (c0 == c1) {
+          A[r + c0] = (unsigned)r | ((unsigned)(r + 1) << 16);
+          if (r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
+        } else if (r == g0) {
+          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, k, svid)) sh.sw_fail = 1;
+        }
+      }
+      __syncthreads();
+      if (uni(sh.sw_fail)) return false;
+    }
+    // ---- the sweep: level d -> d + 1
+    int L = L0, pp = 0;
+    for (int d = 0; L > 0; d++) {
+      if (d >= kSwDepth - 1) return false;
+      const lds_u32 *A = m.ent[pp];
+      lds_u32 *B = m.ent[pp ^ 1];
+      const int C = (L + NT - 1) / NT;
+      if (C > kSwPerThread) return false;
+      const int lo = tid * C, hi = min(L, lo + C);
+      int nl = 0, nr = 0;
+      unsigned kind = 0u;                                              // 2 bits an entry: 1 = goes left, 2 = goes right
+      for (int idx = lo; idx < hi; idx++) {
+        const unsigned w = A[idx], x = w & 0xffffu, T = w >> 16;
+        const unsigned ev = m.evp[x], vp = ev & kSwPos;
+        const int dep = sw_depth(vp);
+        if (d >= 1 && !(ev & kSwProbe) && (int)T <= limit) {           // who moves in a candidate turn
+          const unsigned tw = m.tailmask[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
+          if (tw & bit) {
+            const int ci = (int)m.tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
+            if (ci < kSwCandMax) m.path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+          }
+        }
+        if (dep == d) { m.TDx[x] = (unsigned short)T; continue; }
+        const unsigned right = (vp >> (dep - d - 1)) & 1u;
+        kind |= (right ? 2u : 1u) << (2 * (idx - lo));
+        nl += right ? 0 : 1; nr += right ? 1 : 0;
+      }
+      int el, er;
+      block_excl_scan2<NT>(sh, nl, nr, el, er);
+      const int totl = uni(sh.scan_total), totr = uni(sh.scan_total2);
+      for (int idx = lo; idx < hi; idx++) {
+        const unsigned kd = (kind >> (2 * (idx - lo))) & 3u;
+        if (!kd) continue;
+        // T of the entry in front: probes are looked through, a landed entry too while the value behind it is < its birth
+        unsigned v = 0u;
+        int j = idx - 1;
+        if (j >= 0) {
+          const unsigned wj = A[j];
+          const unsigned evj = m.evp[wj & 0xffffu];
+          if (!(evj & (kSwProbe | kSwLanded))) v = wj >> 16;
+          else {
+            while (j >= 0 && (m.evp[A[j] & 0xffffu] & (kSwProbe | kSwLanded))) j--;
+            v = j >= 0 ? (A[j] >> 16) : 0u;
+            for (int s = j + 1; s < idx; s++) {
+              const unsigned ws = A[s], xs = ws & 0xffffu, es = m.evp[xs];
+              if (es & kSwProbe) continue;
+              const unsigned b = m.ebirth[xs];
+              if (v < b) continue;
+              v = (ws >> 16) > b ? (ws >> 16) : b;
+            }
+          }
+        }
+        const unsigned x = A[idx] & 0xffffu;
+        const int at = kd == 1u ? el++ : totl + er++;
+        B[at] = x | (v << 16);
+      }
+      __syncthreads();
+      L = totl + totr; pp ^= 1;
+    }
+    // ---- every chain again from the table
+    if (tid == 0) { sh.sw_changed = 0; }
+    lds_u32 *ncnt = m.ent[0];                                          // new events per element (then their prefix)
+    for (int r = tid; r <= nB; r += NT) ncnt[r] = 0u;
+    __syncthreads();
+    for (int r = tid; r < nB; r += NT) {
+      const int c0 = m.ep[r], oc = (int)m.ep[r + 1] - c0;
+      const unsigned q0 = oc ? evq[c0] : (m.evp[r] & kSwPos);
+      if (q0 < (unsigned)(n - k + 1)) continue;                       // never on a tail position at first: no chain
+      int g0, len;
+      group_of(r, g0, len);
+      unsigned nh[kSwChain];
+      int nn = 0;
+      unsigned vp = q0;
+      bool changed = false;
+      for (int t = 0; t < kSwChain; t++) {
+        if (vp < (unsigned)(n - k + 1)) break;
+        const int turn = n - (int)vp + 1;
+        if (turn > limit) break;
+        if (t > oc || (t > 0 && nh[t - 1] != evh[c0 + t - 1])) break;   // this incarnation was not in the sweep: next round
+        const unsigned x = t < oc ? (unsigned)(nB + c0 + t) : (unsigned)r;
+        if ((int)m.TDx[x] < turn) break;                                // it left the leaf before its turn
+        // landing: past the elements that move in this turn while they are strictly better
+        const unsigned tw = m.tailmask[(turn - 1) >> 5], bit = 1u << ((turn - 1) & 31);
+        const int ci = (int)m.tpre[(turn - 1) >> 5] + __popc(tw & (bit - 1u));
+        if (!(tw & bit) || ci >= kSwCandMax) { sh.sw_fail = 1; break; }
+        const unsigned short *row = m.path + (size_t)ci * kSwDepth;
+        unsigned h = 1u;
+        for (int dd = 1; dd < kSwDepth; dd++) {
+          const unsigned y = row[dd];
+          if (y == 0xffffu || y == (unsigned)r) break;
+          int yg, yl;
+          group_of((int)y, yg, yl);
+          if (!(yg < g0)) break;
+          const unsigned yv = m.evp[y] & kSwPos;
+          h = yv >> (sw_depth(yv) - dd);
+        }
+        nh[nn++] = h;
+        vp = h;
+      }
+      if (nn == kSwChain && vp >= (unsigned)(n - k + 1) && n - (int)vp + 1 <= limit) sh.sw_fail = 1;   // a fourth event: not held
+      changed = nn != oc;
+      for (int t = 0; t < nn && t < oc; t++) changed |= nh[t] != evh[c0 + t];
+      if (len > 1) {
+        for (int t = 0; t < nn; t++) {
+          if (nh[t] >= (unsigned)(n - k + 1) && n - (int)nh[t] + 1 > limit) { atomicMax(&sh.sw_limit, n - (int)nh[t] + 1); changed = true; }
+        }
+      }
+      for (int t = 0; t < nn; t++) {
+        if (nh[t] >= (unsigned)(n - k + 1)) { const int b = n - (int)nh[t]; atomicOr((unsigned *)&m.tailmask[b >> 5], 1u << (b & 31)); }
+      }
+      if (changed) sh.sw_changed = 1;
+      ncnt[r] = (unsigned)nn;
+      m.chain[r] = u32x4{nn > 0 ? nh[0] : 0u, nn > 1 ? nh[1] : 0u, nn > 2 ? nh[2] : 0u, q0};
+    }
+    __syncthreads();
+    if (uni(sh.sw_fail)) return false;
+    if (!uni(sh.sw_changed)) break;
+    // ---- the new event table (sorted by element), the entries' positions
+    {
+      const int C = (nB + 1 + NT - 1) / NT;
+      const int lo = tid * C, hi = min(nB + 1, lo + C);
+      int tot = 0;
+      for (int r = lo; r < hi; r++) tot += (int)ncnt[r];
+      int ex = block_excl_scan<NT>(sh, tot);
+      const int total = uni(sh.scan_total);
+      if (total > kSwEvMax) return false;
+      lds_u32 *const nq = m.evq[cur ^ 1], *const nhh = m.evh[cur ^ 1];
+      lds_u16 *const nel = m.evel[cur ^ 1];
+      for (int r = lo; r < hi && r < nB; r++) {
+        const int nn = (int)ncnt[r];
+        const int oc = (int)m.ep[r + 1] - (int)m.ep[r];
+        if (nn == 0 && oc == 0) continue;
+        const u32x4 ch = m.chain[r];
+        const unsigned hs[3] = {ch.x, ch.y, ch.z};
+        unsigned q = ch.w;
+        for (int t = 0; t < nn; t++) { nq[ex + t] = q; nhh[ex + t] = hs[t]; nel[ex + t] = (unsigned short)r; q = hs[t]; }
+        m.evp[r] = q | (nn ? kSwLanded : 0u);
+        m.ebirth[r] = (unsigned short)(nn ? n - (int)nq[ex + nn - 1] + 1 : 0);
+        ex += nn;
+      }
+      __syncthreads();
+      for (int c = tid; c < total; c += NT) m.evp[nB + c] = nq[c] | kSwProbe;
+      if (tid == 0) sh.sw_nev = total;
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) sh.sw_info = round;                                    // rounds it took (diagnostic: jamd_beam_prune_info())
+  __syncthreads();
+  return true;
+}

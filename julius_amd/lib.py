@@ -135,6 +135,7 @@ def load():
         "jamd_beam_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
+        "jamd_beam_prune_info": (ci, [vp, P(ci)]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
@@ -651,6 +652,12 @@ class Beam:
         _check(load().jamd_beam_prune_order(self.h, sc.ctypes.data, len(sc), out.ctypes.data, C.byref(n)),
                "jamd_beam_prune_order")
         return out[:n.value].copy()
+
+    def prune_info(self):
+        """Rounds of the sweep replay in the latest prune_order() call (-1 = it gave the frame up, 0 = not used)."""
+        r = C.c_int()
+        _check(load().jamd_beam_prune_info(self.h, C.byref(r)), "jamd_beam_prune_info")
+        return r.value
 
     def stream_begin(self, nutt: int):
         self._nutt = nutt

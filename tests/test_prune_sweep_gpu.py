@@ -1,0 +1,78 @@
+"""The sweep replay of the rank-pruning step (csrc/beam_sweep.h): hundreds of tail candidates resolved together --
+iterated sweeps over the closed form's move table instead of the extraction loop of sort_token_upward()
+(libjulius/src/beam.c:1368-1383) -- against the oracle's sequential restatement, on real frames of the C4 task (beam
+4000, tests/golden/prune_frames_c4.npz: token scores in creation order, dumped from the oracle's first pass by
+tools/dump_prune_inputs.py) and on synthetic frames of that shape with sprinkled exact ties."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from beamutil import load_beam_golden
+from julius_amd import lib
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def _beam(engine, beam, mode="exact"):
+    g = load_beam_golden("beam_rank.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    return lib.Beam(engine, lx, beam, -1.0, max_utts=1).set_order_mode(mode)
+
+
+def test_real_frames_of_the_c4_task(engine, oracle):
+    z = np.load(GOLD / "prune_frames_c4.npz")
+    beam = int(z["beam"])
+    bm = _beam(engine, beam)
+    swept = 0
+    for name in sorted(k for k in z.files if k.startswith("f")):
+        sc = z[name]
+        got = bm.prune_order(sc)
+        info = bm.prune_info()
+        want = oracle.sort_token_no_order(sc, beam)
+        assert np.array_equal(got, want), (name, len(sc), info)
+        swept += info > 0
+    assert swept >= 3, swept            # the frames with a tied element on a tail position go through the sweep
+    bm.close()
+
+
+@pytest.mark.parametrize("beam", [2000, 4000])
+def test_sweep_on_synthetic_frames(engine, oracle, beam):
+    """Frames 2.05 - 4.5 beams large (the upward sort), continuous scores with a fraction of exact duplicates: hundreds of
+    tail candidates, some of them tied -- the sweep has to run, converge and give the sequential loop's order."""
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(beam + 1)
+    stats = []
+    for mult in (2.05, 2.3, 2.6, 3.1, 3.7, 4.5):
+        n = int(mult * beam) + int(rng.integers(0, 50))
+        for dup in (0.002, 0.01, 0.05, 0.3):
+            sc = (-rng.random(n) * 300.0 - 5000.0).astype(np.float32)
+            nd = max(2, int(dup * n))
+            sc[rng.integers(0, n, nd)] = sc[rng.integers(0, n, nd)]
+            got = bm.prune_order(sc)
+            info = bm.prune_info()
+            want = oracle.sort_token_no_order(sc, beam)
+            assert np.array_equal(got, want), (n, beam, dup, info)
+            stats.append(info)
+    assert sum(1 for s in stats if s > 0) >= len(stats) // 2, stats
+    bm.close()
+
+
+def test_sweep_with_heavy_ties(engine, oracle):
+    """Few score levels: large tie groups with landed members (release-time order inside a group), groups too large for
+    the sweep (it hands the frame to the extraction loop) -- the result is the sequential loop's either way."""
+    beam = 3000
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(11)
+    seen = set()
+    for n in (6200, 7500, 9000, 12000):
+        for levels in (40, 400, 4000, 40000):
+            sc = (-rng.integers(0, levels, n).astype(np.float32) * 0.5 - 2000.0).astype(np.float32)
+            got = bm.prune_order(sc)
+            info = bm.prune_info()
+            want = oracle.sort_token_no_order(sc, beam)
+            assert np.array_equal(got, want), (n, levels, info)
+            seen.add(1 if info > 0 else info)
+    assert 1 in seen, seen
+    bm.close()
