@@ -547,8 +547,9 @@ int  jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order,
 /* How the latest jamd_beam_prune_order() call resolved the events of the extraction loop (tail positions that hold a
  * top element, beam.c:1369-1383): *sweep_rounds = rounds of the all-at-once sweep replay (csrc/beam_sweep.h) when it
  * ran and converged, -1 = it ran and handed the frame to the extraction loop, 0 = not needed (few candidates, or no
- * tied element among them).  Diagnostic / test entry. */
-int  jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds);
+ * tied element among them); *sweep_us (may be NULL) = its duration on the device, *sweep_events (may be NULL) = events
+ * it held at the end.  Diagnostic / test entry. */
+int  jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds, int *sweep_us, int *sweep_events);
 int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
 /* Word trellis of utterance u in emission order (last_tre indexes the same
  * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:

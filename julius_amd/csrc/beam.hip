@@ -1848,7 +1848,7 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
     const size_t cap = ((size_t)n + 1024 + 3) & ~(size_t)3;     // multiple of 4: the heap and the top-list scratch stay aligned
     JAMD_HIP(hipMalloc(&p, cap * 4)); b->owned.push_back(p); b->d_pkeys = (unsigned *)p;
     // out[cap] + nout (+ pad) | heap u64[cap + 2] | top-list scratch u32x4[beam + 256] (wide layout) | sweep replay scratch
-    JAMD_HIP(hipMalloc(&p, 4 * (cap + 4) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256) + xbeam_sweep_bytes(b->w.beam))); b->owned.push_back(p); b->d_pout = (int *)p;
+    JAMD_HIP(hipMalloc(&p, 4 * (cap + 16) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256) + xbeam_sweep_bytes(b->w.beam))); b->owned.push_back(p); b->d_pout = (int *)p;
     b->pcap = cap;
   }
   std::vector<unsigned> keys((size_t)n);
@@ -1859,7 +1859,7 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   hipStream_t st = b->eng->stream;
   JAMD_HIP(hipMemcpyAsync(b->d_pkeys, keys.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
   int *d_nout = b->d_pout + b->pcap;
-  unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 4);
+  unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 16);
   u32x4 *d_collect = reinterpret_cast<u32x4 *>(d_heap + b->pcap + 2);
   unsigned char *d_sweep = reinterpret_cast<unsigned char *>(d_collect + (size_t)b->w.beam + 256);
   xbeam_prune_order_launch(use_half_shape(b, 1) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, d_sweep, st);
@@ -1872,10 +1872,16 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   return JAMD_OK;
 }
 
-int jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds) {
+int jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds, int *sweep_us, int *sweep_events) {
   if (!b || !sweep_rounds || !b->d_pout) { jamd_set_error("jamd_beam_prune_info: bad argument (or no jamd_beam_prune_order() call yet)"); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(b->eng->device));
-  JAMD_HIP(hipMemcpy(sweep_rounds, b->d_pout + b->pcap + 1, 4, hipMemcpyDeviceToHost));
+  int v[11];
+  JAMD_HIP(hipMemcpy(v, b->d_pout + b->pcap + 1, sizeof(v), hipMemcpyDeviceToHost));
+  if (getenv("JAMD_SWEEP_PROF")) fprintf(stderr, "sweep phases (us): setup %d  tables %d  level0 %d  levels %d  chains %d  rebuild %d | level phase 1 %d  phase 2 %d\n",
+                                         v[3] / 100, v[4] / 100, v[5] / 100, v[6] / 100, v[7] / 100, v[8] / 100, v[9] / 100, v[10] / 100);
+  *sweep_rounds = v[0];
+  if (sweep_us) *sweep_us = v[1] / 100;            // wall_clock64(): 100 MHz
+  if (sweep_events) *sweep_events = v[2];
   return JAMD_OK;
 }
 

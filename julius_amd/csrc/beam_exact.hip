@@ -71,6 +71,7 @@ struct XShared {
   unsigned wsum[NT / 64], wsum2[NT / 64];
   int scan_total, scan_total2;
   int sw_nev, sw_limit, sw_fail, sw_changed;     // the sweep replay (beam_sweep.h)
+  int sw_ticks, sw_nev_out, sw_prof[8];                      // its duration (100 MHz ticks), events held at the end
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
 };
 
@@ -1711,14 +1712,14 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
   for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }
-  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; sh.sw_info = 0; }
+  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; sh.sw_info = 0; sh.sw_ticks = 0; sh.sw_nev_out = 0; for (int i = 0; i < 8; i++) sh.sw_prof[i] = 0; }
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
   const int nk = exact_prune<WIDE, NT>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
                                    xw.prune_mode, gcol);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
-  if (threadIdx.x == 0) { nout[0] = nk; nout[1] = sh.sw_info; }
+  if (threadIdx.x == 0) { nout[0] = nk; nout[1] = sh.sw_info; nout[2] = sh.sw_ticks; nout[3] = sh.sw_nev_out; for (int i = 0; i < 8; i++) nout[4 + i] = sh.sw_prof[i]; }
 }
 
 }  // namespace

@@ -44,7 +44,7 @@
 
 constexpr int kSwEvMax = 1024;           // events (probe entries) held
 constexpr int kSwCandMax = 1024;         // candidate turns with a path row
-constexpr int kSwDepth = kMaxL + 2;      // path row: one slot per depth
+constexpr int kSwDepth = kMaxL + 4;      // path row: one slot per depth, three 16-byte words
 constexpr int kSwChain = 3;              // events per element
 constexpr int kSwGroup = 48;             // entries of a tie group that holds events (ordered by one thread)
 constexpr int kSwRounds = 24;
@@ -53,10 +53,12 @@ constexpr int kSwPerThread = 8;          // list entries per thread in a pass
 typedef JAMD_LDS unsigned short lds_u16;
 constexpr unsigned kSwPos = 0x3fffffu;   // heap position (< 2^(kMaxL+1))
 constexpr unsigned kSwProbe = 0x80000000u, kSwLanded = 0x40000000u;
+// a list entry: entry number (13 bits) | landed << 14 | probe << 15 | T << 16
+constexpr unsigned kSwX = 0x1fffu, kSwXLanded = 0x4000u, kSwXProbe = 0x8000u;
+constexpr unsigned kSwXF = 0x2000u;     // (inside a level pass) the T field of this probe / landed entry holds what the entry BEHIND it reads
 
 struct SweepMem {
   lds_u32 *evp;                  // [M] position | flags, per entry (x < nB: the element's current incarnation; nB + c: the probe of event c)
-  lds_u16 *ebirth;               // [nB] turn of the element's last event (landed entries)
   lds_u16 *gid;                  // [nB] tie group: 0x8000 | length at the group's first rank, else that rank
   lds_u16 *ep;                   // [nB + 1] events of the elements in front (the event table is sorted by element)
   lds_u32 *ent[2];               // [M] the list of a level, ping-pong: entry | T << 16
@@ -64,7 +66,10 @@ struct SweepMem {
   lds_u16 *evel[2];              // [kSwEvMax] element
   lds_u16 *tpre;                 // [words + 1] prefix popcount of the tail mask
   lds_u32 *tailmask;
-  unsigned short *TDx;           // global [M] T at the entry's own depth
+  lds_u16 *TDx;                  // [M] T at the entry's own depth
+  lds_u32 *wsum;                 // [2][NT / 64] wave sums of a level's scan, double buffered
+  const lds_u32 *cur_evq;        // the event table in use (a landed element's birth = the turn of its last event)
+  int n;
   unsigned short *path;          // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
   unsigned *ids;                 // global [nB] token ids
   u32x4 *chain;                  // global [nB] new chain of an element: landings (x, y, z), count (w)
@@ -73,13 +78,18 @@ struct SweepMem {
 // LDS and global scratch the sweep needs for a top list of nB entries
 __host__ __device__ inline int sweep_lds_bytes(int nB, int k) {
   const int M = nB + kSwEvMax;
-  return 4 * M + 2 * nB + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * kSwEvMax + 2 * ((k + 31) / 32 + 4) + 64;
+  return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * kSwEvMax + 6 * ((k + 31) / 32 + 4) + 256;
 }
 __host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
-  return 2 * (size_t)(b_cap + kSwEvMax) + 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 16 * (size_t)b_cap + 64;
+  return 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 16 * (size_t)b_cap + 64;
 }
 
 __device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
+// workgroup barrier that orders LDS traffic only: the global stores of a level pass (who moves when: consumed after the
+// whole sweep) stay in flight instead of being waited for at every barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// turn in which landed element x (kSwLanded set) took its present position
+__device__ __forceinline__ int sw_birth(const SweepMem &m, unsigned x) { return m.n - (int)m.cur_evq[(int)m.ep[x + 1] - 1] + 1; }
 
 // block-wide exclusive scan with max (one unsigned per thread, identity 0)
 template <int NT>
@@ -124,7 +134,7 @@ __device__ __forceinline__ bool sweep_order_group(const SweepMem &m, int nB, int
   bool sched = false;
   for (int i = 0; i < cnt; i++) {
     const unsigned x = dst[i];
-    if (x < (unsigned)nB && (m.evp[x] & kSwLanded) && (int)m.ebirth[x] >= tstart) sched = true;
+    if (x < (unsigned)nB && (m.evp[x] & kSwLanded) && sw_birth(m, x) >= tstart) sched = true;
   }
   if (sched) {
     // turn by turn: the first member in pre-order that is present and not out yet
@@ -136,9 +146,9 @@ __device__ __forceinline__ bool sweep_order_group(const SweepMem &m, int nB, int
       for (int i = 0; i < cnt; i++) {
         const unsigned x = dst[i];
         if (x >= (unsigned)nB || ((out >> i) & 1ull)) continue;
-        const int b = (m.evp[x] & kSwLanded) ? (int)m.ebirth[x] : 0;
+        const int b = (m.evp[x] & kSwLanded) ? sw_birth(m, x) : 0;
         if (b < t) { pick = i; break; }
-        if (early < 0 || b < ((m.evp[dst[early]] & kSwLanded) ? (int)m.ebirth[dst[early]] : 0)) early = i;
+        if (early < 0 || b < ((m.evp[dst[early]] & kSwLanded) ? sw_birth(m, dst[early]) : 0)) early = i;
       }
       if (pick < 0) pick = early;                                       // (not in a consistent state)
       out |= 1ull << pick;
@@ -170,9 +180,10 @@ __device__ __forceinline__ bool sweep_order_group(const SweepMem &m, int nB, int
     }
   }
   for (int i = 0; i < cnt; i++) {                                      // the order of the next frame (last round's values stand)
-    const unsigned w = dst[i];
+    const unsigned w = dst[i], x = w & 0xffffu;
     const int t = (int)(w >> 16);
-    if ((w & 0xffffu) < (unsigned)nB && t <= k) svid[k - t] = (int)m.ids[w & 0xffffu];
+    if (x < (unsigned)nB && t <= k) svid[k - t] = (int)m.ids[x];
+    dst[i] = w | (x >= (unsigned)nB ? kSwXProbe : ((m.evp[x] & kSwLanded) ? kSwXLanded : 0u));
   }
   return true;
 }
@@ -187,13 +198,16 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
                                           const lds_u64 *compR, const lds_u32 *vposR, const lds_u32 *idR, lds_u32 *tailmask,
                                           int nB, int n, int k, int ilast, lds_i32 *svid) {
   const int tid = tid_now();
+  const unsigned long long clk0 = wall_clock64();
+  unsigned long long clk = clk0;
+#define SWTICK(i) do { if (tid == 0) { const unsigned long long c_ = wall_clock64(); sh.sw_prof[i] += (int)(c_ - clk); clk = c_; } } while (0)
   const int M = nB + kSwEvMax;
   const int nwords = (k + 31) / 32 + 1;
-  if (nB > kSwPerThread * NT || M > 0xffff || nB >= 0x8000 || sweep_lds_bytes(nB, k) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
+  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
   // ---- the lists leave the region through the global scratch, then it is laid out afresh
   SweepMem m;
-  m.TDx = reinterpret_cast<unsigned short *>(gs);
-  m.path = m.TDx + ((M + 7) & ~7);
+  m.n = n;
+  m.path = reinterpret_cast<unsigned short *>(gs);
   m.ids = reinterpret_cast<unsigned *>(m.path + (size_t)kSwCandMax * kSwDepth);
   m.chain = reinterpret_cast<u32x4 *>(m.ids + ((nB + 3) & ~3));
   unsigned *const stage = reinterpret_cast<unsigned *>(m.chain);      // [nB] positions, [nB] score bits, the tail mask
@@ -206,15 +220,16 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     m.evp = (lds_u32 *)take(4 * M);
     m.ent[0] = (lds_u32 *)take(4 * M);
     m.ent[1] = (lds_u32 *)take(4 * M);
-    m.ebirth = (lds_u16 *)take(2 * nB);
+    m.TDx = (lds_u16 *)take(2 * M);
     m.gid = (lds_u16 *)take(2 * nB);
     m.ep = (lds_u16 *)take(2 * (nB + 2));
     for (int b = 0; b < 2; b++) { m.evq[b] = (lds_u32 *)take(4 * kSwEvMax); m.evh[b] = (lds_u32 *)take(4 * kSwEvMax); m.evel[b] = (lds_u16 *)take(2 * kSwEvMax); }
     m.tailmask = (lds_u32 *)take(4 * (nwords + 1));
     m.tpre = (lds_u16 *)take(2 * (nwords + 2));
+    m.wsum = (lds_u32 *)take(4 * 2 * (NT / 64));
   }
   lds_u32 *score = m.ent[1];                                           // (until the groups are known)
-  for (int r = tid; r < nB; r += NT) { m.evp[r] = stage[r]; score[r] = stage[nB + r]; m.ebirth[r] = 0; }
+  for (int r = tid; r < nB; r += NT) { m.evp[r] = stage[r]; score[r] = stage[nB + r]; }
   for (int w = tid; w < nwords; w += NT) m.tailmask[w] = stage[2 * nB + w];
   if (tid == 0) m.tailmask[nwords] = 0u;
   __syncthreads();
@@ -246,6 +261,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
   };
   if (tid == 0) { sh.sw_nev = 0; sh.sw_limit = ilast; sh.sw_fail = 0; }
   __syncthreads();
+  SWTICK(0);
   int cur = 0;                                                         // event table in use
   int round = 0;
   for (;;) {
@@ -254,6 +270,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     const int nev = uni(sh.sw_nev), limit = uni(sh.sw_limit);
     const int L0 = nB + nev;
     lds_u32 *const evq = m.evq[cur], *const evh = m.evh[cur];
+    m.cur_evq = evq;
     lds_u16 *const evel = m.evel[cur];
     // ---- ep[r] = events of the elements in front of r; prefix popcount of the tail mask; path rows cleared
     {
@@ -288,6 +305,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       unsigned *p32 = reinterpret_cast<unsigned *>(m.path);
       for (int i = tid; i < (nrows * kSwDepth + 1) / 2; i += NT) p32[i] = 0xffffffffu;
     }
+    SWTICK(1);
     // ---- level 0: the entries in extraction order.  A group without events keeps the order of the sorted list.
     {
       lds_u32 *A = m.ent[0];
@@ -305,65 +323,95 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       __syncthreads();
       if (uni(sh.sw_fail)) return false;
     }
+    SWTICK(2);
     // ---- the sweep: level d -> d + 1
     int L = L0, pp = 0;
+    const lds_u16 *const l_ep = m.ep;                                   // (locals: `m` itself may live in scratch memory)
+    const lds_u32 *const l_evq = evq, *const l_evp = m.evp, *const l_tail = m.tailmask;
+    const lds_u16 *const l_tpre = m.tpre;
+    lds_u16 *const l_TDx = m.TDx;
+    unsigned short *const l_path = m.path;
+    lds_u32 *const l_wsum = m.wsum, *const l_ent0 = m.ent[0], *const l_ent1 = m.ent[1];
     for (int d = 0; L > 0; d++) {
       if (d >= kSwDepth - 1) return false;
-      const lds_u32 *A = m.ent[pp];
-      lds_u32 *B = m.ent[pp ^ 1];
+      lds_u32 *A = pp ? l_ent1 : l_ent0;
+      lds_u32 *B = pp ? l_ent0 : l_ent1;
       const int C = (L + NT - 1) / NT;
       if (C > kSwPerThread) return false;
       const int lo = tid * C, hi = min(L, lo + C);
       int nl = 0, nr = 0;
       unsigned kind = 0u;                                              // 2 bits an entry: 1 = goes left, 2 = goes right
+      unsigned spec = 0u;                                              // probes and landed entries among mine
+      // What the entry behind reads is the T of the entry in front -- except behind a probe (looked through: it delays
+      // nobody) and behind a landed entry born in turn b (looked through while the value in front of it is < b).  Those
+      // few entries put that value into their own slot here (bit kSwXF: a slot is read whole, old or new), so that the
+      // second half of the pass reads one word per entry.
       for (int idx = lo; idx < hi; idx++) {
-        const unsigned w = A[idx], x = w & 0xffffu, T = w >> 16;
-        const unsigned ev = m.evp[x], vp = ev & kSwPos;
+        const unsigned w = A[idx], x = w & kSwX, T = w >> 16;
+        const unsigned ev = l_evp[x], vp = ev & kSwPos;
         const int dep = sw_depth(vp);
+        if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << (idx - lo);
         if (d >= 1 && !(ev & kSwProbe) && (int)T <= limit) {           // who moves in a candidate turn
-          const unsigned tw = m.tailmask[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
+          const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
           if (tw & bit) {
-            const int ci = (int)m.tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
-            if (ci < kSwCandMax) m.path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+            const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
+            if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
           }
         }
-        if (dep == d) { m.TDx[x] = (unsigned short)T; continue; }
+        if (dep == d) { l_TDx[x] = (unsigned short)T; continue; }
         const unsigned right = (vp >> (dep - d - 1)) & 1u;
         kind |= (right ? 2u : 1u) << (2 * (idx - lo));
         nl += right ? 0 : 1; nr += right ? 1 : 0;
       }
-      int el, er;
-      block_excl_scan2<NT>(sh, nl, nr, el, er);
-      const int totl = uni(sh.scan_total), totr = uni(sh.scan_total2);
+      while (spec) {                                                   // (a wave runs this once or twice, not once per entry)
+        const int idx = lo + __ffs((int)spec) - 1;
+        spec &= spec - 1u;
+        const unsigned w = A[idx];
+        int j = idx - 1;
+        unsigned wj = j >= 0 ? A[j] : 0u;
+        while (j >= 0 && (wj & (kSwXProbe | kSwXLanded)) && !(wj & kSwXF)) { j--; wj = j >= 0 ? A[j] : 0u; }
+        unsigned v = wj >> 16;
+        for (int s = j + 1; s <= idx; s++) {
+          const unsigned ws = s == idx ? w : A[s];
+          if (ws & kSwXF) { v = ws >> 16; continue; }
+          if (ws & kSwXProbe) continue;
+          const unsigned b = (unsigned)(n - (int)l_evq[(int)l_ep[(ws & kSwX) + 1u] - 1] + 1);
+          if (v < b) continue;
+          v = (ws >> 16) > b ? (ws >> 16) : b;
+        }
+        A[idx] = (w & 0xffffu) | kSwXF | (v << 16);
+      }
+      SWTICK(6);
+      // exclusive scan of (left, right) counts over the workgroup: one barrier (the wave sums alternate between two buffers)
+      int el, er, totl, totr;
+      {
+        const int lane = tid & 63, wv = tid >> 6;
+        unsigned pack = (unsigned)nl | ((unsigned)nr << 16), incl = pack;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        lds_u32 *ws = l_wsum + (d & 1) * (NT / 64);
+        if (lane == 63) ws[wv] = incl;
+        lds_barrier();
+        unsigned base = 0u, tot = 0u;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) { const unsigned v = ws[w]; tot += v; base += w < wv ? v : 0u; }
+        const unsigned ex = base + incl - pack;
+        el = (int)(ex & 0xffffu); er = (int)(ex >> 16);
+        totl = uni((int)(tot & 0xffffu)); totr = uni((int)(tot >> 16));
+      }
       for (int idx = lo; idx < hi; idx++) {
         const unsigned kd = (kind >> (2 * (idx - lo))) & 3u;
         if (!kd) continue;
-        // T of the entry in front: probes are looked through, a landed entry too while the value behind it is < its birth
-        unsigned v = 0u;
-        int j = idx - 1;
-        if (j >= 0) {
-          const unsigned wj = A[j];
-          const unsigned evj = m.evp[wj & 0xffffu];
-          if (!(evj & (kSwProbe | kSwLanded))) v = wj >> 16;
-          else {
-            while (j >= 0 && (m.evp[A[j] & 0xffffu] & (kSwProbe | kSwLanded))) j--;
-            v = j >= 0 ? (A[j] >> 16) : 0u;
-            for (int s = j + 1; s < idx; s++) {
-              const unsigned ws = A[s], xs = ws & 0xffffu, es = m.evp[xs];
-              if (es & kSwProbe) continue;
-              const unsigned b = m.ebirth[xs];
-              if (v < b) continue;
-              v = (ws >> 16) > b ? (ws >> 16) : b;
-            }
-          }
-        }
-        const unsigned x = A[idx] & 0xffffu;
+        const unsigned v = idx > 0 ? (A[idx - 1] >> 16) : 0u;
         const int at = kd == 1u ? el++ : totl + er++;
-        B[at] = x | (v << 16);
+        B[at] = (A[idx] & (0xffffu & ~kSwXF)) | (v << 16);
       }
-      __syncthreads();
+      lds_barrier();
+      SWTICK(7);
       L = totl + totr; pp ^= 1;
     }
+    __syncthreads();                                                   // (the moves written to global memory)
+    SWTICK(3);
     // ---- every chain again from the table
     if (tid == 0) { sh.sw_changed = 0; }
     lds_u32 *ncnt = m.ent[0];                                          // new events per element (then their prefix)
@@ -390,14 +438,18 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const unsigned tw = m.tailmask[(turn - 1) >> 5], bit = 1u << ((turn - 1) & 31);
         const int ci = (int)m.tpre[(turn - 1) >> 5] + __popc(tw & (bit - 1u));
         if (!(tw & bit) || ci >= kSwCandMax) { sh.sw_fail = 1; break; }
-        const unsigned short *row = m.path + (size_t)ci * kSwDepth;
+        const u32x4 *row = reinterpret_cast<const u32x4 *>(m.path + (size_t)ci * kSwDepth);
+        const u32x4 r0 = row[0], r1 = row[1], r2 = row[2];
+        const unsigned rw[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         unsigned h = 1u;
+        bool stop = false;
+#pragma unroll
         for (int dd = 1; dd < kSwDepth; dd++) {
-          const unsigned y = row[dd];
-          if (y == 0xffffu || y == (unsigned)r) break;
+          const unsigned y = (rw[dd >> 1] >> (16 * (dd & 1))) & 0xffffu;
+          if (stop || y == 0xffffu || y == (unsigned)r) { stop = true; continue; }
           int yg, yl;
           group_of((int)y, yg, yl);
-          if (!(yg < g0)) break;
+          if (!(yg < g0)) { stop = true; continue; }
           const unsigned yv = m.evp[y] & kSwPos;
           h = yv >> (sw_depth(yv) - dd);
         }
@@ -420,6 +472,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       m.chain[r] = u32x4{nn > 0 ? nh[0] : 0u, nn > 1 ? nh[1] : 0u, nn > 2 ? nh[2] : 0u, q0};
     }
     __syncthreads();
+    SWTICK(4);
     if (uni(sh.sw_fail)) return false;
     if (!uni(sh.sw_changed)) break;
     // ---- the new event table (sorted by element), the entries' positions
@@ -442,7 +495,6 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         unsigned q = ch.w;
         for (int t = 0; t < nn; t++) { nq[ex + t] = q; nhh[ex + t] = hs[t]; nel[ex + t] = (unsigned short)r; q = hs[t]; }
         m.evp[r] = q | (nn ? kSwLanded : 0u);
-        m.ebirth[r] = (unsigned short)(nn ? n - (int)nq[ex + nn - 1] + 1 : 0);
         ex += nn;
       }
       __syncthreads();
@@ -451,8 +503,10 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       cur ^= 1;
       __syncthreads();
     }
+    SWTICK(5);
   }
-  if (tid == 0) sh.sw_info = round;                                    // rounds it took (diagnostic: jamd_beam_prune_info())
+  if (tid == 0) { sh.sw_info = round; sh.sw_ticks = (int)(wall_clock64() - clk0); sh.sw_nev_out = sh.sw_nev; }   // diagnostic: jamd_beam_prune_info()
   __syncthreads();
   return true;
+#undef SWTICK
 }

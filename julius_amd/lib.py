@@ -135,7 +135,7 @@ def load():
         "jamd_beam_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
-        "jamd_beam_prune_info": (ci, [vp, P(ci)]),
+        "jamd_beam_prune_info": (ci, [vp, P(ci), P(ci), P(ci)]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
@@ -655,8 +655,9 @@ class Beam:
 
     def prune_info(self):
         """Rounds of the sweep replay in the latest prune_order() call (-1 = it gave the frame up, 0 = not used)."""
-        r = C.c_int()
-        _check(load().jamd_beam_prune_info(self.h, C.byref(r)), "jamd_beam_prune_info")
+        r, us, ne = C.c_int(), C.c_int(), C.c_int()
+        _check(load().jamd_beam_prune_info(self.h, C.byref(r), C.byref(us), C.byref(ne)), "jamd_beam_prune_info")
+        self.last_sweep_us, self.last_sweep_events = us.value, ne.value
         return r.value
 
     def stream_begin(self, nutt: int):
