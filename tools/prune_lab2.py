@@ -99,8 +99,11 @@ class Sweep:
             real_before = np.cumsum(~eprobe[order]) - (~eprobe[order])
             A = order; T = real_before + 1
             TD = np.zeros(M, np.int64); moves = {}
+            posend = np.zeros(M, np.int64)       # where an entry that is still in the heap after cnt turns sits then
             d = 0
             while len(A):
+                for x, t in zip(A, T):
+                    if t > self.cnt: posend[x] = int(evp[x]) >> (dep[x] - d)
                 # moves of real entries at this level
                 if d >= 1:
                     for x, t in zip(A, T):
@@ -152,7 +155,9 @@ class Sweep:
                         if h >= n - self.cnt + 1 and n - h + 1 > limit: limit = n - h + 1; changed = True
                 chains[e] = new; nev += len(new)
             if verbose: print("  round", rnd, "entries", M, "events", nev, "changed", changed)
-            if not changed: return chains, rnd
+            if not changed:
+                self.last = dict(ex=ex, evp=evp, eprobe=eprobe, dep=dep, moves=moves, TD=TD, posend=posend)
+                return chains, rnd
         return None, max_rounds
 
 def final_order(gkey, vpos0, chains):
@@ -199,8 +204,63 @@ def check_up(sc, k, verbose=False):
     o = final_order(gk, vpos0, chains)[:k]
     return [int(ids[j]) for j in o] == out, rounds, sum(len(c) for c in chains)
 
+def check_down(sc, k, verbose=False):
+    """sort_token_downward(): min-heap, R = n - k extractions; the survivors are the residual heap H[1..k]."""
+    n = len(sc); R = n - k
+    H = heapify(sc, False)
+    out, Hf = extract(sc, H, R, False)
+    want = Hf[1:k + 1]
+    vR = np.sort(sc)[R - 1]
+    ids = np.nonzero(sc <= vR)[0]
+    pos = np.zeros(n, np.int64); pos[np.array(H[1:])] = np.arange(1, n + 1)
+    score = sc[ids]; vpos0 = pos[ids]
+    u = np.unique(score); gk = np.searchsorted(u, score)
+    sw = Sweep(gk, n, R)
+    chains, rounds = sw.run(vpos0, R, verbose=verbose)
+    if chains is None: return False, rounds, 0
+    L = sw.last
+    ex, evp, eprobe, dep, moves = L["ex"], L["evp"], L["eprobe"], L["dep"], L["moves"]
+    event_turn = set(t for c in chains for (q, t, h) in c)
+    P = list(H)
+    for i in range(1, R + 1):
+        if i in event_turn: continue
+        q = n - i + 1; m = n - i
+        f = 1; d = 1
+        while (i, d) in moves:
+            x = moves[(i, d)]; f = int(evp[x]) >> (dep[x] - d); d += 1
+        s = P[q]; p = f
+        while 2 * p <= m:
+            c = 2 * p
+            if c < m and sc[P[c]] > sc[P[c + 1]]: c += 1
+            if sc[s] <= sc[P[c]]: break
+            P[p] = P[c]; p = c
+        P[p] = s
+    res = P[1:k + 1]
+    for x in range(len(ex)):
+        if not eprobe[x] and L["posend"][x] > 0:
+            assert L["posend"][x] <= k
+            res[int(L["posend"][x]) - 1] = int(ids[ex[x]])
+    return res == want, rounds, sum(len(c) for c in chains)
+
 if __name__ == "__main__":
-    if sys.argv[1] == "real":
+    if sys.argv[1] == "realdown":
+        recs = load(sys.argv[2]); step = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+        dn = [(k, sc) for k, sc in recs if not k < len(sc) - k and len(sc) > k]
+        for k, sc in dn[::step]:
+            ok, rounds, nev = check_down(sc, k)
+            print(f"n={len(sc)} k={k} exact={ok} rounds={rounds} events={nev}", flush=True)
+    elif sys.argv[1] == "fuzzdown":
+        rng = np.random.default_rng(int(sys.argv[2])); N = int(sys.argv[3]); bad = 0; rmax = 0
+        for it in range(N):
+            k = int(rng.integers(1, 200)); n = int(rng.integers(k + 1, 2 * k + 1))
+            nlev = int(rng.choice([3, 8, 30, 1000]))
+            sc = rng.integers(0, nlev, n).astype(np.float32)
+            ok, rounds, nev = check_down(sc, k)
+            rmax = max(rmax, rounds)
+            if not ok:
+                bad += 1; print("MISMATCH", it, n, k, nlev, rounds, nev); np.save(f"/tmp/lab/badd_{it}.npy", np.append(sc, k))
+        print("fuzz down done: bad", bad, "of", N, "max rounds", rmax)
+    elif sys.argv[1] == "real":
         recs = load(sys.argv[2]); step = int(sys.argv[3]) if len(sys.argv) > 3 else 40
         for k, sc in recs[::step]:
             n = len(sc)
