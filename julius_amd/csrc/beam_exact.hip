@@ -408,9 +408,9 @@ __device__ __noinline__ void heap_extract_pipelined(lds_u64 *H, int n, int cnt) 
 // k-th largest of the score bits in H[1..n] (radix select, 11 bits a pass over the bits in which the
 // frame's max and min differ).  Returns the value; all threads.
 template <int NT, typename HP>
-__device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k, lds_u32 *hist) {
+__device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k, lds_u32 *hist, unsigned xm = 0u) {
   unsigned need = (unsigned)k;
-  const unsigned maxb = uni(sh.maxbits), diff = maxb ^ uni(sh.minbits);
+  const unsigned maxb = xm ? ~uni(sh.minbits) : uni(sh.maxbits), diff = uni(sh.maxbits) ^ uni(sh.minbits);
   int remaining = diff ? 32 - __clz(diff) : 0;
   unsigned prefix = remaining < 32 ? (maxb >> remaining) : 0u;
   const int tid = tid_now();
@@ -421,7 +421,7 @@ __device__ __forceinline__ unsigned kth_largest(XShared &sh, HP H, int n, int k,
     const int shift = remaining - w;
     const unsigned dmask = (1u << w) - 1u;
     for (int p = 1 + tid; p <= n; p += NT) {
-      const unsigned b = (unsigned)(H[p] >> 32);
+      const unsigned b = (unsigned)(H[p] >> 32) ^ xm;
       const unsigned hi = (shift + w < 32) ? (b >> (shift + w)) : 0u;
       if (hi == prefix) atomicAdd((unsigned *)&hist[(b >> shift) & dmask], 1u);
     }
@@ -678,24 +678,32 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     PTICK5(5);
     PTICK(4);
     bool done = false;
-    if (upward && mode != 1 && pm.b_cap > 0) {
+    // sort_token_downward() (beam < tokens <= 2 beam) has a closed form too: the same lists over the n - k SMALLEST
+    // elements of the min-heap (score bits complemented), the sweep replay for their moves, and a replay of the short
+    // sifts below the extracted region for the residual heap (down_finish()).  Full shape with the sweep's scratch only.
+    bool down_ok = false;
+    if constexpr (kLdsHeap && NT == jamdb::NT) down_ok = !upward && pm.sw_glob != nullptr;
+    const int cnt = upward ? k : n - k;                            // extractions
+    const unsigned xm = upward ? 0u : 0xffffffffu;
+    if ((upward || down_ok) && mode != 1 && pm.b_cap > 0) {
       // closed form of the extraction loop
-      const unsigned vk = kth_largest<NT>(sh, Hh, n, k, pm.hist);
+      const unsigned vk = kth_largest<NT>(sh, Hh, n, cnt, pm.hist, xm);
       // The top list sorted by (score descending, pre-order of the heap position ascending).  A bitonic network is 55
       // dependent steps at this size; the scores are spread well over their range, so the list is sorted by counting
       // instead: 2048 score bins between the k-th largest score and the maximum (monotone in the score, equal scores
       // in one bin), a prefix sum over the bins, a scatter by bin, and inside its bin (a handful of entries unless many
       // scores are equal) every entry counts the composites greater than its own.  The composites are distinct.
-      const unsigned span = uni(sh.maxbits) - vk;
+      const unsigned span = (upward ? uni(sh.maxbits) : ~uni(sh.minbits)) - vk;
       const int bshift = span ? max(0, 32 - __clz(span) - 11) : 0;
       auto bin_of = [&](unsigned scb) { return (int)min(2047u, (scb - vk) >> bshift); };
       if (tid == 0) { sh.nB = 0; sh.i_last = 0; }
-      for (int i = tid; i < (k + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
+      for (int i = tid; i < (cnt + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
       __syncthreads();                                   // (kth_largest() left the histogram cleared)
       for (int p0 = 1; p0 <= n; p0 += NT) {
         const int p = p0 + tid;
         const unsigned long long hv = p <= n ? Hh[p] : 0ull;
-        const unsigned hi = (unsigned)(hv >> 32);
+        const unsigned hi = (unsigned)(hv >> 32) ^ xm;
+        if (!upward && p <= n) Hglob[p] = hv;            // the heap itself: down_finish() replays the sifts below the extracted region on it
         const bool in = p <= n && hi >= vk;
         const int slot = wave_alloc(&sh.nB, in);
         if (in && slot < pm.b_cap) {
@@ -753,7 +761,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           const unsigned p = prekey_pos(0xffffffffu - (unsigned)cr);
           pm.vposR[r] = p;
           if constexpr (!WIDE) pm.idR[r] = (unsigned)Hh[p];
-          if (p >= (unsigned)(n - k + 1)) {
+          if (p >= (unsigned)(n - cnt + 1)) {
             atomicOr((unsigned *)&pm.tailmask[(n - (int)p) >> 5], 1u << ((n - (int)p) & 31));
             const unsigned sc = (unsigned)(cr >> 32);
             const bool tied = (r > 0 && (unsigned)(pm.compR[r - 1] >> 32) == sc) || (r + 1 < nB && (unsigned)(pm.compR[r + 1] >> 32) == sc);
@@ -762,6 +770,26 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         }
         __syncthreads();
         PTICK(6);
+        if (!upward) {
+          // the residual heap: every event matters (the survivors stay in heap layout), so the sweep runs over all turns
+          bool ok = false;
+          if constexpr (kLdsHeap && NT == jamdb::NT) {
+            const int tailb = sweep_down_bytes(cnt);
+            if (pm.sw_bytes > tailb + 1024) {
+              SweepDown dn;
+              unsigned char JAMD_LDS *tl = pm.sw_region + ((pm.sw_bytes - tailb) & ~15);
+              dn.fd = (lds_u32 *)tl; dn.posend = dn.fd + cnt + 1; dn.evbits = dn.posend + kSwLeft;
+              ok = sweep_replay<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, cnt,
+                                    cnt, svid, kSwEvDown, &dn);
+              __syncthreads();
+              if (ok) ok = down_finish<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, Hglob, n, k, dn, sweep_ids(pm.sw_glob), nB, svid);
+              if (!ok && tid == 0) sh.sw_info = -1;
+              __syncthreads();
+            }
+          }
+          if (ok) { done = true; PTICK(7); }
+          else build_heap();
+        } else {
         // Tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1).  The chain
         // scans only READ the rank lists, so all candidates are scanned at once, one wave each; wave 0 then walks
         // the candidates in turn order and applies the events.  An event moves one element (and shifts the ranks
@@ -804,7 +832,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           if constexpr (NT == jamdb::NT) {         // (the half shape serves narrow beams: a handful of candidates)
            if (pm.sw_glob) {
             swept = sweep_replay<NT>(sh, pm.sw_region, pm.sw_bytes, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, k,
-                                     uni(ctl[3]), svid);
+                                     uni(ctl[3]), svid, kSwEvMax, nullptr);
             if (!swept && tid == 0) sh.sw_info = -1;
             __syncthreads();
            }
@@ -936,6 +964,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         for (int j = tid; j < k; j += NT) svid[j] = (int)pm.idR[k - 1 - j];    // tindex[n-k+j]: ascending
         done = true;
         }                                                        // (!give_up)
+        }                                                        // (upward)
       }                                                          // (more ties on the cut than the lists hold: the heap is untouched)
     }
     if (!done) {

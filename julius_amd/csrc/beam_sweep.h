@@ -57,6 +57,17 @@ constexpr unsigned kSwProbe = 0x80000000u, kSwLanded = 0x40000000u;
 constexpr unsigned kSwX = 0x1fffu, kSwXLanded = 0x4000u, kSwXProbe = 0x8000u;
 constexpr unsigned kSwXF = 0x2000u;     // (inside a level pass) the T field of this probe / landed entry holds what the entry BEHIND it reads
 
+// What sort_token_downward() needs from the sweep beside the chains (all in LDS, behind the sweep's own image):
+struct SweepDown {
+  lds_u32 *fd;                   // [cnt + 1] per turn: (depth << 21 | position) of the deepest position an element left = where the hole
+                                 //           leaves the extracted region (0: the root)
+  lds_u32 *posend;               // [kSwLeft] position after the last turn of the elements that are not extracted (ties on the cut), by rank - (nB - kSwLeft)
+  lds_u32 *evbits;               // [(cnt + 31) / 32 + 1] turns that are events (bit i - 1)
+};
+constexpr int kSwLeft = 512;
+constexpr int kSwEvDown = 256;           // events held when sorting downward (a min-heap's leaves rarely hold one of the smallest)
+__host__ __device__ inline int sweep_down_bytes(int cnt) { return 4 * (cnt + 1) + 4 * kSwLeft + 4 * ((cnt + 31) / 32 + 1) + 48; }
+
 struct SweepMem {
   lds_u32 *evp;                  // [M] position | flags, per entry (x < nB: the element's current incarnation; nB + c: the probe of event c)
   lds_u16 *gid;                  // [nB] tie group: 0x8000 | length at the group's first rank, else that rank
@@ -76,15 +87,17 @@ struct SweepMem {
 };
 
 // LDS and global scratch the sweep needs for a top list of nB entries
-__host__ __device__ inline int sweep_lds_bytes(int nB, int k) {
-  const int M = nB + kSwEvMax;
-  return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * kSwEvMax + 6 * ((k + 31) / 32 + 4) + 256;
+__host__ __device__ inline int sweep_lds_bytes(int nB, int k, int evmax) {
+  const int M = nB + evmax;
+  return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * evmax + 6 * ((k + 31) / 32 + 4) + 512;
 }
 __host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
   return 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 16 * (size_t)b_cap + 64;
 }
 
 __device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
+// token ids of the top list in the sweep's global scratch (rank order of the list handed to sweep_replay())
+__device__ __forceinline__ unsigned *sweep_ids(unsigned char *gs) { return reinterpret_cast<unsigned *>(gs + 2 * (size_t)kSwCandMax * kSwDepth); }
 // workgroup barrier that orders LDS traffic only: the global stores of a level pass (who moves when: consumed after the
 // whole sweep) stay in flight instead of being waited for at every barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -196,19 +209,19 @@ __device__ __forceinline__ bool sweep_order_group(const SweepMem &m, int nB, int
 template <int NT>
 __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *region, int region_bytes, unsigned char *gs,
                                           const lds_u64 *compR, const lds_u32 *vposR, const lds_u32 *idR, lds_u32 *tailmask,
-                                          int nB, int n, int k, int ilast, lds_i32 *svid) {
+                                          int nB, int n, int k, int ilast, lds_i32 *svid, int evmax, const SweepDown *down) {
   const int tid = tid_now();
   const unsigned long long clk0 = wall_clock64();
   unsigned long long clk = clk0;
 #define SWTICK(i) do { if (tid == 0) { const unsigned long long c_ = wall_clock64(); sh.sw_prof[i] += (int)(c_ - clk); clk = c_; } } while (0)
-  const int M = nB + kSwEvMax;
+  const int M = nB + evmax;
   const int nwords = (k + 31) / 32 + 1;
-  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
+  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k, evmax) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
   // ---- the lists leave the region through the global scratch, then it is laid out afresh
   SweepMem m;
   m.n = n;
   m.path = reinterpret_cast<unsigned short *>(gs);
-  m.ids = reinterpret_cast<unsigned *>(m.path + (size_t)kSwCandMax * kSwDepth);
+  m.ids = sweep_ids(gs);
   m.chain = reinterpret_cast<u32x4 *>(m.ids + ((nB + 3) & ~3));
   unsigned *const stage = reinterpret_cast<unsigned *>(m.chain);      // [nB] positions, [nB] score bits, the tail mask
   for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
@@ -223,7 +236,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     m.TDx = (lds_u16 *)take(2 * M);
     m.gid = (lds_u16 *)take(2 * nB);
     m.ep = (lds_u16 *)take(2 * (nB + 2));
-    for (int b = 0; b < 2; b++) { m.evq[b] = (lds_u32 *)take(4 * kSwEvMax); m.evh[b] = (lds_u32 *)take(4 * kSwEvMax); m.evel[b] = (lds_u16 *)take(2 * kSwEvMax); }
+    for (int b = 0; b < 2; b++) { m.evq[b] = (lds_u32 *)take(4 * evmax); m.evh[b] = (lds_u32 *)take(4 * evmax); m.evel[b] = (lds_u16 *)take(2 * evmax); }
     m.tailmask = (lds_u32 *)take(4 * (nwords + 1));
     m.tpre = (lds_u16 *)take(2 * (nwords + 2));
     m.wsum = (lds_u32 *)take(4 * 2 * (NT / 64));
@@ -300,6 +313,10 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       }
       __syncthreads();
     }
+    if (down) {
+      for (int i = tid; i <= k; i += NT) down->fd[i] = 0u;
+      for (int i = tid; i < kSwLeft; i += NT) down->posend[i] = 0u;
+    }
     const int nrows = min((int)m.tpre[nwords], kSwCandMax);
     {
       unsigned *p32 = reinterpret_cast<unsigned *>(m.path);
@@ -315,9 +332,9 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const int c0 = m.ep[g0], c1 = m.ep[g0 + len];
         if (c0 == c1) {
           A[r + c0] = (unsigned)r | ((unsigned)(r + 1) << 16);
-          if (r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
+          if (!down && r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
         } else if (r == g0) {
-          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, k, svid)) sh.sw_fail = 1;
+          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, down ? 0 : k, svid)) sh.sw_fail = 1;
         }
       }
       __syncthreads();
@@ -332,6 +349,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     lds_u16 *const l_TDx = m.TDx;
     unsigned short *const l_path = m.path;
     lds_u32 *const l_wsum = m.wsum, *const l_ent0 = m.ent[0], *const l_ent1 = m.ent[1];
+    lds_u32 *const l_fd = down ? down->fd : nullptr, *const l_posend = down ? down->posend : nullptr;
     for (int d = 0; L > 0; d++) {
       if (d >= kSwDepth - 1) return false;
       lds_u32 *A = pp ? l_ent1 : l_ent0;
@@ -356,6 +374,14 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
           if (tw & bit) {
             const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
             if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+          }
+        }
+        if (l_fd && !(ev & kSwProbe)) {                                // sorting downward: where the hole leaves the extracted region,
+          const unsigned anc = vp >> (dep - d);                        // and where the elements that stay end up
+          if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
+          else {
+            const int li = (int)x - (nB - kSwLeft);
+            if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
           }
         }
         if (dep == d) { l_TDx[x] = (unsigned short)T; continue; }
@@ -483,7 +509,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       for (int r = lo; r < hi; r++) tot += (int)ncnt[r];
       int ex = block_excl_scan<NT>(sh, tot);
       const int total = uni(sh.scan_total);
-      if (total > kSwEvMax) return false;
+      if (total > evmax) return false;
       lds_u32 *const nq = m.evq[cur ^ 1], *const nhh = m.evh[cur ^ 1];
       lds_u16 *const nel = m.evel[cur ^ 1];
       for (int r = lo; r < hi && r < nB; r++) {
@@ -505,8 +531,92 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     }
     SWTICK(5);
   }
+  if (down) {
+    const int nev = uni(sh.sw_nev);
+    for (int i = tid; i < (k + 31) / 32 + 1; i += NT) down->evbits[i] = 0u;
+    __syncthreads();
+    for (int c = tid; c < nev; c += NT) { const int b = n - (int)m.evq[cur][c]; atomicOr((unsigned *)&down->evbits[b >> 5], 1u << (b & 31)); }
+    if (uni(sh.sw_fail)) return false;
+  }
   if (tid == 0) { sh.sw_info = round; sh.sw_ticks = (int)(wall_clock64() - clk0); sh.sw_nev_out = sh.sw_nev; }   // diagnostic: jamd_beam_prune_info()
   __syncthreads();
   return true;
 #undef SWTICK
+}
+
+// sort_token_downward() (beam.c:1414-1457), the part the sweep does not give: the residual heap.  Every turn i takes the
+// tail element s = H[n - i + 1]; when s is not one of the extracted elements it sinks from the position where the hole
+// left the extracted region (fd[i]) through the elements that stay -- a few levels at most, the extracted region covers
+// the top of the heap.  The sifts of different turns touch the same positions only when one starts below the other
+// (the lower one is the earlier turn: the extracted region shrinks from below) or when a sift ends on the tail position a
+// later turn reads; so every sift waits for at most three earlier ones -- the turns that freed its start's two children
+// and the latest turn that freed an ancestor of its tail position -- and otherwise all of them run at once, one lane
+// each, in windows of NT turns.  P = the heap as heapify left it (global copy, loaded to LDS here).
+// Out: svid[0..k) = the token ids at heap positions 1..k after the last turn (= tindex[0..k), :1512-1514).
+template <int NT>
+__device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *region, int region_bytes, const unsigned long long *Pg,
+                                         int n, int k, SweepDown dn, const unsigned *ids, int nB, lds_i32 *svid) {
+  const int tid = tid_now();
+  const int R = n - k;
+  if (8 * (n + 2) + 2 * (n + 2) + (R + 8) + 64 > region_bytes || n >= 0xffff) return false;
+  volatile lds_u64 *P = (volatile lds_u64 *)region;
+  lds_u16 *strip = (lds_u16 *)(region + 8 * (n + 2));
+  volatile JAMD_LDS unsigned char *done = (volatile JAMD_LDS unsigned char *)(region + 8 * (n + 2) + ((2 * (n + 2) + 15) & ~15));
+  for (int p = tid; p <= n; p += NT) { P[p] = p ? Pg[p] : 0ull; strip[p] = 0xffffu; }
+  for (int i = tid; i <= R; i += NT) done[i] = i == 0 ? 1 : 0;
+  __syncthreads();
+  auto is_event = [&](int i) { return (dn.evbits[(i - 1) >> 5] >> ((i - 1) & 31)) & 1u; };
+  auto start_of = [&](int i) { const unsigned w = dn.fd[i]; return w ? (int)(w & 0x1fffffu) : 1; };
+  for (int i = 1 + tid; i <= R; i += NT) if (!is_event(i)) strip[start_of(i)] = (unsigned short)i;
+  __syncthreads();
+  for (int base = 0; base < R; base += NT) {
+    const int i = base + tid + 1;
+    bool mine = i <= R && !is_event(i);
+    int f = 1, d1 = 0, d2 = 0, d3 = 0;
+    const int q = n - i + 1, m = n - i;
+    if (mine) {
+      f = start_of(i);
+      if (2 * f <= n) { const int s = strip[2 * f]; if (s < i) d1 = s; }
+      if (2 * f + 1 <= n) { const int s = strip[2 * f + 1]; if (s < i) d2 = s; }
+      for (int a = q; a >= 1; a >>= 1) {                                  // the latest earlier turn that freed the tail position or one above it
+        const int s = strip[a];
+        if (s == 0xffff) continue;
+        if (s < i) d3 = s; else break;
+      }
+    }
+    int guard = 0;
+    while (__any(mine)) {
+      if (mine && done[d1] && done[d2] && done[d3]) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const unsigned long long s = P[q];
+        const unsigned sv = (unsigned)(s >> 32);
+        int p = f, child;
+        while ((child = 2 * p) <= m) {
+          unsigned long long c = P[child];
+          if (child < m) {
+            const unsigned long long c2 = P[child + 1];
+            if ((unsigned)(c >> 32) > (unsigned)(c2 >> 32)) { child++; c = c2; }
+          }
+          if (sv <= (unsigned)(c >> 32)) break;
+          P[p] = c;
+          p = child;
+        }
+        P[p] = s;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        done[i] = 1;
+        mine = false;
+      }
+      if (++guard > (1 << 22)) { sh.sw_fail = 1; break; }                  // (a dependency that never resolves: not in a consistent state)
+    }
+    __syncthreads();
+    if (uni(sh.sw_fail)) return false;
+  }
+  for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)P[1 + j];
+  __syncthreads();
+  for (int li = tid; li < kSwLeft; li += NT) {                              // the elements of the list that were not extracted (ties on the cut)
+    const unsigned pe = dn.posend[li];
+    if (pe) { if (pe <= (unsigned)k) svid[pe - 1] = (int)ids[nB - kSwLeft + li]; else sh.sw_fail = 1; }
+  }
+  __syncthreads();
+  return !uni(sh.sw_fail);
 }

@@ -33,7 +33,7 @@ def test_real_frames_of_the_c4_task(engine, oracle):
         want = oracle.sort_token_no_order(sc, beam)
         assert np.array_equal(got, want), (name, len(sc), info)
         swept += info > 0
-    assert swept >= 3, swept            # the frames with a tied element on a tail position go through the sweep
+    assert swept >= 6, swept            # frames with a tied element on a tail position, and every downward frame
     bm.close()
 
 
@@ -75,4 +75,33 @@ def test_sweep_with_heavy_ties(engine, oracle):
             assert np.array_equal(got, want), (n, levels, info)
             seen.add(1 if info > 0 else info)
     assert 1 in seen, seen
+    bm.close()
+
+
+@pytest.mark.parametrize("beam", [1500, 4000])
+def test_downward_sort_through_the_sweep(engine, oracle, beam):
+    """beam < tokens <= 2 beam: sort_token_downward() (beam.c:1414-1457) -- the survivors are the residual MIN-heap after
+    n - beam extractions, in heap layout.  Device: closed form over the extracted elements + replay of the sifts below
+    them (down_finish()); frames with few and with many events, ties on the cut, ties everywhere."""
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(beam + 7)
+    stats = []
+    for mult in (1.02, 1.2, 1.45, 1.7, 1.9, 1.98, 2.0):
+        n = min(2 * beam, int(mult * beam) + int(rng.integers(0, 20)))
+        for kind in ("distinct", "dup", "levels400", "levels8"):
+            if kind == "distinct":
+                sc = (rng.permutation(n).astype(np.float32) * -0.37 - 100.0).astype(np.float32)
+            elif kind == "dup":
+                sc = (-rng.random(n) * 300.0 - 5000.0).astype(np.float32)
+                nd = max(2, int(0.03 * n))
+                sc[rng.integers(0, n, nd)] = sc[rng.integers(0, n, nd)]
+            else:
+                levels = 400 if kind == "levels400" else 8
+                sc = (-rng.integers(0, levels, n).astype(np.float32) * 0.5 - 2000.0).astype(np.float32)
+            got = bm.prune_order(sc)
+            info = bm.prune_info()
+            want = oracle.sort_token_no_order(sc, beam)
+            assert np.array_equal(got, want), (n, beam, kind, info)
+            stats.append(info)
+    assert sum(1 for s in stats if s > 0) >= len(stats) // 2, stats
     bm.close()
