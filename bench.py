@@ -453,6 +453,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
         sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         beam_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         res_local = bm.results()
+        pstats = [x // max(1, steps + warmup) for x in bm.prune_stats(0, reset=True)] if mode.startswith("exact") else [0] * 8   # per step
         # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
         nutt_all = nutt * dd.world
         if dd.world > 1:
@@ -487,7 +488,9 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
                               "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
                  "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,
                            "mean_peak_tokens": float(np.mean([x.max_tokens for x in res_local])),
-                           "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us)}}
+                           "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us),
+                           "prune_paths_utt0": dict(zip(("frames_pruned", "up_closed_form", "up_wave_replay", "up_sweep", "up_sweep_gave_up",
+                                                         "down_closed_form", "extraction_loop", "sweep_rounds"), pstats))}}
             if ri == 0 and dd.world == 1 and not args.no_cpu_baseline:
                 r["parity"], cpu = e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_local, jargs, wd, ref_built, use_dnn)
                 if cpu is not None:

@@ -550,6 +550,14 @@ int  jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order,
  * tied element among them); *sweep_us (may be NULL) = its duration on the device, *sweep_events (may be NULL) = events
  * it held at the end.  Diagnostic / test entry. */
 int  jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds, int *sweep_us, int *sweep_events);
+/* How the rank pruning steps (sort_token_no_order(), beam.c:1492) of utterance `utt` were resolved by the exact-order
+ * kernel since the work area was created or the counters were last reset -- frames counted by path:
+ *   [0] frames pruned (more tokens than the beam)          [1] upward, closed form, no tied element on a tail position
+ *   [2] upward, wave-serial event replay                   [3] upward, sweep replay converged
+ *   [4] upward, sweep gave the frame to the extraction loop [5] downward, closed form (sweep + residual-heap replay)
+ *   [6] extraction loop itself (pipelined / serial)        [7] sweep rounds, total.
+ * reset != 0 clears them.  Diagnostic. */
+int  jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[8], int reset);
 int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
 /* Word trellis of utterance u in emission order (last_tre indexes the same
  * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:

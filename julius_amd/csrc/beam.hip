@@ -1604,6 +1604,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
       place(&xw.o_collect, ((size_t)beam_width + 256) * 16);
       place(&xw.o_sweep, xbeam_sweep_bytes(beam_width));
+      place(&xw.o_pstat, 8 * sizeof(int));
     }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
@@ -1632,7 +1633,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       XWork &xh = b->xw_half;
       const int svh = xh.w.sv_bytes;
       xh.w = w; xh.w.sv_bytes = svh;
-      xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect; xh.o_sweep = b->xw.o_sweep;
+      xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect; xh.o_sweep = b->xw.o_sweep; xh.o_pstat = b->xw.o_pstat;
     }
     if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
   }
@@ -1869,6 +1870,16 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   JAMD_HIP(hipStreamSynchronize(st));
   if (*nkeep < 0 || *nkeep > n) { jamd_set_error("jamd_beam_prune_order: the kernel reported %d of %d tokens kept", *nkeep, n); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpy(order, b->d_pout, 4 * (size_t)*nkeep, hipMemcpyDeviceToHost));
+  return JAMD_OK;
+}
+
+int jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[8], int reset) {
+  if (!b || !stats || utt < 0 || utt >= b->max_utts) { jamd_set_error("jamd_beam_prune_stats: bad argument"); return JAMD_EINVAL; }
+  if (b->exact_status != 0) { jamd_set_error("jamd_beam_prune_stats: the exact-order kernel does not serve this work area"); return JAMD_ESTATE; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  unsigned char *p = b->w.slices + (size_t)utt * b->w.utt_stride + b->xw.o_pstat;
+  JAMD_HIP(hipMemcpy(stats, p, 8 * sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) JAMD_HIP(hipMemset(p, 0, 8 * sizeof(int)));
   return JAMD_OK;
 }
 

@@ -12,6 +12,7 @@ struct XWork {
   unsigned o_heap;             // u64 [tok_cap + 2] heap of a frame with more tokens than the LDS heap holds
   unsigned o_collect;          // u32x4 [beam + 256] wide layout: the top list on its way from the heap to the sorted lists
   unsigned o_sweep;            // xbeam_sweep_bytes(beam): scratch of the sweep replay (beam_sweep.h), 0 = none
+  unsigned o_pstat;            // int [8]: how this utterance's pruning steps were resolved (jamd_beam_prune_stats())
   int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())

@@ -215,6 +215,7 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   unsigned char JAMD_LDS *sw_region;   // the sweep replay (beam_sweep.h): all of the pruning step's overlay, laid out afresh
   int sw_bytes;
   unsigned char *sw_glob;        // its global scratch (sweep_global_bytes()), nullptr = no sweep
+  int *pstat;                    // [8] how the pruning steps of this utterance were resolved (jamd_beam_prune_stats()), or nullptr
 };
 
 template <bool UP, typename HP>
@@ -662,6 +663,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     __syncthreads();
     return n;
   }
+#define PSTAT(i, v) do { if (pm.pstat && tid == 0) pm.pstat[i] += (v); } while (0)
+  PSTAT(0, 1);
   const bool upward = k < n - k;
   const bool in_lds = n <= heap_cap;
   auto run = [&](auto Hh) -> void {
@@ -779,15 +782,16 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
               SweepDown dn;
               unsigned char JAMD_LDS *tl = pm.sw_region + ((pm.sw_bytes - tailb) & ~15);
               dn.fd = (lds_u32 *)tl; dn.posend = dn.fd + cnt + 1; dn.evbits = dn.posend + kSwLeft;
-              ok = sweep_replay<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, cnt,
-                                    cnt, svid, kSwEvDown, &dn);
+              const int evmax = sweep_pick_evmax(nB, cnt, (pm.sw_bytes - tailb) & ~15);
+              if (evmax) ok = sweep_replay<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, cnt,
+                                               cnt, svid, evmax, &dn);
               __syncthreads();
               if (ok) ok = down_finish<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, Hglob, n, k, dn, sweep_ids(pm.sw_glob), nB, svid);
               if (!ok && tid == 0) sh.sw_info = -1;
               __syncthreads();
             }
           }
-          if (ok) { done = true; PTICK(7); }
+          if (ok) { done = true; PTICK(7); PSTAT(5, 1); PSTAT(7, sh.sw_info); }
           else build_heap();
         } else {
         // Tail positions holding a top element, in the order of their turns (bit b <-> extraction b + 1).  The chain
@@ -831,14 +835,15 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           bool swept = false;
           if constexpr (NT == jamdb::NT) {         // (the half shape serves narrow beams: a handful of candidates)
            if (pm.sw_glob) {
-            swept = sweep_replay<NT>(sh, pm.sw_region, pm.sw_bytes, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, k,
-                                     uni(ctl[3]), svid, kSwEvMax, nullptr);
+            const int evmax = sweep_pick_evmax(nB, k, pm.sw_bytes);
+            if (evmax) swept = sweep_replay<NT>(sh, pm.sw_region, pm.sw_bytes, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, k,
+                                                uni(ctl[3]), svid, evmax, nullptr);
             if (!swept && tid == 0) sh.sw_info = -1;
             __syncthreads();
            }
           }
-          if (swept) { done = true; PTICK(7); }
-          else give_up = true;
+          if (swept) { done = true; PTICK(7); PSTAT(3, 1); PSTAT(7, sh.sw_info); }
+          else { give_up = true; PSTAT(4, 1); }
         }
         if (give_up) {
           build_heap();
@@ -961,6 +966,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         }
         __syncthreads();
         PTICK(7);
+        PSTAT(uni(ctl[3]) > 0 && uni(ctl[0]) > 0 ? 2 : 1, 1);
         for (int j = tid; j < k; j += NT) svid[j] = (int)pm.idR[k - 1 - j];    // tindex[n-k+j]: ascending
         done = true;
         }                                                        // (!give_up)
@@ -968,6 +974,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       }                                                          // (more ties on the cut than the lists hold: the heap is untouched)
     }
     if (!done) {
+      PSTAT(6, 1);
       // the extraction loop itself: pipelined on one wave when the heap is in LDS, else (and in the cross-check
       // mode JAMD_ORDER_EXACT_SERIAL) sequentially on one lane
       bool piped = false;
@@ -985,6 +992,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
   };
   if (in_lds) run(H); else run(Hglob);
   return k;
+#undef PSTAT
 #undef PTICK
 }
 
@@ -1102,6 +1110,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.b_cap = xw.b_cap;
   pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
   pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;
+  pm.pstat = xw.o_sweep ? reinterpret_cast<int *>(ub + xw.o_pstat) : nullptr;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
   u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
@@ -1738,6 +1747,7 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   pm.b_cap = xw.b_cap;
   pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
   pm.sw_glob = gsweep;
+  pm.pstat = nullptr;
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
   for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }

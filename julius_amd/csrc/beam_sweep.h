@@ -45,7 +45,8 @@
 constexpr int kSwEvMax = 1024;           // events (probe entries) held
 constexpr int kSwCandMax = 1024;         // candidate turns with a path row
 constexpr int kSwDepth = kMaxL + 4;      // path row: one slot per depth, three 16-byte words
-constexpr int kSwChain = 3;              // events per element
+constexpr int kSwChain = 8;              // events per element (an element can bounce from tail leaf to tail leaf: five in real frames)
+constexpr int kSwChainRec = 12;          // words of an element's new chain in the global scratch: landings, then the first position
 constexpr int kSwGroup = 48;             // entries of a tie group that holds events (ordered by one thread)
 constexpr int kSwRounds = 24;
 constexpr int kSwPerThread = 8;          // list entries per thread in a pass
@@ -65,7 +66,6 @@ struct SweepDown {
   lds_u32 *evbits;               // [(cnt + 31) / 32 + 1] turns that are events (bit i - 1)
 };
 constexpr int kSwLeft = 512;
-constexpr int kSwEvDown = 256;           // events held when sorting downward (a min-heap's leaves rarely hold one of the smallest)
 __host__ __device__ inline int sweep_down_bytes(int cnt) { return 4 * (cnt + 1) + 4 * kSwLeft + 4 * ((cnt + 31) / 32 + 1) + 48; }
 
 struct SweepMem {
@@ -83,7 +83,7 @@ struct SweepMem {
   int n;
   unsigned short *path;          // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
   unsigned *ids;                 // global [nB] token ids
-  u32x4 *chain;                  // global [nB] new chain of an element: landings (x, y, z), count (w)
+  unsigned *chain;               // global [nB][kSwChainRec] new chain of an element: its landings, word kSwChain = its first position
 };
 
 // LDS and global scratch the sweep needs for a top list of nB entries
@@ -91,8 +91,14 @@ __host__ __device__ inline int sweep_lds_bytes(int nB, int k, int evmax) {
   const int M = nB + evmax;
   return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * evmax + 6 * ((k + 31) / 32 + 4) + 512;
 }
+// the most events (a multiple of 64, at most kSwEvMax) whose image fits `avail` bytes of LDS; 0 = none
+__host__ __device__ inline int sweep_pick_evmax(int nB, int k, int avail) {
+  int ev = kSwEvMax;
+  while (ev >= 64 && sweep_lds_bytes(nB, k, ev) > avail) ev -= 64;
+  return ev >= 64 ? ev : 0;
+}
 __host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
-  return 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 16 * (size_t)b_cap + 64;
+  return 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 4 * (size_t)kSwChainRec * (size_t)b_cap + 64;
 }
 
 __device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
@@ -216,14 +222,14 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
 #define SWTICK(i) do { if (tid == 0) { const unsigned long long c_ = wall_clock64(); sh.sw_prof[i] += (int)(c_ - clk); clk = c_; } } while (0)
   const int M = nB + evmax;
   const int nwords = (k + 31) / 32 + 1;
-  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k, evmax) > region_bytes || 4 * (2 * nB + nwords) > 16 * nB) return false;
+  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k, evmax) > region_bytes || 4 * (2 * nB + nwords) > 4 * kSwChainRec * nB) return false;
   // ---- the lists leave the region through the global scratch, then it is laid out afresh
   SweepMem m;
   m.n = n;
   m.path = reinterpret_cast<unsigned short *>(gs);
   m.ids = sweep_ids(gs);
-  m.chain = reinterpret_cast<u32x4 *>(m.ids + ((nB + 3) & ~3));
-  unsigned *const stage = reinterpret_cast<unsigned *>(m.chain);      // [nB] positions, [nB] score bits, the tail mask
+  m.chain = m.ids + ((nB + 3) & ~3);
+  unsigned *const stage = m.chain;      // [nB] positions, [nB] score bits, the tail mask
   for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
   for (int w = tid; w < nwords; w += NT) stage[2 * nB + w] = tailmask[w];
   __syncthreads();
@@ -482,7 +488,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         nh[nn++] = h;
         vp = h;
       }
-      if (nn == kSwChain && vp >= (unsigned)(n - k + 1) && n - (int)vp + 1 <= limit) sh.sw_fail = 1;   // a fourth event: not held
+      if (nn == kSwChain && vp >= (unsigned)(n - k + 1) && n - (int)vp + 1 <= limit) sh.sw_fail = 1;   // one more event: not held
       changed = nn != oc;
       for (int t = 0; t < nn && t < oc; t++) changed |= nh[t] != evh[c0 + t];
       if (len > 1) {
@@ -495,7 +501,11 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       }
       if (changed) sh.sw_changed = 1;
       ncnt[r] = (unsigned)nn;
-      m.chain[r] = u32x4{nn > 0 ? nh[0] : 0u, nn > 1 ? nh[1] : 0u, nn > 2 ? nh[2] : 0u, q0};
+      {
+        unsigned *rec = m.chain + (size_t)r * kSwChainRec;
+        for (int t = 0; t < nn; t++) rec[t] = nh[t];
+        rec[kSwChain] = q0;
+      }
     }
     __syncthreads();
     SWTICK(4);
@@ -516,10 +526,9 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const int nn = (int)ncnt[r];
         const int oc = (int)m.ep[r + 1] - (int)m.ep[r];
         if (nn == 0 && oc == 0) continue;
-        const u32x4 ch = m.chain[r];
-        const unsigned hs[3] = {ch.x, ch.y, ch.z};
-        unsigned q = ch.w;
-        for (int t = 0; t < nn; t++) { nq[ex + t] = q; nhh[ex + t] = hs[t]; nel[ex + t] = (unsigned short)r; q = hs[t]; }
+        const unsigned *rec = m.chain + (size_t)r * kSwChainRec;
+        unsigned q = rec[kSwChain];
+        for (int t = 0; t < nn; t++) { const unsigned h = rec[t]; nq[ex + t] = q; nhh[ex + t] = h; nel[ex + t] = (unsigned short)r; q = h; }
         m.evp[r] = q | (nn ? kSwLanded : 0u);
         ex += nn;
       }

@@ -136,6 +136,7 @@ def load():
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_prune_info": (ci, [vp, P(ci), P(ci), P(ci)]),
+        "jamd_beam_prune_stats": (ci, [vp, ci, vp, ci]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
         "jamd_beam_stream_push_dev": (ci, [vp, vp, ci, vp, ci, ci, vp]),
         "jamd_beam_trellis": (ci, [vp, ci, vp, ci, P(ci)]),
@@ -659,6 +660,12 @@ class Beam:
         _check(load().jamd_beam_prune_info(self.h, C.byref(r), C.byref(us), C.byref(ne)), "jamd_beam_prune_info")
         self.last_sweep_us, self.last_sweep_events = us.value, ne.value
         return r.value
+
+    def prune_stats(self, utt=0, reset=False):
+        """Frames of utterance `utt` by the path their rank pruning step took (jamd_beam_prune_stats)."""
+        st = np.zeros(8, np.int32)
+        _check(load().jamd_beam_prune_stats(self.h, utt, st.ctypes.data, 1 if reset else 0), "jamd_beam_prune_stats")
+        return [int(x) for x in st]
 
     def stream_begin(self, nutt: int):
         self._nutt = nutt
