@@ -48,6 +48,7 @@ typedef struct {
   int nstate;
   const HTK_Param *param;    /* utterance the cache was filled for */
   int filled;                /* frames [0, filled) are in the cache */
+  int from_zero;             /* the scoring carries history from frame to frame: a grown input is scored from frame 0 again */
 } wrap_ctx;
 
 static jamd_engine *g_eng = NULL;
@@ -108,9 +109,11 @@ static void examine(wrap_ctx *c)
     jlog("Stat: jamd: unknown Gaussian pruning function (a plugin?); scoring stays on libsent's CPU code\n");
     return;
   }
-  if (gprune >= JAMD_GPRUNE_HEU && wrk->OP_hmminfo->is_tied_mixture)
+  if (gprune >= JAMD_GPRUNE_HEU && wrk->OP_hmminfo->is_tied_mixture) {
+    c->from_zero = 1;
     jlog("Stat: jamd: -gprune heu/beam over tied-mixture codebooks: the thresholds of frame t come from frame t-1 of the same input "
          "(every frame is scored on the device), i.e. the reference's values under eager scoring\n");
+  }
   if (jamd_flatten_hmminfo(wrk->OP_hmminfo, &fg) != 0) die("cannot flatten the acoustic model");
   if (jamd_gmm_create(g_eng, &fg.desc, gprune, wrk->OP_gprune_num, &c->gmm) != JAMD_OK) die("jamd_gmm_create");
   c->nstate = fg.desc.nstate;
@@ -143,7 +146,11 @@ static void ensure(HMMWork *wrk, HTK_Param *param)
   T = param->samplenum;
   if (c->param != param) { c->param = param; c->filled = 0; }
   if (c->filled >= T) return;
-  if (c->gms != NULL) c->filled = 0;        /* the selection carries state from frame to frame: always from frame 0 */
+  /* State carried from frame to frame -- the Gaussian selection, and gprune heu/beam over tied-mixture codebooks (frame
+   * t's thresholds are the codebook's winners of frame t-1, calc_tied_mix.c:203-215) -- is the state of ONE device
+   * call: when the input grows (a second call on the same param), score from frame 0 again, else the first new frame
+   * would take the no-history branch and differ from the reference's eager-scoring values. */
+  if (c->gms != NULL || c->from_zero) c->filled = 0;
   n = T - c->filled;
   fr = jamd_pack_param(param, c->filled, T);
   sc = (float *)malloc(sizeof(float) * (size_t)n * c->nstate);

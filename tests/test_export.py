@@ -79,3 +79,27 @@ def test_export_verification_gmms(ref, tmp_path):
         assert np.array_equal(got[k], want["model"][k]), k
     assert got["model_names"] == names[::-1]                       # the loader prepends: reverse file order
     assert [bool(v) for v in got["is_voice"]] == [n not in ("noise", "cough") for n in got["model_names"]]
+
+
+def test_product_shim_makefile_builds_the_bindings(tmp_path):
+    """julius_amd/shim/Makefile -- the product's own recipe for the reference-side half of the boundary -- builds the
+    flatten objects and the three bindings against a Julius tree without touching oracle/ (only the config headers of
+    an unconfigured tree come from oracle/refcfg here); the pass-1 shim exports exactly beam.o's five symbols
+    (libjulius/include/julius/extern.h:57-61)."""
+    import os, subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    ref = Path(os.environ.get("JULIUS_REF", "/root/reference"))
+    if not (ref / "libsent/include/sent/stddefs.h").exists():
+        import pytest
+        pytest.skip("no Julius source tree on this box")
+    subprocess.run(["make", "-s", "-C", str(root / "julius_amd/shim"), "objs", f"JULIUS_SRC={ref}", f"JULIUS_CFG={root / 'oracle/refcfg'}",
+                    f"OBJDIR={tmp_path}"], check=True)
+    for o in ("jamd_flatten.o", "jamd_flatten_lex.o", "jamd_pass1_shim.o", "jamd_outprob_wrap.o", "jamd_gmm_wrap.o"):
+        assert (tmp_path / o).stat().st_size > 1000
+    syms = subprocess.run(["nm", "-g", "--defined-only", str(tmp_path / "jamd_pass1_shim.o")], check=True, capture_output=True, text=True).stdout
+    have = {ln.split()[-1] for ln in syms.splitlines() if " T " in ln}
+    want = {"get_back_trellis_init", "get_back_trellis_proceed", "get_back_trellis_end", "fsbeam_free", "finalize_1st_pass"}
+    assert want <= have, have
+    wrap = subprocess.run(["make", "-s", "-C", str(root / "julius_amd/shim"), "print-wrap", f"JULIUS_SRC={ref}"], check=True, capture_output=True, text=True).stdout
+    assert "--wrap=outprob_state" in wrap and "--wrap=gmm_proceed" in wrap
