@@ -1,13 +1,17 @@
 /*
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
- *   jamd_batch [-d device] [-b beam] [-bs score_width] [-gprune none|safe N|heu N|beam N] [-order exact|fast|strict] [-shard R N]
- *              [-rej verification.blob]
+ *   jamd_batch [-d device | -devices 0,1,..|0-7] [-b beam] [-bs score_width] [-gprune none|safe N|heu N|beam N]
+ *              [-order exact|fast|strict] [-shard R N] [-rej verification.blob]
  *              (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
  *
  * -shard R N: this process takes the utterances u with u % N == R (one process per GPU, e.g.
  * `for r in 0..7: jamd_batch -d $r -shard $r 8 ...`): utterances are independent, the model is
  * replicated, nothing is exchanged.
+ * -devices LIST: the same sharding INSIDE one process -- one host thread with its own engine, models and first-pass
+ * work area per listed device (a device may be listed twice), utterance u of the file list on list entry u % n; the
+ * result lines of all devices are merged and printed in file-list order when every device is done (BASELINE
+ * configs[4]: one node, eight GPUs, one batch).  Combines with -shard (R N processes x n devices each).
  *
  * model.blob / lexicon.blob are written once by a Julius process through the shim
  * (jamd_gmm_save / jamd_lexicon_save); a DNN is read from Julius' own dnnconf + .npy files.
@@ -24,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <time.h>
 #include "julius_amd.h"
 
@@ -96,20 +101,152 @@ static void score(chunk *c, int nstate, jamd_gmm *gm, jamd_dnn *dn, jamd_gms *gs
   if (gs != NULL && jamd_gms_apply_dev(gs, c->d_frames, c->off[c->n], c->off, c->n, c->d_scores, stream) != JAMD_OK) die("Gaussian mixture selection");
 }
 
-int main(int argc, char **argv)
+/* options (shared by the device threads, read-only once parsed) */
+static const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL, *rejp = NULL;
+static int beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, order = -1;
+static float bs = -1.0f;
+
+/* one device's share of the file list: files[0..nfile) are ITS utterances, gidx[] their numbers in the whole list; with
+ * out != NULL the result lines go to out[gidx[u]] (merged by main), else they are printed as the launches complete */
+typedef struct { int device; char **files; int *gidx; int nfile; char **out; } devjob;
+
+static void emit(devjob *j, int u, const char *text)
 {
-  const char *am = NULL, *dnnconf = NULL, *lexp = NULL, *list = NULL, *gmsp = NULL, *rejp = NULL;
-  int device = 0, beam = 800, gprune = JAMD_GPRUNE_NONE, gnum = 0, strict = 0, order = -1, shard_r = 0, shard_n = 1, i;
-  float bs = -1.0f;
+  if (j->out != NULL) j->out[j->gidx[u]] = strdup(text);
+  else fputs(text, stdout);
+}
+
+static void *run_device(void *arg)
+{
+  devjob *j = (devjob *)arg;
+  char **files = j->files;
+  const int nfile = j->nfile;
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
-  char **files = NULL; int nfile = 0, capfile = 0, nline = 0, veclen, nstate, first, k;
+  int veclen, nstate, first, k;
   chunk ck[2];
   void *s_copy = NULL, *s_beam = NULL;
+  size_t linecap = 1 << 16;
+  char *text = (char *)malloc(linecap);
+
+  if (text == NULL) die("out of memory");
+  if (jamd_engine_create(j->device, &e) != JAMD_OK) die("engine");
+  if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }
+  else if (jamd_dnn_load(e, dnnconf, &dn) != JAMD_OK) die("DNN");
+  veclen = gm ? jamd_gmm_veclen(gm) : jamd_dnn_veclen(dn);
+  nstate = gm ? jamd_gmm_nstate(gm) : jamd_dnn_nstate(dn);
+  if (gmsp != NULL) {                                 /* -gshmm of the exported configuration */
+    if (jamd_gms_load(e, gmsp, &gs) != JAMD_OK) die("selection model");
+    if (strict && jamd_gms_set_strict_order(gs, 1) != JAMD_OK) die("strict order");
+    if (jamd_gms_nstate(gs) != nstate) { fprintf(stderr, "jamd_batch: %s belongs to another acoustic model\n", gmsp); exit(1); }
+  }
+  if (rejp != NULL) {                                 /* -gmm / -gmmnum / -gmmreject of the exported configuration */
+    if (jamd_rejgmm_load(e, rejp, &rj) != JAMD_OK) die("verification GMMs");
+    if (jamd_rejgmm_veclen(rj) != veclen) { fprintf(stderr, "jamd_batch: %s is for %d-dim input\n", rejp, jamd_rejgmm_veclen(rj)); exit(1); }
+  }
+  if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
+  if (jamd_beam_create(e, lx, beam, bs, LAUNCH, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
+  if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
+  if (!strict && order >= 0 && jamd_beam_set_order_mode(bm, order) != JAMD_OK) die("order mode");
+
+  /* Launches of up to LAUNCH utterances over two streams: `s_copy` uploads and scores, `s_beam` searches.  While the
+   * first pass of launch k runs, the host reads the files of launch k+1, uploads them and -- once that first pass is
+   * on the device (jamd_beam_wait_started(): queued any earlier, the scoring workgroups take the LDS the first pass
+   * wants for its second utterance per CU and it takes twice as long) -- queues their scoring, which fills the CUs
+   * that the shorter utterances of launch k leave. */
+  if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
+  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy); score(&ck[0], nstate, gm, dn, gs, s_copy); }
+  for (first = 0, k = 0; first < nfile; first += launch, k++) {
+    chunk *c = &ck[k & 1];
+    const int n = c->n;
+    const int *off = c->off;
+    int u;
+    float *us = NULL;
+    jamd_pass1_result *res = (jamd_pass1_result *)malloc(sizeof(jamd_pass1_result) * LAUNCH);
+    if (res == NULL) die("out of memory");
+    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch k */
+    if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
+    if (first + launch < nfile) {
+      chunk *nx = &ck[(k + 1) & 1];
+      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy);
+      if (jamd_beam_wait_started(bm) != JAMD_OK) die("first pass");
+      { struct timespec ms = {0, 1000000}; nanosleep(&ms, NULL); }            /* its workgroups are on the CUs by now */
+      score(nx, nstate, gm, dn, gs, s_copy);
+    }
+    if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+    if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
+      const int nm = jamd_rejgmm_nmodel(rj);
+      float *d_fs = NULL, *d_us = NULL;
+      us = (float *)malloc(sizeof(float) * (size_t)n * nm);
+      if (us == NULL || jamd_malloc(e, sizeof(float) * (size_t)off[n] * nm, (void **)&d_fs) != JAMD_OK ||
+          jamd_malloc(e, sizeof(float) * (size_t)n * nm, (void **)&d_us) != JAMD_OK ||
+          jamd_rejgmm_frame_scores_dev(rj, c->d_frames, off[n], d_fs, s_beam) != JAMD_OK ||
+          jamd_rejgmm_utt_scores_dev(rj, d_fs, off[n], off, n, d_us, s_beam) != JAMD_OK ||
+          jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_memcpy_d2h(e, us, d_us, sizeof(float) * (size_t)n * nm) != JAMD_OK) die("input verification");
+      jamd_free(e, d_fs); jamd_free(e, d_us);
+    }
+    for (u = 0; u < n; u++) {
+      int w;
+      size_t at = 0;
+      if ((size_t)res[u].wnum * 12 + strlen(files[first + u]) + 512 > linecap) { linecap = 2 * ((size_t)res[u].wnum * 12 + strlen(files[first + u]) + 512); text = (char *)realloc(text, linecap); if (text == NULL) die("out of memory"); }
+      at += (size_t)sprintf(text + at, "%s status=%d score=%.9g words=", files[first + u], res[u].status, (double)res[u].score);
+      for (w = 0; w < res[u].wnum; w++) at += (size_t)sprintf(text + at, "%s%d", w ? " " : "", res[u].wseq[w]);
+      if (rj != NULL) {
+        int win, acc; float cm;
+        if (jamd_rejgmm_verdict(rj, us + (size_t)u * jamd_rejgmm_nmodel(rj), &win, &cm, &acc) != JAMD_OK) die("verdict");
+        at += (size_t)sprintf(text + at, " gmm=%s gmmscore=%.9g cm=%.9g accepted=%d", jamd_rejgmm_model_name(rj, win),
+                              (double)us[(size_t)u * jamd_rejgmm_nmodel(rj) + win], (double)cm, acc);
+      }
+      sprintf(text + at, "\n");
+      emit(j, first + u, text);
+    }
+    free(us); free(res);
+    jamd_free(e, c->d_frames); jamd_free(e, c->d_scores); free(c->frames);
+    c->d_frames = c->d_scores = NULL; c->frames = NULL;
+  }
+  jamd_stream_destroy(e, s_copy); jamd_stream_destroy(e, s_beam);
+  jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
+  if (rj) jamd_rejgmm_destroy(rj);
+  if (gs) jamd_gms_destroy(gs);
+  if (gm) jamd_gmm_destroy(gm);
+  if (dn) jamd_dnn_destroy(dn);
+  jamd_engine_destroy(e);
+  free(text);
+  return NULL;
+}
+
+/* "0,1,2" or "0-7" or "0-3,0-3" -> device numbers; returns how many (0 = malformed) */
+static int parse_devices(const char *spec, int *dev, int cap)
+{
+  int n = 0;
+  const char *p = spec;
+  while (*p) {
+    char *end;
+    long a = strtol(p, &end, 10), b;
+    if (end == p || a < 0) return 0;
+    b = a;
+    if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); if (end == p || b < a) return 0; }
+    for (; a <= b; a++) { if (n == cap) return 0; dev[n++] = (int)a; }
+    if (*end == ',') end++; else if (*end) return 0;
+    p = end;
+  }
+  return n;
+}
+
+int main(int argc, char **argv)
+{
+  int device = 0, shard_r = 0, shard_n = 1, i, d;
+  int devs[64], ndev = 0;
+  const char *devspec = NULL;
+  char **files = NULL; int nfile = 0, capfile = 0;
   char line[4096];
   FILE *fl;
+  devjob jobs[64];
+  pthread_t th[64];
+  char **out = NULL;
 
   for (i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-d") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-devices") && i + 1 < argc) devspec = argv[++i];
     else if (!strcmp(argv[i], "-b") && i + 1 < argc) beam = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-bs") && i + 1 < argc) bs = (float)atof(argv[++i]);
     else if (!strcmp(argv[i], "-gprune") && i + 1 < argc) {
@@ -135,101 +272,44 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-filelist") && i + 1 < argc) list = argv[++i];
     else { fprintf(stderr, "jamd_batch: unknown option %s\n", argv[i]); return 2; }
   }
-  if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n || launch < 1 || launch > LAUNCH) {
+  if (devspec != NULL) ndev = parse_devices(devspec, devs, 64); else { devs[0] = device; ndev = 1; }
+  if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n || launch < 1 || launch > LAUNCH || ndev < 1) {
     fprintf(stderr, "usage: jamd_batch (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
-                    "[-d dev] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512]\n");
+                    "[-d dev | -devices 0,1,..|0-7] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512]\n");
     return 2;
   }
   setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* the upload/scoring stream and the first-pass stream must not share a hardware queue */
   if (jamd_abi_version() != JAMD_ABI_VERSION) { fprintf(stderr, "jamd_batch: ABI mismatch\n"); return 1; }
-  if (jamd_engine_create(device, &e) != JAMD_OK) die("engine");
-  if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }
-  else if (jamd_dnn_load(e, dnnconf, &dn) != JAMD_OK) die("DNN");
-  veclen = gm ? jamd_gmm_veclen(gm) : jamd_dnn_veclen(dn);
-  nstate = gm ? jamd_gmm_nstate(gm) : jamd_dnn_nstate(dn);
-  if (gmsp != NULL) {                                 /* -gshmm of the exported configuration */
-    if (jamd_gms_load(e, gmsp, &gs) != JAMD_OK) die("selection model");
-    if (strict && jamd_gms_set_strict_order(gs, 1) != JAMD_OK) die("strict order");
-    if (jamd_gms_nstate(gs) != nstate) { fprintf(stderr, "jamd_batch: %s belongs to another acoustic model\n", gmsp); return 1; }
-  }
-  if (rejp != NULL) {                                 /* -gmm / -gmmnum / -gmmreject of the exported configuration */
-    if (jamd_rejgmm_load(e, rejp, &rj) != JAMD_OK) die("verification GMMs");
-    if (jamd_rejgmm_veclen(rj) != veclen) { fprintf(stderr, "jamd_batch: %s is for %d-dim input\n", rejp, jamd_rejgmm_veclen(rj)); return 1; }
-  }
-  if (jamd_lexicon_load(e, lexp, &lx) != JAMD_OK) die("lexicon");
-  if (jamd_beam_create(e, lx, beam, bs, LAUNCH, 1 << 18, &bm) != JAMD_OK) die("first-pass work area");
-  if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
-  if (!strict && order >= 0 && jamd_beam_set_order_mode(bm, order) != JAMD_OK) die("order mode");
 
   if ((fl = fopen(list, "r")) == NULL) { fprintf(stderr, "jamd_batch: cannot open %s\n", list); return 1; }
   while (fgets(line, sizeof(line), fl)) {
     size_t n = strlen(line);
     while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r' || line[n - 1] == ' ')) line[--n] = 0;
     if (n == 0) continue;
-    if (shard_n > 1 && (i = nline++) % shard_n != shard_r) continue;     /* another process's utterance */
     if (nfile == capfile) { capfile = capfile ? 2 * capfile : 64; files = (char **)realloc(files, sizeof(char *) * capfile); }
     files[nfile++] = strdup(line);
   }
   fclose(fl);
 
-  /* Launches of up to LAUNCH utterances over two streams: `s_copy` uploads and scores, `s_beam` searches.  While the
-   * first pass of launch k runs, the host reads the files of launch k+1, uploads them and -- once that first pass is
-   * on the device (jamd_beam_wait_started(): queued any earlier, the scoring workgroups take the LDS the first pass
-   * wants for its second utterance per CU and it takes twice as long) -- queues their scoring, which fills the CUs
-   * that the shorter utterances of launch k leave. */
-  if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
-  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy); score(&ck[0], nstate, gm, dn, gs, s_copy); }
-  for (first = 0, k = 0; first < nfile; first += launch, k++) {
-    chunk *c = &ck[k & 1];
-    const int n = c->n;
-    const int *off = c->off;
+  /* utterance u of the list belongs to shard u % (shard_n * ndev); this process holds shards shard_r * ndev + d */
+  if (ndev > 1) out = (char **)calloc((size_t)nfile + 1, sizeof(char *));
+  for (d = 0; d < ndev; d++) {
+    devjob *j = &jobs[d];
     int u;
-    float *us = NULL;
-    static jamd_pass1_result res[LAUNCH];
-    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch k */
-    if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
-    if (first + launch < nfile) {
-      chunk *nx = &ck[(k + 1) & 1];
-      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy);
-      if (jamd_beam_wait_started(bm) != JAMD_OK) die("first pass");
-      { struct timespec ms = {0, 1000000}; nanosleep(&ms, NULL); }            /* its workgroups are on the CUs by now */
-      score(nx, nstate, gm, dn, gs, s_copy);
-    }
-    if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
-    if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
-      const int nm = jamd_rejgmm_nmodel(rj);
-      float *d_fs = NULL, *d_us = NULL;
-      us = (float *)malloc(sizeof(float) * (size_t)n * nm);
-      if (us == NULL || jamd_malloc(e, sizeof(float) * (size_t)off[n] * nm, (void **)&d_fs) != JAMD_OK ||
-          jamd_malloc(e, sizeof(float) * (size_t)n * nm, (void **)&d_us) != JAMD_OK ||
-          jamd_rejgmm_frame_scores_dev(rj, c->d_frames, off[n], d_fs, s_beam) != JAMD_OK ||
-          jamd_rejgmm_utt_scores_dev(rj, d_fs, off[n], off, n, d_us, s_beam) != JAMD_OK ||
-          jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_memcpy_d2h(e, us, d_us, sizeof(float) * (size_t)n * nm) != JAMD_OK) die("input verification");
-      jamd_free(e, d_fs); jamd_free(e, d_us);
-    }
-    for (u = 0; u < n; u++) {
-      int w;
-      printf("%s status=%d score=%.9g words=", files[first + u], res[u].status, (double)res[u].score);
-      for (w = 0; w < res[u].wnum; w++) printf("%s%d", w ? " " : "", res[u].wseq[w]);
-      if (rj != NULL) {
-        int win, acc; float cm;
-        if (jamd_rejgmm_verdict(rj, us + (size_t)u * jamd_rejgmm_nmodel(rj), &win, &cm, &acc) != JAMD_OK) die("verdict");
-        printf(" gmm=%s gmmscore=%.9g cm=%.9g accepted=%d", jamd_rejgmm_model_name(rj, win),
-               (double)us[(size_t)u * jamd_rejgmm_nmodel(rj) + win], (double)cm, acc);
-      }
-      printf("\n");
-    }
-    free(us);
-    jamd_free(e, c->d_frames); jamd_free(e, c->d_scores); free(c->frames);
-    c->d_frames = c->d_scores = NULL; c->frames = NULL;
+    j->device = devs[d]; j->nfile = 0; j->out = out;
+    j->files = (char **)malloc(sizeof(char *) * ((size_t)nfile + 1));
+    j->gidx = (int *)malloc(sizeof(int) * ((size_t)nfile + 1));
+    for (u = 0; u < nfile; u++)
+      if (u % (shard_n * ndev) == shard_r * ndev + d) { j->files[j->nfile] = files[u]; j->gidx[j->nfile++] = u; }
   }
-  jamd_stream_destroy(e, s_copy); jamd_stream_destroy(e, s_beam);
-  jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
-  if (rj) jamd_rejgmm_destroy(rj);
-  if (gs) jamd_gms_destroy(gs);
-  if (gm) jamd_gmm_destroy(gm);
-  if (dn) jamd_dnn_destroy(dn);
-  jamd_engine_destroy(e);
+  if (ndev == 1) run_device(&jobs[0]);
+  else {
+    for (d = 0; d < ndev; d++) if (pthread_create(&th[d], NULL, run_device, &jobs[d]) != 0) { fprintf(stderr, "jamd_batch: cannot start a device thread\n"); return 1; }
+    for (d = 0; d < ndev; d++) pthread_join(th[d], NULL);
+    for (i = 0; i < nfile; i++) if (out[i] != NULL) { fputs(out[i], stdout); free(out[i]); }
+    free(out);
+  }
+  for (d = 0; d < ndev; d++) { free(jobs[d].files); free(jobs[d].gidx); }
   for (i = 0; i < nfile; i++) free(files[i]);
   free(files);
   return 0;

@@ -275,6 +275,17 @@ def word_state_path(task, ws, rng):
     return seq + list(phys["silE"])
 
 
+def make_path_utterance(task, nwords=8, seed=0, frames_per_state=3, noise=0.6):
+    """make_utterance() through the task's own triphone models (word_state_path): frames drawn around the centres of
+    the states the random word sequence really passes, so that both passes of the reference recognise it."""
+    rng = np.random.default_rng(seed)
+    model = task["model"]
+    ws = [task["words"][int(i)] for i in rng.integers(0, len(task["words"]), size=nwords)]
+    st = np.repeat(np.array(word_state_path(task, ws, rng)), frames_per_state)
+    fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
+    return fr.astype(np.float32), [w for w, _ in ws]
+
+
 def make_dnn_utterance(task, dnn, nwords=30, seed=0, frames_per_state=3, noise=0.5):
     """An utterance for the DNN-HMM task: frames in the network's INPUT space (one dims[0]-vector per frame, the
     form `-input htkparam` hands to dnn_calc_outprob(): parvec[t] is the spliced vector already, calc_dnn.c:800-803)
@@ -413,10 +424,14 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
         # forward 2-gram (a b) needs its reversed tuple (b a) among the RL 2-grams
         # (ngram_read_arpa.c:305-318); tuples are sorted in 1-gram order.
         rl2 = sorted({(j, i) for i, j, _ in big})
+        first2 = {}                          # i -> the first two k with (i, k) among the RL 2-grams, in their order
+        for (i2, k) in rl2:
+            lst = first2.setdefault(i2, [])
+            if len(lst) < 2:
+                lst.append(k)
         rl3 = []
         for (j, i) in rl2[::3]:
-            ks = [k for (i2, k) in rl2 if i2 == i][:2]
-            rl3 += [(j, i, k) for k in ks]
+            rl3 += [(j, i, k) for k in first2.get(i, [])]
         rl3 = sorted(set(rl3))
         rl = workdir / "lm_rl.arpa"
         with open(rl, "w") as f:

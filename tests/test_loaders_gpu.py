@@ -122,6 +122,22 @@ def test_standalone_c_driver(oracle, tmp_path):
                                 str(tmp_path / "list"), "-b", str(g["beam_width"]), "-launch", per_launch],
                                check=True, capture_output=True, text=True).stdout.strip().splitlines()
         assert again == out
+    # BASELINE configs[4] inside one process: one host thread + engine + work area per listed device (here the same
+    # device twice and three times), utterances dealt round-robin, result lines merged in file-list order
+    for devices in ("0,0", "0-0,0,0"):
+        merged = subprocess.run([str(exe), "-am", str(tmp_path / "am.blob"), "-lex", str(tmp_path / "lex.blob"), "-filelist",
+                                 str(tmp_path / "list"), "-b", str(g["beam_width"]), "-devices", devices],
+                                check=True, capture_output=True, text=True).stdout.strip().splitlines()
+        assert merged == out
+    # and combined with process-level shards: 2 processes x 2 device threads = 4 shards
+    lines = {}
+    for r in range(2):
+        part = subprocess.run([str(exe), "-am", str(tmp_path / "am.blob"), "-lex", str(tmp_path / "lex.blob"), "-filelist",
+                               str(tmp_path / "list"), "-b", str(g["beam_width"]), "-devices", "0,0", "-shard", str(r), "2"],
+                              check=True, capture_output=True, text=True).stdout.strip().splitlines()
+        for ln in part:
+            lines[ln.split(" ", 1)[0]] = ln
+    assert [lines[n] for n in names] == out
 
 
 @pytest.mark.parametrize("gms", [False, True])

@@ -85,3 +85,63 @@ def test_two_ranks_equal_serial(oracle):
         total += len(fr)
     assert np.array_equal(table, shard.pack_results(want))
     assert frames == total
+
+
+# ---------------------------------------------------------------------------------- the same with the device engine
+def _gpu_worker(rank, world, port, workdir, nutt, q):
+    """A rank of the N-GPU job with the PRODUCT doing the work: `jamd_batch -shard rank world` (C, C ABI only) decodes
+    this rank's utterances on the device; the ranks exchange nothing but the result records (gloo here, RCCL in bench.py)."""
+    import subprocess
+    from julius_amd import lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_beam_golden("beam_rank.npz")
+    out = subprocess.run([str(lib._PKG / "jamd_batch"), "-am", f"{workdir}/am.blob", "-lex", f"{workdir}/lex.blob", "-filelist",
+                          f"{workdir}/list", "-b", str(g["beam_width"]), "-shard", str(rank), str(world)],
+                         check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    mine = shard.shard_indices(nutt, rank, world)
+    assert len(out) == len(mine)
+    res = []
+    for ln in out:
+        f = ln.split(" ", 3)
+        ws = [int(x) for x in f[3].split("=", 1)[1].split()]
+        res.append(SimpleNamespace(status=int(f[1].split("=")[1]), wnum=len(ws), frames=0, score=float(f[2].split("=")[1]), wseq=ws))
+    table = shard.gather_results(shard.pack_results(res), nutt, rank, world)
+    if rank == 0:
+        q.put(table)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_drive_the_device_batch_driver(oracle, tmp_path):
+    """world 2 on one device: every rank runs jamd_batch over its shard, the gathered table equals the oracle's serial
+    decode of the whole batch (the same check as above with the device engine in place of the oracle)."""
+    from julius_amd import lexblob, synth
+    g = load_beam_golden("beam_rank.npz")
+    nutt, world = 5, 2
+    lexblob.save_gmm(g["am"], tmp_path / "am.blob")
+    lexblob.save(g["lex"], tmp_path / "lex.blob")
+    names, frames = [], []
+    for u in range(nutt):
+        fr = g["utts"][u % len(g["utts"])]["frames"][: 60 + 7 * u]
+        frames.append(fr)
+        names.append(str(tmp_path / f"u{u}.mfc"))
+        synth.write_htk_param(names[-1], fr)
+    (tmp_path / "list").write_text("\n".join(names) + "\n")
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, str(tmp_path), nutt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    table = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    want = [_decode(oracle, g, oracle.gmm_outprob(g["am"], fr)) for fr in frames]
+    for w in want:
+        w.frames = 0
+    assert np.array_equal(table, shard.pack_results(want))

@@ -78,6 +78,41 @@ def test_reference_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, s
             assert_canonical_close(tr1, tr0, max_diff=8)
 
 
+def test_full_size_two_pass_with_backward_trigram(ref, tmp_path, monkeypatch):
+    """SURVEY 8f N2 at the size of BASELINE configs[1-2]: 20 000-word dictionary, 3 000 x 16 tied-state triphones,
+    forward 2-gram (-nlr) for the first pass AND backward 3-gram (-nrl) for the second, the reference's complete two-pass
+    recogniser (recogmain.c:1292-1345) on top of the device first pass (boundary B, exact tie order) against the plain
+    reference: pass-1 best, the trellis the second pass consumes, and the final sentence1 / score1 are identical on
+    utterances the model really recognises (frames drawn along the words' own triphone states)."""
+    _order_env(monkeypatch, "exact")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+    if not pyoracle.REF_AMD_SO.exists():
+        pytest.skip("oracle/_ref/libjref_amd.so not built")
+    task = synth.make_triphone_task(tmp_path, nphone=40, S=3000, M=16, nword=20000, nvar=25, seed=0, maxlen=8,
+                                    nbigram_per_word=10, with_rl3=True)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"], "-nrl", task["arpa_rl"],
+            "-input", "htkparam", "-b", "800", "-b2", "30", "-n", "1", "-s", "500", "-gprune", "none"]
+    plain = pyoracle.RefEngine(ref, args)
+    amd = pyoracle.RefEngine(pyoracle.Ref(so=pyoracle.REF_AMD_SO), args)
+    assert plain.beam_width == 800
+    found = 0
+    for u in range(4):
+        fr, words = synth.make_path_utterance(task, nwords=6 + 2 * u, seed=700 + u)
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        tr0, (w0, s0) = plain.recognize(tmp_path / "u.mfc")
+        st0, f0, fs0 = plain.final_result()
+        tr1, (w1, s1) = amd.recognize(tmp_path / "u.mfc")
+        st1, f1, fs1 = amd.final_result()
+        d1, n1 = amd.cache_fill()
+        assert d1 == n1                                                # the second pass read device scores only
+        assert st1 == st0 and np.array_equal(w1, w0) and s1 == s0
+        assert np.array_equal(f1, f0) and fs1 == fs0
+        for k in tr0:
+            assert np.array_equal(tr1[k], tr0[k]), k
+        found += int(st0 == 0 and len(f0) >= len(words))
+    assert found >= 3, found                                           # real sentences, not failed searches on both sides
+
+
 # ------------------------------------------------------------------ boundary O (scoring only)
 def _compare_exact(plain, wrapped, mfc):
     tr0, (w0, s0) = plain.recognize(mfc)
