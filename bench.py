@@ -432,8 +432,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
             count[0] += 1
             s_score.wait_event(consumed[b])
             if tailfill:
-                bm.wait_started()                               # the previous step's first pass is next to run ...
-                time.sleep(1e-3)                                # ... and has its workgroups on the CUs
+                bm.stream_wait_resident(s_score.cuda_stream)    # the scoring starts once the previous step's first pass holds its CUs
             if mark:
                 mark[0].record(s_score)
             scorer.outprob_dev(d_fr.data_ptr(), T, d_scs[b].data_ptr(), s_score.cuda_stream)

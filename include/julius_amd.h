@@ -539,6 +539,13 @@ int  jamd_beam_workgroup_shape(const jamd_beam *b, int nutt);
  * first pass wants, and the first pass of 512 utterances takes twice as long; queued once it runs they only fill the
  * CUs its shorter utterances leave (julius_amd/host/jamd_batch.c, bench.py: -5 % per step). */
 int  jamd_beam_wait_started(jamd_beam *b);
+/* The same ordering WITHOUT the host: work queued on `stream` after this call starts only when the workgroups of the
+ * latest first-pass launch of this work area that fit the device at once (one per CU; two in the exact-order kernel's
+ * half shape) have started -- they bump a counter in signal memory as their first instruction and `stream`'s command
+ * processor waits on it (hipStreamWaitValue32).  A pipelining host calls it between the first-pass launch of batch k
+ * and the scoring launches of batch k+1 (jamd_batch.c, bench.py): no event wait, no sleep, nothing to time.  Devices
+ * without wait-on-memory fall back to jamd_beam_wait_started() plus a millisecond's pause inside this call. */
+int  jamd_beam_stream_wait_resident(jamd_beam *b, void *stream);
 /* The rank-pruning step alone (sort_token_no_order(), beam.c:1492): given the scores of the n tokens of
  * a frame in creation order (host array), writes the token indices the next frame visits, in visiting
  * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the

@@ -119,6 +119,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
   __shared__ Shared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   const int u = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0 && wk.resident) __hip_atomic_fetch_add(wk.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this workgroup holds its CU now
   // smode 0: whole utterances.  smode 1 / 2: streaming -- this launch advances every utterance
   // by the rows utt_off[u]..utt_off[u+1]) of `scores`; 2 = also run get_back_trellis_end() and
   // the traceback.  The state between launches lives in wk.stream[u] and in the slice at o_sv.
@@ -1294,6 +1295,9 @@ struct jamd_beam {
   int shape_mode = JAMD_SHAPE_AUTO;
   bool stream_half = false;        // the shape of the open streaming session (the parked state is the layout's)
   hipEvent_t ev_started = nullptr; // recorded right before the latest first-pass launch (jamd_beam_wait_started())
+  unsigned *d_resident = nullptr;  // signal memory: first-pass workgroups started so far (Work::resident), nullptr = the device cannot wait on memory
+  unsigned resident_target = 0;    // its value once the workgroups of the latest launch that fit the device at once have started
+  unsigned launched_wg = 0;        // workgroups of all launches so far
   unsigned *d_pkeys = nullptr; int *d_pout = nullptr; size_t pcap = 0;   // jamd_beam_prune_order() scratch
   bool timed = false;               // JAMD_BEAM_TIMING=1: launch the instrumented instantiation
   int streaming = 0;               // utterances of the open streaming session, 0 = none
@@ -1343,9 +1347,22 @@ static int upload_utt_off(jamd_beam *b, const int *utt_off, int nutt, hipStream_
 
 // An event behind everything the launch stream holds before the first-pass kernel: it completes when that kernel is
 // next to run (jamd_beam_wait_started()).
-static int mark_started(jamd_beam *b, hipStream_t st) {
+static int mark_started(jamd_beam *b, hipStream_t st, int nutt, bool counted) {
   if (!b->ev_started) JAMD_HIP(hipEventCreateWithFlags(&b->ev_started, hipEventDisableTiming));
   JAMD_HIP(hipEventRecord(b->ev_started, st));
+  if (counted) {
+    // what fits the device at once: one workgroup per CU, two in the exact-order kernel's half shape
+    const int cap = b->eng->num_cu * ((b->exact && !b->strict && use_half_shape(b, nutt)) ? 2 : 1);
+    // ... less a sixteenth: a launch that fills the device has nearly all of its workgroups placed within microseconds,
+    // but the last handful may start only when others end (measured on 512 utterances: any threshold up to 98 % releases
+    // the waiting stream at once, 100 % holds it for 170 ms; JAMD_RESIDENT_SHARE=<percent> for experiments)
+    int share = nutt < cap ? nutt : cap;
+    int pct = 94;
+    { const char *pc = getenv("JAMD_RESIDENT_SHARE"); if (pc && atoi(pc) > 0 && atoi(pc) <= 100) pct = atoi(pc); }
+    share = (int)((long long)share * pct / 100);
+    b->resident_target = b->launched_wg + (unsigned)(share > 0 ? share : 1);
+    b->launched_wg += (unsigned)nutt;
+  } else b->resident_target = b->launched_wg;
   return JAMD_OK;
 }
 
@@ -1611,6 +1628,22 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   }
   if (rc == JAMD_OK) rc = alloc((void **)&w.slices, U * (size_t)w.utt_stride, true);    // zero: empty Viterbi cells
   if (rc == JAMD_OK) rc = alloc((void **)&w.res, U * sizeof(jamd_pass1_result), true);
+  w.resident = nullptr;
+  if (rc == JAMD_OK) {
+    // a counter the first-pass workgroups bump when they start, in signal memory so that another stream's command
+    // processor can wait on it (jamd_beam_stream_wait_resident()); JAMD_NO_WAIT_VALUE=1 keeps the host-side wait
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, e->device);
+    const char *off = getenv("JAMD_NO_WAIT_VALUE");
+    if (can && !(off && off[0] == '1')) {
+      void *p = nullptr;
+      if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess && p) {
+        if (hipMemset(p, 0, 8) == hipSuccess) { b->d_resident = (unsigned *)p; w.resident = b->d_resident; }
+        else (void)hipFree(p);
+      }
+      (void)hipGetLastError();
+    }
+  }
   if (rc == JAMD_OK) {
     // the attribute is per kernel, not per work area: always ask for the whole budget
     hipError_t ae = hipFuncSetAttribute((const void *)beam_pass1_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1649,6 +1682,7 @@ void jamd_beam_destroy(jamd_beam *b) {
   (void)hipSetDevice(b->eng->device);
   for (void *p : b->owned) (void)hipFree(p);
   if (b->ev_started) (void)hipEventDestroy(b->ev_started);
+  if (b->d_resident) (void)hipFree(b->d_resident);
   delete b;
 }
 
@@ -1670,7 +1704,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
-  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st, nutt, !b->strict); if (rc != JAMD_OK) return rc; }
   if (b->lex->multipath && !b->strict) {
     jamd_set_error("jamd_beam_pass1_dev: a multipath lexicon is decoded by the strict-order kernel only: "
                    "jamd_beam_set_strict_order(b, 1)");
@@ -1745,7 +1779,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, chunk_off, nutt, st); if (rc != JAMD_OK) return rc; }
-  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st, nutt, true); if (rc != JAMD_OK) return rc; }
   if (b->exact) {
     b->xw.w.stream = b->w.stream; b->xw_half.w.stream = b->w.stream;
     xbeam_launch(b->lex->d, b->stream_half ? b->xw_half : b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
@@ -1826,6 +1860,22 @@ int jamd_beam_wait_started(jamd_beam *b) {
   if (!b->ev_started) return JAMD_OK;                  // nothing launched yet
   JAMD_HIP(hipSetDevice(b->eng->device));
   JAMD_HIP(hipEventSynchronize(b->ev_started));
+  return JAMD_OK;
+}
+
+int jamd_beam_stream_wait_resident(jamd_beam *b, void *stream) {
+  if (!b) { jamd_set_error("jamd_beam_stream_wait_resident: NULL"); return JAMD_EINVAL; }
+  if (!b->ev_started) return JAMD_OK;                  // nothing launched yet
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  if (b->d_resident) {
+    // the command processor of `stream` waits until the counter the first-pass workgroups bump when they start has
+    // reached the latest launch's share; the host is not involved
+    JAMD_HIP(hipStreamWaitValue32(jamd_stream(b->eng, stream), b->d_resident, b->resident_target, hipStreamWaitValueGte, 0xffffffffu));
+    return JAMD_OK;
+  }
+  JAMD_HIP(hipEventSynchronize(b->ev_started));       // no wait-on-memory on this device: the host waits, and gives the dispatcher a moment
+  struct timespec ms = {0, 1000000};
+  nanosleep(&ms, nullptr);
   return JAMD_OK;
 }
 

@@ -75,6 +75,8 @@ struct StreamState {     // what a streaming utterance carries from one launch t
 
 struct Work {            // per-utterance slices are addressed with the strides below
   StreamState *stream;           // [utt] (allocated by jamd_beam_stream_begin)
+  unsigned *resident;            // workgroups of the first-pass kernels that have started, ever (signal memory: a stream can wait
+                                 // on it, jamd_beam_stream_wait_resident()), or nullptr
   // Per-utterance arrays live in ONE slice per utterance (slices + utt * utt_stride) and are
   // addressed as slice base + 32-bit offset, for the same reason as the lexicon arena (LexDev):
   unsigned char *slices; unsigned long long utt_stride;

@@ -32,6 +32,12 @@ int jamd_device_count(void) {
 int jamd_engine_create(int device, jamd_engine **out) {
   if (!out) { jamd_set_error("jamd_engine_create: out is NULL"); return JAMD_EINVAL; }
   *out = nullptr;
+  // The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and
+  // two streams on one queue run their kernels one after the other; the pipelined hosts of this library (scoring
+  // stream + first-pass stream, include/julius_amd.h) need them concurrent.  The variable is read when the runtime
+  // initialises: set here it takes effect when this is the process's first HIP call; a process that initialised HIP
+  // earlier sets it itself (bench.py does, before importing torch).
+  if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
   int n = 0;
   hipError_t err = hipGetDeviceCount(&n);
   if (err != hipSuccess || n <= 0) {

@@ -168,8 +168,7 @@ static void *run_device(void *arg)
     if (first + launch < nfile) {
       chunk *nx = &ck[(k + 1) & 1];
       load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy);
-      if (jamd_beam_wait_started(bm) != JAMD_OK) die("first pass");
-      { struct timespec ms = {0, 1000000}; nanosleep(&ms, NULL); }            /* its workgroups are on the CUs by now */
+      if (jamd_beam_stream_wait_resident(bm, s_copy) != JAMD_OK) die("first pass");   /* s_copy goes on once the first pass holds its CUs */
       score(nx, nstate, gm, dn, gs, s_copy);
     }
     if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");

@@ -134,6 +134,7 @@ def load():
         "jamd_beam_set_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_wait_started": (ci, [vp]),
+        "jamd_beam_stream_wait_resident": (ci, [vp, vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_prune_info": (ci, [vp, P(ci), P(ci), P(ci)]),
         "jamd_beam_prune_stats": (ci, [vp, ci, vp, ci]),
@@ -643,6 +644,11 @@ class Beam:
     def wait_started(self):
         """Host waits until the latest first-pass launch is next to run (jamd_beam_wait_started)."""
         _check(load().jamd_beam_wait_started(self.h), "jamd_beam_wait_started")
+
+    def stream_wait_resident(self, stream: int = 0):
+        """Work queued on `stream` behind this call starts once the latest first-pass launch holds its CUs
+        (jamd_beam_stream_wait_resident: a wait on device memory, no host involvement)."""
+        _check(load().jamd_beam_stream_wait_resident(self.h, stream), "jamd_beam_stream_wait_resident")
 
     def prune_order(self, scores):
         """sort_token_no_order() alone: the visiting order the exact-order kernel derives for tokens with
