@@ -136,6 +136,27 @@ def ref_gmm_worker(nframes, seed):
     return {"frames": nframes, "seconds": am.last_seconds}
 
 
+def ref_e2e_worker(spec_path):
+    """One host core of the compiled reference over some utterances of the end-to-end task: julius -1pass (lazy scoring +
+    get_back_trellis_proceed) on the files the spec names; the canonical trellises, sentences and times go to an .npz."""
+    from oracle import pyoracle
+    spec = json.loads(Path(spec_path).read_text())
+    t0 = time.perf_counter()
+    eng = pyoracle.RefEngine(pyoracle.Ref(), spec["jargs"])
+    load_s = time.perf_counter() - t0
+    out = {"load_s": np.float64(load_s)}
+    for u, mfc in zip(spec["utts"], spec["files"]):
+        t0 = time.perf_counter()
+        rtr, (rw, rs) = eng.recognize(mfc)
+        out[f"sec_{u}"] = np.float64(time.perf_counter() - t0)
+        out[f"w_{u}"] = np.asarray(rw, np.int32)
+        out[f"s_{u}"] = np.float64(rs)
+        for k, v in rtr.items():
+            out[f"tr_{u}_{k}"] = v
+    np.savez(spec["out"], **out)
+    return {"ok": True}
+
+
 def cpu_baseline_gmm(model, frames, spot, budget=10.0):
     """Compiled reference on a bounded sample: one core, then N processes side by side.  `spot` = (tt, ss,
     device values): 64 full-size rows checked against the reference's own scores for those frames."""
@@ -335,6 +356,35 @@ def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None):
     return task, jargs, prefix
 
 
+def first_pass_roofline(work, beam_ms, nutt, shape, sc_ms):
+    """SURVEY 8d's substitute figures for the first pass (irregular gather / scatter: no algorithmic-bytes roofline): the
+    work of one step counted by the kernel -- tokens created, survivors visited, word ends -- and the bytes that work
+    touches under a fixed per-item model, against the LDS bandwidth of the CUs the launch holds
+    (128 B/clk/CU for 4-byte operations, MI355X_MICROARCH.md) and against the L2 bandwidth.  The kernel is a dependent-latency
+    chain per utterance, so the fraction is small by nature; it is here to be tracked, not to be close to 1."""
+    tokens, surv, wends, frames = (float(x) for x in work)
+    sec = beam_ms * 1e-3
+    # per survivor visited: its record (32 B) + two node records (32 B) + ~2.3 candidates x (16 B cell + 4 B first visit + 8 B arc);
+    # per token created: record 32 B + key 4 B + heap entry 8 B + survivor copy 32 B when it is kept
+    lds_bytes = surv * (32 + 2.3 * 20) + tokens * (4 + 8 + 8)
+    l2_bytes = surv * (32 + 2.3 * 8) + tokens * (32 + 8) + wends * 800
+    cus = min(256, nutt if shape != "half" else (nutt + 1) // 2)
+    lds_peak = cus * 128 * 2.4e9
+    return {"bound": "latency (LDS / L2 gather-scatter)", "achieved": (lds_bytes + l2_bytes) / sec / 1e9 if sec > 0 else None,
+            "peak": lds_peak / 1e9, "unit": "GB/s", "frac": (lds_bytes / sec) / lds_peak if sec > 0 else None, "traffic": None,
+            "note": "no algorithmic-bytes roofline (SURVEY.md 8d): achieved = modelled LDS + L2 bytes touched per second, peak = LDS "
+                    f"bandwidth of the {cus} CUs the launch holds, frac = LDS share of it",
+            "tokens_created_per_s": tokens / sec if sec > 0 else None, "survivors_visited_per_s": surv / sec if sec > 0 else None,
+            "word_ends_per_s": wends / sec if sec > 0 else None,
+            "tokens_created_per_frame": tokens / frames if frames else None, "survivors_per_frame": surv / frames if frames else None,
+            "lds_bytes_per_frame": lds_bytes / frames if frames else None, "l2_bytes_per_frame": l2_bytes / frames if frames else None,
+            "l2_GBps": l2_bytes / sec / 1e9 if sec > 0 else None,
+            "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
+            "timing_note": "HIP events on each stream; under the two-stream pipeline the scoring events include the wait for CUs that the "
+                           "first pass of the previous step still holds",
+            "beam_frames_per_s": frames / sec if sec > 0 else None, "beam_us_per_frame_per_utt": beam_ms * 1e3 / (frames / max(1, nutt)) if frames else None}
+
+
 def trellis_diff(a, b):
     """Two canonical trellises (dicts of arrays in (endtime, wid) order): number of entries that are not in both
     or differ in any field."""
@@ -452,7 +502,13 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
         sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         beam_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         res_local = bm.results()
-        pstats = [x // max(1, steps + warmup) for x in bm.prune_stats(0, reset=True)] if mode.startswith("exact") else [0] * 8   # per step
+        # per-step counters of the exact-order kernel: the paths of utterance 0's pruning steps, the work of all utterances
+        nlaunch = max(1, steps + warmup)
+        if mode.startswith("exact"):
+            allst = np.array([bm.prune_stats(u, reset=True) for u in range(nutt)], dtype=np.int64) // nlaunch
+            pstats, work = [int(x) for x in allst[0][:8]], allst[:, 8:12].sum(axis=0)
+        else:
+            pstats, work = [0] * 8, np.zeros(4, np.int64)
         # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
         nutt_all = nutt * dd.world
         if dd.world > 1:
@@ -477,14 +533,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
                             "workgroup_shape": bm.workgroup_shape(nutt) + (" (two utterances per CU)" if bm.workgroup_shape(nutt) == "half" else " (one utterance per CU)"),
                             "pipelined": ("scoring of step k+1 on a second stream, released once the first pass of step k is running (it fills the CUs "
                                           "the first pass leaves)" if pipelined else "no")},
-                 "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                              "note": "irregular gather/scatter: no algorithmic-bytes roofline (SURVEY.md 8d); figure of merit "
-                                      "is frames/s of the first pass over the batch",
-                              "score_kernels_ms": sc_ms, "beam_kernel_ms": beam_ms,
-                              "timing_note": ("HIP events on each stream; under the two-stream pipeline the scoring events include the wait "
-                                              "for CUs that the first pass of the previous step still holds") if pipelined else "HIP events, one stream",
-                              "beam_frames_per_s": T / (beam_ms * 1e-3),
-                              "beam_us_per_frame_per_utt": beam_ms * 1e3 / max(len(x) for x in utts)},
+                 "roofline": first_pass_roofline(work, beam_ms, nutt, bm.workgroup_shape(nutt), sc_ms),
                  "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,
                            "mean_peak_tokens": float(np.mean([x.max_tokens for x in res_local])),
                            "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us),
@@ -532,40 +581,57 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
         bm.set_order_mode(mode0)
     cpu = None
     if ref_built:
-        # (1) the compiled reference, one core, lazy scoring: bounded to ~25 s (at least 4 utterances; C4: at least 2)
-        ref = pyoracle.Ref()
+        # (1) the compiled reference, lazy scoring, ONE CORE PER PROCESS: the utterances are dealt to worker processes
+        # (at most 16, one core each), so that all distinct C3 utterances and 12 of C4's are compared within the run;
+        # the one-core figure below is frames / core-seconds summed over the workers
+        want = nuniq if not use_dnn else min(nuniq, 12)
+        nproc = max(1, min(16, want, (os.cpu_count() or 2) // 2))
+        specs = []
+        for u in range(want):
+            synth.write_htk_param(wd / f"ref_u{u}.mfc", uniq[u], parmkind=synth.PARM_USER if use_dnn else synth.MFCC_E_D_A)
+        for w in range(nproc):
+            mine = list(range(w, want, nproc))
+            spec = {"jargs": [str(a) for a in jargs], "utts": mine, "files": [str(wd / f"ref_u{u}.mfc") for u in mine],
+                    "out": str(wd / f"ref_out{w}.npz")}
+            (wd / f"ref_spec{w}.json").write_text(json.dumps(spec))
+            specs.append(spec)
         t0 = time.perf_counter()
-        rengine = pyoracle.RefEngine(ref, jargs)
-        load_s = time.perf_counter() - t0
+        procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--ref-e2e-worker", str(wd / f"ref_spec{w}.json")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for w in range(nproc)]
+        for pr in procs:
+            pr.wait()
+        wall = time.perf_counter() - t0
         vs = {"utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
               "reference_atoms": [], "reference_found_a_sentence": 0}
-        spent, frames_done = 0.0, 0
-        for u in range(nuniq):
-            if u >= (2 if use_dnn else 4) and spent > 25.0:
-                break
-            synth.write_htk_param(wd / "u.mfc", uniq[u], parmkind=synth.PARM_USER if use_dnn else synth.MFCC_E_D_A)
-            t0 = time.perf_counter()
-            rtr, (rw, rs) = rengine.recognize(wd / "u.mfc")
-            spent += time.perf_counter() - t0
-            frames_done += len(uniq[u])
-            rfound = len(rw) > 0                       # (a failed first pass leaves pass1_wnum = 0)
-            d = trellis_diff(canon_exact[u], rtr)
-            vs["utts"] += 1
-            vs["trellis_identical"] += int(d == 0)
-            vs["atoms_differing"].append(d)
-            vs["reference_atoms"].append(int(len(rtr["wid"])))
-            vs["reference_found_a_sentence"] += int(rfound)
-            dsent = sent(res_exact[u])
-            vs["pass1_sentence_identical"] += int((dsent == list(rw)) if rfound else (dsent is None))
-            vs["score_identical"] += int((res_exact[u].status == 0 and float(res_exact[u].score) == float(rs)) if rfound
-                                         else res_exact[u].status != 0)
+        spent, frames_done, load_s = 0.0, 0, 0.0
+        for w, spec in enumerate(specs):
+            if not Path(spec["out"]).exists():
+                continue                                  # a worker died: its utterances are not counted
+            z = np.load(spec["out"])
+            load_s = max(load_s, float(z["load_s"]))
+            for u in spec["utts"]:
+                rtr = {k[len(f"tr_{u}_"):]: z[k] for k in z.files if k.startswith(f"tr_{u}_")}
+                rw, rs = z[f"w_{u}"], float(z[f"s_{u}"])
+                spent += float(z[f"sec_{u}"])
+                frames_done += len(uniq[u])
+                rfound = len(rw) > 0                       # (a failed first pass leaves pass1_wnum = 0)
+                d = trellis_diff(canon_exact[u], rtr)
+                vs["utts"] += 1
+                vs["trellis_identical"] += int(d == 0)
+                vs["atoms_differing"].append(d)
+                vs["reference_atoms"].append(int(len(rtr["wid"])))
+                vs["reference_found_a_sentence"] += int(rfound)
+                dsent = sent(res_exact[u])
+                vs["pass1_sentence_identical"] += int((dsent == list(rw)) if rfound else (dsent is None))
+                vs["score_identical"] += int((res_exact[u].status == 0 and float(res_exact[u].score) == float(rs)) if rfound
+                                             else res_exact[u].status != 0)
         par["device_vs_compiled_reference"] = vs
         what = ("julius -1pass (compiled reference: dnn_calc_outprob FMA path, 1 thread, + get_back_trellis_proceed)" if use_dnn
                 else "julius -1pass (compiled reference: lazy outprob cache + get_back_trellis_proceed)")
         cpu = {"value": frames_done * NS / spent, "unit": "frame*states/s" + ("" if use_dnn else " (nominal: the lazy search scores only the states it visits)"),
                "cores": 1, "kind": "reference", "rtf_inv": frames_done / 100.0 / spent,
-               "sample": f"{what} on {vs['utts']} utterances = {frames_done} frames, {spent:.1f} s on 1 of {os.cpu_count()} "
-                         f"host cores (model load {load_s:.1f} s not counted)"}
+               "sample": f"{what} on {vs['utts']} utterances = {frames_done} frames, {spent:.1f} core-seconds over {nproc} worker processes of "
+                         f"one core each ({wall:.1f} s wall, {os.cpu_count()} host cores; model load {load_s:.1f} s not counted)"}
     return par, cpu
 
 
@@ -614,9 +680,13 @@ def main():
     ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
                     help="e2e: first-pass tie order mode (default: the work area's default = exact)")
     ap.add_argument("--cpu-worker", nargs=2, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--ref-e2e-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         print(json.dumps(ref_gmm_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]))))
+        return 0
+    if args.ref_e2e_worker:
+        print(json.dumps(ref_e2e_worker(args.ref_e2e_worker)))
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)

@@ -562,9 +562,10 @@ int  jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds, int *sweep_us, int *s
  *   [0] frames pruned (more tokens than the beam)          [1] upward, closed form, no tied element on a tail position
  *   [2] upward, wave-serial event replay                   [3] upward, sweep replay converged
  *   [4] upward, sweep gave the frame to the extraction loop [5] downward, closed form (sweep + residual-heap replay)
- *   [6] extraction loop itself (pipelined / serial)        [7] sweep rounds, total.
- * reset != 0 clears them.  Diagnostic. */
-int  jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[8], int reset);
+ *   [6] extraction loop itself (pipelined / serial)        [7] sweep rounds, total
+ * and the work of the frames (sums over the frames): [8] tokens created, [9] survivors visited, [10] word ends among them,
+ * [11] frames; [12..15] reserved.  reset != 0 clears them.  Diagnostic. */
+int  jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[16], int reset);
 int  jamd_beam_results(jamd_beam *b, jamd_pass1_result *out, int nutt);
 /* Word trellis of utterance u in emission order (last_tre indexes the same
  * array).  bt_relocate_rw()/bt_sort_rw() order (libjulius/src/backtrellis.c:

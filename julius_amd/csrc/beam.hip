@@ -1621,7 +1621,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
       place(&xw.o_collect, ((size_t)beam_width + 256) * 16);
       place(&xw.o_sweep, xbeam_sweep_bytes(beam_width));
-      place(&xw.o_pstat, 8 * sizeof(int));
+      place(&xw.o_pstat, 16 * sizeof(int));
     }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
@@ -1923,13 +1923,13 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   return JAMD_OK;
 }
 
-int jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[8], int reset) {
+int jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[16], int reset) {
   if (!b || !stats || utt < 0 || utt >= b->max_utts) { jamd_set_error("jamd_beam_prune_stats: bad argument"); return JAMD_EINVAL; }
   if (b->exact_status != 0) { jamd_set_error("jamd_beam_prune_stats: the exact-order kernel does not serve this work area"); return JAMD_ESTATE; }
   JAMD_HIP(hipSetDevice(b->eng->device));
   unsigned char *p = b->w.slices + (size_t)utt * b->w.utt_stride + b->xw.o_pstat;
-  JAMD_HIP(hipMemcpy(stats, p, 8 * sizeof(int), hipMemcpyDeviceToHost));
-  if (reset) JAMD_HIP(hipMemset(p, 0, 8 * sizeof(int)));
+  JAMD_HIP(hipMemcpy(stats, p, 16 * sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) JAMD_HIP(hipMemset(p, 0, 16 * sizeof(int)));
   return JAMD_OK;
 }
 

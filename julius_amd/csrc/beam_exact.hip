@@ -1404,6 +1404,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     // ---- C0: creation order = rank of the node's first visit (create_token() :1148)
     const int n_new = uni(sh.n_new);
     if (n_new > max_tokens) max_tokens = n_new;
+    if (pm.pstat && tid == 0) { pm.pstat[8] += n_new; pm.pstat[9] += n_surv; pm.pstat[10] += sh.n_we; pm.pstat[11] += 1; }   // work counters (jamd_beam_prune_stats())
     if (n_new > wk.tok_cap) {              // cannot happen (tok_cap bounds the reachable nodes); never write past the arrays
       if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
       stopped = true;

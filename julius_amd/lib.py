@@ -669,7 +669,7 @@ class Beam:
 
     def prune_stats(self, utt=0, reset=False):
         """Frames of utterance `utt` by the path their rank pruning step took (jamd_beam_prune_stats)."""
-        st = np.zeros(8, np.int32)
+        st = np.zeros(16, np.int32)
         _check(load().jamd_beam_prune_stats(self.h, utt, st.ctypes.data, 1 if reset else 0), "jamd_beam_prune_stats")
         return [int(x) for x in st]
 
