@@ -423,6 +423,18 @@ int  jamd_binhmm_to_blob(const char *binhmm_path, const char *blob_path);
  * (julius_amd/shim/jamd_flatten_lex.c) in a process that loaded the dictionary and LM
  * with Julius' own readers. */
 int  jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out);
+/* The same with the N-gram half read DIRECTLY from a binary N-gram file (mkbingram v5 -- what `-d` names;
+ * libsent/src/ngram/ngram_read_bin.c:240-365,603): the 1-gram / 2-gram tables of the first pass and the choice of the
+ * 2-gram (forward, or the additional forward 2-gram of a backward N-gram, ngram_access.c:449-466) come from the file,
+ * the cross-word LM table is built from them; the tree half -- nodes, factoring values, word -> N-gram ids, class
+ * probabilities -- stays PREFIX.lex's, which is the output of libjulius/src/wchmm.c over the dictionary and not a file
+ * format.  The two must share their vocabulary (names in N-gram id order: PREFIX.lex records it; refused otherwise).
+ * With the N-gram the tree was built from the result equals jamd_lexicon_load()'s; a retrained N-gram over the same
+ * vocabulary keeps the tree's 1-gram factoring values (re-export to refresh them). */
+int  jamd_lexicon_load_ngram(jamd_engine *e, const char *path, const char *bingram_path, jamd_lexicon **out);
+/* Host only: do PREFIX.lex and a binary N-gram share their vocabulary (JAMD_OK, else JAMD_EINVAL with the reason), and
+ * -- *same_tables, may be NULL -- are the file's first-pass tables byte for byte the ones PREFIX.lex holds? */
+int  jamd_bingram_check(const char *lex_path, const char *bingram_path, int *same_tables);
 void jamd_lexicon_destroy(jamd_lexicon *l);
 
 /* First-pass status of one utterance */

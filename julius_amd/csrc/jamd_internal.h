@@ -92,6 +92,17 @@ static inline int jamd_reserve_dyn_lds(const void *kernel, size_t dyn, const cha
   return JAMD_OK;
 }
 
+// The first-pass tables of a binary N-gram file (mkbingram v5), as jamd_lexicon_desc carries them (csrc/readers.hip)
+#include <string>
+#include <vector>
+struct JamdNgramTables {
+  int mode = 0, nword = 0, nbigram = 0, n = 0, dir = 0;
+  std::vector<float> uni_prob, uni_bo, bi_prob;
+  std::vector<int> bi_bgn, bi_num, bi_wid;
+  std::string names;                     // the vocabulary, every name followed by NUL, in N-gram id order
+};
+bool jamd_read_bingram_tables(const char *path, JamdNgramTables &out);
+
 static inline hipStream_t jamd_stream(jamd_engine *e, void *s) {
   return s ? (hipStream_t)s : e->stream;
 }

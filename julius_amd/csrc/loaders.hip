@@ -195,11 +195,40 @@ int jamd_rejgmm_load(jamd_engine *e, const char *path, jamd_rejgmm **out) {
   return rc;
 }
 
-int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
-  if (!e || !path || !out) { jamd_set_error("jamd_lexicon_load: NULL argument"); return JAMD_EINVAL; }
+// The lexicon file's N-gram half against a binary N-gram: same vocabulary (names in id order), and -- `same_tables` --
+// the same first-pass tables.  Returns false with the error set when the vocabularies differ.
+static bool ngram_matches(const Blob &b, const char *path, const JamdNgramTables &t, const char *bingram, bool *same_tables) {
+  auto nm = b.find("ng_wname");
+  if (nm == b.end() || nm->second.dtype != 2) {
+    jamd_set_error("%s carries no N-gram vocabulary (written by an older jamd_export): export it again", path); return false;
+  }
+  if ((size_t)nm->second.count != t.names.size() || memcmp(nm->second.data.data(), t.names.data(), t.names.size()) != 0) {
+    jamd_set_error("%s was built for another vocabulary than %s (the tree's word -> N-gram ids and factoring values would not fit)", path, bingram);
+    return false;
+  }
+  if (same_tables) {
+    bool ok = true;
+    auto same = [&](const char *name, const void *p, size_t bytes) {
+      auto it = b.find(name);
+      if (it == b.end() || (size_t)it->second.count * 4 != bytes || memcmp(it->second.data.data(), p, bytes) != 0) ok = false;
+    };
+    same("ng_uni_prob", t.uni_prob.data(), 4 * t.uni_prob.size()); same("ng_uni_bo", t.uni_bo.data(), 4 * t.uni_bo.size());
+    same("ng_bi_bgn", t.bi_bgn.data(), 4 * t.bi_bgn.size()); same("ng_bi_num", t.bi_num.data(), 4 * t.bi_num.size());
+    same("ng_bi_wid", t.bi_wid.data(), 4 * t.bi_wid.size()); same("ng_bi_prob", t.bi_prob.data(), 4 * t.bi_prob.size());
+    *same_tables = ok;
+  }
+  return true;
+}
+
+static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, jamd_lexicon **out) {
   *out = nullptr;
   Blob b;
   if (!read_blob(path, "JAMDLEX1", b)) return JAMD_EINVAL;
+  JamdNgramTables ng;
+  if (bingram) {
+    if (!jamd_read_bingram_tables(bingram, ng)) return JAMD_EINVAL;
+    if (!ngram_matches(b, path, ng, bingram, nullptr)) return JAMD_EINVAL;
+  }
   bool ok = true;
   auto ir = b.find("ints"); auto fr = b.find("floats");
   if (ir == b.end() || fr == b.end() || ir->second.dtype != 0 || fr->second.dtype != 1 || ir->second.count < 18 || fr->second.count < 4) {
@@ -239,7 +268,38 @@ int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
     d.init_node = view<int>(b, "init_node", 0, d.ninit, ok); d.init_lscore = view<float>(b, "init_lscore", 1, d.ninit, ok);
   }
   if (!ok) return JAMD_EINVAL;
+  if (bingram) {
+    // the N-gram half from the binary N-gram itself (libsent/src/ngram/ngram_read_bin.c:240-365): 1-gram and 2-gram
+    // tables, which 2-gram the first pass reads; the cross-word LM table is built from them when the lexicon is created.
+    // The tree half -- nodes, word -> N-gram ids, class probabilities, factoring values -- stays the file's.
+    if (d.lm_type != JAMD_LM_NGRAM) { jamd_set_error("%s is a grammar lexicon: no N-gram to replace", path); return JAMD_EINVAL; }
+    d.ng_mode = ng.mode; d.ng_nword = ng.nword; d.ng_nbigram = ng.nbigram;
+    d.ng_uni_prob = ng.uni_prob.data(); d.ng_uni_bo = ng.uni_bo.data();
+    d.ng_bi_bgn = ng.bi_bgn.data(); d.ng_bi_num = ng.bi_num.data(); d.ng_bi_wid = ng.bi_wid.data(); d.ng_bi_prob = ng.bi_prob.data();
+  }
   return jamd_lexicon_create(e, &d, out);
+}
+
+int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
+  if (!e || !path || !out) { jamd_set_error("jamd_lexicon_load: NULL argument"); return JAMD_EINVAL; }
+  return load_lexicon(e, path, nullptr, out);
+}
+
+int jamd_lexicon_load_ngram(jamd_engine *e, const char *path, const char *bingram_path, jamd_lexicon **out) {
+  if (!e || !path || !bingram_path || !out) { jamd_set_error("jamd_lexicon_load_ngram: NULL argument"); return JAMD_EINVAL; }
+  return load_lexicon(e, path, bingram_path, out);
+}
+
+int jamd_bingram_check(const char *lex_path, const char *bingram_path, int *same_tables) {
+  if (!lex_path || !bingram_path) { jamd_set_error("jamd_bingram_check: NULL argument"); return JAMD_EINVAL; }
+  Blob b;
+  if (!read_blob(lex_path, "JAMDLEX1", b)) return JAMD_EINVAL;
+  JamdNgramTables ng;
+  if (!jamd_read_bingram_tables(bingram_path, ng)) return JAMD_EINVAL;
+  bool same = false;
+  if (!ngram_matches(b, lex_path, ng, bingram_path, &same)) return JAMD_EINVAL;
+  if (same_tables) *same_tables = same ? 1 : 0;
+  return JAMD_OK;
 }
 
 int jamd_dnn_load(jamd_engine *e, const char *dnnconf, jamd_dnn **out) {

@@ -230,7 +230,101 @@ bool put(FILE *f, const char *name, int dtype, int count, const void *data) {
   return count <= 0 || fwrite(data, 4, (size_t)count, f) == (size_t)count;
 }
 
+// ---- binary N-gram ---------------------------------------------------------------------------------------
+struct Tuple {                            // NGRAM_TUPLE_INFO, libsent/include/sent/ngram2.h:137-156
+  unsigned totalnum = 0, bgnlistlen = 0, context_num = 0;
+  bool is24bit = false, ct_compaction = false;
+  std::vector<unsigned> bgn; std::vector<unsigned> num; std::vector<unsigned> nnid2wid;
+  std::vector<float> prob, bo_wt;
+};
+
+bool read_bingram(const char *path, int &n_out, int &dir_out, bool &reversed, std::vector<std::string> &wname,
+                  std::vector<Tuple> &t, std::vector<float> &bo_wt_1, std::vector<float> &p_2) {
+  Reader r;
+  if (!r.open(path)) return false;
+  char hd[512];
+  r.swap = false;
+  r.raw(hd, 1, 512);
+  if (!r.ok) return false;
+  hd[511] = 0;
+  if (strncmp(hd, "julius_bingram_v5", 17) != 0) {
+    jamd_set_error("%s: not a julius_bingram_v5 file (older versions are converted by mkbingram)", path); return false;
+  }
+  // second header line: "word=<size> byteorder=LE|BE" (ngram_read_bin.c check_header())
+  const char *l2 = strchr(hd, '\n');
+  if (!l2 || !strstr(l2, "word=4byte(int)")) { jamd_set_error("%s: 2-byte word ids (WORDS_INT build expected)", path); return false; }
+  const char *bo = strstr(l2, "byteorder=");
+  r.swap = bo != nullptr && strncmp(bo + 10, "BE", 2) == 0;          // files of this version carry their writer's order
+  if (!bo) r.swap = true;                                            // no tag: big-endian (older writers)
+  const int n = r.get<int>(), dir = r.get<int>();
+  const unsigned char rev = r.get<unsigned char>();
+  if (!r.ok || n < 2 || n > 10) { jamd_set_error("%s: N=%d", path, n); return false; }
+  n_out = n; dir_out = dir; reversed = rev != 0;
+  t.assign((size_t)n, Tuple());
+  for (int m = 0; m < n; m++) t[(size_t)m].totalnum = r.get<unsigned>();
+  const int wlen = r.get<int>();
+  if (!r.ok || wlen < 0) { jamd_set_error("%s: bad word list", path); return false; }
+  std::vector<char> names((size_t)wlen + 1, 0);
+  r.raw(names.data(), 1, (size_t)wlen);
+  for (int p = 0; p < wlen;) { wname.emplace_back(names.data() + p); p += (int)wname.back().size() + 1; }
+  if (!r.ok || wname.size() != t[0].totalnum) { jamd_set_error("%s: %zu names for %u words", path, wname.size(), t[0].totalnum); return false; }
+  for (int m = 0; m < n && r.ok; m++) {
+    Tuple &x = t[(size_t)m];
+    x.is24bit = r.get<unsigned char>() != 0; x.ct_compaction = r.get<unsigned char>() != 0;
+    x.bgnlistlen = r.get<unsigned>(); x.context_num = r.get<unsigned>();
+    if (!r.ok || x.totalnum > (1u << 30) || x.bgnlistlen > (1u << 30) || x.context_num > (1u << 30)) { r.ok = false; break; }
+    if (m > 0) {
+      x.bgn.resize(x.bgnlistlen);
+      if (x.is24bit) {
+        std::vector<unsigned char> up(x.bgnlistlen); std::vector<unsigned short> lo(x.bgnlistlen);
+        r.raw(up.data(), 1, up.size()); r.raw(lo.data(), 2, lo.size());
+        for (size_t i = 0; i < up.size(); i++) x.bgn[i] = up[i] == 255 ? 0xffffffffu : ((unsigned)up[i] << 16) | lo[i];   // NNID_INVALID_UPPER
+      } else r.raw(x.bgn.data(), 4, x.bgn.size());
+      x.num.resize(x.bgnlistlen);
+      r.raw(x.num.data(), 4, x.num.size());                          // WORD_ID = int in the WORDS_INT build
+      x.nnid2wid.resize(x.totalnum);
+      r.raw(x.nnid2wid.data(), 4, x.nnid2wid.size());
+    }
+    x.prob.resize(x.totalnum);
+    r.raw(x.prob.data(), 4, x.prob.size());
+    if (r.get<int>() != 0) { x.bo_wt.resize(x.context_num); r.raw(x.bo_wt.data(), 4, x.bo_wt.size()); }
+    if (r.get<int>() != 0) r.skip((size_t)x.totalnum * 3);           // nnid2ctid (only for N >= 3 lookups)
+  }
+  if (r.ok && r.get<int>() != 0) { bo_wt_1.resize(t[0].context_num); r.raw(bo_wt_1.data(), 4, bo_wt_1.size()); }
+  if (r.ok && r.get<int>() != 0) { p_2.resize(t[1].totalnum); r.raw(p_2.data(), 4, p_2.size()); }
+  if (!r.ok) { jamd_set_error("%s: truncated or malformed", path); return false; }
+  return true;
+}
+
 }  // namespace
+
+// The tables the first pass reads from a binary N-gram (which 2-gram: bi_prob_func_set(), ngram_access.c:449-466;
+// DIR_LR = 0, DIR_RL = 1), in the arrays of jamd_lexicon_desc.
+bool jamd_read_bingram_tables(const char *path, JamdNgramTables &o) {
+  int n = 0, dir = 0; bool reversed = false;
+  std::vector<std::string> wname; std::vector<Tuple> t; std::vector<float> bo_wt_1, p_2;
+  if (!read_bingram(path, n, dir, reversed, wname, t, bo_wt_1, p_2)) return false;
+  const Tuple &t1 = t[0], &t2 = t[1];
+  const int V = (int)t1.totalnum;
+  const std::vector<float> *bo, *bp;
+  if (reversed) { o.mode = JAMD_NG_ADDITIONAL_OLD; bo = &bo_wt_1; bp = &p_2; }
+  else if (dir == 0) { o.mode = JAMD_NG_NORMAL; bo = &t1.bo_wt; bp = &t2.prob; }
+  else if (!bo_wt_1.empty()) { o.mode = JAMD_NG_ADDITIONAL; bo = &bo_wt_1; bp = &p_2; }
+  else { o.mode = JAMD_NG_COMPUTE; bo = &t1.bo_wt; bp = &t2.prob; }
+  if ((int)bo->size() < V || bp->size() < t2.totalnum || (int)t2.bgn.size() < V || (int)t2.num.size() < V || (int)t1.prob.size() < V) {
+    jamd_set_error("%s: 2-gram tables shorter than the vocabulary", path); return false;
+  }
+  o.nword = V; o.nbigram = (int)t2.totalnum; o.n = n; o.dir = dir;
+  o.uni_prob.assign(t1.prob.begin(), t1.prob.begin() + V);
+  o.uni_bo.assign(bo->begin(), bo->begin() + V);
+  o.bi_prob.assign(bp->begin(), bp->begin() + t2.totalnum);
+  o.bi_bgn.resize((size_t)V); o.bi_num.resize((size_t)V); o.bi_wid.resize(t2.totalnum);
+  for (int i = 0; i < V; i++) { o.bi_bgn[(size_t)i] = t2.bgn[(size_t)i] == 0xffffffffu ? -1 : (int)t2.bgn[(size_t)i]; o.bi_num[(size_t)i] = (int)t2.num[(size_t)i]; }
+  for (size_t i = 0; i < o.bi_wid.size(); i++) o.bi_wid[i] = (int)t2.nnid2wid[i];
+  o.names.clear();
+  for (const std::string &w : wname) { o.names += w; o.names.push_back('\0'); }
+  return true;
+}
 
 extern "C" {
 

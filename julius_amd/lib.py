@@ -97,6 +97,8 @@ def load():
         "jamd_gmm_load_binhmm": (ci, [vp, C.c_char_p, ci, ci, P(vp)]),
         "jamd_binhmm_to_blob": (ci, [C.c_char_p, C.c_char_p]),
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
+        "jamd_lexicon_load_ngram": (ci, [vp, C.c_char_p, C.c_char_p, P(vp)]),
+        "jamd_bingram_check": (ci, [C.c_char_p, C.c_char_p, P(ci)]),
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),
         "jamd_gmm_veclen": (ci, [vp]),
@@ -577,12 +579,16 @@ class Lexicon:
         self.h = h
 
     @classmethod
-    def from_file(cls, eng: Engine, path):
-        """jamd_lexicon_load(): a JAMDLEX1 blob read by the library itself."""
+    def from_file(cls, eng: Engine, path, bingram=None):
+        """jamd_lexicon_load(): a JAMDLEX1 blob read by the library itself; with `bingram` the N-gram half comes from
+        that binary N-gram file (jamd_lexicon_load_ngram())."""
         self = cls.__new__(cls)
         self.eng, self.lex, self._keep = eng, None, None
         h = C.c_void_p()
-        _check(load().jamd_lexicon_load(eng.h, str(path).encode(), C.byref(h)), "jamd_lexicon_load")
+        if bingram is not None:
+            _check(load().jamd_lexicon_load_ngram(eng.h, str(path).encode(), str(bingram).encode(), C.byref(h)), "jamd_lexicon_load_ngram")
+        else:
+            _check(load().jamd_lexicon_load(eng.h, str(path).encode(), C.byref(h)), "jamd_lexicon_load")
         self.h = h
         return self
 

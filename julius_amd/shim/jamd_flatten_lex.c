@@ -365,6 +365,28 @@ static int put_rec(FILE *f, const char *name, int dtype, int count, const void *
   return 0;
 }
 
+/* Appends the N-gram vocabulary (every name followed by NUL, in N-gram id order) to a lexicon file as the record
+ * "ng_wname": jamd_lexicon_load_ngram() / jamd_bingram_check() refuse a binary N-gram over another vocabulary (the
+ * tree's word -> N-gram ids would not fit).  The record count in the header is bumped. */
+int jamd_lexicon_append_ngram_names(const char *path, const NGRAM_INFO *ng)
+{
+  FILE *f;
+  int nrec = 0, i;
+  size_t len = 0, at = 0;
+  char *buf;
+  if (ng == NULL || ng->wname == NULL) return JAMD_OK;              /* a grammar: nothing to record */
+  for (i = 0; i < (int)ng->max_word_num; i++) len += strlen(ng->wname[i]) + 1;
+  if ((buf = (char *)malloc(len + 4)) == NULL) return JAMD_ENOMEM;
+  for (i = 0; i < (int)ng->max_word_num; i++) { size_t n = strlen(ng->wname[i]) + 1; memcpy(buf + at, ng->wname[i], n); at += n; }
+  if ((f = fopen(path, "r+b")) == NULL) { free(buf); return JAMD_EINVAL; }
+  if (fseek(f, 8, SEEK_SET) != 0 || fread(&nrec, 4, 1, f) != 1) { fclose(f); free(buf); return JAMD_EINVAL; }
+  nrec++;
+  if (fseek(f, 8, SEEK_SET) != 0 || fwrite(&nrec, 4, 1, f) != 1 || fseek(f, 0, SEEK_END) != 0 ||
+      put_rec(f, "ng_wname", 2, (int)len, buf) != 0) { fclose(f); free(buf); return JAMD_EINVAL; }
+  free(buf);
+  return fclose(f) == 0 ? JAMD_OK : JAMD_EINVAL;
+}
+
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");

@@ -486,6 +486,8 @@ int jref_engine_save_lexicon(void *h, const char *path)
                                                           : jamd_flatten_lexicon(e->recog->process_list, &fl);
   if (rc != 0) return rc;
   rc = jamd_lexicon_save(&fl.desc, path);
+  if (rc == 0 && e->recog->process_list->lmtype == LM_PROB && e->recog->process_list->lm != NULL)
+    rc = jamd_lexicon_append_ngram_names(path, e->recog->process_list->lm->ngram);     /* as jamd_export does */
   jamd_flat_lexicon_free(&fl);
   return rc;
 }
@@ -623,3 +625,20 @@ int jref_write_binhmm(const char *hmmdefs, const char *outfile)
   return ok ? 0 : -3;
 }
 
+/* mkbingram's work through the reference's own writer (libsent/src/ngram/ngram_write_bin.c): the input of the direct
+ * binary N-gram reader's tests.  arpa_rl != NULL: backward N-gram + additional forward 2-gram (the -nlr / -nrl pair). */
+int jref_write_bingram(const char *arpa_lr, const char *arpa_rl, const char *outfile)
+{
+  NGRAM_INFO *ng = ngram_info_new();
+  FILE *fp;
+  int ok;
+  char header[64] = "written by oracle/ref_driver.c\n";
+  if (arpa_rl != NULL) {
+    if (!init_ngram_arpa(ng, (char *)arpa_rl, DIR_RL)) return -1;
+    if (arpa_lr != NULL && !init_ngram_arpa_additional(ng, (char *)arpa_lr)) return -1;
+  } else if (!init_ngram_arpa(ng, (char *)arpa_lr, DIR_LR)) return -1;
+  if ((fp = fopen_writefile((char *)outfile)) == NULL) return -2;
+  ok = ngram_write_bin(fp, ng, header);
+  fclose_writefile(fp);
+  return ok ? 0 : -3;
+}

@@ -79,3 +79,67 @@ def test_device_model_from_binhmm(engine, tmp_path):
     want = lib.Gmm(engine, am).outprob_host(fr)
     got = lib.Gmm.from_binhmm(engine, binhmm).outprob_host(fr)
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------- binary N-gram
+def _bingram_task(tmp_path, with_rl, seed=73):
+    ref = _ref()
+    ref.lib.jref_write_bingram.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    task = synth.make_triphone_task(tmp_path, seed=seed, nword=80, nphone=8, S=120, M=2, with_rl3=with_rl)
+    bingram = tmp_path / "lm.bingram"
+    rc = ref.lib.jref_write_bingram(str(task["arpa"]).encode(), str(task["arpa_rl"]).encode() if with_rl else None,
+                                    str(bingram).encode())
+    assert rc == 0
+    subprocess.run([str(EXPORT), "-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-d", str(bingram),
+                    "-input", "htkparam", "-jamdout", str(tmp_path / "exp")], check=True, capture_output=True)
+    return task, bingram
+
+
+@pytest.mark.parametrize("with_rl", [False, True])
+def test_bingram_tables_equal_the_exported_lexicon(tmp_path, with_rl):
+    """SURVEY 8f N3, LM half: the binary N-gram mkbingram writes (v5), read directly (csrc/readers.hip restating
+    libsent/src/ngram/ngram_read_bin.c:240-365), gives byte for byte the first-pass tables jamd_export wrote through
+    Julius' own reader -- forward 2-gram alone (DIR_LR), and backward 3-gram + additional forward 2-gram (the -nlr/-nrl
+    pair: bi_prob_additional(), ngram_access.c:351).  A binary N-gram over another vocabulary is refused."""
+    task, bingram = _bingram_task(tmp_path, with_rl)
+    L = lib.load()
+    same = C.c_int(-1)
+    rc = L.jamd_bingram_check(str(tmp_path / "exp.lex").encode(), str(bingram).encode(), C.byref(same))
+    assert rc == 0 and same.value == 1, L.jamd_last_error()
+    recs = _blob_records(tmp_path / "exp.lex", b"JAMDLEX1")
+    names = recs["ng_wname"][1].split(b"\0")
+    assert b"<s>" in names and b"</s>" in names
+    # another vocabulary (one word more in the LM): refused, with the reason
+    other = tmp_path / "o"
+    other.mkdir()
+    task2 = synth.make_triphone_task(other, seed=73, nword=81, nphone=8, S=120, M=2, with_rl3=with_rl)
+    ref = _ref()
+    assert ref.lib.jref_write_bingram(str(task2["arpa"]).encode(), str(task2["arpa_rl"]).encode() if with_rl else None,
+                                      str(other / "lm.bingram").encode()) == 0
+    assert L.jamd_bingram_check(str(tmp_path / "exp.lex").encode(), str(other / "lm.bingram").encode(), None) != 0
+    assert b"vocabulary" in L.jamd_last_error()
+    # a retrained N-gram over the SAME vocabulary is accepted, its tables differ
+    lines = open(task["arpa"]).read().replace("-0.3", "-0.4")
+    (tmp_path / "lm2.arpa").write_text(lines)
+    assert ref.lib.jref_write_bingram(str(tmp_path / "lm2.arpa").encode(), str(task["arpa_rl"]).encode() if with_rl else None,
+                                      str(tmp_path / "lm2.bingram").encode()) == 0
+    rc = L.jamd_bingram_check(str(tmp_path / "exp.lex").encode(), str(tmp_path / "lm2.bingram").encode(), C.byref(same))
+    assert rc == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rl", [False, True])
+def test_lexicon_with_ngram_read_directly(engine, tmp_path, with_rl):
+    """jamd_lexicon_load_ngram(PREFIX.lex, lm.bingram): tree half from jamd_export, N-gram half from the binary N-gram;
+    with the N-gram the tree was built from the first pass gives jamd_lexicon_load()'s result exactly."""
+    task, bingram = _bingram_task(tmp_path, with_rl, seed=75)
+    am = lib.Gmm.from_file(engine, tmp_path / "exp.am")
+    outs = []
+    for lx in (lib.Lexicon.from_file(engine, tmp_path / "exp.lex"), lib.Lexicon.from_file(engine, tmp_path / "exp.lex", bingram=bingram)):
+        bm = lib.Beam(engine, lx, 200, -1.0, max_utts=2)
+        scs = [am.outprob_host(synth.make_utterance(task, nwords=4 + u, seed=900 + u)[0]) for u in range(2)]
+        res, tre = bm.pass1_host(scs)
+        outs.append([(r.status, r.score, list(r.wseq[:r.wnum]), t.tobytes()) for r, t in zip(res, tre)])
+        assert all(r.status == 0 for r in res)
+        bm.close()
+    assert outs[0] == outs[1]
