@@ -234,7 +234,8 @@ def run_gmm(args, dd: Dist, steps, warmup):
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("frames_per_launch") == T:
+                # only a measurement of THIS kernel instantiation at THIS launch size counts
+                if tj.get("frames_per_launch") == T and tj.get("kernel") == gmm.last_kernel():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
