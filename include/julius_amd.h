@@ -480,7 +480,12 @@ void jamd_beam_destroy(jamd_beam *b);
  * of [.][nstate] (what outprob_state() would return for every state: the output
  * of jamd_gmm_outprob_dev / jamd_dnn_outprob_dev).  utt_off is a HOST array of
  * nutt+1 ints.  Asynchronous on `stream`; results are read with
- * jamd_beam_results() / jamd_beam_trellis(), which synchronise. */
+ * jamd_beam_results() / jamd_beam_trellis(), which synchronise.
+ * ONE launch per work area at a time: the utterance table, the slices and the result records of a jamd_beam belong to
+ * its latest launch, so the next jamd_beam_pass1_dev() / jamd_beam_stream_push_dev() on the same work area goes on the
+ * SAME stream (it then queues behind the first) or after the first has completed; work areas are independent of each
+ * other.  The same holds for the scoring calls of one jamd_gmm with history pruning (utterance boundaries are staged per
+ * model). */
 int  jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const int *utt_off,
                          int nutt, void *stream);
 /* Streaming form of jamd_beam_pass1_dev() for input that arrives in pieces (Julius calls

@@ -1066,7 +1066,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   const Work &wk = xw.w;
   if (threadIdx.x == 0 && wk.resident) __hip_atomic_fetch_add(wk.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this workgroup holds its share of a CU now
-  const int u = utt_off[gridDim.x + 1 + blockIdx.x];                         // longest utterance first (upload_utt_off())
+  const int u = min(max(utt_off[gridDim.x + 1 + blockIdx.x], 0), (int)gridDim.x - 1);   // longest utterance first (upload_utt_off()); clamped: never outside the launch's slices
   int tid = threadIdx.x;                                                     // refreshed every frame: see tid_now()
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
   StreamState *ss = smode ? wk.stream + u : nullptr;

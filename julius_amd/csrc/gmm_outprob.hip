@@ -572,8 +572,11 @@ static int set_utterances(jamd_gmm *g, const int *utt_off, int nutt, hipStream_t
     JAMD_HIP(hipMalloc(&g->d_cur_utt_off, sizeof(int) * ((size_t)nutt + 1)));
     g->utt_off_cap = (size_t)nutt + 1;
   }
-  JAMD_HIP(hipMemcpyAsync(g->d_cur_utt_off, utt_off, sizeof(int) * ((size_t)nutt + 1), hipMemcpyHostToDevice, st));
-  JAMD_HIP(hipStreamSynchronize(st));   // utt_off is the caller's memory
+  // utt_off is the caller's memory: staged in a buffer the model owns, so that the copy needs no host wait (a pipelining
+  // host keeps its scoring stream asynchronous).  One scoring call per model in flight: the staging buffer and
+  // d_cur_utt_off are reused by the next call on this model (include/julius_amd.h).
+  g->h_utt_off.assign(utt_off, utt_off + nutt + 1);
+  JAMD_HIP(hipMemcpyAsync(g->d_cur_utt_off, g->h_utt_off.data(), sizeof(int) * ((size_t)nutt + 1), hipMemcpyHostToDevice, st));
   g->cur_nutt = nutt;
   return JAMD_OK;
 }

@@ -270,13 +270,17 @@ int jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param)
 }
 
 /* one launch over entries [first, first+n): score all frames, run the first pass, fetch everything */
-static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int keep)
+/* keep bit 0: store the score rows for the later passes; bit 1: on failure leave the inputs queued for a retry with a
+ * smaller launch instead of marking them failed */
+static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int keepflags)
 {
+  const int keep = keepflags & 1, retry = (keepflags & 2) != 0;
   jamd_beam *bb = NULL;
   float *frames = NULL, *d_frames = NULL, *d_scores = NULL;
   jamd_pass1_result *res = NULL;
   int *off = (int *)malloc(sizeof(int) * (n + 1)), u, rc = JAMD_EINVAL, veclen = c->pre[first].veclen;
   size_t total = 0;
+  if (off == NULL) { jlog("ERROR: jamd: batch first pass: out of memory\n"); return JAMD_ENOMEM; }
   off[0] = 0;
   for (u = 0; u < n; u++) { total += (size_t)c->pre[first + u].T; off[u + 1] = (int)total; }
   frames = (float *)malloc(sizeof(float) * total * veclen);
@@ -313,8 +317,13 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
   }
   rc = JAMD_OK;
 out:
-  if (rc != JAMD_OK) jlog("ERROR: jamd: batch first pass failed: %s\n", jamd_last_error());
-  for (u = 0; u < n; u++) { free(c->pre[first + u].frames); c->pre[first + u].frames = NULL; if (rc != JAMD_OK) c->pre[first + u].done = -1; }
+  if (rc != JAMD_OK && retry) jlog("STAT: jamd: a launch of %d queued inputs did not fit (%s): trying half of it\n", n, jamd_last_error());
+  else if (rc != JAMD_OK) jlog("ERROR: jamd: batch first pass failed: %s\n", jamd_last_error());
+  for (u = 0; u < n; u++) {
+    if (rc != JAMD_OK && retry) { c->pre[first + u].done = 0; continue; }          /* frames stay for the retry */
+    free(c->pre[first + u].frames); c->pre[first + u].frames = NULL;
+    if (rc != JAMD_OK) c->pre[first + u].done = -1;
+  }
   if (bb) jamd_beam_destroy(bb);
   if (d_frames) jamd_free(g_eng, d_frames);
   if (d_scores) jamd_free(g_eng, d_scores);
@@ -335,7 +344,10 @@ int jamd_pass1_prefetch_run(RecogProcess *r)
     while (first + n < c->npre && c->pre[first + n].done == 0 && n < 512 &&
            c->pre[first + n].veclen == c->pre[first].veclen &&
            (n == 0 || fr + (size_t)c->pre[first + n].T <= ((size_t)1 << 20))) { fr += (size_t)c->pre[first + n].T; n++; }
-    if (prefetch_chunk(c, r, first, n, keep) != JAMD_OK) rc = JAMD_EINVAL;
+    /* a launch that does not fit the device (score matrix + work area of n utterances: sized for an MI355X) is retried
+     * in halves rather than given up: prefetch_chunk() leaves the inputs queued (done = 0) when told so */
+    while (n > 1 && prefetch_chunk(c, r, first, n, keep | 2) != JAMD_OK) n = (n + 1) / 2;
+    if (n == 1 && c->pre[first].done == 0 && prefetch_chunk(c, r, first, 1, keep) != JAMD_OK) rc = JAMD_EINVAL;
     first += n; nrun += n;
   }
   jlog("STAT: jamd: batch first pass over %d queued inputs\n", nrun);
