@@ -698,7 +698,17 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       // scores are equal) every entry counts the composites greater than its own.  The composites are distinct.
       const unsigned span = (upward ? uni(sh.maxbits) : ~uni(sh.minbits)) - vk;
       const int bshift = span ? max(0, 32 - __clz(span) - 11) : 0;
-      auto bin_of = [&](unsigned scb) { return (int)min(2047u, (scb - vk) >> bshift); };
+      // Bins over [k-th score, best]: linear in the score bits -- or, when the list crowds a few linear bins (peaked
+      // scores: most of the beam sits just above the cut, a few tokens far above), on a LOG scale of the distance from
+      // the cut: 32 octaves x 64 steps, fine where the list is dense.  Both are monotone in the score.
+      bool logbins = false;
+      auto bin_of = [&](unsigned scb) {
+        const unsigned dlt = scb - vk;
+        if (!logbins) return (int)min(2047u, dlt >> bshift);
+        if (dlt == 0u) return 0;
+        const int lz = __clz((int)dlt);
+        return (int)((unsigned)(31 - lz) << 6 | ((lz == 31 ? 0u : (dlt << (lz + 1))) >> 26));
+      };
       if (tid == 0) { sh.nB = 0; sh.i_last = 0; }
       for (int i = tid; i < (cnt + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
       __syncthreads();                                   // (kth_largest() left the histogram cleared)
@@ -718,6 +728,27 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       }
       __syncthreads();
       const int nB = uni(sh.nB);
+      if (nB <= pm.b_cap) {
+        // crowded bins (an entry counts the larger composites of its bin: quadratic in the bin) -> count again on the log scale
+        constexpr int BPT0 = 2048 / NT;
+        unsigned mx = 0u;
+#pragma unroll
+        for (int x = 0; x < BPT0; x++) mx = max(mx, pm.hist[BPT0 * tid + x]);
+        mx = block_excl_scan_max<NT>(sh, mx);               // (exclusive: the last thread's own bins are added below)
+        if (tid == NT - 1) { unsigned own = 0u; for (int x = 0; x < BPT0; x++) own = max(own, pm.hist[BPT0 * tid + x]); sh.sel_count = max(mx, own); }
+        __syncthreads();
+        if (uni(sh.sel_count) > 48u) {
+          logbins = true;
+          for (int i = tid; i < 2048; i += NT) pm.hist[i] = 0u;
+          __syncthreads();
+          for (int e = tid; e < nB; e += NT) {
+            unsigned hi;
+            if constexpr (WIDE) hi = G[e].y; else hi = (unsigned)(pm.compT[e] >> 32);
+            atomicAdd((unsigned *)&pm.hist[bin_of(hi)], 1u);
+          }
+          __syncthreads();
+        }
+      }
       PTICK(5);
       if (nB <= pm.b_cap) {
         {
