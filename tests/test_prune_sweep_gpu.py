@@ -105,3 +105,32 @@ def test_downward_sort_through_the_sweep(engine, oracle, beam):
             stats.append(info)
     assert sum(1 for s in stats if s > 0) >= len(stats) // 2, stats
     bm.close()
+
+
+@pytest.mark.parametrize("beam", [2500, 4000])
+def test_randomised_sizes_and_tie_densities(engine, oracle, beam):
+    """A seeded sweep over frame sizes from just above the beam to five beams (both sort directions) and over tie
+    densities from none to three score levels: whatever path the device takes -- closed form, wave-serial replay,
+    sweep replay, downward closed form, extraction loop -- the order is the sequential loop's."""
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(1000 + beam)
+    paths = {}
+    for it in range(70):
+        n = int(rng.integers(beam + 1, 5 * beam))
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            sc = (rng.permutation(n).astype(np.float32) * -0.37 - 100.0).astype(np.float32)
+        elif kind <= 2:
+            sc = (-rng.random(n) * float(rng.choice([3.0, 300.0, 30000.0])) - 5000.0).astype(np.float32)
+            nd = max(2, int(float(rng.choice([0.001, 0.01, 0.1, 0.6])) * n))
+            sc[rng.integers(0, n, nd)] = sc[rng.integers(0, n, nd)]
+        else:
+            levels = int(rng.choice([3, 17, 150, 2000, 30000]))
+            sc = (-rng.integers(0, levels, n).astype(np.float32) * 0.5 - 2000.0).astype(np.float32)
+        got = bm.prune_order(sc)
+        info = bm.prune_info()
+        want = oracle.sort_token_no_order(sc, beam)
+        assert np.array_equal(got, want), (it, n, beam, kind, info)
+        paths[1 if info > 0 else info] = paths.get(1 if info > 0 else info, 0) + 1
+    assert paths.get(1, 0) >= 10, paths
+    bm.close()
