@@ -356,47 +356,55 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     unsigned short *const l_path = m.path;
     lds_u32 *const l_wsum = m.wsum, *const l_ent0 = m.ent[0], *const l_ent1 = m.ent[1];
     lds_u32 *const l_fd = down ? down->fd : nullptr, *const l_posend = down ? down->posend : nullptr;
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;      // the lanes in front of mine
     for (int d = 0; L > 0; d++) {
       if (d >= kSwDepth - 1) return false;
       lds_u32 *A = pp ? l_ent1 : l_ent0;
       lds_u32 *B = pp ? l_ent0 : l_ent1;
+      // a wave takes 64 * C consecutive entries, row by row (row i: entries wbase + 64 i + lane): the lanes of a wave read
+      // consecutive words, and an entry's place among the left- / right-goers of its wave is a ballot and a popcount
       const int C = (L + NT - 1) / NT;
       if (C > kSwPerThread) return false;
-      const int lo = tid * C, hi = min(L, lo + C);
-      int nl = 0, nr = 0;
-      unsigned kind = 0u;                                              // 2 bits an entry: 1 = goes left, 2 = goes right
-      unsigned spec = 0u;                                              // probes and landed entries among mine
+      const int wbase = wv * 64 * C;
+      int nl = 0, nr = 0;                                              // the wave's totals (uniform)
+      unsigned kind = 0u;                                              // 2 bits a row: 1 = goes left, 2 = goes right
+      unsigned spec = 0u;                                              // rows in which my entry is a probe or a landed entry
       // What the entry behind reads is the T of the entry in front -- except behind a probe (looked through: it delays
       // nobody) and behind a landed entry born in turn b (looked through while the value in front of it is < b).  Those
       // few entries put that value into their own slot here (bit kSwXF: a slot is read whole, old or new), so that the
       // second half of the pass reads one word per entry.
-      for (int idx = lo; idx < hi; idx++) {
-        const unsigned w = A[idx], x = w & kSwX, T = w >> 16;
-        const unsigned ev = l_evp[x], vp = ev & kSwPos;
-        const int dep = sw_depth(vp);
-        if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << (idx - lo);
-        if (d >= 1 && !(ev & kSwProbe) && (int)T <= limit) {           // who moves in a candidate turn
-          const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
-          if (tw & bit) {
-            const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
-            if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+      for (int i = 0; i < C; i++) {
+        const int idx = wbase + 64 * i + lane;
+        unsigned kd = 0u;
+        if (idx < L) {
+          const unsigned w = A[idx], x = w & kSwX, T = w >> 16;
+          const unsigned ev = l_evp[x], vp = ev & kSwPos;
+          const int dep = sw_depth(vp);
+          if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << i;
+          if (d >= 1 && !(ev & kSwProbe) && (int)T <= limit) {         // who moves in a candidate turn
+            const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
+            if (tw & bit) {
+              const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
+              if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+            }
           }
-        }
-        if (l_fd && !(ev & kSwProbe)) {                                // sorting downward: where the hole leaves the extracted region,
-          const unsigned anc = vp >> (dep - d);                        // and where the elements that stay end up
-          if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
-          else {
-            const int li = (int)x - (nB - kSwLeft);
-            if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
+          if (l_fd && !(ev & kSwProbe)) {                              // sorting downward: where the hole leaves the extracted region,
+            const unsigned anc = vp >> (dep - d);                      // and where the elements that stay end up
+            if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
+            else {
+              const int li = (int)x - (nB - kSwLeft);
+              if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
+            }
           }
+          if (dep == d) l_TDx[x] = (unsigned short)T;
+          else kd = ((vp >> (dep - d - 1)) & 1u) ? 2u : 1u;
         }
-        if (dep == d) { l_TDx[x] = (unsigned short)T; continue; }
-        const unsigned right = (vp >> (dep - d - 1)) & 1u;
-        kind |= (right ? 2u : 1u) << (2 * (idx - lo));
-        nl += right ? 0 : 1; nr += right ? 1 : 0;
+        kind |= kd << (2 * i);
+        nl += __popcll(__ballot(kd == 1u)); nr += __popcll(__ballot(kd == 2u));
       }
-      while (spec) {                                                   // (a wave runs this once or twice, not once per entry)
-        const int idx = lo + __ffs((int)spec) - 1;
+      while (spec) {                                                   // (a wave runs this once or twice, not once per row)
+        const int idx = wbase + 64 * (__ffs((int)spec) - 1) + lane;
         spec &= spec - 1u;
         const unsigned w = A[idx];
         int j = idx - 1;
@@ -414,29 +422,28 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         A[idx] = (w & 0xffffu) | kSwXF | (v << 16);
       }
       SWTICK(6);
-      // exclusive scan of (left, right) counts over the workgroup: one barrier (the wave sums alternate between two buffers)
+      // the waves' totals -> where each wave's left- and right-goers start (one barrier: the totals alternate between two buffers)
       int el, er, totl, totr;
       {
-        const int lane = tid & 63, wv = tid >> 6;
-        unsigned pack = (unsigned)nl | ((unsigned)nr << 16), incl = pack;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
         lds_u32 *ws = l_wsum + (d & 1) * (NT / 64);
-        if (lane == 63) ws[wv] = incl;
+        if (lane == 0) ws[wv] = (unsigned)nl | ((unsigned)nr << 16);
         lds_barrier();
         unsigned base = 0u, tot = 0u;
 #pragma unroll
         for (int w = 0; w < NT / 64; w++) { const unsigned v = ws[w]; tot += v; base += w < wv ? v : 0u; }
-        const unsigned ex = base + incl - pack;
-        el = (int)(ex & 0xffffu); er = (int)(ex >> 16);
+        el = (int)(base & 0xffffu); er = (int)(base >> 16);
         totl = uni((int)(tot & 0xffffu)); totr = uni((int)(tot >> 16));
       }
-      for (int idx = lo; idx < hi; idx++) {
-        const unsigned kd = (kind >> (2 * (idx - lo))) & 3u;
-        if (!kd) continue;
-        const unsigned v = idx > 0 ? (A[idx - 1] >> 16) : 0u;
-        const int at = kd == 1u ? el++ : totl + er++;
-        B[at] = (A[idx] & (0xffffu & ~kSwXF)) | (v << 16);
+      for (int i = 0; i < C; i++) {
+        const int idx = wbase + 64 * i + lane;
+        const unsigned kd = (kind >> (2 * i)) & 3u;
+        const unsigned long long ml = __ballot(kd == 1u), mr = __ballot(kd == 2u);
+        if (kd) {
+          const unsigned v = idx > 0 ? (A[idx - 1] >> 16) : 0u;
+          const int at = kd == 1u ? el + __popcll(ml & lt_mask) : totl + er + __popcll(mr & lt_mask);
+          B[at] = (A[idx] & (0xffffu & ~kSwXF)) | (v << 16);
+        }
+        el += __popcll(ml); er += __popcll(mr);
       }
       lds_barrier();
       SWTICK(7);
