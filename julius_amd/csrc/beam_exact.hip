@@ -71,7 +71,8 @@ struct XShared {
   unsigned wsum[NT / 64], wsum2[NT / 64];
   int scan_total, scan_total2;
   int sw_nev, sw_limit, sw_fail, sw_changed;     // the sweep replay (beam_sweep.h)
-  int sw_ticks, sw_nev_out, sw_prof[8];                      // its duration (100 MHz ticks), events held at the end
+  int sw_ticks, sw_nev_out, sw_prof[8];
+  int pst[16];                                   // this launch's share of jamd_beam_prune_stats(): kept here, added to the slice once at the end                      // its duration (100 MHz ticks), events held at the end
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
 };
 
@@ -215,7 +216,7 @@ struct PruneMem {                // LDS regions of the pruning step (they overla
   unsigned char JAMD_LDS *sw_region;   // the sweep replay (beam_sweep.h): all of the pruning step's overlay, laid out afresh
   int sw_bytes;
   unsigned char *sw_glob;        // its global scratch (sweep_global_bytes()), nullptr = no sweep
-  int *pstat;                    // [8] how the pruning steps of this utterance were resolved (jamd_beam_prune_stats()), or nullptr
+  int *pstat;                    // [16] how the pruning steps of this utterance were resolved (XShared::pst), or nullptr
 };
 
 template <bool UP, typename HP>
@@ -685,7 +686,9 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     // elements of the min-heap (score bits complemented), the sweep replay for their moves, and a replay of the short
     // sifts below the extracted region for the residual heap (down_finish()).  Full shape with the sweep's scratch only.
     bool down_ok = false;
-    if constexpr (kLdsHeap && NT == jamdb::NT) down_ok = !upward && pm.sw_glob != nullptr;
+    // (wide layout, full shape only: the narrow layout's beams have a handful of tail candidates, and the mere presence of
+    // this code in the kernel costs its steps 0-C 2.5 us each per frame at beam 800 -- profiles/r04_ab_sweep_code_presence.txt)
+    if constexpr (kLdsHeap && WIDE && NT == jamdb::NT) down_ok = !upward && pm.sw_glob != nullptr;
     const int cnt = upward ? k : n - k;                            // extractions
     const unsigned xm = upward ? 0u : 0xffffffffu;
     if ((upward || down_ok) && mode != 1 && pm.b_cap > 0) {
@@ -709,7 +712,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         const int lz = __clz((int)dlt);
         return (int)((unsigned)(31 - lz) << 6 | ((lz == 31 ? 0u : (dlt << (lz + 1))) >> 26));
       };
-      if (tid == 0) { sh.nB = 0; sh.i_last = 0; }
+      if (tid == 0) { sh.nB = 0; sh.i_last = 0; sh.sel_count = 0u; }
       for (int i = tid; i < (cnt + 31) / 32 + 1; i += NT) pm.tailmask[i] = 0u;
       __syncthreads();                                   // (kth_largest() left the histogram cleared)
       for (int p0 = 1; p0 <= n; p0 += NT) {
@@ -734,8 +737,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         unsigned mx = 0u;
 #pragma unroll
         for (int x = 0; x < BPT0; x++) mx = max(mx, pm.hist[BPT0 * tid + x]);
-        mx = block_excl_scan_max<NT>(sh, mx);               // (exclusive: the last thread's own bins are added below)
-        if (tid == NT - 1) { unsigned own = 0u; for (int x = 0; x < BPT0; x++) own = max(own, pm.hist[BPT0 * tid + x]); sh.sel_count = max(mx, own); }
+        if (mx > 48u) atomicMax(&sh.sel_count, mx);        // (cleared with nB above)
         __syncthreads();
         if (uni(sh.sel_count) > 48u) {
           logbins = true;
@@ -807,7 +809,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         if (!upward) {
           // the residual heap: every event matters (the survivors stay in heap layout), so the sweep runs over all turns
           bool ok = false;
-          if constexpr (kLdsHeap && NT == jamdb::NT) {
+          if constexpr (kLdsHeap && WIDE && NT == jamdb::NT) {
             const int tailb = sweep_down_bytes(cnt);
             if (pm.sw_bytes > tailb + 1024) {
               SweepDown dn;
@@ -864,7 +866,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         bool give_up = false;
         if (uni(ctl[0]) > kMaxCand && uni(ctl[3]) > 0) {
           bool swept = false;
-          if constexpr (NT == jamdb::NT) {         // (the half shape serves narrow beams: a handful of candidates)
+          if constexpr (WIDE && NT == jamdb::NT) {         // (the narrow layout and the half shape serve narrow beams: a handful of candidates)
            if (pm.sw_glob) {
             const int evmax = sweep_pick_evmax(nB, k, pm.sw_bytes);
             if (evmax) swept = sweep_replay<NT>(sh, pm.sw_region, pm.sw_bytes, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, k,
@@ -1142,7 +1144,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   pm.b_cap = xw.b_cap;
   pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
   pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;
-  pm.pstat = xw.o_sweep ? reinterpret_cast<int *>(ub + xw.o_pstat) : nullptr;
+  pm.pstat = xw.o_sweep ? sh.pst : nullptr;               // (a generic pointer to LDS: a handful of accesses per frame)
+  int *const pstat_glob = xw.o_sweep ? reinterpret_cast<int *>(ub + xw.o_pstat) : nullptr;
+  if (tid == 0) for (int i = 0; i < 16; i++) sh.pst[i] = 0;
   lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
   unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
   u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
@@ -1693,6 +1697,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
       res->natom = min(sh.n_atom, wk.atom_cap); res->frames = T; res->max_tokens = max_tokens;
       res->ties = 0;
       if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
+      if (pstat_glob) for (int i = 0; i < 16; i++) pstat_glob[i] += sh.pst[i];
     }
     return;
   }
@@ -1739,6 +1744,7 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   if (tid == 0) {
     res->natom = natom; res->ties = 0; res->max_tokens = max_tokens;
     res->ties_node = 0; res->ties_wordend = 0; res->ties_cut = 0;
+    if (pstat_glob) for (int i = 0; i < 16; i++) pstat_glob[i] += sh.pst[i];
     if (TIMED) for (int i = 0; i < 8; i++) res->phase_us[i] += (int)(ph[i] / 100ull);
 #ifdef JAMD_DEV
     if (TIMED && JAMD_XBEAM_PROBE == 4) res->phase_us[7] = (int)((clock64() - cyc0) * 100ull / (wall_clock64() - wall0));   // MHz
