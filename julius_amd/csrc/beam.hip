@@ -1275,7 +1275,8 @@ struct jamd_lexicon {
   jamd_engine *eng = nullptr;
   LexDev d{};
   int maxfan = 2, nscword = 0;
-  bool multipath = false;          // JAMD_LM_MULTIPATH lexicon: strict-order kernel only (beam_strict_mp_kernel)
+  bool multipath = false;          // JAMD_LM_MULTIPATH lexicon: its own frame (beam_exact_mp.h; strict order: beam_strict_mp_kernel)
+  bool mp_parallel = false;        // ... and no root reaches a word-end node along its own arcs: the frame-parallel kernel can decode it
   std::vector<void *> owned;
 };
 
@@ -1439,6 +1440,19 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   JAMD_HIP(hipSetDevice(e->device));
   jamd_lexicon *l = new jamd_lexicon();
   l->eng = e; l->maxfan = maxfan; l->nscword = h->nscword; l->multipath = multipath;
+  if (multipath) {
+    // A root that reaches a word-end node along its own arcs (a word of tee models only): a cross-word transition would
+    // improve a word end inside the loop that visits the word ends (beam.c:2779-2825), and the result depends on the loop's
+    // position -- strict order only.  Roots are non-emitting; so is every word end of a multipath lexicon.
+    bool ok = true;
+    for (int s = 0; s < h->startnum && ok; s++) {
+      const int r = h->startnode[s];
+      if (h->self_a[r] != JAMD_LOG_ZERO && h->stend[r] >= 0) ok = false;
+      if (h->next_a[r] != JAMD_LOG_ZERO && r + 1 < h->nnode && h->stend[r + 1] >= 0) ok = false;
+      for (int k = h->ac_off[r]; k < h->ac_off[r + 1]; k++) if (h->stend[h->ac_to[k]] >= 0) ok = false;
+    }
+    l->mp_parallel = ok;
+  }
   LexDev &d = l->d;
   d.nnode = h->nnode; d.nword = h->nword; d.startnum = h->startnum; d.isolatenum = h->isolatenum;
   d.nshared = (int)shared.size(); d.nlc = h->nlc; d.cdset_method = h->cdset_method; d.cdmax_num = h->cdmax_num;
@@ -1559,8 +1573,8 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   Work &w = b->w;
   w.beam = beam_width; w.width = score_pruning_width; w.nnode = l->d.nnode; w.nword = l->d.nword;
   w.atom_cap = atoms_per_utt;
-  // every survivor reaches at most maxfan nodes, cross-word candidates only reach roots
-  w.tok_cap = beam_width * l->maxfan + l->d.startnum + l->d.ninit + 1;
+  // every survivor reaches at most maxfan nodes, cross-word candidates only reach roots (multipath: what the roots reach)
+  w.tok_cap = beam_width * l->maxfan + l->d.startnum * (l->multipath ? l->maxfan : 1) + l->d.ninit + 1;
   const size_t U = (size_t)max_utts;
   int rc = JAMD_OK;
   auto alloc = [&](void **p, size_t bytes, bool zero) -> int {
@@ -1607,8 +1621,11 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     place(&w.o_lmcache, (size_t)w.nscword * sizeof(unsigned long long));
     // exact-order kernel (beam_exact.hip): its LDS layout, and its three extra per-utterance arrays
     XWork &xw = b->xw;
-    b->exact_status = l->multipath ? -4 : xbeam_layout(&xw, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, false);
-    b->half_status = b->exact_status != 0 ? -2 : xbeam_layout(&b->xw_half, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, true);
+    const bool mp = l->multipath;
+    const int mp_roots = (l->d.lm_type == JAMD_LM_NGRAM) ? l->d.isolatenum : l->d.startnum;   // roots a word end is followed by
+    b->exact_status = (mp && !l->mp_parallel) ? -4
+                      : xbeam_layout(&xw, w, l->maxfan, mp ? mp_roots : l->d.startnum, l->d.ninit, l->d.nshared, false, mp);
+    b->half_status = (b->exact_status != 0 || mp) ? -2 : xbeam_layout(&b->xw_half, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, true);
     size_t sv_max = (size_t)w.sv_bytes;
     if (b->exact_status == 0 && (size_t)xw.w.sv_bytes > sv_max) sv_max = (size_t)xw.w.sv_bytes;
     if (b->half_status == 0 && (size_t)b->xw_half.w.sv_bytes > sv_max) sv_max = (size_t)b->xw_half.w.sv_bytes;
@@ -1616,12 +1633,19 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     if (b->exact_status == 0) {
       // the bitmap holds one bit per visiting index: maxfan per survivor plus startnum per word end
       size_t bits = (size_t)(beam_width + 2) * (size_t)(l->maxfan + l->d.startnum) + (size_t)l->d.nshared + (size_t)l->d.ninit + 64;
+      if (mp) bits = (size_t)(beam_width + 2) * (size_t)l->maxfan * (size_t)(mp_roots > 1 ? mp_roots : 1) + (size_t)l->d.nshared * l->maxfan + 64;
       place(&xw.o_nodefirst, (size_t)w.nnode * sizeof(unsigned));
       place(&xw.o_bitmap, (bits + 31) / 32 * 4);
       place(&xw.o_heap, ((size_t)w.tok_cap + 2) * sizeof(unsigned long long));
       place(&xw.o_collect, ((size_t)beam_width + 256) * 16);
       place(&xw.o_sweep, xbeam_sweep_bytes(beam_width));
       place(&xw.o_pstat, 16 * sizeof(int));
+      xw.o_nodetok = xw.o_arr = xw.o_key2 = 0;
+      if (mp) {
+        place(&xw.o_nodetok, (size_t)w.nnode * sizeof(unsigned));
+        place(&xw.o_arr, (size_t)w.tok_cap * sizeof(int));
+        place(&xw.o_key2, (size_t)w.tok_cap * sizeof(unsigned));
+      }
     }
     if (at >= ((size_t)1 << 32)) { jamd_set_error("jamd_beam_create: per-utterance work area exceeds 4 GB"); rc = JAMD_EINVAL; }
     w.utt_stride = at;
@@ -1705,8 +1729,8 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
   { const int rc = mark_started(b, st, nutt, !b->strict); if (rc != JAMD_OK) return rc; }
-  if (b->lex->multipath && !b->strict) {
-    jamd_set_error("jamd_beam_pass1_dev: a multipath lexicon is decoded by the strict-order kernel only: "
+  if (b->lex->multipath && !b->strict && !b->exact) {
+    jamd_set_error("jamd_beam_pass1_dev: this multipath lexicon is decoded by the strict-order kernel only: "
                    "jamd_beam_set_strict_order(b, 1)");
     return JAMD_ESTATE;
   }
@@ -1761,8 +1785,8 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
       jamd_set_error("jamd_beam_stream_push_dev: utterance %d would exceed 32767 frames", u); return JAMD_EINVAL;
     }
   }
-  if (b->lex->multipath && !b->strict) {
-    jamd_set_error("jamd_beam_stream_push_dev: a multipath lexicon is decoded by the strict-order kernel only");
+  if (b->lex->multipath && !b->strict && !b->exact) {
+    jamd_set_error("jamd_beam_stream_push_dev: this multipath lexicon is decoded by the strict-order kernel only");
     return JAMD_ESTATE;
   }
   if (b->strict && (!final || b->stream_pushes != 0)) {
@@ -1829,7 +1853,7 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
         jamd_set_error("jamd_beam_set_order_mode: the exact-order kernel cannot serve this work area (%s)",
                        b->exact_status == -1 ? "visiting index exceeds 32 bits"
                        : b->exact_status == -2 ? "beam too wide for the LDS image" : b->exact_status == -3 ? "more than 2^21 tokens per frame"
-                       : b->exact_status == -4 ? "multipath lexicon" : "no LDS");
+                       : b->exact_status == -4 ? "multipath lexicon in which a root reaches a word end along its own arcs" : "no LDS");
         return JAMD_ESTATE;
       }
       b->xw.prune_mode = b->xw_half.prune_mode = mode == JAMD_ORDER_EXACT_SERIAL ? 1 : 0;

@@ -13,6 +13,11 @@ struct XWork {
   unsigned o_collect;          // u32x4 [beam + 256] wide layout: the top list on its way from the heap to the sorted lists
   unsigned o_sweep;            // xbeam_sweep_bytes(beam): scratch of the sweep replay (beam_sweep.h), 0 = none
   unsigned o_pstat;            // int [8]: how this utterance's pruning steps were resolved (jamd_beam_prune_stats())
+  // multipath lexicons (beam_exact_mp.h)
+  unsigned o_nodetok;          // u32 [nnode]   token id + 1 of the node's token of the frame's first half (0 = none)
+  unsigned o_arr;              // int [tok_cap] tindex[]: the frame's tokens as the mid-frame sort left them + the appended ones
+  unsigned o_key2;             // u32 [tok_cap] their score bits in that arrangement (input of the frame's final cut)
+  int mp;                      // 1 = multipath lexicon: beam_exact_mp_kernel
   int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())
@@ -34,7 +39,8 @@ struct XWork {
 // even for the wide layout), -3 = more tokens per frame than the heap's position keys can number.
 // half = the half shape: 512 threads and half a CU's LDS, so that two utterances share a CU and one's barriers and
 // wave-serial sections overlap the other's work (-2 when a typical frame would not fit that image).
-int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half);
+// mp = multipath lexicon (nroot = the roots a word end is followed by: isolated roots under an N-gram, all under a grammar).
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half, bool mp = false);
 // places the per-launch part of the image (cells, pruning overlay, score row of nstate floats or none)
 void xbeam_place(XWork *xw, int nstate);
 hipError_t xbeam_prepare();

@@ -74,6 +74,7 @@ struct XShared {
   int sw_ticks, sw_nev_out, sw_prof[8];
   int pst[16];                                   // this launch's share of jamd_beam_prune_stats(): kept here, added to the slice once at the end                      // its duration (100 MHz ticks), events held at the end
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
+  unsigned emaxbits;                             // multipath frame: best score among the tokens on emitting nodes (the score-pruning envelope)
 };
 
 struct XCells {
@@ -1766,6 +1767,8 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   }
 }
 
+#include "beam_exact_mp.h"
+
 // diagnostic: the pruning step alone on given score bits (tests/test_prune_order.py fuzzes it against the
 // sequential heap)
 template <bool WIDE, int NT>
@@ -1912,8 +1915,9 @@ void xbeam_place(XWork *xw, int nstate) {
   xw->w.row_cache = 1;
 }
 
-int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half) {
+int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int nshared, bool half, bool mp) {
   xw->w = w;
+  xw->mp = mp ? 1 : 0;
   xw->nt = half ? kHalfNT : NT;
   xw->lds_budget = half ? kHalfDynLds : kMaxDynLds;
   const int beam = w.beam;
@@ -1921,6 +1925,10 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   int need = maxfan + nroot;                         // transition numbers of one source
   if (ninit > need) need = ninit;
   if (maxfan + nshared > need) need = maxfan + nshared;
+  if (mp) {                                          // second half of a multipath frame: root number * maxfan + the root's transition
+    if (nroot * maxfan > need) need = nroot * maxfan;
+    if (nshared * maxfan > need) need = nshared * maxfan;
+  }
   int s1 = 1; while ((1 << s1) < need + 1) s1++;
   int jb = 1; while ((1 << jb) < beam + 2) jb++;
   if (s1 + jb > 32) return -1;
@@ -1945,6 +1953,8 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
 hipError_t xbeam_prepare() {
   const void *fn[] = {(const void *)beam_exact_kernel<false, false, NT>, (const void *)beam_exact_kernel<true, false, NT>,
                       (const void *)beam_exact_kernel<false, true, NT>, (const void *)beam_exact_kernel<true, true, NT>,
+                      (const void *)beam_exact_mp_kernel<false, false, NT>, (const void *)beam_exact_mp_kernel<true, false, NT>,
+                      (const void *)beam_exact_mp_kernel<false, true, NT>, (const void *)beam_exact_mp_kernel<true, true, NT>,
                       (const void *)prune_order_kernel<false, NT>, (const void *)prune_order_kernel<true, NT>};
   for (const void *f : fn) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
@@ -1971,7 +1981,16 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
     if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode); \
     else hipLaunchKernelGGL((beam_exact_kernel<false, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);      \
   } while (0)
-  if (xw.nt == kHalfNT) JAMD_XLAUNCH(true, kHalfNT);
+  if (xw.mp) {                                         // multipath lexicons: their own frame (beam_exact_mp.h), full shape only
+    if (xw.wide) {
+      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, true, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, true, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+    } else {
+      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, false, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, false, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+    }
+  }
+  else if (xw.nt == kHalfNT) JAMD_XLAUNCH(true, kHalfNT);
   else if (xw.wide) JAMD_XLAUNCH(true, NT);
   else JAMD_XLAUNCH(false, NT);
 #undef JAMD_XLAUNCH

@@ -1,0 +1,164 @@
+"""GPU: multipath lexicons on the frame-parallel exact-order kernel (csrc/beam_exact_mp.h).
+
+The reference's multipath frame (beam.c:2747-2836, :2930-2943, :3066-3073): word-internal transitions of all
+survivors, the beam over the NEW tokens, cross-word transitions from the word ends among those with the root expanded
+along its own arcs inside the frame, output probabilities on emitting nodes, the final cut over tindex[] as the
+mid-frame sort left it.  Same tasks as the oracle's own multipath tests (tests/test_beam_oracle.py) and the strict
+kernel's (tests/test_beam_gpu.py): the word trellis must equal the compiled reference's atom for atom."""
+import numpy as np
+import pytest
+
+from julius_amd import lexblob, lib, synth
+from beamutil import assert_trellis_equal, load_beam_golden, ref_grammar_task, ref_task
+
+pytestmark = pytest.mark.gpu
+
+SKIP_TRANS = np.array([[0, 1, 0, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2], [0, 0, 0, .6, .4], [0, 0, 0, 0, 0]])
+SPLIT_TRANS = np.array([[0, .7, .3, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2], [0, 0, 0, .6, .4], [0, 0, 0, 0, 0]])
+
+
+def test_multipath_golden_default_order(engine, oracle):
+    g = load_beam_golden("beam_multipath.npz")
+    assert g["lex"]["lm_type"] == 0x100
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
+    res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])     # default = exact order
+    for r, atoms, u in zip(res, tre, g["utts"]):
+        assert r.status == 0
+        assert_trellis_equal(atoms, u["trellis"])
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
+
+
+@pytest.mark.parametrize("seed,beam,extra", [
+    (41, 200, ["-sepnum", "5"]),
+    (42, 30, ["-sepnum", "2"]),
+    (43, 150, ["-sepnum", "4", "-bs", "40", "-iwcd1", "max"]),
+    (44, 120, ["-sepnum", "0", "-iwcd1", "avg", "-transp", "-1.5"]),
+    (45, 150, ["-sepnum", "4", "skip"]),       # state-skip and early-exit arcs: the model itself needs multipath
+    (46, 150, ["-sepnum", "4", "split"]),      # two entry arcs as well
+    (47, 150, ["-sepnum", "4", "-bs", "60"]),
+    (48, 40, ["-sepnum", "0", "-iwcd1", "avg"]),
+])
+def test_multipath_ngram_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra):
+    kw = dict(ntransparent=12) if "-transp" in extra else {}
+    if extra[-1] in ("skip", "split"):
+        kw["trans"] = SKIP_TRANS if extra[-1] == "skip" else SPLIT_TRANS
+        extra = extra[:-1]
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra), **kw)
+    else:
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], **kw)
+    assert eng.multipath == 1 and lex["lm_type"] == 0x100
+    bs = float(extra[extra.index("-bs") + 1]) if "-bs" in extra else -1.0
+    utts = [synth.make_utterance(task, nwords=3 + 2 * u, seed=100 * seed + u)[0] for u in range(3)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, bs, max_utts=len(utts), atoms_per_utt=1 << 17)
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    res, tre = bm.pass1_host(scores)
+    bm.set_strict_order(True)
+    sres, stre = bm.pass1_host(scores)
+    for fr, r, atoms, sr, satoms in zip(utts, res, tre, sres, stre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert_trellis_equal(atoms, rtr)
+        assert_trellis_equal(satoms, rtr)
+        assert r.status == sr.status
+        if r.status == 0:
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+
+
+@pytest.mark.parametrize("seed,beam,extra,wrap", [
+    (49, 100, ["-penalty1", "-2.0"], True),
+    (51, 120, ["-penalty1", "-2.0"], True),
+    (52, 40, ["-iwcd1", "avg", "-penalty1", "-1.0"], False),
+])
+def test_multipath_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra, wrap):
+    eng, lex, am, task = ref_grammar_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], wrap=wrap, nword=70)
+    assert lex["lm_type"] == 0x101
+    utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + 2 * u, seed=100 * seed + u)[0] for u in range(3)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, -1.0, max_utts=len(utts), atoms_per_utt=1 << 17)
+    res, tre = bm.pass1_host([oracle.gmm_outprob(am, fr) for fr in utts])
+    for fr, r, atoms in zip(utts, res, tre):
+        synth.write_htk_param(tmp_path / "u.mfc", fr)
+        rtr, (rwseq, rscore) = eng.recognize(tmp_path / "u.mfc")
+        assert_trellis_equal(atoms, rtr)
+        assert r.status == 0
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
+
+
+def test_multipath_wordlist_vs_oracle(engine, oracle, ref, tmp_path):
+    """Isolated word recognition (-w) with -multipath: every listed word starts with a token, no cross-word
+    transition, best word on the last frame (beam.c:1762-1788, :2875, find_1pass_result_word())."""
+    from oracle import pyoracle
+    from julius_amd import lexblob
+    task = synth.make_wordlist_task(tmp_path, seed=5, triphone=True)
+    args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-w", task["wordlist"], "-wsil", "silB", "silE", "silB",
+            "-input", "htkparam", "-gprune", "none", "-b", "60", "-multipath"]
+    eng = pyoracle.RefEngine(ref, args)
+    eng.save_lexicon(tmp_path / "lex.blob")
+    lex = lexblob.load(tmp_path / "lex.blob")
+    assert lex["lm_type"] == 0x102
+    am = ref.am_load(task["hmmdefs"], hmmlist=task["hmmlist"]).export()
+    utts = [synth.make_wordlist_utterance(task, seed=u)[0] for u in range(4)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, eng.beam_width, -1.0, max_utts=len(utts))
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    res, tre = bm.pass1_host(scores)
+    for sc, r, atoms in zip(scores, res, tre):
+        oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, -1.0)
+        assert rc == 0 and r.status == 0
+        assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+        assert list(r.wseq[:r.wnum]) == list(wseq) and r.score == score
+
+
+@pytest.mark.parametrize("beam,nword", [(300, 400), (1200, 1500)])
+def test_multipath_larger_task_vs_oracle(engine, oracle, ref, tmp_path, beam, nword):
+    """A lexicon large enough that every frame's new tokens exceed the beam (the mid-frame sort really sorts; beam 1200
+    runs the wide layout), checked against the CPU restatement (pinned to the reference on the small tasks above)."""
+    eng, lex, am, task = ref_task(ref, tmp_path, 71, beam, ["-sepnum", "10", "-multipath"], nword=nword)
+    assert lex["lm_type"] == 0x100
+    utts = [synth.make_utterance(task, nwords=4 + u, seed=7100 + u)[0] for u in range(3)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, beam, -1.0, max_utts=len(utts), atoms_per_utt=1 << 18)
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    res, tre = bm.pass1_host(scores)
+    sorted_frames = 0
+    for sc, r, atoms in zip(scores, res, tre):
+        oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, beam, -1.0)
+        assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+        assert (r.status == 0) == (rc == 0)
+        if rc == 0:
+            assert list(r.wseq[:r.wnum]) == list(wseq) and r.score == score
+        sorted_frames += int(r.max_tokens > beam)
+    assert sorted_frames > 0
+
+
+@pytest.mark.parametrize("chunks", [[1] * 400, [7] * 60, [0, 25, 0, 3, 1000]])
+def test_multipath_streaming_equals_one_shot(engine, oracle, chunks):
+    """jamd_beam_stream_*: pieces of a multipath utterance (frame by frame, ragged, empty pushes) give the one-shot
+    trellis; the transition-only last call (get_back_trellis_end() :3066-3073) runs in the final push."""
+    g = load_beam_golden("beam_multipath.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    S = scores[0].shape[1]
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(scores))
+    bm.stream_begin(len(scores))
+    pos = [0] * len(scores)
+    for ci, c in enumerate(chunks):
+        part, off = [], [0]
+        for u, sc in enumerate(scores):
+            n = min(len(sc) - pos[u], (c + u) if c else 0)
+            part.append(sc[pos[u]:pos[u] + n]); pos[u] += n; off.append(off[-1] + n)
+        final = ci == len(chunks) - 1
+        rows = np.concatenate(part) if off[-1] else np.zeros((1, S), np.float32)
+        d = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(d.ptr, S, np.array(off, np.int32), final=final)
+        bm.results(len(scores))
+        d.free()
+    assert all(p == len(sc) for p, sc in zip(pos, scores))
+    res = bm.results(len(scores))
+    for u, r in enumerate(res):
+        gu = g["utts"][u]
+        assert r.status == 0
+        assert_trellis_equal(bm.trellis(u), gu["trellis"])
+        assert np.array_equal(np.array(r.wseq[:r.wnum]), gu["wseq"]) and r.score == gu["score"]
