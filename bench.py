@@ -330,7 +330,7 @@ def run_dnn(args, dd: Dist, steps, warmup):
 
 
 # ------------------------------------------------------------------------------------------------ C3 / C4 end to end
-def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None):
+def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None, multipath=False):
     """The C3 / C4 task in the REFERENCE'S OWN FORMATS (HTK hmmdefs + HMMList, HTK dictionary, ARPA 2-gram; for C4
     also the dnnconf with its .npy weight files and the state prior list), then the device blobs through jamd_export
     = Julius' loaders + wchmm builder + our flattening walk (julius_amd/shim/jamd_export.c, built next to the library).
@@ -347,7 +347,7 @@ def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None):
         task["dnnconf"] = synth.write_dnnconf(workdir, dnn, context_len=11)
         am = ["-dnnconf", task["dnnconf"], "-notypecheck"]
     jargs = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"]] + am + [
-        "-input", "htkparam", "-1pass", "-b", str(beam)]
+        "-input", "htkparam", "-1pass", "-b", str(beam)] + (["-multipath"] if multipath else [])
     export = ROOT / "julius_amd" / "jamd_export"
     if not export.exists():
         return task, jargs, None
@@ -399,7 +399,7 @@ def trellis_diff(a, b):
     return int(diff + (~same).sum())
 
 
-def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
+def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
     """configs[2] (GMM) / configs[3] (DNN) end to end on the device: acoustic scores -> exact-order first pass.
     `runs` = list of (key, utterances per GPU, steps, warmup, scaling): every run shares the models, the lexicon and the
     distinct utterances; the FIRST run carries the parity block and the CPU baseline.  Returns {key: result}."""
@@ -413,7 +413,9 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
     # pass ends in a sentence), or -- flat=True, the worst case for the rank pruning step -- random-init weights over noise
     dnn = (synth.make_dnn(seed=0) if flat else synth.make_decodable_dnn(seed=0)) if use_dnn else None
     NS = int(dnn["dims"][-1]) if use_dnn else S
-    task, jargs, prefix = build_reference_task(wd, args.nword, beam, dnn)
+    task, jargs, prefix = build_reference_task(wd, args.nword, beam, dnn, multipath)
+    if multipath and prefix is None:
+        raise SystemExit("bench.py: the multipath workload needs julius_amd/jamd_export (the multipath lexicon is the reference's)")
     ref_built = prefix is not None
     if ref_built:
         lx = lib.Lexicon.from_file(eng, str(prefix) + ".lex")
@@ -521,6 +523,8 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
             st = np.asarray(table)[:, 0]
             total_frames = T * dd.world * steps
             cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
+            if multipath:
+                cfg += " decoded with -multipath (non-emitting word-begin / word-end nodes, the reference's two-half frame: beam.c:2747-2836)"
             if scaling == "strong":
                 cfg += f" as configs[4]: the fixed batch of {nutt_all} utterances sharded over {dd.world} GPU(s)"
             r = {"metric": "frames_x_states_scored_per_sec", "value": total_frames * NS / elapsed,
@@ -541,7 +545,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
                            "prune_paths_utt0": dict(zip(("frames_pruned", "up_closed_form", "up_wave_replay", "up_sweep", "up_sweep_gave_up",
                                                          "down_closed_form", "extraction_loop", "sweep_rounds"), pstats))}}
             if ri == 0 and dd.world == 1 and not args.no_cpu_baseline:
-                r["parity"], cpu = e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_local, jargs, wd, ref_built, use_dnn)
+                r["parity"], cpu = e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_local, jargs, wd, ref_built, use_dnn, multipath)
                 if cpu is not None:
                     r["cpu_baseline"] = cpu
             out[key] = r
@@ -551,7 +555,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False):
     return out
 
 
-def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, use_dnn):
+def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, use_dnn, multipath=False):
     """Checker leg (after the timed region).  (1) The device first pass against the COMPILED REFERENCE's
     (julius -1pass over the same files: for C4 that is the reference's own dnn_calc_outprob() + beam.c): word trellis
     entry by entry, pass-1 sentence, score -- which is also the lazy-scoring CPU baseline of SURVEY 8d.  (2) exact-order
@@ -565,7 +569,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
     def sent(r):
         return list(r.wseq[:r.wnum]) if r.status == 0 else None
 
-    if mode0 != "fast":
+    if mode0 != "fast" and not multipath:              # (the canonical-tie kernel does not take multipath lexicons)
         bm.set_order_mode("fast")
         bm.pass1_dev(d_sc.data_ptr(), NS, off)
         res_fast = bm.results()
@@ -585,7 +589,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
         # (1) the compiled reference, lazy scoring, ONE CORE PER PROCESS: the utterances are dealt to worker processes
         # (at most 16, one core each), so that all distinct C3 utterances and 12 of C4's are compared within the run;
         # the one-core figure below is frames / core-seconds summed over the workers
-        want = nuniq if not use_dnn else min(nuniq, 12)
+        want = min(nuniq, 12) if (use_dnn or multipath) else nuniq
         nproc = max(1, min(16, want, (os.cpu_count() or 2) // 2))
         specs = []
         for u in range(want):
@@ -675,6 +679,9 @@ def main():
     ap.add_argument("--flat", action="store_true",
                     help="e2e-dnn: the flat-score stream (random-init weights over noise frames: nothing decodes, every frame "
                          "saturates the beam) instead of the input that decodes")
+    ap.add_argument("--multipath", action="store_true",
+                    help="e2e: the C3 task decoded with -multipath (reference-built multipath lexicon; the exact-order kernel's "
+                         "multipath frame, csrc/beam_exact_mp.h)")
     ap.add_argument("--batch-total", type=int, default=None, help="e2e --strong: utterances in the fixed batch (default 512)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
     ap.add_argument("--distinct", type=int, default=32, help="e2e: distinct utterances in the batch")
@@ -718,19 +725,24 @@ def main():
         per_gpu = pick(args.utts, 512)
         strong_total = args.batch_total or C5_TOTAL_UTTS
         runs = []
-        if wl == "all" or not args.strong:
+        if wl == "all" or not (args.strong or args.multipath):
             runs.append(("e2e", per_gpu, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
-        if wl == "all" or args.strong:
+        if wl == "all" or (args.strong and not args.multipath):
             runs.append(("e2e_strong", max(1, strong_total // dd.world), pick(args.steps, 4), pick(args.warmup, 1), "strong"))
-        if not args.strong and args.utts is None:
+        if not args.strong and not args.multipath and args.utts is None:
             runs.append(("e2e_256", 256, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
-        r = run_e2e(args, dd, runs, use_dnn=False)
+        r = run_e2e(args, dd, runs, use_dnn=False) if runs else {}
+        if wl == "all" or args.multipath:
+            # the same task decoded with -multipath: one utterance per CU (the multipath frame has the full shape only)
+            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
+                             use_dnn=False, multipath=True))
         if dd.rank == 0:
             if nested:
                 line.update(r)
             else:
-                line = top(r[runs[0][0]])
-                for k in list(r)[1:]:
+                ks = list(r)
+                line = top(r[ks[0]])
+                for k in ks[1:]:
                     line[k] = r[k]
     if wl in ("all", "e2e-dnn"):
         # configs[3] end to end at the reference recipe's beam (-b 4000), reference-built lexicon, parity vs julius -1pass:

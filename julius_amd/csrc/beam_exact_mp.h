@@ -135,6 +135,8 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
       for (int i = 0; i < 8; i++) res->phase_us[i] = 0;
     }
     for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;
+    // (an utterance can end between steps C1 and O -- the transition-only last call, an overflow -- and leave entries behind)
+    for (int i = tid; i < wk.nnode; i += NT) NODETOK(i) = 0u;
     __syncthreads();
     if (nrows <= 0) {
       if (tid == 0) { if (smode != 1) res->status = JAMD_PASS1_FAIL; if (ss) { ss->started = 0; ss->active = 1; } }
@@ -579,6 +581,7 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
       n_tot = n1 + uni(sh.n_arc);
     }
     if (n_tot > max_tokens) max_tokens = n_tot;
+    if (pm.pstat && tid == 0) { pm.pstat[8] += n_tot; pm.pstat[9] += n_surv; pm.pstat[10] += n_we; pm.pstat[11] += 1; }   // work counters (jamd_beam_prune_stats())
     if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[1] += n_ - tc; tc = n_; }
     // ---- O: output probabilities on emitting nodes (:2930-2943); nodetok[] is emptied on the way
     {

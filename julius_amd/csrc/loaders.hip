@@ -262,7 +262,7 @@ static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, j
   d.ng_uni_prob = view<float>(b, "ng_uni_prob", 1, d.ng_nword, ok); d.ng_uni_bo = view<float>(b, "ng_uni_bo", 1, d.ng_nword, ok);
   d.ng_bi_bgn = view<int>(b, "ng_bi_bgn", 0, d.ng_nword, ok); d.ng_bi_num = view<int>(b, "ng_bi_num", 0, d.ng_nword, ok);
   d.ng_bi_wid = view<int>(b, "ng_bi_wid", 0, d.ng_nbigram, ok); d.ng_bi_prob = view<float>(b, "ng_bi_prob", 1, d.ng_nbigram, ok);
-  if (d.lm_type != JAMD_LM_NGRAM) {
+  if ((d.lm_type & 0xff) != JAMD_LM_NGRAM) {                   // (JAMD_LM_MULTIPATH is a flag beside the LM kind)
     d.cat_pair = view<unsigned char>(b, "cat_pair", 2, (long long)d.ncat * d.ncat, ok);
     d.start2wid = view<int>(b, "start2wid", 0, d.startnum, ok);
     d.init_node = view<int>(b, "init_node", 0, d.ninit, ok); d.init_lscore = view<float>(b, "init_lscore", 1, d.ninit, ok);
@@ -272,7 +272,7 @@ static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, j
     // the N-gram half from the binary N-gram itself (libsent/src/ngram/ngram_read_bin.c:240-365): 1-gram and 2-gram
     // tables, which 2-gram the first pass reads; the cross-word LM table is built from them when the lexicon is created.
     // The tree half -- nodes, word -> N-gram ids, class probabilities, factoring values -- stays the file's.
-    if (d.lm_type != JAMD_LM_NGRAM) { jamd_set_error("%s is a grammar lexicon: no N-gram to replace", path); return JAMD_EINVAL; }
+    if ((d.lm_type & 0xff) != JAMD_LM_NGRAM) { jamd_set_error("%s is a grammar lexicon: no N-gram to replace", path); return JAMD_EINVAL; }
     d.ng_mode = ng.mode; d.ng_nword = ng.nword; d.ng_nbigram = ng.nbigram;
     d.ng_uni_prob = ng.uni_prob.data(); d.ng_uni_bo = ng.uni_bo.data();
     d.ng_bi_bgn = ng.bi_bgn.data(); d.ng_bi_num = ng.bi_num.data(); d.ng_bi_wid = ng.bi_wid.data(); d.ng_bi_prob = ng.bi_prob.data();

@@ -91,7 +91,7 @@ int main(int argc, char **argv)
   }
   {
     jamd_flat_lexicon fl;
-    if (jamd_flatten_lexicon(r, &fl) != JAMD_OK) { fprintf(stderr, "jamd_export: this lexicon / LM configuration is not covered by the device first pass\n"); return 1; }
+    if ((r->am->hmminfo->multipath ? jamd_flatten_lexicon_multipath(r, &fl) : jamd_flatten_lexicon(r, &fl)) != JAMD_OK) { fprintf(stderr, "jamd_export: this lexicon / LM configuration is not covered by the device first pass\n"); return 1; }
     snprintf(path, sizeof(path), "%s.lex", prefix);
     rc = jamd_lexicon_save(&fl.desc, path);
     if (rc == JAMD_OK && r->lmtype == LM_PROB && r->lm != NULL) rc = jamd_lexicon_append_ngram_names(path, r->lm->ngram);

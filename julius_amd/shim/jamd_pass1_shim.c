@@ -21,8 +21,8 @@
  * the reference's own allocator (bt_new / bt_store), and finalize_1st_pass()
  * indexes it with bt_relocate_rw / bt_sort_rw exactly as the reference does.
  *
- * Supported configuration (anything else is refused loudly at _init()): N-gram
- * LM, non-multipath acoustic model -- GMM with any -gprune method, or DNN (-dnnconf) --
+ * Supported configuration (anything else is refused loudly at _init()): N-gram LM, grammar or word
+ * list; acoustic model -- multipath ones included -- GMM with any -gprune method, or DNN (-dnnconf);
  * no short-pause segmentation, buffered input.  The "no nodes left in beam" condition is
  * reported by failing the utterance (J_RESULT_STATUS_FAIL) instead of segmenting.
  */
@@ -38,7 +38,7 @@ typedef struct {
   HTK_HMM_INFO *hmminfo;
   int beam_width; float bs_width;
   jamd_gmm *gmm; jamd_dnn *dnn; jamd_lexicon *lex; jamd_beam *beam; jamd_gms *gms;
-  int strict;                /* JAMD_STRICT_ORDER=1 / JAMD_ORDER_MODE=strict, or a multipath model (strict-order kernel only) */
+  int strict;                /* JAMD_STRICT_ORDER=1 / JAMD_ORDER_MODE=strict, or a multipath model the exact-order kernel cannot serve */
   jamd_trellis_atom *iatoms; int iatom_cap;   /* trellis so far, read back for -progout interim results */
   int order_mode;            /* -1 = the work area's default (exact order where the beam fits), else JAMD_ORDER_* (JAMD_ORDER_MODE) */
   int nstate;
@@ -141,7 +141,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     return FALSE;
   }
   /* tie order (julius_amd.h, JAMD_ORDER_*): default = the reference's order (exact-order kernel); JAMD_ORDER_MODE =
-   * fast | exact | strict chooses; multipath models are served by the strict-order kernel only */
+   * fast | exact | strict chooses; multipath models: exact (their own frame-parallel frame) or strict */
   c->order_mode = -1;
   {
     const char *om = getenv("JAMD_ORDER_MODE");
@@ -149,7 +149,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     else if (om != NULL && !strcmp(om, "exact")) c->order_mode = JAMD_ORDER_EXACT;
     else if (om != NULL && !strcmp(om, "strict")) c->order_mode = JAMD_ORDER_STRICT;
   }
-  c->strict = r->am->hmminfo->multipath || c->order_mode == JAMD_ORDER_STRICT ||
+  c->strict = c->order_mode == JAMD_ORDER_STRICT ||
               (getenv("JAMD_STRICT_ORDER") != NULL && atoi(getenv("JAMD_STRICT_ORDER")) != 0);
   if (r->am->hmmwrk.OP_gshmm != NULL && r->am->dnn != NULL) {
     jlog("ERROR: jamd: Gaussian mixture selection (-gshmm) with a DNN-HMM is not supported\n");
@@ -211,6 +211,9 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
   rc = jamd_beam_create(g_eng, c->lex, r->trellis_beam_width, r->config->pass1.score_pruning_width, 1,
                         1 << 20, &c->beam);
   if (rc != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
+  /* a multipath model runs on the exact-order kernel's multipath frame (csrc/beam_exact_mp.h) where that can serve the
+   * lexicon and the beam; else (a root that reaches a word end along its own arcs, a beam too wide) in strict order */
+  if (r->am->hmminfo->multipath && (jamd_beam_order_mode(c->beam) != JAMD_ORDER_EXACT || c->order_mode == JAMD_ORDER_FAST)) c->strict = 1;
   if (c->strict && jamd_beam_set_strict_order(c->beam, 1) != JAMD_OK) { jlog("ERROR: jamd: %s\n", jamd_last_error()); return FALSE; }
   if (!c->strict && c->order_mode == JAMD_ORDER_FAST) jamd_beam_set_order_mode(c->beam, JAMD_ORDER_FAST);
   if (!c->strict && c->order_mode == JAMD_ORDER_EXACT && jamd_beam_set_order_mode(c->beam, JAMD_ORDER_EXACT) != JAMD_OK) {

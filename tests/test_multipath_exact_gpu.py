@@ -22,11 +22,15 @@ def test_multipath_golden_default_order(engine, oracle):
     assert g["lex"]["lm_type"] == 0x100
     lx = lib.Lexicon(engine, g["lex"])
     bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(g["utts"]))
-    res, tre = bm.pass1_host([oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]])     # default = exact order
-    for r, atoms, u in zip(res, tre, g["utts"]):
-        assert r.status == 0
-        assert_trellis_equal(atoms, u["trellis"])
-        assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    for rep in range(2):                                      # the work area is reusable: same slices, second batch reversed
+        order = list(range(len(scores)))[::-1] if rep else list(range(len(scores)))
+        res, tre = bm.pass1_host([scores[i] for i in order])      # default = exact order
+        for r, atoms, i in zip(res, tre, order):
+            u = g["utts"][i]
+            assert r.status == 0
+            assert_trellis_equal(atoms, u["trellis"])
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
 
 
 @pytest.mark.parametrize("seed,beam,extra", [

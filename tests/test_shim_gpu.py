@@ -480,12 +480,13 @@ def test_verification_gmm_on_device(ref, tmp_path, monkeypatch, so):
             assert fin0[0] < 0 and not want[3]                 # J_RESULT_STATUS_REJECT_GMM
 
 
-@pytest.mark.parametrize("lm", ["ngram", "grammar"])
-def test_multipath_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, lm):
-    """-multipath: the shim flattens the multipath lexicon and decodes it with the strict-order kernel
-; trellis, pass-1 and final results as the plain reference."""
-    monkeypatch.setenv("JAMD_STRICT_ORDER", "0")
-    monkeypatch.setenv("JAMD_STREAM_CHUNK", "0")
+@pytest.mark.parametrize("lm,order", [("ngram", "exact"), ("grammar", "exact"), ("ngram", "chunks"), ("grammar", "strict")])
+def test_multipath_two_pass_over_device_first_pass(ref, tmp_path, monkeypatch, lm, order):
+    """-multipath: the shim flattens the multipath lexicon and decodes it with the exact-order kernel's multipath frame
+    (csrc/beam_exact_mp.h; in one piece and in 16-frame pieces) or, asked to, in strict order; trellis, pass-1 and final
+    results as the plain reference."""
+    monkeypatch.setenv("JAMD_STRICT_ORDER", "1" if order == "strict" else "0")
+    monkeypatch.setenv("JAMD_STREAM_CHUNK", "16" if order == "chunks" else "0")
     if not pyoracle.REF_AMD_SO.exists():
         pytest.skip("oracle/_ref/libjref_amd.so not built")
     if lm == "ngram":
