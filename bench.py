@@ -510,8 +510,9 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         if mode.startswith("exact"):
             allst = np.array([bm.prune_stats(u, reset=True) for u in range(nutt)], dtype=np.int64) // nlaunch
             pstats, work = [int(x) for x in allst[0][:8]], allst[:, 8:12].sum(axis=0)
+            mpstat = [int(x) for x in allst[:, 12:14].sum(axis=0)]
         else:
-            pstats, work = [0] * 8, np.zeros(4, np.int64)
+            pstats, work, mpstat = [0] * 8, np.zeros(4, np.int64), [0, 0]
         # the only collective of the job: every rank gets the per-utterance result records of all ranks (RCCL over xGMI)
         nutt_all = nutt * dd.world
         if dd.world > 1:
@@ -544,6 +545,8 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                            "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us),
                            "prune_paths_utt0": dict(zip(("frames_pruned", "up_closed_form", "up_wave_replay", "up_sweep", "up_sweep_gave_up",
                                                          "down_closed_form", "extraction_loop", "sweep_rounds"), pstats))}}
+            if multipath:      # frames whose new tokens exceeded the beam (the mid-frame sort really sorted)
+                r["pass1"]["multipath_frames"] = {"mid_frame_sorted": mpstat[0], "all": int(work[3])}
             if ri == 0 and dd.world == 1 and not args.no_cpu_baseline:
                 r["parity"], cpu = e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_local, jargs, wd, ref_built, use_dnn, multipath)
                 if cpu is not None:

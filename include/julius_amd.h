@@ -299,7 +299,8 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * lookups, the LM factoring tables (libjulius/src/factoring_sub.c:345-468) and
  * the forward 2-gram the beam reads through ngram->bigram_prob
  * (libsent/src/ngram/ngram_access.c:288-403).  N-gram LM with 1-gram factoring (the
- * reference's default "fast" setup) or DFA grammar with per-category trees; non-multipath models.  All indices are
+ * reference's default "fast" setup), DFA grammar with per-category trees, or isolated word list; multipath models
+ * through jamd_flatten_lexicon_multipath() (JAMD_LM_MULTIPATH below).  All indices are
  * 32-bit; WORD_INVALID is -1 here.  Built by jamd_flatten_lexicon()
  * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess. */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
@@ -317,8 +318,13 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
 
 /* OR-ed into lm_type by jamd_flatten_lexicon_multipath(): a multipath lexicon (hmminfo->multipath:
  * non-emitting word-begin / word-end nodes, word_head[] = wchmm->wordbegin[], wordend_a unused,
- * the frame loop of beam.c:2747-2836).  The oracle decodes these; jamd_lexicon_create() does not
- * accept them yet. */
+ * the frame loop of beam.c:2747-2836: word-internal transitions, the beam over the NEW tokens, cross-word transitions
+ * from the word ends among them with the root expanded along its own arcs inside the frame, output probabilities on
+ * emitting nodes, the final cut).  Decoded by the exact-order kernel's multipath frame (csrc/beam_exact_mp.h: one
+ * workgroup per utterance, full shape, streaming included) in the reference's own tie order, or by the strict-order
+ * kernel (JAMD_ORDER_STRICT); JAMD_ORDER_FAST does not take them.  One kind of lexicon is strict-order only: a root
+ * that reaches a word-end node along its own arcs (a word made of tee models only) -- jamd_beam_order_mode() then
+ * reports JAMD_ORDER_FAST for the new work area and jamd_beam_set_order_mode(b, JAMD_ORDER_EXACT) says why. */
 #define JAMD_LM_MULTIPATH 0x100
 
 #define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */
@@ -512,7 +518,7 @@ int  jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate
 int  jamd_beam_set_strict_order(jamd_beam *b, int on);
 /* How exact score ties are resolved (they are the only freedom a parallel schedule has; every
  * float is the reference's float in all modes):
- *   JAMD_ORDER_EXACT   (default for non-multipath lexicons and beams up to about 12 000: up to ~950 the survivors live
+ *   JAMD_ORDER_EXACT   (default; multipath lexicons included; beams up to about 12 000: up to ~950 the survivors live
  *       in LDS; wider beams keep them in the utterance's slice of HBM and the pruning step overlays the whole LDS
  *       image; the closed-form extraction serves beams up to 4 400, beyond that the heap's extraction loop itself
  *       runs pipelined on one wave):

@@ -19,6 +19,10 @@
 // Step 5's input is the whole array of step 2, so step 2 is carried out LITERALLY (heapify + the extraction loop,
 // pipelined on one wave when the heap is in LDS): the closed forms of exact_prune() deliver the survivors' order, not
 // the arrangement of the rest.  Step 5 itself is exact_prune() over the keys gathered in that arrangement.
+// (A partial heap sort over DISTINCT scores extracts in score order whatever the arrangement, so tindex[] matters to
+// step 5 only when two of its survivors -- or the last survivor and the first loser -- tie, or when it runs downward.
+// Measured on the 20 000-word task: that is 99 % of the frames -- pronunciation variants and homophones tie exactly --,
+// so a variant that sorted literally only on demand was slower; profiles/r04_multipath_*.)
 //
 // Visiting indices.  First half: (survivor position << s1) | transition number, as in the ordinary kernel.  Second
 // half: (rank of the word end among the frame's word ends << s1) | (root number * XW + transition number of the root);
@@ -457,7 +461,12 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
             werec[tid] = rec;
           }
           __syncthreads();
-          for (int x = tid; x < items; x += NT) {
+          int parts = NT / (items > 0 ? items : 1);              // the word ends of the chunk are split over the idle threads
+          if (parts < 1) parts = 1;
+          if (parts > nrec) parts = nrec;
+          const int total = items * parts;
+          for (int y = tid; y < total; y += NT) {
+            const int part = y / items, x = y - part * items;
             const int i = x / XW, a = x - i * XW;
             const int2 ir = lx.iso_root(i);
             if (ir.x == head_root) continue;                                      // :2336-2341
@@ -465,7 +474,7 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
             int to; float trn;
             if (!root_trans(na, ir.x, a, to, trn)) continue;
             unsigned long long best = 0ull; unsigned nfirst = 0u;
-            for (int wv = 0; wv < nrec; wv++) {
+            for (int wv = part; wv < nrec; wv += parts) {
               const u32x4 rec = werec[wv];
               if (rec.w) continue;
               const int ctx = (int)rec.y;
@@ -581,6 +590,7 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
       n_tot = n1 + uni(sh.n_arc);
     }
     if (n_tot > max_tokens) max_tokens = n_tot;
+    if (pm.pstat && tid == 0 && n1 > wk.beam) pm.pstat[12] += 1;             // frames whose new tokens exceeded the beam
     if (pm.pstat && tid == 0) { pm.pstat[8] += n_tot; pm.pstat[9] += n_surv; pm.pstat[10] += n_we; pm.pstat[11] += 1; }   // work counters (jamd_beam_prune_stats())
     if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[1] += n_ - tc; tc = n_; }
     // ---- O: output probabilities on emitting nodes (:2930-2943); nodetok[] is emptied on the way
