@@ -683,7 +683,7 @@ def main():
                     help="e2e-dnn: the flat-score stream (random-init weights over noise frames: nothing decodes, every frame "
                          "saturates the beam) instead of the input that decodes")
     ap.add_argument("--multipath", action="store_true",
-                    help="e2e: the C3 task decoded with -multipath (reference-built multipath lexicon; the exact-order kernel's "
+                    help="e2e / e2e-dnn: the task decoded with -multipath (reference-built multipath lexicon; the exact-order kernel's "
                          "multipath frame, csrc/beam_exact_mp.h)")
     ap.add_argument("--batch-total", type=int, default=None, help="e2e --strong: utterances in the fixed batch (default 512)")
     ap.add_argument("--nword", type=int, default=20000, help="e2e: vocabulary size")
@@ -753,12 +753,16 @@ def main():
         # labelled worst case of the rank pruning step
         strong_total = args.batch_total or C5_TOTAL_UTTS
         runs = []
-        if wl == "all" or not (args.strong or args.flat):
+        if wl == "all" or not (args.strong or args.flat or args.multipath):
             runs.append(("e2e_dnn", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak"))
-        if wl == "all" or (args.strong and not args.flat):
+        if wl == "all" or (args.strong and not args.flat and not args.multipath):
             runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 2), pick(args.warmup, 1), "strong"))
         r = run_e2e(args, dd, runs, use_dnn=True) if runs else {}
-        if wl == "all" or args.flat:
+        if wl == "all" or args.multipath:
+            # the reference's DNN recipe as its README gives it: -b 4000 WITH -multipath (the multipath frame, wide layout)
+            r.update(run_e2e(args, dd, [("e2e_dnn_mp", pick(args.utts, 256), pick(args.steps, 1), pick(args.warmup, 1), "weak")],
+                             use_dnn=True, multipath=True))
+        if wl == "all" or (args.flat and not args.multipath):
             r.update(run_e2e(args, dd, [("e2e_dnn_flat", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
                              use_dnn=True, flat=True))
         if dd.rank == 0:

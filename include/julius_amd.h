@@ -574,6 +574,10 @@ int  jamd_beam_stream_wait_resident(jamd_beam *b, void *stream);
  * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the
  * exact-order kernel's pruning code on the device; diagnostic / test entry. */
 int  jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, int *nkeep);
+/* The same step with the WHOLE array out: tindex[0..n) = the token ids at array positions 0..n-1 after
+ * sort_token_no_order() (residual heap and extracted part: what the multipath frame's final cut starts from,
+ * csrc/beam_exact_mp.h) beside order[].  Test entry like jamd_beam_prune_order(); full workgroup shape. */
+int  jamd_beam_prune_arrange(jamd_beam *b, const float *scores, int n, int *order, int *nkeep, int *tindex);
 /* How the latest jamd_beam_prune_order() call resolved the events of the extraction loop (tail positions that hold a
  * top element, beam.c:1369-1383): *sweep_rounds = rounds of the all-at-once sweep replay (csrc/beam_sweep.h) when it
  * ran and converged, -1 = it ran and handed the frame to the extraction loop, 0 = not needed (few candidates, or no

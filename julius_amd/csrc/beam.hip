@@ -1296,6 +1296,7 @@ struct jamd_beam {
   int shape_mode = JAMD_SHAPE_AUTO;
   bool stream_half = false;        // the shape of the open streaming session (the parked state is the layout's)
   hipEvent_t ev_started = nullptr; // recorded right before the latest first-pass launch (jamd_beam_wait_started())
+  int *d_parr = nullptr;           // jamd_beam_prune_arrange(): the whole array
   unsigned *d_resident = nullptr;  // signal memory: first-pass workgroups started so far (Work::resident), nullptr = the device cannot wait on memory
   unsigned resident_target = 0;    // its value once the workgroups of the latest launch that fit the device at once have started
   unsigned launched_wg = 0;        // workgroups of all launches so far
@@ -1913,7 +1914,7 @@ int jamd_beam_order_mode(const jamd_beam *b) {
   return b->strict ? JAMD_ORDER_STRICT : b->exact ? (b->xw.prune_mode ? JAMD_ORDER_EXACT_SERIAL : JAMD_ORDER_EXACT) : JAMD_ORDER_FAST;
 }
 
-int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, int *nkeep) {
+static int prune_order_impl(jamd_beam *b, const float *scores, int n, int *order, int *nkeep, int *arr) {
   if (!b || !scores || !order || !nkeep || n < 1) { jamd_set_error("jamd_beam_prune_order: bad argument"); return JAMD_EINVAL; }
   if (b->exact_status != 0) { jamd_set_error("jamd_beam_prune_order: the exact-order kernel cannot serve this work area"); return JAMD_ESTATE; }
   if (n > (1 << 20)) { jamd_set_error("jamd_beam_prune_order: n=%d too large", n); return JAMD_EINVAL; }
@@ -1925,7 +1926,9 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
     // out[cap] + nout (+ pad) | heap u64[cap + 2] | top-list scratch u32x4[beam + 256] (wide layout) | sweep replay scratch
     JAMD_HIP(hipMalloc(&p, 4 * (cap + 16) + 8 * (cap + 2) + 16 * ((size_t)b->w.beam + 256) + xbeam_sweep_bytes(b->w.beam))); b->owned.push_back(p); b->d_pout = (int *)p;
     b->pcap = cap;
+    b->d_parr = nullptr;
   }
+  if (arr && !b->d_parr) { void *p = nullptr; JAMD_HIP(hipMalloc(&p, 4 * b->pcap)); b->owned.push_back(p); b->d_parr = (int *)p; }
   std::vector<unsigned> keys((size_t)n);
   for (int i = 0; i < n; i++) {
     float f = scores[i] + 0.0f; unsigned u; memcpy(&u, &f, 4);
@@ -1937,14 +1940,24 @@ int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, 
   unsigned long long *d_heap = reinterpret_cast<unsigned long long *>(b->d_pout + b->pcap + 16);
   u32x4 *d_collect = reinterpret_cast<u32x4 *>(d_heap + b->pcap + 2);
   unsigned char *d_sweep = reinterpret_cast<unsigned char *>(d_collect + (size_t)b->w.beam + 256);
-  xbeam_prune_order_launch(use_half_shape(b, 1) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, d_sweep, st);
+  xbeam_prune_order_launch((!arr && use_half_shape(b, 1)) ? b->xw_half : b->xw, b->d_pkeys, n, b->w.beam, b->d_pout, d_nout, d_heap, d_collect, d_sweep, arr ? b->d_parr : nullptr, st);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_prune_order: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpyAsync(nkeep, d_nout, 4, hipMemcpyDeviceToHost, st));
   JAMD_HIP(hipStreamSynchronize(st));
   if (*nkeep < 0 || *nkeep > n) { jamd_set_error("jamd_beam_prune_order: the kernel reported %d of %d tokens kept", *nkeep, n); return JAMD_ELAUNCH; }
   JAMD_HIP(hipMemcpy(order, b->d_pout, 4 * (size_t)*nkeep, hipMemcpyDeviceToHost));
+  if (arr) JAMD_HIP(hipMemcpy(arr, b->d_parr, 4 * (size_t)n, hipMemcpyDeviceToHost));
   return JAMD_OK;
+}
+
+int jamd_beam_prune_order(jamd_beam *b, const float *scores, int n, int *order, int *nkeep) {
+  return prune_order_impl(b, scores, n, order, nkeep, nullptr);
+}
+
+int jamd_beam_prune_arrange(jamd_beam *b, const float *scores, int n, int *order, int *nkeep, int *tindex) {
+  if (!tindex) { jamd_set_error("jamd_beam_prune_arrange: bad argument"); return JAMD_EINVAL; }
+  return prune_order_impl(b, scores, n, order, nkeep, tindex);
 }
 
 int jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[16], int reset) {
@@ -1960,10 +1973,11 @@ int jamd_beam_prune_stats(jamd_beam *b, int utt, int stats[16], int reset) {
 int jamd_beam_prune_info(jamd_beam *b, int *sweep_rounds, int *sweep_us, int *sweep_events) {
   if (!b || !sweep_rounds || !b->d_pout) { jamd_set_error("jamd_beam_prune_info: bad argument (or no jamd_beam_prune_order() call yet)"); return JAMD_EINVAL; }
   JAMD_HIP(hipSetDevice(b->eng->device));
-  int v[11];
+  int v[15];
   JAMD_HIP(hipMemcpy(v, b->d_pout + b->pcap + 1, sizeof(v), hipMemcpyDeviceToHost));
   if (getenv("JAMD_SWEEP_PROF")) fprintf(stderr, "sweep phases (us): setup %d  tables %d  level0 %d  levels %d  chains %d  rebuild %d | level phase 1 %d  phase 2 %d\n",
                                          v[3] / 100, v[4] / 100, v[5] / 100, v[6] / 100, v[7] / 100, v[8] / 100, v[9] / 100, v[10] / 100);
+  if (getenv("JAMD_SWEEP_PROF") && (v[11] | v[12] | v[13] | v[14])) fprintf(stderr, "sift replay (us): load %d  first window's dependencies %d  sifts %d  output %d\n", v[11] / 100, v[12] / 100, v[13] / 100, v[14] / 100);
   *sweep_rounds = v[0];
   if (sweep_us) *sweep_us = v[1] / 100;            // wall_clock64(): 100 MHz
   if (sweep_events) *sweep_events = v[2];

@@ -47,7 +47,7 @@ hipError_t xbeam_prepare();
 void xbeam_launch(const LexDev &lx, const XWork &xw, const float *scores, int nstate, const int *d_utt_off, int nutt,
                   int smode, bool timed, hipStream_t st);
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, hipStream_t st);
+                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, int *d_arr, hipStream_t st);
 size_t xbeam_sweep_bytes(int beam);   // global scratch of the sweep replay per utterance
 
 }  // namespace jamdb

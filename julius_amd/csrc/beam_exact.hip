@@ -74,6 +74,7 @@ struct XShared {
   int sw_ticks, sw_nev_out, sw_prof[8];
   int pst[16];                                   // this launch's share of jamd_beam_prune_stats(): kept here, added to the slice once at the end                      // its duration (100 MHz ticks), events held at the end
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
+  int df_prof[4];                                // down_finish(): load, dependencies, sifts, output (100 MHz ticks; development)
   unsigned emaxbits;                             // multipath frame: best score among the tokens on emitting nodes (the score-pruning envelope)
 };
 
@@ -645,10 +646,14 @@ __device__ __noinline__ int replay_tail(const PruneMem &pm, int nB, int n, int k
 // WIDE (the wide-beam layout): the heap is laid over the list areas -- it is dead once the top elements are
 // collected, so they travel through `G` (a scratch array in the utterance's slice) with their token ids, and the
 // sorted list is built where the heap was; vposR lies over the sorting scratch.
-template <bool WIDE, int NT>
+// FULL (the multipath frame's mid-frame sort, beam_exact_mp.h): the caller wants tindex[] WHOLE -- arr_full[0..n) = the token
+// ids at array positions 0..n-1 after the sort, residual heap and extracted part -- beside svid[] (the part the next step
+// visits).  Both directions then run sweep replay + sift replay (the closed form of the downward sort, mirrored for the
+// upward one), or, where that cannot run, the extraction loop itself.
+template <bool WIDE, int NT, bool FULL = false>
 __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, int n, int k, lds_u64 *H, int heap_cap,
                            unsigned long long *Hglob, PruneMem pm, lds_i32 *svid, int mode, u32x4 *G,
-                           unsigned long long *tp = nullptr) {
+                           unsigned long long *tp = nullptr, int *arr_full = nullptr) {
   const int tid = tid_now();
   unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
   (void)tc3_;
@@ -662,6 +667,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
 #endif
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
+    if constexpr (FULL) { for (int j = tid; j < n; j += NT) arr_full[j] = j; }
     __syncthreads();
     return n;
   }
@@ -689,10 +695,11 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     bool down_ok = false;
     // (wide layout, full shape only: the narrow layout's beams have a handful of tail candidates, and the mere presence of
     // this code in the kernel costs its steps 0-C 2.5 us each per frame at beam 800 -- profiles/r04_ab_sweep_code_presence.txt)
-    if constexpr (kLdsHeap && WIDE && NT == jamdb::NT) down_ok = !upward && pm.sw_glob != nullptr;
+    if constexpr (kLdsHeap && (WIDE || FULL) && NT == jamdb::NT) down_ok = (FULL || !upward) && pm.sw_glob != nullptr;
+    // (FULL: down_ok = "the whole array can come out of the closed form", either direction)
     const int cnt = upward ? k : n - k;                            // extractions
     const unsigned xm = upward ? 0u : 0xffffffffu;
-    if ((upward || down_ok) && mode != 1 && pm.b_cap > 0) {
+    if ((upward || down_ok) && (!FULL || down_ok) && mode != 1 && pm.b_cap > 0) {
       // closed form of the extraction loop
       const unsigned vk = kth_largest<NT>(sh, Hh, n, cnt, pm.hist, xm);
       // The top list sorted by (score descending, pre-order of the heap position ascending).  A bitonic network is 55
@@ -720,7 +727,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         const int p = p0 + tid;
         const unsigned long long hv = p <= n ? Hh[p] : 0ull;
         const unsigned hi = (unsigned)(hv >> 32) ^ xm;
-        if (!upward && p <= n) Hglob[p] = hv;            // the heap itself: down_finish() replays the sifts below the extracted region on it
+        if ((FULL || !upward) && p <= n) Hglob[p] = hv;  // the heap itself: down_finish() replays the sifts below the extracted region on it
         const bool in = p <= n && hi >= vk;
         const int slot = wave_alloc(&sh.nB, in);
         if (in && slot < pm.b_cap) {
@@ -807,20 +814,30 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         }
         __syncthreads();
         PTICK(6);
-        if (!upward) {
+        if (FULL || !upward) {
           // the residual heap: every event matters (the survivors stay in heap layout), so the sweep runs over all turns
           bool ok = false;
-          if constexpr (kLdsHeap && WIDE && NT == jamdb::NT) {
+          if constexpr (kLdsHeap && (WIDE || FULL) && NT == jamdb::NT) {
             const int tailb = sweep_down_bytes(cnt);
-            if (pm.sw_bytes > tailb + 1024) {
+            // (the sift replay holds the whole heap in LDS: a frame too large for it goes to the extraction loop at once)
+            if (pm.sw_bytes > tailb + 1024 && 10 * (n + 2) + cnt + 72 <= ((pm.sw_bytes - tailb) & ~15) && n < 0xffff) {
               SweepDown dn;
               unsigned char JAMD_LDS *tl = pm.sw_region + ((pm.sw_bytes - tailb) & ~15);
               dn.fd = (lds_u32 *)tl; dn.posend = dn.fd + cnt + 1; dn.evbits = dn.posend + kSwLeft;
+              dn.want_order = FULL ? 1 : 0;
               const int evmax = sweep_pick_evmax(nB, cnt, (pm.sw_bytes - tailb) & ~15);
               if (evmax) ok = sweep_replay<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, pm.sw_glob, pm.compR, pm.vposR, pm.idR, pm.tailmask, nB, n, cnt,
                                                cnt, svid, evmax, &dn);
               __syncthreads();
-              if (ok) ok = down_finish<NT>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, Hglob, n, k, dn, sweep_ids(pm.sw_glob), nB, svid);
+              if constexpr (FULL) {                          // svid[] = the extracted elements, last extracted first: tindex[n - cnt ..)
+                if (ok) for (int j = tid; j < cnt; j += NT) arr_full[n - cnt + j] = svid[j];
+                __syncthreads();
+              }
+              if (ok) ok = upward ? down_finish<NT, false>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, Hglob, n, n - cnt, dn, sweep_ids(pm.sw_glob), nB, svid, FULL ? arr_full : nullptr)
+                                  : down_finish<NT, true>(sh, pm.sw_region, (pm.sw_bytes - tailb) & ~15, Hglob, n, n - cnt, dn, sweep_ids(pm.sw_glob), nB, svid, FULL ? arr_full : nullptr);
+              if constexpr (FULL) {                          // downward: what the next step visits is the residual heap
+                if (ok && !upward) { __threadfence_block(); __syncthreads(); for (int j = tid; j < k; j += NT) svid[j] = arr_full[j]; }
+              }
               if (!ok && tid == 0) sh.sw_info = -1;
               __syncthreads();
             }
@@ -1021,6 +1038,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
       if (!piped && tid == 0) { if (upward) heap_extract_serial<true>(Hh, n, k); else heap_extract_serial<false>(Hh, n, n - k); }
       __syncthreads();
       for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)(upward ? Hh[n - k + 1 + j] : Hh[1 + j]);
+      if constexpr (FULL) { for (int p = tid; p < n; p += NT) arr_full[p] = (int)(unsigned)Hh[p + 1]; }
     }
     __syncthreads();
   };
@@ -1771,9 +1789,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 
 // diagnostic: the pruning step alone on given score bits (tests/test_prune_order.py fuzzes it against the
 // sequential heap)
-template <bool WIDE, int NT>
+template <bool WIDE, int NT, bool FULL>
 __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigned *keys, int n, int k, int *out, int *nout,
-                                                         unsigned long long *hglob, u32x4 *gcol, unsigned char *gsweep) {
+                                                         unsigned long long *hglob, u32x4 *gcol, unsigned char *gsweep, int *arr) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
   PruneMem pm;
@@ -1793,14 +1811,14 @@ __global__ void __launch_bounds__(NT) prune_order_kernel(XWork xw, const unsigne
   lds_i32 *svid = (lds_i32 *)(dyn_lds + xw.off_we);
   unsigned mx = 0u, mn = 0xffffffffu;
   for (int i = threadIdx.x; i < n; i += NT) { const unsigned b = keys[i]; if (b > mx) mx = b; if (b < mn) mn = b; }
-  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; sh.sw_info = 0; sh.sw_ticks = 0; sh.sw_nev_out = 0; for (int i = 0; i < 8; i++) sh.sw_prof[i] = 0; }
+  if (threadIdx.x == 0) { sh.maxbits = 0u; sh.minbits = 0xffffffffu; sh.sw_info = 0; sh.sw_ticks = 0; sh.sw_nev_out = 0; for (int i = 0; i < 8; i++) sh.sw_prof[i] = 0; for (int i = 0; i < 4; i++) sh.df_prof[i] = 0; }
   __syncthreads();
   atomicMax(&sh.maxbits, mx); atomicMin(&sh.minbits, mn);
   __syncthreads();
-  const int nk = exact_prune<WIDE, NT>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
-                                   xw.prune_mode, gcol);
+  const int nk = exact_prune<WIDE, NT, FULL>(sh, keys, n, k, (lds_u64 *)(dyn_lds + xw.off_heap), xw.heap_cap, hglob, pm, svid,
+                                         xw.prune_mode, gcol, nullptr, arr);
   for (int j = threadIdx.x; j < nk; j += NT) out[j] = svid[j];
-  if (threadIdx.x == 0) { nout[0] = nk; nout[1] = sh.sw_info; nout[2] = sh.sw_ticks; nout[3] = sh.sw_nev_out; for (int i = 0; i < 8; i++) nout[4 + i] = sh.sw_prof[i]; }
+  if (threadIdx.x == 0) { nout[0] = nk; nout[1] = sh.sw_info; nout[2] = sh.sw_ticks; nout[3] = sh.sw_nev_out; for (int i = 0; i < 8; i++) nout[4 + i] = sh.sw_prof[i]; for (int i = 0; i < 4; i++) nout[12 + i] = sh.df_prof[i]; }
 }
 
 }  // namespace
@@ -1955,14 +1973,15 @@ hipError_t xbeam_prepare() {
                       (const void *)beam_exact_kernel<false, true, NT>, (const void *)beam_exact_kernel<true, true, NT>,
                       (const void *)beam_exact_mp_kernel<false, false, NT>, (const void *)beam_exact_mp_kernel<true, false, NT>,
                       (const void *)beam_exact_mp_kernel<false, true, NT>, (const void *)beam_exact_mp_kernel<true, true, NT>,
-                      (const void *)prune_order_kernel<false, NT>, (const void *)prune_order_kernel<true, NT>};
+                      (const void *)prune_order_kernel<false, NT, false>, (const void *)prune_order_kernel<true, NT, false>,
+                      (const void *)prune_order_kernel<false, NT, true>, (const void *)prune_order_kernel<true, NT, true>};
   for (const void *f : fn) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     if (e != hipSuccess) return e;
   }
   // the half shape is always the wide layout (xbeam_layout())
   const void *fh[] = {(const void *)beam_exact_kernel<false, true, kHalfNT>, (const void *)beam_exact_kernel<true, true, kHalfNT>,
-                      (const void *)prune_order_kernel<true, kHalfNT>};
+                      (const void *)prune_order_kernel<true, kHalfNT, false>};
   for (const void *f : fh) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfDynLds);
     if (e != hipSuccess) return e;
@@ -1997,10 +2016,14 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
 }
 
 void xbeam_prune_order_launch(const XWork &xw, const unsigned *d_keys, int n, int k, int *d_out, int *d_nout,
-                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, hipStream_t st) {
-  if (xw.nt == kHalfNT) hipLaunchKernelGGL((prune_order_kernel<true, kHalfNT>), dim3(1), dim3(kHalfNT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
-  else if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
-  else hipLaunchKernelGGL((prune_order_kernel<false, NT>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep);
+                              unsigned long long *d_hglob, u32x4 *d_collect, unsigned char *d_sweep, int *d_arr, hipStream_t st) {
+  if (d_arr) {                                          // the whole array (exact_prune<FULL>: full shape only)
+    if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT, true>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep, d_arr);
+    else hipLaunchKernelGGL((prune_order_kernel<false, NT, true>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep, d_arr);
+  }
+  else if (xw.nt == kHalfNT) hipLaunchKernelGGL((prune_order_kernel<true, kHalfNT, false>), dim3(1), dim3(kHalfNT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep, nullptr);
+  else if (xw.wide) hipLaunchKernelGGL((prune_order_kernel<true, NT, false>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep, nullptr);
+  else hipLaunchKernelGGL((prune_order_kernel<false, NT, false>), dim3(1), dim3(NT), xw.lds_bytes, st, xw, d_keys, n, k, d_out, d_nout, d_hglob, d_collect, d_sweep, nullptr);
 }
 
 size_t xbeam_sweep_bytes(int beam) { return sweep_global_bytes(beam + 256); }

@@ -3,7 +3,7 @@
 // (cells, creation-order bitmap, heaps, exact_prune()) and the slice macros are that file's.
 //
 // The reference runs a different frame for such models (beam.c:2747-2836, :2930-2943, :3066-3073; the frame as
-// restated in oracle/jamd_oracle_beam.c and decoded one lane per utterance by beam_strict_mp_kernel):
+// decoded one lane per utterance by beam_strict_mp_kernel, beam.hip):
 //   1  word-internal transitions of every survivor                               (steps 0', A', C1: tokens WITHOUT this
 //                                                                                  frame's output probability)
 //   2  sort_token_no_order() over the NEW tokens                                  (step M)
@@ -16,9 +16,11 @@
 // Frame 0 goes through this too (the initial tokens carry the LM score only, :1657, :1733), and one transition-only
 // call ends the input (t == T: steps 1-3 without the cross-word part).
 //
-// Step 5's input is the whole array of step 2, so step 2 is carried out LITERALLY (heapify + the extraction loop,
-// pipelined on one wave when the heap is in LDS): the closed forms of exact_prune() deliver the survivors' order, not
-// the arrangement of the rest.  Step 5 itself is exact_prune() over the keys gathered in that arrangement.
+// Step 5's input is the whole array of step 2 -- residual heap included.  exact_prune<FULL> delivers it: the extracted
+// part is the sweep replay's extraction order, the residual heap comes out of the sift replay below the extracted region
+// (beam_sweep.h: written for the downward sort, mirrored for the upward one); where that machinery cannot run (heap
+// outside LDS, too many events) step 2 is carried out literally (heapify + the extraction loop, pipelined on one wave).
+// Step 5 itself is exact_prune() over the keys gathered in that arrangement.
 // (A partial heap sort over DISTINCT scores extracts in score order whatever the arrangement, so tindex[] matters to
 // step 5 only when two of its survivors -- or the last survivor and the first loser -- tie, or when it runs downward.
 // Measured on the 20 000-word task: that is 99 % of the frames -- pronunciation variants and homophones tie exactly --,
@@ -325,6 +327,7 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
     {
       auto dense1 = [&](unsigned fv) -> int { return dbase[fv >> s1] + (int)(fv & submask); };
       const int Wsh = rank_setup(nbits, n1, dense1, [](int) { return true; });
+      unsigned mymax1 = ord(JAMD_LOG_ZERO), mymin1 = 0xffffffffu;
       for (int s = tid; s < n1; s += NT) {
         const int2 t2 = TOUCHED(s);
         const int node = t2.x, slot = t2.y;
@@ -349,25 +352,29 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
           nw.last_lscore = max_successor_prob(lx, tk.last_cword, nr.y, memo) * lmw + pen;
         nw.score = unord((unsigned)(key >> 32));
         CUR(id) = nw;
-        CURKEY(id) = (unsigned)(key >> 32);
+        const unsigned kb = (unsigned)(key >> 32);
+        CURKEY(id) = kb;
+        mymax1 = max(mymax1, kb); mymin1 = min(mymin1, kb);
         NODETOK(node) = (unsigned)id + 1u;
         ARR(id) = id;
       }
+      atomicMax(&sh.maxbits, mymax1); atomicMin(&sh.minbits, mymin1);      // (the mid-frame sort's bins span them)
       __syncthreads();
     }
     if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[0] += n_ - tc; tc = n_; }
-    // ---- M: the beam over the new tokens (:2774): literally, the whole array matters to step D
+    // ---- M: the beam over the new tokens (:2774), the WHOLE array: step D starts from it.  exact_prune<FULL>: the sorted
+    //         list + sweep replay give the extracted part, the sift replay below the extracted region the residual heap
+    //         (beam_sweep.h; either direction); frames that machinery cannot hold run the extraction loop itself.
     int r_lo = 0, r_hi = n1 - 1;                             // tindex[r_lo..r_hi]: what the second half visits
     if (n1 > wk.beam) {
       const int k = wk.beam;
-      literal_sort<NT>(&CURKEY(0), n1, k, Hlds, xw.heap_cap, Hglob);
-      if (n1 <= xw.heap_cap) { for (int p = tid; p < n1; p += NT) ARR(p) = (int)(unsigned)Hlds[p + 1]; }
-      else { for (int p = tid; p < n1; p += NT) ARR(p) = (int)(unsigned)Hglob[p + 1]; }
+      exact_prune<WIDE, NT, true>(sh, &CURKEY(0), n1, k, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, nullptr, &ARR(0));
       if (k < n1 - k) { r_lo = n1 - k; r_hi = n1 - 1; } else { r_lo = 0; r_hi = k - 1; }
       __syncthreads();
-      clear_cells();                                         // the heap lay over the cell area
+      clear_cells();                                         // the pruning step lay over the cell area
       __syncthreads();
     }
+    if (tid == 0) { sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }      // (step O collects them again)
     if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[3] += n_ - tc; tc = n_; }
     // ---- B0: word ends among tindex[r_lo..r_hi], in that order: save_trellis() :2209-2247
     const int atom_base = uni(sh.n_atom);

@@ -64,6 +64,7 @@ struct SweepDown {
                                  //           leaves the extracted region (0: the root)
   lds_u32 *posend;               // [kSwLeft] position after the last turn of the elements that are not extracted (ties on the cut), by rank - (nB - kSwLeft)
   lds_u32 *evbits;               // [(cnt + 31) / 32 + 1] turns that are events (bit i - 1)
+  int want_order;                // 1: svid[] receives the extraction order as well (the caller wants the whole array: residual heap AND extracted part)
 };
 constexpr int kSwLeft = 512;
 __host__ __device__ inline int sweep_down_bytes(int cnt) { return 4 * (cnt + 1) + 4 * kSwLeft + 4 * ((cnt + 31) / 32 + 1) + 48; }
@@ -338,9 +339,9 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const int c0 = m.ep[g0], c1 = m.ep[g0 + len];
         if (c0 == c1) {
           A[r + c0] = (unsigned)r | ((unsigned)(r + 1) << 16);
-          if (!down && r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
+          if ((!down || down->want_order) && r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
         } else if (r == g0) {
-          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, down ? 0 : k, svid)) sh.sw_fail = 1;
+          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, (down && !down->want_order) ? 0 : k, svid)) sh.sw_fail = 1;
         }
       }
       __syncthreads();
@@ -568,13 +569,18 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
 // later turn reads; so every sift waits for at most three earlier ones -- the turns that freed its start's two children
 // and the latest turn that freed an ancestor of its tail position -- and otherwise all of them run at once, one lane
 // each, in windows of NT turns.  P = the heap as heapify left it (global copy, loaded to LDS here).
-// Out: svid[0..k) = the token ids at heap positions 1..k after the last turn (= tindex[0..k), :1512-1514).
-template <int NT>
+// MINHEAP = the downward sort; false = the same replay for sort_token_upward() (:1342-1383: the k BEST are extracted from a
+// max-heap, the comparisons mirrored) -- wanted when the caller needs tindex[] whole (the multipath frame's mid-frame sort).
+// Out: svid[0..k) = the token ids at heap positions 1..k after the last turn (= tindex[0..k), :1512-1514); or, arr_full
+// given, arr_full[0..k) instead (global; k may exceed what svid[] holds) and svid[] untouched.
+template <int NT, bool MINHEAP>
 __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *region, int region_bytes, const unsigned long long *Pg,
-                                         int n, int k, SweepDown dn, const unsigned *ids, int nB, lds_i32 *svid) {
+                                         int n, int k, SweepDown dn, const unsigned *ids, int nB, lds_i32 *svid, int *arr_full) {
   const int tid = tid_now();
   const int R = n - k;
   if (8 * (n + 2) + 2 * (n + 2) + (R + 8) + 64 > region_bytes || n >= 0xffff) return false;
+  unsigned long long dclk = wall_clock64();
+#define DFTICK(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); sh.df_prof[i] += (int)(n_ - dclk); dclk = n_; } } while (0)
   volatile lds_u64 *P = (volatile lds_u64 *)region;
   lds_u16 *strip = (lds_u16 *)(region + 8 * (n + 2));
   volatile JAMD_LDS unsigned char *done = (volatile JAMD_LDS unsigned char *)(region + 8 * (n + 2) + ((2 * (n + 2) + 15) & ~15));
@@ -585,6 +591,7 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
   auto start_of = [&](int i) { const unsigned w = dn.fd[i]; return w ? (int)(w & 0x1fffffu) : 1; };
   for (int i = 1 + tid; i <= R; i += NT) if (!is_event(i)) strip[start_of(i)] = (unsigned short)i;
   __syncthreads();
+  DFTICK(0);
   for (int base = 0; base < R; base += NT) {
     const int i = base + tid + 1;
     bool mine = i <= R && !is_event(i);
@@ -600,6 +607,7 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
         if (s < i) d3 = s; else break;
       }
     }
+    if (base == 0) DFTICK(1);
     int guard = 0;
     while (__any(mine)) {
       if (mine && done[d1] && done[d2] && done[d3]) {
@@ -611,9 +619,9 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
           unsigned long long c = P[child];
           if (child < m) {
             const unsigned long long c2 = P[child + 1];
-            if ((unsigned)(c >> 32) > (unsigned)(c2 >> 32)) { child++; c = c2; }
+            if (MINHEAP ? ((unsigned)(c >> 32) > (unsigned)(c2 >> 32)) : ((unsigned)(c >> 32) < (unsigned)(c2 >> 32))) { child++; c = c2; }
           }
-          if (sv <= (unsigned)(c >> 32)) break;
+          if (MINHEAP ? (sv <= (unsigned)(c >> 32)) : (sv >= (unsigned)(c >> 32))) break;
           P[p] = c;
           p = child;
         }
@@ -627,12 +635,20 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
     __syncthreads();
     if (uni(sh.sw_fail)) return false;
   }
-  for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)P[1 + j];
+  DFTICK(2);
+  if (arr_full) { for (int j = tid; j < k; j += NT) arr_full[j] = (int)(unsigned)P[1 + j]; }
+  else { for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)P[1 + j]; }
   __syncthreads();
   for (int li = tid; li < kSwLeft; li += NT) {                              // the elements of the list that were not extracted (ties on the cut)
     const unsigned pe = dn.posend[li];
-    if (pe) { if (pe <= (unsigned)k) svid[pe - 1] = (int)ids[nB - kSwLeft + li]; else sh.sw_fail = 1; }
+    if (pe) {
+      if (pe > (unsigned)k) sh.sw_fail = 1;
+      else if (arr_full) arr_full[pe - 1] = (int)ids[nB - kSwLeft + li];
+      else svid[pe - 1] = (int)ids[nB - kSwLeft + li];
+    }
   }
   __syncthreads();
+  DFTICK(3);
+#undef DFTICK
   return !uni(sh.sw_fail);
 }

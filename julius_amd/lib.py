@@ -138,6 +138,7 @@ def load():
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_stream_wait_resident": (ci, [vp, vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
+        "jamd_beam_prune_arrange": (ci, [vp, vp, ci, vp, P(ci), vp]),
         "jamd_beam_prune_info": (ci, [vp, P(ci), P(ci), P(ci)]),
         "jamd_beam_prune_stats": (ci, [vp, ci, vp, ci]),
         "jamd_beam_stream_begin": (ci, [vp, ci]),
@@ -665,6 +666,16 @@ class Beam:
         _check(load().jamd_beam_prune_order(self.h, sc.ctypes.data, len(sc), out.ctypes.data, C.byref(n)),
                "jamd_beam_prune_order")
         return out[:n.value].copy()
+
+    def prune_arrange(self, scores):
+        """sort_token_no_order() with the whole array out: (visiting order, tindex[0..n)) -- jamd_beam_prune_arrange()."""
+        sc = _f32(scores)
+        out = np.zeros(len(sc), np.int32)
+        arr = np.zeros(len(sc), np.int32)
+        n = C.c_int()
+        _check(load().jamd_beam_prune_arrange(self.h, sc.ctypes.data, len(sc), out.ctypes.data, C.byref(n), arr.ctypes.data),
+               "jamd_beam_prune_arrange")
+        return out[:n.value].copy(), arr
 
     def prune_info(self):
         """Rounds of the sweep replay in the latest prune_order() call (-1 = it gave the frame up, 0 = not used)."""

@@ -144,7 +144,7 @@ def _vec(v):
     return " ".join(f"{float(x):.9e}" for x in v)
 
 
-def write_hmmdefs(path, model, phones=None, trans=None, kind="MFCC_E_D_A", state_names=None):
+def write_hmmdefs(path, model, phones=None, trans=None, kind="MFCC_E_D_A", state_names=None, sp_state=None):
     """HTK ascii hmmdefs holding the model's states as ~s macros (state id =
     order of appearance) and 3-state left-to-right ~h models.
 
@@ -194,6 +194,13 @@ def write_hmmdefs(path, model, phones=None, trans=None, kind="MFCC_E_D_A", state
         L.append(f'~h "{name}"\n<BEGINHMM>\n<NUMSTATES> 5')
         L.append(f'<STATE> 2\n~s "{sn(a)}"\n<STATE> 3\n~s "{sn(b)}"\n<STATE> 4\n~s "{sn(c)}"')
         L.append('~t "t0"\n<ENDHMM>')
+    if sp_state is not None:
+        # a short-pause model the reference appends to every word with -iwsp (wchmm.c; multipath only): one emitting
+        # state and an entry -> exit skip (a tee model)
+        sn = state_names[sp_state] if state_names else f"s{sp_state}"
+        L.append(f'~h "sp"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n~s "{sn}"')
+        L.append("<TRANSP> 3\n 0.000000e+00 6.000000e-01 4.000000e-01\n 0.000000e+00 7.000000e-01 3.000000e-01\n"
+                 " 0.000000e+00 0.000000e+00 0.000000e+00\n<ENDHMM>")
     Path(path).write_text("\n".join(L) + "\n")
     return phones
 
@@ -331,7 +338,7 @@ def write_dnnconf(workdir, dnn, feature_len=None, context_len=1, num_threads=1):
 
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
-                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None):
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None, sp=False):
     """Write a complete synthetic recognition task the reference can load:
     tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
     forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
@@ -355,10 +362,10 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
             phys.append((f"{c}_v{v}", st))
     phys.append(("silB", (S - 6, S - 5, S - 4)))
     phys.append(("silE", (S - 3, S - 2, S - 1)))
-    write_hmmdefs(workdir / "hmmdefs", model, phones=phys, trans=trans)
+    write_hmmdefs(workdir / "hmmdefs", model, phones=phys, trans=trans, sp_state=(S - 5) if sp else None)
     # logical triphones -> physical variants; contexts include silB/silE
     ctx = phones + sil
-    lines = ["silB silB", "silE silE"]
+    lines = ["silB silB", "silE silE"] + (["sp sp"] if sp else [])      # -iwsp -spmodel sp
     for c in phones:
         for l in ctx:
             for r in ctx:

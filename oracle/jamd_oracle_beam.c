@@ -231,6 +231,24 @@ int jo_sort_token_no_order(const float *scores, int n, int beam_width, int *orde
   return k;
 }
 
+/* The same with the whole array out: tindex[0..n) after the sort (what the multipath frame's second sort starts from). */
+int jo_sort_token_arrange(const float *scores, int n, int beam_width, int *order, int *tindex)
+{
+  beam B; int i, k;
+  memset(&B, 0, sizeof(B));
+  B.tn = 0;
+  B.tlist[0] = (tok *)malloc(sizeof(tok) * (n > 0 ? n : 1));
+  B.tindex[0] = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+  for (i = 0; i < n; i++) { B.tlist[0][i].score = scores[i]; B.tindex[0][i] = i; }
+  B.tnum[0] = n;
+  sort_token_no_order(&B, beam_width);
+  k = 0;
+  for (i = B.n_start; i <= B.n_end; i++) order[k++] = B.tindex[0][i];
+  for (i = 0; i < n; i++) tindex[i] = B.tindex[0][i];
+  free(B.tlist[0]); free(B.tindex[0]);
+  return k;
+}
+
 /* propagate_token(), beam.c:1945-1980 */
 static void propagate_token(beam *b, int next_node, float next_score, int last_tre, int last_cword,
                             float last_lscore)

@@ -196,6 +196,16 @@ class Oracle:
         k = self.lib.jo_sort_token_no_order(_p(sc), len(sc), beam_width, _p(out))
         return out[:k].copy()
 
+    def sort_token_arrange(self, scores, beam_width):
+        """The same with the whole array: (visiting order, tindex[0..n) after the sort)."""
+        sc = _f32(scores)
+        out = np.zeros(max(len(sc), 1), np.int32)
+        arr = np.zeros(max(len(sc), 1), np.int32)
+        self.lib.jo_sort_token_arrange.restype = C.c_int
+        self.lib.jo_sort_token_arrange.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        k = self.lib.jo_sort_token_arrange(_p(sc), len(sc), beam_width, _p(out), _p(arr))
+        return out[:k].copy(), arr[:len(sc)].copy()
+
     def dnn_outprob(self, dnn, frames, simd=DNN_FMA):
         dims = _i32(dnn["dims"])
         nl = len(dims) - 1

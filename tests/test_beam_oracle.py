@@ -155,6 +155,7 @@ SPLIT_TRANS = np.array([[0, .7, .3, 0, 0], [0, .5, .3, .2, 0], [0, 0, .5, .3, .2
     (44, 120, ["-sepnum", "0", "-iwcd1", "avg", "-transp", "-1.5"]),
     (45, 150, ["-sepnum", "4", "skip"]),       # state-skip and early-exit arcs: the model itself needs multipath
     (46, 150, ["-sepnum", "4", "split"]),      # two entry arcs as well
+    (53, 150, ["-sepnum", "10", "-iwcd1", "max", "iwsp"]),   # -iwsp -spmodel sp (the reference's DNN recipe): a skippable pause behind every word
 ])
 def test_oracle_matches_reference_multipath(oracle, ref, tmp_path, seed, beam, extra):
     """-multipath: non-emitting word-begin / word-end nodes, frame 0 through get_back_trellis_proceed(),
@@ -166,6 +167,10 @@ def test_oracle_matches_reference_multipath(oracle, ref, tmp_path, seed, beam, e
         kw["trans"] = SKIP_TRANS if extra[-1] == "skip" else SPLIT_TRANS
         extra = extra[:-1]
         eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra), **kw)
+        assert len(lex["ac_to"]) > 0
+    elif extra[-1] == "iwsp":
+        extra = extra[:-1]
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath", "-iwsp", "-spmodel", "sp"], sp=True, nword=80, **kw)
         assert len(lex["ac_to"]) > 0
     else:
         eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], **kw)

@@ -42,6 +42,8 @@ def test_multipath_golden_default_order(engine, oracle):
     (46, 150, ["-sepnum", "4", "split"]),      # two entry arcs as well
     (47, 150, ["-sepnum", "4", "-bs", "60"]),
     (48, 40, ["-sepnum", "0", "-iwcd1", "avg"]),
+    (53, 150, ["-sepnum", "10", "-iwcd1", "max", "iwsp"]),    # the DNN recipe's -iwsp: a skippable short-pause model behind every word
+    (54, 60, ["-sepnum", "3", "-bs", "80", "iwsp"]),
 ])
 def test_multipath_ngram_vs_reference_live(engine, oracle, ref, tmp_path, seed, beam, extra):
     kw = dict(ntransparent=12) if "-transp" in extra else {}
@@ -49,6 +51,10 @@ def test_multipath_ngram_vs_reference_live(engine, oracle, ref, tmp_path, seed, 
         kw["trans"] = SKIP_TRANS if extra[-1] == "skip" else SPLIT_TRANS
         extra = extra[:-1]
         eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra), **kw)
+    elif extra[-1] == "iwsp":
+        extra = extra[:-1]
+        eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath", "-iwsp", "-spmodel", "sp"], sp=True, nword=80, **kw)
+        assert len(lex["ac_to"]) > 0                          # the skips around the short pause are extra arcs
     else:
         eng, lex, am, task = ref_task(ref, tmp_path, seed, beam, list(extra) + ["-multipath"], **kw)
     assert eng.multipath == 1 and lex["lm_type"] == 0x100

@@ -134,3 +134,41 @@ def test_randomised_sizes_and_tie_densities(engine, oracle, beam):
         paths[1 if info > 0 else info] = paths.get(1 if info > 0 else info, 0) + 1
     assert paths.get(1, 0) >= 10, paths
     bm.close()
+
+
+@pytest.mark.parametrize("beam", [800, 2500, 4000])
+def test_whole_array_of_the_sort(engine, oracle, beam):
+    """jamd_beam_prune_arrange(): tindex[] WHOLE after sort_token_no_order() -- residual heap and extracted part -- as the
+    multipath frame's mid-frame sort needs it (csrc/beam_exact_mp.h): sweep replay + sift replay in both directions (beam
+    800: the narrow layout; wider: the wide one), against the sequential code.  Sizes on both sides of 2 x beam, tie
+    densities from none to heavy."""
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(7 * beam + 3)
+    closed = 0
+    for mult in (1.02, 1.3, 1.7, 1.97, 2.05, 2.4, 3.0, 4.2, 6.0):
+        n = int(mult * beam) + int(rng.integers(0, 40))
+        for dup in (0.0, 0.01, 0.2):
+            sc = (-rng.random(n) * 300.0 - 5000.0).astype(np.float32)
+            nd = int(dup * n)
+            if nd:
+                sc[rng.integers(0, n, nd)] = sc[rng.integers(0, n, nd)]
+            order, arr = bm.prune_arrange(sc)
+            info = bm.prune_info()
+            worder, warr = oracle.sort_token_arrange(sc, beam)
+            assert np.array_equal(order, worder), (n, beam, dup, info)
+            assert np.array_equal(arr, warr), (n, beam, dup, info, int((arr != warr).sum()))
+            closed += info > 0
+    assert closed > 0
+    # real frames of the C4 task and few score levels (everything ties)
+    if beam == 4000:
+        z = np.load(GOLD / "prune_frames_c4.npz")
+        for name in sorted(k for k in z.files if k.startswith("f")):
+            order, arr = bm.prune_arrange(z[name])
+            worder, warr = oracle.sort_token_arrange(z[name], beam)
+            assert np.array_equal(order, worder) and np.array_equal(arr, warr), name
+    for levels in (3, 40):
+        sc = (-rng.integers(0, levels, 3 * beam).astype(np.float32) - 100.0)
+        order, arr = bm.prune_arrange(sc)
+        worder, warr = oracle.sort_token_arrange(sc, beam)
+        assert np.array_equal(order, worder) and np.array_equal(arr, warr), levels
+    bm.close()

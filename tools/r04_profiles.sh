@@ -35,6 +35,10 @@ JAMD_BEAM_TIMING=1 timeout 300 python bench.py --workload e2e --utts 1 --steps 3
 JAMD_BEAM_TIMING=1 timeout 300 python bench.py --workload e2e-dnn --utts 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_e2e_dnn_1_exact_phases.json
 JAMD_BEAM_TIMING=1 timeout 300 python bench.py --workload e2e-dnn --flat --utts 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_e2e_dnn_flat_1_exact_phases.json
 timeout 300 python bench.py --workload e2e --utts 64 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_e2e_64_per_gpu.json
+# the multipath frame (csrc/beam_exact_mp.h): phase clocks of one utterance, C3 task with -multipath and the DNN recipe (-b 4000 -multipath)
+JAMD_BEAM_TIMING=1 timeout 300 python bench.py --workload e2e --multipath --utts 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/multipath_1_phases.json
+JAMD_BEAM_TIMING=1 timeout 300 python bench.py --workload e2e-dnn --multipath --utts 1 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/multipath_dnn_1_phases.json
+JAMD_SWEEP_PROF=1 timeout 120 python tools/arrange_timing.py > $O/arrange_timing_real_frames.json 2> $O/arrange_timing_phases.txt
 JAMD_SWEEP_PROF=1 timeout 120 python tools/sweep_timing.py > $O/sweep_timing_real_frames.json 2> $O/sweep_timing_phases.txt
 bash tools/kernel_timeline.sh ${R}_e2e512 --workload e2e --utts 512 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cp gpurun_out/timeline_${R}_e2e512/timeline.txt $O/e2e_512_kernel_timeline.txt 2>/dev/null
@@ -43,7 +47,7 @@ python - <<PY
 import json
 j=json.load(open("$O/bench_default.json"))
 print("C2", round(j["ms_per_step"],1), j["value"], j["roofline"]["frac"], j["roofline"]["kernel_ms"], j.get("parity_spot_check"))
-for k in ("e2e","e2e_strong","e2e_256","e2e_dnn","e2e_dnn_strong","e2e_dnn_flat","dnn"):
+for k in ("e2e","e2e_strong","e2e_256","e2e_mp","e2e_dnn","e2e_dnn_strong","e2e_dnn_mp","e2e_dnn_flat","dnn"):
     v=j.get(k)
     if not v: print(k, "missing"); continue
     print(k, "ms/step", round(v["ms_per_step"],1), "rtf_inv", round(v["rtf_inv"]), v["roofline"].get("beam_kernel_ms"), v["roofline"].get("frac"), v.get("parity",{}).get("device_vs_compiled_reference",{}).get("trellis_identical"), v.get("parity_spot_check"))
