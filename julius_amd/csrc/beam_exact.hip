@@ -819,8 +819,8 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
           bool ok = false;
           if constexpr (kLdsHeap && (WIDE || FULL) && NT == jamdb::NT) {
             const int tailb = sweep_down_bytes(cnt);
-            // (the sift replay holds the whole heap in LDS: a frame too large for it goes to the extraction loop at once)
-            if (pm.sw_bytes > tailb + 1024 && 10 * (n + 2) + cnt + 72 <= ((pm.sw_bytes - tailb) & ~15) && n < 0xffff) {
+            // (the sift replay holds the whole heap in LDS, 8 bytes a token: a frame too large for it goes to the extraction loop at once)
+            if (pm.sw_bytes > tailb + 1024 && 8 * (n + 2) + cnt + 80 <= ((pm.sw_bytes - tailb) & ~15) && n < 0xffff) {
               SweepDown dn;
               unsigned char JAMD_LDS *tl = pm.sw_region + ((pm.sw_bytes - tailb) & ~15);
               dn.fd = (lds_u32 *)tl; dn.posend = dn.fd + cnt + 1; dn.evbits = dn.posend + kSwLeft;

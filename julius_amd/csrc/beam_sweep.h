@@ -578,13 +578,17 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
                                          int n, int k, SweepDown dn, const unsigned *ids, int nB, lds_i32 *svid, int *arr_full) {
   const int tid = tid_now();
   const int R = n - k;
-  if (8 * (n + 2) + 2 * (n + 2) + (R + 8) + 64 > region_bytes || n >= 0xffff) return false;
+  // LDS image, 8 bytes a token: the score bits by heap-time position (read only), the heap as 16-bit heap-time positions
+  // (what the sifts move), the strip, one byte a turn
+  const int o_p16 = (4 * (n + 2) + 15) & ~15, o_strip = o_p16 + ((2 * (n + 2) + 15) & ~15), o_done = o_strip + ((2 * (n + 2) + 15) & ~15);
+  if (o_done + R + 16 > region_bytes || n >= 0xffff) return false;
   unsigned long long dclk = wall_clock64();
 #define DFTICK(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); sh.df_prof[i] += (int)(n_ - dclk); dclk = n_; } } while (0)
-  volatile lds_u64 *P = (volatile lds_u64 *)region;
-  lds_u16 *strip = (lds_u16 *)(region + 8 * (n + 2));
-  volatile JAMD_LDS unsigned char *done = (volatile JAMD_LDS unsigned char *)(region + 8 * (n + 2) + ((2 * (n + 2) + 15) & ~15));
-  for (int p = tid; p <= n; p += NT) { P[p] = p ? Pg[p] : 0ull; strip[p] = 0xffffu; }
+  const lds_u32 *S = (const lds_u32 *)region;
+  volatile lds_u16 *P = (volatile lds_u16 *)(region + o_p16);
+  lds_u16 *strip = (lds_u16 *)(region + o_strip);
+  volatile JAMD_LDS unsigned char *done = (volatile JAMD_LDS unsigned char *)(region + o_done);
+  for (int p = tid; p <= n; p += NT) { ((lds_u32 *)region)[p] = p ? (unsigned)(Pg[p] >> 32) : 0u; P[p] = (unsigned short)p; strip[p] = 0xffffu; }
   for (int i = tid; i <= R; i += NT) done[i] = i == 0 ? 1 : 0;
   __syncthreads();
   auto is_event = [&](int i) { return (dn.evbits[(i - 1) >> 5] >> ((i - 1) & 31)) & 1u; };
@@ -612,16 +616,18 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
     while (__any(mine)) {
       if (mine && done[d1] && done[d2] && done[d3]) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const unsigned long long s = P[q];
-        const unsigned sv = (unsigned)(s >> 32);
+        const unsigned short s = P[q];
+        const unsigned sv = S[s];
         int p = f, child;
         while ((child = 2 * p) <= m) {
-          unsigned long long c = P[child];
+          unsigned short c = P[child];
+          unsigned cv = S[c];
           if (child < m) {
-            const unsigned long long c2 = P[child + 1];
-            if (MINHEAP ? ((unsigned)(c >> 32) > (unsigned)(c2 >> 32)) : ((unsigned)(c >> 32) < (unsigned)(c2 >> 32))) { child++; c = c2; }
+            const unsigned short c2 = P[child + 1];
+            const unsigned cv2 = S[c2];
+            if (MINHEAP ? (cv > cv2) : (cv < cv2)) { child++; c = c2; cv = cv2; }
           }
-          if (MINHEAP ? (sv <= (unsigned)(c >> 32)) : (sv >= (unsigned)(c >> 32))) break;
+          if (MINHEAP ? (sv <= cv) : (sv >= cv)) break;
           P[p] = c;
           p = child;
         }
@@ -636,8 +642,8 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
     if (uni(sh.sw_fail)) return false;
   }
   DFTICK(2);
-  if (arr_full) { for (int j = tid; j < k; j += NT) arr_full[j] = (int)(unsigned)P[1 + j]; }
-  else { for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)P[1 + j]; }
+  if (arr_full) { for (int j = tid; j < k; j += NT) arr_full[j] = (int)(unsigned)Pg[P[1 + j]]; }
+  else { for (int j = tid; j < k; j += NT) svid[j] = (int)(unsigned)Pg[P[1 + j]]; }
   __syncthreads();
   for (int li = tid; li < kSwLeft; li += NT) {                              // the elements of the list that were not extracted (ties on the cut)
     const unsigned pe = dn.posend[li];

@@ -172,3 +172,31 @@ def test_multipath_streaming_equals_one_shot(engine, oracle, chunks):
         assert r.status == 0
         assert_trellis_equal(bm.trellis(u), gu["trellis"])
         assert np.array_equal(np.array(r.wseq[:r.wnum]), gu["wseq"]) and r.score == gu["score"]
+
+
+def test_root_that_reaches_a_word_end_stays_on_the_strict_kernel(engine, oracle):
+    """A word made of tee models only: its root reaches the word-end node along its own arcs, a cross-word transition would
+    improve a word end inside the loop that visits the word ends (beam.c:2779-2825) -- such a lexicon is refused by the
+    frame-parallel multipath frame (jamd_lexicon::mp_parallel) and decoded in strict order."""
+    g = load_beam_golden("beam_multipath.npz")
+    lex = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in g["lex"].items()}
+    root = int(lex["startnode"][0])
+    end = int(np.flatnonzero(lex["stend"] >= 0)[0])
+    # one more arc behind the root's own: root -> a word-end node
+    at = int(lex["ac_off"][root + 1])
+    lex["ac_to"] = np.insert(lex["ac_to"], at, end).astype(np.int32)
+    lex["ac_a"] = np.insert(lex["ac_a"], at, np.float32(-1.0)).astype(np.float32)
+    lex["ac_off"] = lex["ac_off"].copy()
+    lex["ac_off"][root + 1:] += 1
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=1)
+    assert bm.order_mode() != "exact"
+    with pytest.raises(lib.JamdError, match="root reaches a word end"):
+        bm.set_order_mode("exact")
+    sc = oracle.gmm_outprob(g["am"], g["utts"][0]["frames"])
+    with pytest.raises(lib.JamdError):
+        bm.pass1_host([sc])
+    bm.set_strict_order(True)
+    res, tre = bm.pass1_host([sc])
+    oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, g["beam_width"], g["score_pruning_width"])
+    assert_trellis_equal(tre[0], lexblob.canonical_trellis(oatoms))
