@@ -140,11 +140,12 @@ def test_standalone_c_driver(oracle, tmp_path):
     assert [lines[n] for n in names] == out
 
 
-@pytest.mark.parametrize("gms", [False, True])
-def test_export_then_standalone_batch(ref, tmp_path, gms):
+@pytest.mark.parametrize("gms,mp", [(False, False), (True, False), (False, True)])
+def test_export_then_standalone_batch(ref, tmp_path, gms, mp):
     """The whole no-Julius-at-run-time flow: jamd_export (Julius' loaders -> files), then jamd_batch
     (C, C ABI only) over a file list; pass-1 sentences and scores equal the plain reference's --
-    also with Gaussian mixture selection (-gshmm -> PREFIX.gms -> jamd_batch -gms)."""
+    also with Gaussian mixture selection (-gshmm -> PREFIX.gms -> jamd_batch -gms), and with -multipath (the
+    exported lexicon is the reference's multipath lexicon; jamd_batch in its default order = the multipath frame)."""
     import subprocess
     from oracle import pyoracle
     export = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
@@ -156,6 +157,8 @@ def test_export_then_standalone_batch(ref, tmp_path, gms):
                              "-input", "htkparam", "-gprune", "safe", "-tmix", "3", "-b", "150", "-sepnum", "5", "-1pass"]]
     if gms:
         args += ["-gshmm", str(synth.make_gs_model(task, seed=93)[0]), "-gsnum", "7"]
+    if mp:
+        args += ["-multipath"]
     subprocess.run([str(export)] + args + ["-jamdout", str(tmp_path / "m")], check=True, capture_output=True)
     assert (tmp_path / "m.gms").exists() == gms
     eng = pyoracle.RefEngine(ref, args)
@@ -168,7 +171,7 @@ def test_export_then_standalone_batch(ref, tmp_path, gms):
         want.append(p1)
     (tmp_path / "list").write_text("\n".join(names) + "\n")
     out = subprocess.run([str(exe), "-am", str(tmp_path / "m.am"), "-lex", str(tmp_path / "m.lex"), "-filelist",
-                          str(tmp_path / "list"), "-b", "150", "-gprune", "safe", "3", "-strict"] +
+                          str(tmp_path / "list"), "-b", "150", "-gprune", "safe", "3"] + ([] if mp else ["-strict"]) +
                          (["-gms", str(tmp_path / "m.gms")] if gms else []),
                          check=True, capture_output=True, text=True).stdout.strip().splitlines()
     assert len(out) == len(names)
