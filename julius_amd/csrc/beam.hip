@@ -1277,6 +1277,11 @@ struct jamd_lexicon {
   int maxfan = 2, nscword = 0;
   bool multipath = false;          // JAMD_LM_MULTIPATH lexicon: its own frame (beam_exact_mp.h; strict order: beam_strict_mp_kernel)
   bool mp_parallel = false;        // ... and no root reaches a word-end node along its own arcs: the frame-parallel kernel can decode it
+  // multipath: where a token entering a word goes (the root has no output: beam.c:2467-2510) -- one int4 {target node,
+  // transition bits, root number * maxfan + transition number, root number / fscore bits} per transition a root really has,
+  // in visiting order; byte offsets into the lexicon arena + entry counts (XWork carries them to the kernel)
+  unsigned o_mp_iso = 0, o_mp_shared = 0, o_mp_start = 0;
+  int n_mp_iso = 0, n_mp_shared = 0, n_mp_start = 0;
   std::vector<void *> owned;
 };
 
@@ -1502,6 +1507,36 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
   UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac);
   UP(iso_root, iso_root.data(), iso_root.size()); UP(shared_root, shared_root.data(), shared_root.size());
   UP(word_end, word_end.data(), word_end.size());
+  if (multipath) {
+    // the roots' own transitions, flattened once (csrc/beam_exact_mp.h, step B')
+    auto expand = [&](int root, int rootno, int tag, std::vector<int4> &out) {
+      auto bits = [](float f) { int b; memcpy(&b, &f, 4); return b; };
+      if (h->self_a[root] != JAMD_LOG_ZERO) out.push_back(make_int4(root, bits(h->self_a[root]), rootno * maxfan + 0, tag));
+      if (h->next_a[root] != JAMD_LOG_ZERO) out.push_back(make_int4(root + 1, bits(h->next_a[root]), rootno * maxfan + 1, tag));
+      for (int k = h->ac_off[root]; k < h->ac_off[root + 1]; k++)
+        out.push_back(make_int4(h->ac_to[k], bits(h->ac_a[k]), rootno * maxfan + 2 + (k - h->ac_off[root]), tag));
+    };
+    std::vector<int4> e_iso, e_shared, e_start;
+    const int head_root = dfa ? -1 : h->word_head[h->head_silwid];
+    for (size_t i = 0; i < iso_root.size() && !dfa; i++)
+      if (iso_root[i].x != head_root) expand(iso_root[i].x, (int)i, (int)i, e_iso);                       // :2336-2341
+    for (size_t r = 0; r < shared_root.size() && !dfa; r++) {
+      int node; memcpy(&node, &shared_root[r].x, 4);
+      int fs; memcpy(&fs, &shared_root[r].y, 4);
+      if (node != head_root) expand(node, (int)r, fs, e_shared);                                          // :2566-2571
+    }
+    for (int rv = 0; rv < h->startnum && dfa && !wordmode; rv++) {
+      const int r = h->startnum - 1 - rv;                                                                 // roots from startnum-1 down (:2334)
+      expand(h->startnode[r], rv, r, e_start);
+    }
+    auto put = [&](const std::vector<int4> &v, unsigned *off, int *cnt) {
+      const size_t at = (arena.size() + 15) & ~(size_t)15;
+      arena.resize(at + (v.empty() ? 16 : v.size() * sizeof(int4)));
+      if (!v.empty()) memcpy(arena.data() + at, v.data(), v.size() * sizeof(int4));
+      *off = (unsigned)at; *cnt = (int)v.size();
+    };
+    put(e_iso, &l->o_mp_iso, &l->n_mp_iso); put(e_shared, &l->o_mp_shared, &l->n_mp_shared); put(e_start, &l->o_mp_start, &l->n_mp_start);
+  }
   UP(startnode, h->startnode, h->startnum); UP(start2isolate, h->start2isolate, h->startnum);
   UP(lc_tab, h->lc_tab, (size_t)h->nlcrow * (h->nlc + 1)); UP(word_lc, h->word_lc, h->nword);
   UP(set_off, h->set_off, h->nset + 1); UP(set_states, h->set_states, nset_states);
@@ -1642,6 +1677,8 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       place(&xw.o_sweep, xbeam_sweep_bytes(beam_width));
       place(&xw.o_pstat, 16 * sizeof(int));
       xw.o_nodetok = xw.o_arr = xw.o_key2 = 0;
+      xw.o_mp_iso = l->o_mp_iso; xw.o_mp_shared = l->o_mp_shared; xw.o_mp_start = l->o_mp_start;
+      xw.n_mp_iso = l->n_mp_iso; xw.n_mp_shared = l->n_mp_shared; xw.n_mp_start = l->n_mp_start;
       if (mp) {
         place(&xw.o_nodetok, (size_t)w.nnode * sizeof(unsigned));
         place(&xw.o_arr, (size_t)w.tok_cap * sizeof(int));

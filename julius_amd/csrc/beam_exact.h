@@ -18,6 +18,8 @@ struct XWork {
   unsigned o_arr;              // int [tok_cap] tindex[]: the frame's tokens as the mid-frame sort left them + the appended ones
   unsigned o_key2;             // u32 [tok_cap] their score bits in that arrangement (input of the frame's final cut)
   int mp;                      // 1 = multipath lexicon: beam_exact_mp_kernel
+  unsigned o_mp_iso, o_mp_shared, o_mp_start;   // the roots' own transitions (int4 lists in the lexicon arena, jamd_lexicon)
+  int n_mp_iso, n_mp_shared, n_mp_start;
   int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())

@@ -415,36 +415,30 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
       break;
     }
     if (final_call) break;                                   // :2803: the last call saves the word ends and stops
+    unsigned long long tc4 = tc;
+    (void)tc4;
+#define MPTICK(i) do { if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[i] += n_ - tc4; tc4 = n_; } } while (0)
+    MPTICK(4);
 
-    // ---- B': cross-word transitions (:2779-2825), the roots expanded along their own arcs (:2467-2510)
-    auto root_trans = [&](const int4 &na, int root, int a, int &to, float &tr) -> bool {
-      if (a == 0) { to = root; tr = __int_as_float(na.x); return tr != JAMD_LOG_ZERO; }
-      if (a == 1) { to = root + 1; tr = __int_as_float(na.y); return tr != JAMD_LOG_ZERO; }
-      const int e = na.z + a - 2;
-      if (e >= na.w) return false;
-      to = lx.ac_to(e); tr = lx.ac_a(e);
-      return true;
-    };
+    // ---- B': cross-word transitions (:2779-2825), the roots expanded along their own arcs (:2467-2510).  The arcs come
+    //         from lists flattened when the lexicon was created (jamd_lexicon::o_mp_*: one int4 {target, transition,
+    //         root number * XW + transition number, root number | fscore bits} per transition a root really has, in
+    //         visiting order): one load per candidate instead of the root's record, its node record and its arc.
     if (!wordmode && n_we > 0) {
       if (dfa) {
-        const int nroot = lx.startnum;
-        const int per = nroot * XW, total = n_we * per;
+        const int nst = xw.n_mp_start, total = n_we * nst;
         for (int x = tid; x < total; x += NT) {
-          const int w = x / per, rem = x - w * per, rv = rem / XW, a = rem - rv * XW;
-          const int r = nroot - 1 - rv;                                          // roots from startnum-1 down (:2334)
+          const int w = x / nst, e = x - w * nst;
+          const int4 ent = lx.at<int4>(xw.o_mp_start, e);
           const Tok tk = CUR(welist[w]);
           const int sword = tk.pad0;
-          if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
-          const int root = lx.startnode(r);
-          const int4 na = lx.node_a(root);
-          int to; float tr;
-          if (!root_trans(na, root, a, to, tr)) continue;
+          if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(ent.w))) continue;
           const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
           float tmpsum = tk.score;
           float ng = lx.penalty1;
           ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
           tmpsum += ng;
-          xpush(sh, cl, to, tmpsum + tr, ((unsigned)w << s1) | (unsigned)rem);
+          xpush(sh, cl, ent.x, tmpsum + __int_as_float(ent.y), ((unsigned)w << s1) | (unsigned)ent.z);
         }
       } else {
         // beam_inter_word() :2296-2440: a word end is reduced to (score, LM context, rank) once; every (isolated root,
@@ -452,7 +446,7 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
         const int niso = lx.isolatenum;
         lds_v4 *werec = (lds_v4 *)tpre;
         constexpr int kWeChunk = NT / 4;
-        const int items = niso * XW;
+        const int nexp = xw.n_mp_iso;
         for (int w0 = 0; w0 < n_we; w0 += kWeChunk) {
           const int nrec = min(kWeChunk, n_we - w0);
           if (tid < nrec) {
@@ -468,67 +462,73 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
             werec[tid] = rec;
           }
           __syncthreads();
-          int parts = NT / (items > 0 ? items : 1);              // the word ends of the chunk are split over the idle threads
+          int parts = NT / (nexp > 0 ? nexp : 1);                // the word ends of the chunk are split over the idle threads
           if (parts < 1) parts = 1;
           if (parts > nrec) parts = nrec;
-          const int total = items * parts;
+          const int total = nexp * parts;
           for (int y = tid; y < total; y += NT) {
-            const int part = y / items, x = y - part * items;
-            const int i = x / XW, a = x - i * XW;
-            const int2 ir = lx.iso_root(i);
-            if (ir.x == head_root) continue;                                      // :2336-2341
-            const int4 na = lx.node_a(ir.x);
-            int to; float trn;
-            if (!root_trans(na, ir.x, a, to, trn)) continue;
+            const int part = y / nexp, e = y - part * nexp;
+            const int4 ent = lx.at<int4>(xw.o_mp_iso, e);
+            const int i = ent.w;
+            const float trn = __int_as_float(ent.y);
+            const int wn = lx.iwtab ? 0 : lx.iso_root(i).y;
             unsigned long long best = 0ull; unsigned nfirst = 0u;
-            for (int wv = part; wv < nrec; wv += parts) {
-              const u32x4 rec = werec[wv];
-              if (rec.w) continue;
-              const int ctx = (int)rec.y;
-              const float p = ctx < 0 ? 0.0f
-                              : lx.iwtab ? lx.iwtab[(size_t)ctx * niso + i]
-                              : bigram_prob(lx, ctx, lx.wton(ir.y)) + lx.cprob(ir.y);
-              float tmpsum = __uint_as_float(rec.x);
-              const float ng = p * lmw + pen;
-              tmpsum += ng;
-              if (rec.z & 0x80000000u) tmpsum += lx.lm_penalty_trans;
-              const float cand = tmpsum + trn;
-              if (cand <= JAMD_LOG_ZERO) continue;
-              const unsigned nv = ~(((rec.z & 0x7fffffffu) << s1) | (unsigned)x);
-              const unsigned long long key = ((unsigned long long)ordz(cand) << 32) | nv;
-              if (key > best) best = key;
-              if (nv > nfirst) nfirst = nv;
+            // four word ends at a time: their table reads go out together (a maximum and a minimum do not care about the order)
+            constexpr int G = 4;
+            for (int w0g = part; w0g < nrec; w0g += G * parts) {
+              u32x4 rec[G]; float p[G]; bool live[G];
+#pragma unroll
+              for (int g = 0; g < G; g++) {
+                const int wv = w0g + g * parts;
+                live[g] = wv < nrec;
+                rec[g] = werec[live[g] ? wv : part];
+                live[g] = live[g] && rec[g].w == 0u;
+                const int ctx = (int)rec[g].y;
+                p[g] = (!live[g] || ctx < 0) ? 0.0f
+                       : lx.iwtab ? lx.iwtab[(size_t)ctx * niso + i]
+                       : bigram_prob(lx, ctx, lx.wton(wn)) + lx.cprob(wn);
+              }
+#pragma unroll
+              for (int g = 0; g < G; g++) {
+                if (!live[g]) continue;
+                float tmpsum = __uint_as_float(rec[g].x);
+                const float ng = p[g] * lmw + pen;
+                tmpsum += ng;
+                if (rec[g].z & 0x80000000u) tmpsum += lx.lm_penalty_trans;
+                const float cand = tmpsum + trn;
+                if (cand <= JAMD_LOG_ZERO) continue;
+                const unsigned nv = ~(((rec[g].z & 0x7fffffffu) << s1) | (unsigned)ent.z);
+                const unsigned long long key = ((unsigned long long)ordz(cand) << 32) | nv;
+                if (key > best) best = key;
+                if (nv > nfirst) nfirst = nv;
+              }
             }
-            if (best != 0ull) xpush_key(sh, cl, to, best, nfirst);
+            if (best != 0ull) xpush_key(sh, cl, ent.x, best, nfirst);
           }
           __syncthreads();
         }
+        MPTICK(5);
         if (sh.we_best != 0ull) {                       // beam_inter_word_factoring() :2549-2637
           const unsigned long long kb = sh.we_best;
           const float best_score = unord((unsigned)(kb >> 32));
           const Tok tk = CUR(welist[(int)(~(unsigned)kb)]);
           const int sword = tk.pad0;
           const bool trans2 = lx.is_transparent(sword) && tk.last_cword >= 0 && lx.is_transparent(tk.last_cword);
-          const int total = lx.nshared * XW;
-          for (int x = tid; x < total; x += NT) {
-            const int r = x / XW, a = x - r * XW;
-            const float2 sr = lx.shared_root(r);
-            const int root = __float_as_int(sr.x);
-            if (root == head_root) continue;                                      // :2566-2571
-            const float ng = sr.y * lmw + pen;
+          const int nsh = xw.n_mp_shared;
+          for (int e = tid; e < nsh; e += NT) {
+            const int4 ent = lx.at<int4>(xw.o_mp_shared, e);
+            const float ng = __int_as_float(ent.w) * lmw + pen;
             float tmpsum = best_score;
             tmpsum += ng;
             if (trans2) tmpsum += lx.lm_penalty_trans;
             if (tmpsum < thr) continue;                                           // :2580
-            const int4 na = lx.node_a(root);
-            int to; float trn;
-            if (!root_trans(na, root, a, to, trn)) continue;
-            xpush(sh, cl, to, tmpsum + trn, ((unsigned)n_we << s1) | (unsigned)x);
+            xpush(sh, cl, ent.x, tmpsum + __int_as_float(ent.y), ((unsigned)n_we << s1) | (unsigned)ent.z);
           }
         }
       }
     }
     __syncthreads();
+    MPTICK(6);
     // ---- C2: the candidates of the second half: a node that holds a token of the first half is improved in place
     //          (propagate_token() :1945: strictly better only), the others are appended in creation order
     const int n2 = uni(sh.n_new);
@@ -599,6 +599,8 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
     if (n_tot > max_tokens) max_tokens = n_tot;
     if (pm.pstat && tid == 0 && n1 > wk.beam) pm.pstat[12] += 1;             // frames whose new tokens exceeded the beam
     if (pm.pstat && tid == 0) { pm.pstat[8] += n_tot; pm.pstat[9] += n_surv; pm.pstat[10] += n_we; pm.pstat[11] += 1; }   // work counters (jamd_beam_prune_stats())
+    MPTICK(7);
+#undef MPTICK
     if (TIMED && tid == 0) { const unsigned long long n_ = wall_clock64(); ph[1] += n_ - tc; tc = n_; }
     // ---- O: output probabilities on emitting nodes (:2930-2943); nodetok[] is emptied on the way
     {
