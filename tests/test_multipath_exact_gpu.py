@@ -96,14 +96,15 @@ def test_multipath_grammar_vs_reference_live(engine, oracle, ref, tmp_path, seed
         assert np.array_equal(np.array(r.wseq[:r.wnum]), rwseq) and r.score == rscore
 
 
-def test_multipath_wordlist_vs_oracle(engine, oracle, ref, tmp_path):
+@pytest.mark.parametrize("beam", [60, 20])
+def test_multipath_wordlist_vs_oracle(engine, oracle, ref, tmp_path, beam):
     """Isolated word recognition (-w) with -multipath: every listed word starts with a token, no cross-word
-    transition, best word on the last frame (beam.c:1762-1788, :2875, find_1pass_result_word())."""
+    transition, best word on the last frame (beam.c:1762-1788, :2875, find_1pass_result_word()); also under a beam of 20."""
     from oracle import pyoracle
     from julius_amd import lexblob
     task = synth.make_wordlist_task(tmp_path, seed=5, triphone=True)
     args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-w", task["wordlist"], "-wsil", "silB", "silE", "silB",
-            "-input", "htkparam", "-gprune", "none", "-b", "60", "-multipath"]
+            "-input", "htkparam", "-gprune", "none", "-b", str(beam), "-multipath"]
     eng = pyoracle.RefEngine(ref, args)
     eng.save_lexicon(tmp_path / "lex.blob")
     lex = lexblob.load(tmp_path / "lex.blob")
@@ -116,9 +117,40 @@ def test_multipath_wordlist_vs_oracle(engine, oracle, ref, tmp_path):
     res, tre = bm.pass1_host(scores)
     for sc, r, atoms in zip(scores, res, tre):
         oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, eng.beam_width, -1.0)
-        assert rc == 0 and r.status == 0
+        assert (rc == 0) == (r.status == 0)
         assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
-        assert list(r.wseq[:r.wnum]) == list(wseq) and r.score == score
+        if rc == 0:
+            assert list(r.wseq[:r.wnum]) == list(wseq) and r.score == score
+
+
+def test_multipath_more_initial_tokens_than_the_beam(engine, oracle, ref, tmp_path):
+    """A grammar whose sentence-initial words outnumber the beam: get_back_trellis_init()'s own sort_token_no_order()
+    (beam.c:1807) cuts the initial tokens (carried out literally by the multipath kernel)."""
+    eng, lex, am, task = ref_grammar_task(ref, tmp_path, 56, 4, ["-penalty1", "-2.0", "-multipath"], wrap=False, nword=70)
+    assert lex["lm_type"] == 0x101 and lex["ninit"] > 4
+    utts = [synth.make_triphone_grammar_utterance(task, nwords=2 + u, seed=5600 + u)[0] for u in range(3)]
+    lx = lib.Lexicon(engine, lex)
+    bm = lib.Beam(engine, lx, 4, -1.0, max_utts=len(utts))
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    res, tre = bm.pass1_host(scores)
+    for sc, r, atoms in zip(scores, res, tre):
+        oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, 4, -1.0)
+        assert r.status == rc
+        assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+
+
+def test_multipath_failure_and_atom_overflow_are_reported(engine, oracle):
+    g = load_beam_golden("beam_multipath.npz")
+    S = len(g["am"]["st_off"]) - 1
+    lx = lib.Lexicon(engine, g["lex"])
+    bm = lib.Beam(engine, lx, 50, -1.0, max_utts=1)
+    sc = np.full((5, S), -1000000.0, np.float32)
+    res, _ = bm.pass1_host([sc])
+    oatoms, wseq, score, rc, died = oracle.beam_pass1(g["lex"], sc, 50, -1.0)
+    assert res[0].status == rc and (rc != 2 or res[0].died_at == died)     # hopeless scores: no sentence (1) or the beam dies (2), as in the oracle
+    small = lib.Beam(engine, lx, g["beam_width"], -1.0, max_utts=1, atoms_per_utt=50)
+    res, _ = small.pass1_host([oracle.gmm_outprob(g["am"], g["utts"][0]["frames"])])
+    assert res[0].status == 3                                               # JAMD_PASS1_OVERFLOW
 
 
 @pytest.mark.parametrize("beam,nword", [(300, 400), (1200, 1500)])
