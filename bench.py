@@ -246,9 +246,10 @@ def run_gmm(args, dd: Dist, steps, warmup):
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf_inv": total_frames / 100.0 / elapsed,
-            "config": {"workload": "C2 (BASELINE.json configs[1]): tied-state triphone GMM outprob only, "
-                                   f"S={S} x M={M} x D={D}, one step = {L} launches x {args.utts} utterances x {FRAMES_PER_UTT} "
-                                   f"frames per GPU ({L * T} frames per GPU per step), gprune none",
+            "config": {"workload": f"C2 = configs[1]: triphone GMM outprob only, S={S} M={M} D={D}, step = {L} launches x {T} frames",
+                       "detail": "BASELINE.json configs[1]: tied-state triphone GMM outprob only, "
+                                 f"S={S} x M={M} x D={D}, one step = {L} launches x {args.utts} utterances x {FRAMES_PER_UTT} "
+                                 f"frames per GPU ({L * T} frames per GPU per step), gprune none",
                        "frames_per_step_per_gpu": L * T, "frames_per_launch": T, "launches_per_step": L,
                        "parallelism": f"utterance-sharded x{dd.world}", "kernel": gmm.last_kernel()},
             "roofline": {"bound": "valu", "achieved": tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (fp32, unfused)",
@@ -532,8 +533,13 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                  "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup, "scaling": scaling,
                  "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": total_frames / 100.0 / elapsed,
                  "frames_per_s": total_frames / elapsed, "frames_per_s_per_gpu": total_frames / elapsed / dd.world,
-                 "config": {"workload": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {beam}, "
-                                        f"{nutt} utterances ({T} frames, {nuniq} distinct) per GPU per step",
+                 "config": {"workload": (f"{'C4' if use_dnn else 'C3'} = configs[{3 if use_dnn else 2}]"
+                                         + (" as configs[4] (fixed batch)" if scaling == "strong" else "")
+                                         + f": {'DNN' if use_dnn else 'GMM'} scores + HIP first pass, {args.nword} words, beam {beam}"
+                                         + (", -multipath" if multipath else "") + (", flat scores" if flat else "")
+                                         + f", {nutt} utts/GPU/step"),
+                            "detail": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {beam}, "
+                                      f"{nutt} utterances ({T} frames, {nuniq} distinct) per GPU per step",
                             "lexicon_built_by_reference": ref_built, "order_mode": mode, "beam": beam,
                             "utts_per_gpu": nutt, "utts_total": nutt_all,
                             "workgroup_shape": bm.workgroup_shape(nutt) + (" (two utterances per CU)" if bm.workgroup_shape(nutt) == "half" else " (one utterance per CU)"),
