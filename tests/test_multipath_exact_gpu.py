@@ -232,3 +232,45 @@ def test_root_that_reaches_a_word_end_stays_on_the_strict_kernel(engine, oracle)
     res, tre = bm.pass1_host([sc])
     oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, g["beam_width"], g["score_pruning_width"])
     assert_trellis_equal(tre[0], lexblob.canonical_trellis(oatoms))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_multipath_kernel_vs_oracle_on_tie_heavy_scores(engine, oracle, ref, tmp_path, seed):
+    """Multipath lexicons built by the reference from small random tasks (plain -multipath, state skips, two entry arcs,
+    -iwsp; N-gram and grammar) under QUANTISED random scores -- exact ties everywhere, between states and between words --
+    with beams from 1 to a few hundred, with and without a score envelope: the mid-frame sort and the final cut go through
+    all of their forms (nothing pruned, downward, upward closed form, whole array through sweep + sift replay, the
+    extraction loop), and the word trellis must equal the CPU restatement's atom for atom."""
+    rng = np.random.default_rng(4200 + seed)
+    kind = ["plain", "skip", "split", "iwsp", "grammar"][seed % 5]
+    nword = int(rng.choice([30, 80, 200]))
+    sep = str(int(rng.choice([0, 3, 20])))
+    if kind == "grammar":
+        eng, lex, am, task = ref_grammar_task(ref, tmp_path, 300 + seed, 50, ["-penalty1", "-1.5", "-multipath"], wrap=bool(seed & 1), nword=max(nword, 70))
+    elif kind == "iwsp":
+        eng, lex, am, task = ref_task(ref, tmp_path, 300 + seed, 50, ["-sepnum", sep, "-multipath", "-iwsp", "-spmodel", "sp"], sp=True, nword=nword)
+    elif kind in ("skip", "split"):
+        eng, lex, am, task = ref_task(ref, tmp_path, 300 + seed, 50, ["-sepnum", sep], nword=nword,
+                                      trans=SKIP_TRANS if kind == "skip" else SPLIT_TRANS)
+    else:
+        eng, lex, am, task = ref_task(ref, tmp_path, 300 + seed, 50, ["-sepnum", sep, "-multipath"], nword=nword)
+    assert lex["lm_type"] & 0x100
+    S = len(am["st_off"]) - 1
+    lx = lib.Lexicon(engine, lex)
+    T = int(rng.integers(25, 90))
+    step = float(rng.choice([0.5, 2.0, 8.0]))
+    scores = [(-np.round(rng.random((T, S)) * 40.0 / step) * step - 20.0).astype(np.float32) for _ in range(3)]
+    for beam in (1, 3, int(rng.integers(5, 40)), int(rng.integers(40, 400))):
+        for width in (-1.0, float(rng.choice([30.0, 80.0]))):
+            bm = lib.Beam(engine, lx, beam, width, max_utts=len(scores), atoms_per_utt=1 << 16)
+            assert bm.order_mode() == "exact"
+            res, tre = bm.pass1_host(scores)
+            for sc, r, atoms in zip(scores, res, tre):
+                oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, width)
+                assert r.status == rc, (seed, kind, beam, width)
+                assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+                if rc == 0:
+                    assert list(r.wseq[:r.wnum]) == list(owseq) and r.score == oscore
+                if rc == 2:
+                    assert r.died_at == died
+            bm.close()
