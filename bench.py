@@ -25,6 +25,12 @@ resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
              hmmdefs (4000 states) + dnnconf/.npy + dict + ARPA loaded by Julius' own readers, lexicon
              built by wchmm.c, MFMA DNN scores -> exact-order first pass; `parity` against the compiled
              reference's julius -1pass (its own dnn_calc_outprob + beam.c) utterance by utterance.
+  e2e_dnn_strong / e2e_dnn_flat = the C4 task as configs[4]'s fixed 512-utterance batch / on the flat-score stream
+             (random-init weights over noise: the worst case of the rank pruning step).
+  e2e_mp, e2e_dnn_mp = the C3 and C4 tasks DECODED WITH -multipath (the form the reference README's DNN recipe runs:
+             -b 4000 -multipath): the lexicon is the reference's multipath lexicon, the first pass is the multipath
+             frame of the exact-order kernel (csrc/beam_exact_mp.h); `parity` against julius -1pass [-dnnconf]
+             -multipath utterance by utterance (`--workload e2e|e2e-dnn --multipath` runs them alone).
   dnn      = nested result for the configs[3] scoring half ("C4"): MFMA fp32 DNN.
   cpu_baseline (top level and nested) = the COMPILED REFERENCE (oracle/_ref, kind "reference") on a
              bounded sample of the same workload: one host core, plus an N-process figure for C2.
