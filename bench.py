@@ -604,7 +604,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
         # (1) the compiled reference, lazy scoring, ONE CORE PER PROCESS: the utterances are dealt to worker processes
         # (at most 16, one core each), so that all distinct C3 utterances and 12 of C4's are compared within the run;
         # the one-core figure below is frames / core-seconds summed over the workers
-        want = min(nuniq, 12) if use_dnn else nuniq           # (the DNN on one host core is what bounds C4's share)
+        want = min(nuniq, 16) if use_dnn else nuniq           # every distinct utterance (C4 has 16; one worker process each)
         nproc = max(1, min(16, want, (os.cpu_count() or 2) // 2))
         specs = []
         for u in range(want):
