@@ -186,3 +186,24 @@ def test_overlapped_heapify_equals_sequential(seed):
         score = [float(x) for x in -rng.integers(0, levels, n) * 0.25 - 50.0]
         for split in (1, 3, 6):
             assert heapify_overlapped(score, split) == heapify_upward(score), (n, levels, split)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_whole_array_model_equals_sequential_heap(seed):
+    """The model behind exact_prune<FULL> (csrc/beam_exact.hip, beam_sweep.h; the multipath frame's mid-frame sort needs
+    tindex[] WHOLE): the extracted part = the sweep replay's extraction order, the residual heap = every non-event turn's
+    tail element sifted down from where the hole left the extracted region -- in pure Python (tools/prune_lab2.py) against
+    the sequential loop of sort_token_upward() / _downward() (beam.c:1342-1480), both directions, from distinct scores to
+    three score levels."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from prune_lab2 import check_full
+    rng = np.random.default_rng(900 + seed)
+    for _ in range(40):
+        k = int(rng.integers(1, 90))
+        n = int(rng.integers(k + 1, 5 * k + 2))
+        nlev = int(rng.choice([3, 8, 30, 1000, 10 ** 6]))
+        sc = rng.integers(0, nlev, n).astype(np.float32)
+        ok, rounds, nev = check_full(sc, k)
+        assert ok, (seed, n, k, nlev, rounds, nev)

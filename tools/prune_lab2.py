@@ -242,6 +242,52 @@ def check_down(sc, k, verbose=False):
             res[int(L["posend"][x]) - 1] = int(ids[ex[x]])
     return res == want, rounds, sum(len(c) for c in chains)
 
+def check_full(sc, k):
+    """sort_token_no_order() with the WHOLE array out -- what the multipath frame's mid-frame sort needs (csrc/beam_exact_mp.h,
+    exact_prune<FULL>): the extracted part from the sweep's extraction order, the residual heap from the sift replay
+    below the extracted region, either direction.  Returns (equal to the sequential loop, rounds, events)."""
+    n = len(sc); up = k < n - k; cnt = k if up else n - k
+    H = heapify(sc, up)
+    out, Hf = extract(sc, H, cnt, up)
+    if up:
+        v = np.sort(sc)[::-1][cnt - 1]; ids = np.nonzero(sc >= v)[0]
+        u = np.unique(sc[ids])[::-1]; gk = np.searchsorted(-u, -sc[ids])
+    else:
+        v = np.sort(sc)[cnt - 1]; ids = np.nonzero(sc <= v)[0]
+        u = np.unique(sc[ids]); gk = np.searchsorted(u, sc[ids])
+    pos = np.zeros(n, np.int64); pos[np.array(H[1:])] = np.arange(1, n + 1)
+    vpos0 = pos[ids]
+    sw = Sweep(gk, n, cnt)
+    chains, rounds = sw.run(vpos0, cnt)
+    if chains is None: return False, rounds, 0
+    L = sw.last
+    ex, evp, eprobe, dep, moves = L["ex"], L["evp"], L["eprobe"], L["dep"], L["moves"]
+    event_turn = set(t for c in chains for (q, t, h) in c)
+    better = (lambda a, b: a > b) if up else (lambda a, b: a < b)
+    P = list(H)
+    for i in range(1, cnt + 1):
+        if i in event_turn: continue
+        q = n - i + 1; m = n - i
+        f = 1; d = 1
+        while (i, d) in moves:                                    # where the hole leaves the extracted region
+            x = moves[(i, d)]; f = int(evp[x]) >> (dep[x] - d); d += 1
+        s = P[q]; p = f
+        while 2 * p <= m:
+            c = 2 * p
+            if c < m and better(sc[P[c + 1]], sc[P[c]]): c += 1
+            if not better(sc[P[c]], sc[s]): break
+            P[p] = P[c]; p = c
+        P[p] = s
+    R = n - cnt
+    res = P[1:R + 1]
+    for x in range(len(ex)):
+        if not eprobe[x] and L["posend"][x] > 0:
+            if L["posend"][x] > R: return False, rounds, 0
+            res[int(L["posend"][x]) - 1] = int(ids[ex[x]])
+    order = [int(ids[j]) for j in final_order(gk, vpos0, chains)[:cnt]]      # i-th extracted -> array position n - i + 1
+    full = res + order[::-1]
+    return full == list(Hf[1:]), rounds, sum(len(c) for c in chains)
+
 if __name__ == "__main__":
     if sys.argv[1] == "realdown":
         recs = load(sys.argv[2]); step = int(sys.argv[3]) if len(sys.argv) > 3 else 10
