@@ -274,3 +274,36 @@ def test_multipath_kernel_vs_oracle_on_tie_heavy_scores(engine, oracle, ref, tmp
                 if rc == 2:
                     assert r.died_at == died
             bm.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_multipath_wide_layout_under_heavy_ties(engine, oracle, ref, tmp_path, seed):
+    """The same fuzz where the WIDE layout runs (beams 1 000 - 2 500 over lexicons of 1 500 - 3 000 words): the mid-frame
+    sort's whole array comes out of sweep replay + sift replay (exact_prune<FULL>) under quantised scores -- hundreds of
+    exactly tied tokens per frame."""
+    rng = np.random.default_rng(4600 + seed)
+    nword = int(rng.choice([1500, 3000]))
+    kind = ["plain", "iwsp", "skip", "plain"][seed]
+    if kind == "iwsp":
+        eng, lex, am, task = ref_task(ref, tmp_path, 400 + seed, 1000, ["-sepnum", "20", "-multipath", "-iwsp", "-spmodel", "sp"], sp=True, nword=nword)
+    elif kind == "skip":
+        eng, lex, am, task = ref_task(ref, tmp_path, 400 + seed, 1000, ["-sepnum", "20"], nword=nword, trans=SKIP_TRANS)
+    else:
+        eng, lex, am, task = ref_task(ref, tmp_path, 400 + seed, 1000, ["-sepnum", "20", "-multipath"], nword=nword)
+    S = len(am["st_off"]) - 1
+    lx = lib.Lexicon(engine, lex)
+    T = int(rng.integers(25, 45))
+    step = float(rng.choice([0.5, 2.0]))
+    scores = [(-np.round(rng.random((T, S)) * 40.0 / step) * step - 20.0).astype(np.float32) for _ in range(2)]
+    sorted_frames = 0
+    for beam in (int(rng.integers(1000, 1400)), int(rng.integers(1800, 2500))):
+        bm = lib.Beam(engine, lx, beam, -1.0, max_utts=len(scores), atoms_per_utt=1 << 17)
+        assert bm.order_mode() == "exact"
+        res, tre = bm.pass1_host(scores)
+        for sc, r, atoms in zip(scores, res, tre):
+            oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, -1.0)
+            assert r.status == rc, (seed, beam)
+            assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+            sorted_frames += int(r.max_tokens > beam)
+        bm.close()
+    assert sorted_frames > 0
