@@ -555,6 +555,10 @@ int  jamd_beam_order_mode(const jamd_beam *b);
 #define JAMD_SHAPE_HALF 2
 int  jamd_beam_set_workgroup_shape(jamd_beam *b, int shape);
 int  jamd_beam_workgroup_shape(const jamd_beam *b, int nutt);
+/* Which LDS image the exact-order kernel uses for this work area in its full shape: 0 = it cannot serve the work area,
+ * 1 = narrow (survivors in LDS: beams up to ~950), 2 = wide (survivors in the utterance's slice; the sweep replay and the
+ * closed form of the downward sort live in this one).  Same results either way; for tests and diagnostics. */
+int  jamd_beam_exact_layout(const jamd_beam *b);
 /* Blocks the host until everything queued ahead of the latest first-pass launch of this work area has completed, i.e.
  * until that kernel is next to run (returns at once when nothing was launched).  For hosts that pipeline batches: a
  * first pass that fills the device (one or two workgroups per CU, all of a CU's LDS) must get its workgroups placed

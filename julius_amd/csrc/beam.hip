@@ -1946,6 +1946,11 @@ int jamd_beam_workgroup_shape(const jamd_beam *b, int nutt) {
   return use_half_shape(b, nutt) ? JAMD_SHAPE_HALF : JAMD_SHAPE_FULL;
 }
 
+int jamd_beam_exact_layout(const jamd_beam *b) {
+  if (!b) return -1;
+  return b->exact_status != 0 ? 0 : (b->xw.wide ? 2 : 1);
+}
+
 int jamd_beam_order_mode(const jamd_beam *b) {
   if (!b) return -1;
   return b->strict ? JAMD_ORDER_STRICT : b->exact ? (b->xw.prune_mode ? JAMD_ORDER_EXACT_SERIAL : JAMD_ORDER_EXACT) : JAMD_ORDER_FAST;

@@ -135,6 +135,7 @@ def load():
         "jamd_beam_order_mode": (ci, [vp]),
         "jamd_beam_set_workgroup_shape": (ci, [vp, ci]),
         "jamd_beam_workgroup_shape": (ci, [vp, ci]),
+        "jamd_beam_exact_layout": (ci, [vp]),
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_stream_wait_resident": (ci, [vp, vp]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
@@ -656,6 +657,10 @@ class Beam:
         """Work queued on `stream` behind this call starts once the latest first-pass launch holds its CUs
         (jamd_beam_stream_wait_resident: a wait on device memory, no host involvement)."""
         _check(load().jamd_beam_stream_wait_resident(self.h, stream), "jamd_beam_stream_wait_resident")
+
+    def exact_layout(self) -> str:
+        """'narrow' / 'wide' LDS image of the exact-order kernel for this work area, or 'none' (jamd_beam_exact_layout)."""
+        return {0: "none", 1: "narrow", 2: "wide"}[load().jamd_beam_exact_layout(self.h)]
 
     def prune_order(self, scores):
         """sort_token_no_order() alone: the visiting order the exact-order kernel derives for tokens with

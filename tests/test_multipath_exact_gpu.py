@@ -263,7 +263,7 @@ def test_multipath_kernel_vs_oracle_on_tie_heavy_scores(engine, oracle, ref, tmp
     for beam in (1, 3, int(rng.integers(5, 40)), int(rng.integers(40, 400))):
         for width in (-1.0, float(rng.choice([30.0, 80.0]))):
             bm = lib.Beam(engine, lx, beam, width, max_utts=len(scores), atoms_per_utt=1 << 16)
-            assert bm.order_mode() == "exact"
+            assert bm.order_mode() == "exact" and bm.exact_layout() == "narrow"
             res, tre = bm.pass1_host(scores)
             for sc, r, atoms in zip(scores, res, tre):
                 oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, width)
@@ -298,7 +298,7 @@ def test_multipath_wide_layout_under_heavy_ties(engine, oracle, ref, tmp_path, s
     sorted_frames = 0
     for beam in (int(rng.integers(1000, 1400)), int(rng.integers(1800, 2500))):
         bm = lib.Beam(engine, lx, beam, -1.0, max_utts=len(scores), atoms_per_utt=1 << 17)
-        assert bm.order_mode() == "exact"
+        assert bm.order_mode() == "exact" and bm.exact_layout() == "wide"
         res, tre = bm.pass1_host(scores)
         for sc, r, atoms in zip(scores, res, tre):
             oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, -1.0)
