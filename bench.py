@@ -616,17 +616,22 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
             (wd / f"ref_spec{w}.json").write_text(json.dumps(spec))
             specs.append(spec)
         t0 = time.perf_counter()
+        errs = [open(wd / f"ref_worker{w}.err", "wb") for w in range(nproc)]
         procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--ref-e2e-worker", str(wd / f"ref_spec{w}.json")],
-                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for w in range(nproc)]
+                                  stdout=subprocess.DEVNULL, stderr=errs[w]) for w in range(nproc)]
         for pr in procs:
             pr.wait()
+        for f in errs:
+            f.close()
         wall = time.perf_counter() - t0
-        vs = {"utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
+        vs = {"wanted": want, "utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
               "reference_atoms": [], "reference_found_a_sentence": 0}
         spent, frames_done, load_s = 0.0, 0, 0.0
         for w, spec in enumerate(specs):
-            if not Path(spec["out"]).exists():
-                continue                                  # a worker died: its utterances are not counted
+            if not Path(spec["out"]).exists():        # a worker died: its utterances are not counted, and the block says so
+                tail = (wd / f"ref_worker{w}.err").read_bytes()[-400:].decode("utf-8", "replace")
+                vs.setdefault("workers_failed", []).append({"worker": w, "rc": procs[w].returncode, "utts": spec["utts"], "stderr_tail": tail})
+                continue
             z = np.load(spec["out"])
             load_s = max(load_s, float(z["load_s"]))
             for u in spec["utts"]:
@@ -645,6 +650,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
                 vs["pass1_sentence_identical"] += int((dsent == list(rw)) if rfound else (dsent is None))
                 vs["score_identical"] += int((res_exact[u].status == 0 and float(res_exact[u].score) == float(rs)) if rfound
                                              else res_exact[u].status != 0)
+        vs["complete"] = vs["utts"] == vs["wanted"]
         par["device_vs_compiled_reference"] = vs
         what = ("julius -1pass (compiled reference: dnn_calc_outprob FMA path, 1 thread, + get_back_trellis_proceed)" if use_dnn
                 else "julius -1pass (compiled reference: lazy outprob cache + get_back_trellis_proceed)")
@@ -656,6 +662,26 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
 
 
 # ------------------------------------------------------------------------------------------------ main
+def emit(full):
+    """stdout contract: every nested block in full as its own EARLIER line ({"bench_detail": key, ...}), the whole tree in
+    bench_detail.json (next to bench.py, and under gpurun_out/ when that exists), and as the LAST line the compact record
+    the driver parses (julius_amd/benchfmt.py: contract keys + a short record per nested configuration, < 6 KB)."""
+    from julius_amd import benchfmt
+    for k, v in full.items():
+        if isinstance(v, dict) and "ms_per_step" in v:
+            print(json.dumps({"bench_detail": k, **v}), flush=True)
+    print(json.dumps({"bench_detail": "top", **{k: v for k, v in full.items() if not (isinstance(v, dict) and "ms_per_step" in v)}}),
+          flush=True)
+    for d in (ROOT, ROOT / "gpurun_out"):
+        if d.is_dir():
+            try:
+                (d / "bench_detail.json").write_text(json.dumps(full, indent=1))
+            except OSError:
+                pass
+    full = dict(full, detail_file="bench_detail.json")
+    print(benchfmt.final_line(full), flush=True)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per GPU) and relay."""
     import socket
@@ -795,7 +821,7 @@ def main():
             else:
                 line = top(r)
     if dd.rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     dd.close()
     return 0
 

@@ -1,0 +1,147 @@
+"""The bench line the driver parses: bench.py's LAST stdout line, kept small.
+
+Round 4's line nested nine full results (29 KB) and the driver could not parse it.  The full result tree now goes to
+earlier stdout lines (one per nested block) and to bench_detail.json; the final line is `compact_line(full)`: the
+contract keys of the top-level workload plus, per nested configuration, only the figures a reader compares
+(ms_per_step, rtf_inv, steps, kernel times, roofline.frac, the CPU baseline's rtf_inv, the parity counts).
+tests/test_benchfmt.py holds the size bound (< 6 KB on a recorded full result) and the round trip."""
+from __future__ import annotations
+
+import json
+
+MAX_LINE_BYTES = 6000
+
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "rtf_inv")
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "rtf_inv")
+
+
+def _num(x, sig=6):
+    """Floats to `sig` significant digits (the line is for reading and comparing, the detail file keeps every digit)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def _parity(par):
+    """{'utts': compared, 'identical': all three of trellis / sentence / score identical, ...} from a parity block."""
+    if not isinstance(par, dict):
+        return None
+    out = {}
+    vs = par.get("device_vs_compiled_reference")
+    if isinstance(vs, dict):
+        out = {"utts": vs.get("utts"), "wanted": vs.get("wanted", vs.get("utts")),
+               "identical": min(vs.get("trellis_identical", 0), vs.get("pass1_sentence_identical", 0), vs.get("score_identical", 0)),
+               "ref_sentences": vs.get("reference_found_a_sentence")}
+        if out["wanted"] != out["utts"]:
+            out["incomplete"] = True
+    for k, v in par.items():
+        if k.startswith("fast_kernel_vs_") and isinstance(v, dict):
+            out["fast_kernel_identical"] = v.get("trellis_identical")
+    return out or None
+
+
+def _cpu(c):
+    if not isinstance(c, dict):
+        return None
+    out = {k: _num(c[k]) for k in _CPU_KEYS if k in c}
+    m = c.get("multi")
+    if isinstance(m, dict) and "value" in m:
+        out["multi"] = {"value": _num(m["value"]), "cores": m.get("cores"), "rtf_inv": _num(m.get("rtf_inv"))}
+    return out
+
+
+def _nested(r):
+    out = {k: _num(r[k]) for k in ("ms_per_step", "rtf_inv", "steps", "scaling") if k in r}
+    roof = r.get("roofline") or {}
+    bound = str(roof.get("bound", "")).split(" ")[0]
+    rr = {"bound": bound, "frac": _num(roof.get("frac"), 4)}
+    # the first-pass lines have no algorithmic roofline: their modelled GB/s stay in the detail file
+    for k in ("kernel_ms", "beam_kernel_ms", "score_kernels_ms", "traffic") + (() if bound == "latency" else ("achieved", "peak")):
+        if roof.get(k) is not None:
+            rr[k] = _num(roof[k], 5)
+    out["roofline"] = rr
+    if isinstance(r.get("cpu_baseline"), dict):
+        c = r["cpu_baseline"]
+        out["cpu_baseline"] = {"rtf_inv": _num(c.get("rtf_inv"), 4), "cores": c.get("cores"), "kind": c.get("kind")}
+        for k in ("multi", "two_pass", "threads"):
+            if isinstance(c.get(k), dict):
+                out["cpu_baseline"][k] = {kk: _num(vv, 4) for kk, vv in c[k].items() if isinstance(vv, (int, float)) and not isinstance(vv, bool)}
+    p = _parity(r.get("parity"))
+    if p:
+        out["parity"] = p
+    if "parity_spot_check" in r:
+        out["parity_spot_check"] = r["parity_spot_check"]
+    p1 = r.get("pass1")
+    if isinstance(p1, dict):
+        out["pass1"] = {"ok": p1.get("ok"), "utts": p1.get("utts")}
+    cfg = r.get("config") or {}
+    c2 = {}
+    for k in ("beam", "utts_per_gpu", "utts_total", "order_mode"):
+        if k in cfg:
+            c2[k] = cfg[k]
+    if "workgroup_shape" in cfg:
+        c2["shape"] = str(cfg["workgroup_shape"]).split(" ")[0]
+    if c2:
+        out["config"] = c2
+    return out
+
+
+def compact_line(full: dict) -> dict:
+    """The driver's line: contract keys of the top-level result + a short record per nested configuration."""
+    line = {k: _num(full[k]) for k in _TOP_KEYS if k in full}
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 160)}
+    for k in ("frames_per_step_per_gpu", "frames_per_launch", "launches_per_step", "parallelism", "kernel", "beam", "utts_per_gpu",
+              "utts_total", "order_mode"):
+        if k in cfg:
+            line["config"][k] = _short(cfg[k], 80) if isinstance(cfg[k], str) else cfg[k]
+    roof = full.get("roofline") or {}
+    line["roofline"] = {k: (_num(roof.get(k)) if k not in ("bound", "unit") else _short(roof.get(k, ""), 40)) for k in _ROOF_KEYS}
+    for k in ("beam_kernel_ms", "score_kernels_ms"):
+        if roof.get(k) is not None:
+            line["roofline"][k] = _num(roof[k])
+    hbm = roof.get("hbm")
+    if isinstance(hbm, dict):
+        line["roofline"]["hbm"] = {k: _num(hbm.get(k)) for k in ("algorithmic_GBs", "algorithmic_frac_of_peak", "compulsory_GBs",
+                                                                  "measured_bytes_per_launch", "peak_GBs") if k in hbm}
+    c = _cpu(full.get("cpu_baseline"))
+    if c:
+        line["cpu_baseline"] = c
+    if "parity_spot_check" in full:
+        line["parity_spot_check"] = full["parity_spot_check"]
+    p = _parity(full.get("parity"))
+    if p:
+        line["parity"] = p
+    if isinstance(full.get("pass1"), dict):
+        line["pass1"] = {"ok": full["pass1"].get("ok"), "utts": full["pass1"].get("utts")}
+    for k, v in full.items():
+        if isinstance(v, dict) and "ms_per_step" in v and k not in line:
+            line[k] = _nested(v)
+    if "detail_file" in full:
+        line["detail_file"] = full["detail_file"]
+    return line
+
+
+def final_line(full: dict) -> str:
+    """json of compact_line(full); if it would still exceed MAX_LINE_BYTES, the nested records shrink to
+    {ms_per_step, rtf_inv, roofline.frac, parity} -- never the contract keys."""
+    line = compact_line(full)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > MAX_LINE_BYTES:
+        for k, v in list(line.items()):
+            if isinstance(v, dict) and "ms_per_step" in v:
+                line[k] = {kk: v[kk] for kk in ("ms_per_step", "rtf_inv", "steps", "parity") if kk in v}
+                line[k]["roofline"] = {"frac": (v.get("roofline") or {}).get("frac")}
+        s = json.dumps(line, separators=(",", ":"))
+    return s

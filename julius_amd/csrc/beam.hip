@@ -1353,10 +1353,26 @@ static int upload_utt_off(jamd_beam *b, const int *utt_off, int nutt, hipStream_
 }
 
 // An event behind everything the launch stream holds before the first-pass kernel: it completes when that kernel is
-// next to run (jamd_beam_wait_started()).
-static int mark_started(jamd_beam *b, hipStream_t st, int nutt, bool counted) {
+// next to run (jamd_beam_wait_started()).  The workgroups of the launch are NOT accounted here: account_launch() does
+// that once the launch is known to have been accepted, so a refused or failed call leaves the resident counter's
+// bookkeeping where the device's counter will really be (a phantom workgroup would make every later
+// jamd_beam_stream_wait_resident() wait for a value the counter never reaches).
+static int mark_started(jamd_beam *b, hipStream_t st) {
   if (!b->ev_started) JAMD_HIP(hipEventCreateWithFlags(&b->ev_started, hipEventDisableTiming));
+  // The counter and its targets are 32-bit and compared with >=: long before they could wrap (2^31 workgroups), drain
+  // the device once and start again from zero.  (A reset enqueued on the launch stream would not do: a wait that another
+  // stream has queued but not yet evaluated would then see 0 against its old target.)
+  if (b->d_resident && b->launched_wg > 0x7fffffffu) {
+    JAMD_HIP(hipDeviceSynchronize());
+    JAMD_HIP(hipMemset(b->d_resident, 0, sizeof(unsigned)));
+    b->launched_wg = 0; b->resident_target = 0;
+  }
   JAMD_HIP(hipEventRecord(b->ev_started, st));
+  return JAMD_OK;
+}
+
+// After a launch that hipGetLastError() accepted.  `counted`: its workgroups bump Work::resident when they start.
+static void account_launch(jamd_beam *b, int nutt, bool counted) {
   if (counted) {
     // what fits the device at once: one workgroup per CU, two in the exact-order kernel's half shape
     const int cap = b->eng->num_cu * ((b->exact && !b->strict && use_half_shape(b, nutt)) ? 2 : 1);
@@ -1370,7 +1386,6 @@ static int mark_started(jamd_beam *b, hipStream_t st, int nutt, bool counted) {
     b->resident_target = b->launched_wg + (unsigned)(share > 0 ? share : 1);
     b->launched_wg += (unsigned)nutt;
   } else b->resident_target = b->launched_wg;
-  return JAMD_OK;
 }
 
 extern "C" {
@@ -1765,13 +1780,13 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   if (nutt == 0) return JAMD_OK;
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
-  { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
-  { const int rc = mark_started(b, st, nutt, !b->strict); if (rc != JAMD_OK) return rc; }
-  if (b->lex->multipath && !b->strict && !b->exact) {
+  if (b->lex->multipath && !b->strict && !b->exact) {   // (state checks come before anything is enqueued or accounted)
     jamd_set_error("jamd_beam_pass1_dev: this multipath lexicon is decoded by the strict-order kernel only: "
                    "jamd_beam_set_strict_order(b, 1)");
     return JAMD_ESTATE;
   }
+  { const int rc = upload_utt_off(b, utt_off, nutt, st); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
   if (b->strict && b->lex->multipath)
     hipLaunchKernelGGL(beam_strict_mp_kernel, dim3((nutt + 63) / 64), dim3(64), 0, st, b->lex->d, b->w, b->sw, dev_scores,
                        nstate, b->d_utt_off, nutt);
@@ -1791,6 +1806,7 @@ int jamd_beam_pass1_dev(jamd_beam *b, const float *dev_scores, int nstate, const
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_pass1_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  account_launch(b, nutt, !b->strict);
   return JAMD_OK;
 }
 
@@ -1841,7 +1857,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   JAMD_HIP(hipSetDevice(b->eng->device));
   hipStream_t st = jamd_stream(b->eng, stream);
   { const int rc = upload_utt_off(b, chunk_off, nutt, st); if (rc != JAMD_OK) return rc; }
-  { const int rc = mark_started(b, st, nutt, true); if (rc != JAMD_OK) return rc; }
+  { const int rc = mark_started(b, st); if (rc != JAMD_OK) return rc; }
   if (b->exact) {
     b->xw.w.stream = b->w.stream; b->xw_half.w.stream = b->w.stream;
     xbeam_launch(b->lex->d, b->stream_half ? b->xw_half : b->xw, dev_scores, nstate, b->d_utt_off, nutt, final ? 2 : 1, b->timed, st);
@@ -1856,6 +1872,7 @@ int jamd_beam_stream_push_dev(jamd_beam *b, const float *dev_scores, int nstate,
   }
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { jamd_set_error("jamd_beam_stream_push_dev: launch failed: %s", hipGetErrorString(le)); return JAMD_ELAUNCH; }
+  account_launch(b, nutt, true);
   if (final) b->streaming = 0;
   return JAMD_OK;
 }

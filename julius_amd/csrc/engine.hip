@@ -8,6 +8,7 @@
 // expressions on the host and uploads the tables.
 #include "jamd_internal.h"
 #include <cmath>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -37,7 +38,10 @@ int jamd_engine_create(int device, jamd_engine **out) {
   // stream + first-pass stream, include/julius_amd.h) need them concurrent.  The variable is read when the runtime
   // initialises: set here it takes effect when this is the process's first HIP call; a process that initialised HIP
   // earlier sets it itself (bench.py does, before importing torch).
-  if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // setenv() is not safe against concurrent getenv()/setenv(): once per process, and a multi-threaded host that creates
+  // engines from several threads should export the variable itself before it starts them (jamd_batch does).
+  static std::once_flag queues_once;
+  std::call_once(queues_once, [] { if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0); });
   int n = 0;
   hipError_t err = hipGetDeviceCount(&n);
   if (err != hipSuccess || n <= 0) {

@@ -498,6 +498,8 @@ void jamd_gmm_destroy(jamd_gmm *g) {
   void *ptrs[] = { g->d_rec, g->d_cur_utt_off, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
                    g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num };
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (g->h_utt_off) (void)hipHostFree(g->h_utt_off);
+  if (g->ev_utt_off) (void)hipEventDestroy(g->ev_utt_off);
   delete g;
 }
 
@@ -572,11 +574,22 @@ static int set_utterances(jamd_gmm *g, const int *utt_off, int nutt, hipStream_t
     JAMD_HIP(hipMalloc(&g->d_cur_utt_off, sizeof(int) * ((size_t)nutt + 1)));
     g->utt_off_cap = (size_t)nutt + 1;
   }
-  // utt_off is the caller's memory: staged in a buffer the model owns, so that the copy needs no host wait (a pipelining
-  // host keeps its scoring stream asynchronous).  One scoring call per model in flight: the staging buffer and
-  // d_cur_utt_off are reused by the next call on this model (include/julius_amd.h).
-  g->h_utt_off.assign(utt_off, utt_off + nutt + 1);
-  JAMD_HIP(hipMemcpyAsync(g->d_cur_utt_off, g->h_utt_off.data(), sizeof(int) * ((size_t)nutt + 1), hipMemcpyHostToDevice, st));
+  // utt_off is the caller's memory: staged in a PINNED buffer the model owns, so that the copy is truly asynchronous (a
+  // pipelining host keeps its scoring stream free of host waits; from pageable memory the runtime would either block or
+  // stage).  An event behind the copy guards the buffer: the next call on this model waits for it before it rewrites the
+  // staging copy (normally long done) -- d_cur_utt_off itself is ordered by the stream.
+  if (g->ev_utt_off) JAMD_HIP(hipEventSynchronize(g->ev_utt_off));
+  else JAMD_HIP(hipEventCreateWithFlags(&g->ev_utt_off, hipEventDisableTiming));
+  if ((size_t)(nutt + 1) > g->h_utt_off_cap) {
+    if (g->h_utt_off) JAMD_HIP(hipHostFree(g->h_utt_off));
+    g->h_utt_off = nullptr; g->h_utt_off_cap = 0;
+    const size_t cap = (size_t)nutt + 1 < 1024 ? 1024 : (size_t)nutt + 1;
+    JAMD_HIP(hipHostMalloc((void **)&g->h_utt_off, sizeof(int) * cap, hipHostMallocDefault));
+    g->h_utt_off_cap = cap;
+  }
+  memcpy(g->h_utt_off, utt_off, sizeof(int) * ((size_t)nutt + 1));
+  JAMD_HIP(hipMemcpyAsync(g->d_cur_utt_off, g->h_utt_off, sizeof(int) * ((size_t)nutt + 1), hipMemcpyHostToDevice, st));
+  JAMD_HIP(hipEventRecord(g->ev_utt_off, st));
   g->cur_nutt = nutt;
   return JAMD_OK;
 }

@@ -71,7 +71,9 @@ struct jamd_gmm {
   float *d_tm_score = nullptr; int *d_tm_id = nullptr; int *d_tm_num = nullptr;
   size_t tm_cap_bytes = 0, tm_id_bytes = 0, tm_num_bytes = 0;
   char last_kernel[64] = {0};
-  std::vector<int> h_utt_off;      // staging copy of the running call's utterance boundaries (history pruning only)
+  // pinned staging copy of the running call's utterance boundaries (history pruning only) and the event behind its
+  // upload: the buffer is rewritten only when the copy that read it is done
+  int *h_utt_off = nullptr; size_t h_utt_off_cap = 0; hipEvent_t ev_utt_off = nullptr;
 };
 
 int jamd_gmm_launch_safe(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st);

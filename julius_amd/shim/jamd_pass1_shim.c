@@ -277,7 +277,8 @@ int jamd_pass1_prefetch_add(RecogProcess *r, HTK_Param *param)
  * smaller launch instead of marking them failed */
 static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int keepflags)
 {
-  const int keep = keepflags & 1, retry = (keepflags & 2) != 0;
+  const int keep = keepflags & 1;
+  int retry = (keepflags & 2) != 0;
   jamd_beam *bb = NULL;
   float *frames = NULL, *d_frames = NULL, *d_scores = NULL;
   jamd_pass1_result *res = NULL;
@@ -288,20 +289,25 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
   for (u = 0; u < n; u++) { total += (size_t)c->pre[first + u].T; off[u + 1] = (int)total; }
   frames = (float *)malloc(sizeof(float) * total * veclen);
   res = (jamd_pass1_result *)malloc(sizeof(jamd_pass1_result) * n);
-  if (frames == NULL || res == NULL) goto out;
+  if (frames == NULL || res == NULL) { rc = JAMD_ENOMEM; goto out; }
   for (u = 0; u < n; u++)
     memcpy(frames + (size_t)off[u] * veclen, c->pre[first + u].frames, sizeof(float) * (size_t)c->pre[first + u].T * veclen);
-  if (jamd_beam_create(g_eng, c->lex, c->beam_width, c->bs_width, n, 1 << 19, &bb) != JAMD_OK) goto out;
-  if (c->strict && jamd_beam_set_strict_order(bb, 1) != JAMD_OK) goto out;
-  if (!c->strict && c->order_mode >= 0 && jamd_beam_set_order_mode(bb, c->order_mode) != JAMD_OK) goto out;
-  if (jamd_malloc(g_eng, sizeof(float) * total * veclen, (void **)&d_frames) != JAMD_OK ||
-      jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores) != JAMD_OK ||
-      jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen) != JAMD_OK ||
-      (c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, (int)total, d_scores, NULL)
-              : jamd_gmm_outprob_utts_dev(c->gmm, d_frames, off, n, d_scores, NULL)) != JAMD_OK ||
-      (c->gms && jamd_gms_apply_dev(c->gms, d_frames, (int)total, off, n, d_scores, NULL) != JAMD_OK) ||
-      jamd_beam_pass1_dev(bb, d_scores, c->nstate, off, n, NULL) != JAMD_OK ||
-      jamd_engine_sync(g_eng) != JAMD_OK || jamd_beam_results(bb, res, n) != JAMD_OK) goto out;
+  /* every step keeps ITS return code: only a launch that did not fit (JAMD_ENOMEM / JAMD_ELAUNCH) is worth retrying smaller */
+#define JAMD_STEP(call) do { rc = (call); if (rc != JAMD_OK) goto out; } while (0)
+  JAMD_STEP(jamd_beam_create(g_eng, c->lex, c->beam_width, c->bs_width, n, 1 << 19, &bb));
+  if (c->strict) JAMD_STEP(jamd_beam_set_strict_order(bb, 1));
+  if (!c->strict && c->order_mode >= 0) JAMD_STEP(jamd_beam_set_order_mode(bb, c->order_mode));
+  JAMD_STEP(jamd_malloc(g_eng, sizeof(float) * total * veclen, (void **)&d_frames));
+  JAMD_STEP(jamd_malloc(g_eng, sizeof(float) * total * c->nstate, (void **)&d_scores));
+  JAMD_STEP(jamd_memcpy_h2d(g_eng, d_frames, frames, sizeof(float) * total * veclen));
+  JAMD_STEP(c->dnn ? jamd_dnn_outprob_dev(c->dnn, d_frames, (int)total, d_scores, NULL)
+                   : jamd_gmm_outprob_utts_dev(c->gmm, d_frames, off, n, d_scores, NULL));
+  if (c->gms) JAMD_STEP(jamd_gms_apply_dev(c->gms, d_frames, (int)total, off, n, d_scores, NULL));
+  JAMD_STEP(jamd_beam_pass1_dev(bb, d_scores, c->nstate, off, n, NULL));
+  JAMD_STEP(jamd_engine_sync(g_eng));
+  JAMD_STEP(jamd_beam_results(bb, res, n));
+#undef JAMD_STEP
+  rc = JAMD_EINVAL;
   for (u = 0; u < n; u++) {
     pre_entry *e = &c->pre[first + u];
     e->res = res[u];
@@ -320,8 +326,9 @@ static int prefetch_chunk(pass1_ctx *c, RecogProcess *r, int first, int n, int k
   }
   rc = JAMD_OK;
 out:
+  if (rc != JAMD_ENOMEM && rc != JAMD_ELAUNCH) retry = 0;     /* a bad model or argument fails the same way at any size */
   if (rc != JAMD_OK && retry) jlog("STAT: jamd: a launch of %d queued inputs did not fit (%s): trying half of it\n", n, jamd_last_error());
-  else if (rc != JAMD_OK) jlog("ERROR: jamd: batch first pass failed: %s\n", jamd_last_error());
+  else if (rc != JAMD_OK) jlog("ERROR: jamd: batch first pass failed (rc %d): %s\n", rc, jamd_last_error());
   for (u = 0; u < n; u++) {
     if (rc != JAMD_OK && retry) { c->pre[first + u].done = 0; continue; }          /* frames stay for the retry */
     free(c->pre[first + u].frames); c->pre[first + u].frames = NULL;
@@ -349,8 +356,13 @@ int jamd_pass1_prefetch_run(RecogProcess *r)
            (n == 0 || fr + (size_t)c->pre[first + n].T <= ((size_t)1 << 20))) { fr += (size_t)c->pre[first + n].T; n++; }
     /* a launch that does not fit the device (score matrix + work area of n utterances: sized for an MI355X) is retried
      * in halves rather than given up: prefetch_chunk() leaves the inputs queued (done = 0) when told so */
-    while (n > 1 && prefetch_chunk(c, r, first, n, keep | 2) != JAMD_OK) n = (n + 1) / 2;
-    if (n == 1 && c->pre[first].done == 0 && prefetch_chunk(c, r, first, 1, keep) != JAMD_OK) rc = JAMD_EINVAL;
+    while (n > 1) {
+      const int crc = prefetch_chunk(c, r, first, n, keep | 2);
+      if (crc == JAMD_OK) break;
+      if (crc != JAMD_ENOMEM && crc != JAMD_ELAUNCH) { rc = crc; break; }   /* reported at once; the inputs are marked failed */
+      n = (n + 1) / 2;
+    }
+    if (n == 1 && c->pre[first].done == 0) { const int crc = prefetch_chunk(c, r, first, 1, keep); if (crc != JAMD_OK) rc = crc; }
     first += n; nrun += n;
   }
   jlog("STAT: jamd: batch first pass over %d queued inputs\n", nrun);
