@@ -328,8 +328,21 @@ def run_dnn(args, dd: Dist, steps, warmup):
             n = int(min(T, max(16, 10.0 / per)))
             want = rd.outprob(frames[:n], want_out=True)
             sec = rd.last_seconds
+            # the reference's OpenMP split of the layer rows (calc_dnn.c:806-833), num_threads = 2 (its
+            # default, Sample.dnnconf) and = half the host's logical cores, on ~3 s samples each
+            threads = {}
+            for nt in sorted({2, max(2, (os.cpu_count() or 2) // 2)}):
+                try:
+                    with tempfile.TemporaryDirectory(prefix="jamd_dnn_t_") as td2:
+                        rt = pyoracle.Ref().dnn_load(dnn, td2, num_threads=nt)
+                        rt.outprob(frames[:8], want_out=False)
+                        nn = int(min(T, max(16, 3.0 / max(rt.last_seconds / 8, 1e-4))))
+                        rt.outprob(frames[:nn], want_out=False)
+                        threads[f"t{nt}_rtf_inv"] = nn / 100.0 / rt.last_seconds
+                except Exception as e:      # (reported, not fatal: the one-thread figure is the baseline)
+                    threads[f"t{nt}_error"] = repr(e)[:80]
         res["parity_spot_check"] = bool(np.array_equal(d_out[:n].cpu().numpy(), want))
-        res["cpu_baseline"] = {"value": n * net.S / sec, "unit": "frame*states/s", "cores": 1, "kind": "reference",
+        res["cpu_baseline"] = {"threads": threads, "value": n * net.S / sec, "unit": "frame*states/s", "cores": 1, "kind": "reference",
                                "rtf_inv": n / 100.0 / sec,
                                "sample": f"{n} frames: compiled reference dnn_calc_outprob() (calc_dnn_fma, table sigmoid, "
                                          f"log-softmax), {sec:.2f} s on 1 of {os.cpu_count()} host cores"}
@@ -404,6 +417,66 @@ def trellis_diff(a, b):
     for k in a:
         same &= a[k][ia] == b[k][ib]
     return int(diff + (~same).sum())
+
+
+def run_batch(args, dd: Dist, wd: Path, prefix, task, uniq, use_dnn, beam, launch, nlaunch, NS, multipath=False):
+    """The PRODUCT's serving loop timed from outside the kernels: `jamd_batch -d <gpu> -time` (C over the
+    C ABI, julius_amd/host/jamd_batch.c) decodes a file list of launch x nlaunch HTK parameter files that sit on tmpfs --
+    fread -> byte swap into pinned staging -> asynchronous H2D -> scoring -> first pass -> D2H of the result records ->
+    result lines --, double-buffered over two streams.  The clock is the process's own (`decode_s`: from the first file
+    read to the last result line, model load excluded and reported beside it).  One "step" = one launch of `launch`
+    utterances.  Every rank runs its own process on its own GPU over its own list (weak scaling, like e2e)."""
+    exe = ROOT / "julius_amd" / "jamd_batch"
+    if prefix is None or not exe.exists():
+        return None
+    shm = Path("/dev/shm") if os.access("/dev/shm", os.W_OK) else wd
+    fd = Path(tempfile.mkdtemp(prefix=f"jamd_batch_r{dd.rank}_", dir=shm))
+    from julius_amd import synth
+    try:
+        paths = []
+        for u, fr in enumerate(uniq):
+            synth.write_htk_param(fd / f"u{u}.mfc", fr, parmkind=synth.PARM_USER if use_dnn else synth.MFCC_E_D_A)
+            paths.append(str(fd / f"u{u}.mfc"))
+        nfile = launch * nlaunch
+        # the same round-robin deal as run_e2e: this rank's i-th utterance is distinct utterance (rank + i * world) % nuniq
+        mine = [paths[(dd.rank + i * dd.world) % len(paths)] for i in range(nfile)]
+        (fd / "list.txt").write_text("\n".join(mine) + "\n")
+        cmd = [str(exe)] + (["-dnnconf", task["dnnconf"]] if use_dnn else ["-am", str(prefix) + ".am"]) + [
+            "-lex", str(prefix) + ".lex", "-b", str(beam), "-filelist", str(fd / "list.txt"), "-d", str(dd.local_rank),
+            "-launch", str(launch), "-time"]
+        dd.fence()
+        t0 = time.perf_counter()
+        pr = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+        wall = time.perf_counter() - t0
+        tj = None
+        for ln in pr.stderr.splitlines():
+            if ln.startswith('{"jamd_batch_time"'):
+                tj = json.loads(ln)["jamd_batch_time"]
+        ok = pr.returncode == 0 and tj is not None
+        decode_s = dd.max_over_ranks(tj["decode_s"] if ok else float("inf"))
+        if dd.rank != 0:
+            return None
+        if not ok:
+            return {"error": f"jamd_batch rc {pr.returncode}: {pr.stderr[-300:]}"}
+        lines = pr.stdout.strip().splitlines()
+        frames = tj["frames"] * dd.world
+        return {"metric": "frames_x_states_scored_per_sec", "value": frames * NS / decode_s, "unit": "frame*states/s", "n_gpus": dd.world,
+                "steps": nlaunch, "warmup": 0, "scaling": "weak", "ms_per_step": decode_s / nlaunch * 1e3, "dtype": "f32",
+                "rtf_inv": frames / 100.0 / decode_s,
+                "config": {"workload": (f"{'C4' if use_dnn else 'C3'} through the product's serving loop: jamd_batch -time over {nfile} HTK files on "
+                                        f"{'tmpfs' if shm != wd else 'the work directory'}, {launch} utterances per launch, beam {beam}"
+                                        + (", -multipath" if multipath else "")),
+                           "beam": beam, "utts_per_gpu": nfile, "utts_total": nfile * dd.world, "launch": launch},
+                "roofline": {"bound": "latency (host loop + LDS / L2 gather-scatter)", "frac": None, "achieved": None, "peak": None,
+                             "unit": "GB/s", "traffic": None},
+                "timing": {"clock": "jamd_batch's own CLOCK_MONOTONIC: first file read -> last result line (model load excluded)",
+                           "decode_s": tj["decode_s"], "models_s": tj["models_s"], "process_wall_s": wall,
+                           "host_read_s": tj["host_read_s"], "host_wait_s": tj["host_wait_s"], "h2d_bytes": tj["h2d_bytes"],
+                           "h2d_GBps_if_serial": tj["h2d_bytes"] / max(tj["decode_s"], 1e-9) / 1e9, "launches": tj["launches"]},
+                "result_lines": len(lines), "result_lines_text": lines[:len(paths)]}
+    finally:
+        import shutil
+        shutil.rmtree(fd, ignore_errors=True)
 
 
 def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
@@ -564,6 +637,25 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                 if cpu is not None:
                     r["cpu_baseline"] = cpu
             out[key] = r
+        if ri == 0 and ref_built and not flat and not args.no_batch and mode.startswith("exact"):
+            # the same task through the product's own host loop (file read + pinned staging + H2D + kernels + D2H), own clock
+            bl = min(nutt, 512)
+            rb = run_batch(args, dd, wd, prefix, task, uniq, use_dnn, beam, bl, args.batch_launches or (2 if use_dnn else 4), NS, multipath)
+            if dd.rank == 0 and rb is not None:
+                if "result_lines_text" in rb:       # the serving loop's result lines against the in-process results of the same utterances
+                    same = 0
+                    txt = rb.pop("result_lines_text")
+                    for u in range(min(nuniq, len(txt))):
+                        rr = res_local[u] if dd.world == 1 else None
+                        if rr is None:
+                            break
+                        words = " ".join(str(int(w)) for w in rr.wseq[:rr.wnum])
+                        want_tail = f"status={rr.status} score={float(rr.score):.9g} words={words}"
+                        same += int(txt[u].split(" ", 1)[1].strip() == want_tail)
+                    if dd.world == 1:
+                        rb["parity"] = {"result_lines_vs_in_process": {"utts": min(nuniq, len(txt)), "identical": same}}
+                    rb["vs_e2e_same_task"] = rb["rtf_inv"] / out[key]["rtf_inv"]
+                out["batch" + key[3:]] = rb
         del d_fr, d_sc, d_scs
     bm.close()
     tmp.cleanup()
@@ -616,9 +708,21 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
             (wd / f"ref_spec{w}.json").write_text(json.dumps(spec))
             specs.append(spec)
         t0 = time.perf_counter()
-        errs = [open(wd / f"ref_worker{w}.err", "wb") for w in range(nproc)]
+        # the FULL two-pass recogniser on a few of the same files (the first pass + Julius' stack decoder),
+        # timed by two extra one-core workers next to the others; their results are not part of the comparison
+        n2 = min(want, 2 if use_dnn else 4)
+        specs2 = []
+        for w in range(min(2, n2)):
+            mine = list(range(w, n2, 2))
+            spec = {"jargs": [str(a) for a in jargs if a != "-1pass"], "utts": mine, "files": [str(wd / f"ref_u{u}.mfc") for u in mine],
+                    "out": str(wd / f"ref2_out{w}.npz")}
+            (wd / f"ref2_spec{w}.json").write_text(json.dumps(spec))
+            specs2.append(spec)
+        errs = [open(wd / f"ref_worker{w}.err", "wb") for w in range(nproc + len(specs2))]
         procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--ref-e2e-worker", str(wd / f"ref_spec{w}.json")],
                                   stdout=subprocess.DEVNULL, stderr=errs[w]) for w in range(nproc)]
+        procs += [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--ref-e2e-worker", str(wd / f"ref2_spec{w}.json")],
+                                   stdout=subprocess.DEVNULL, stderr=errs[nproc + w]) for w in range(len(specs2))]
         for pr in procs:
             pr.wait()
         for f in errs:
@@ -626,7 +730,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
         wall = time.perf_counter() - t0
         vs = {"wanted": want, "utts": 0, "trellis_identical": 0, "pass1_sentence_identical": 0, "score_identical": 0, "atoms_differing": [],
               "reference_atoms": [], "reference_found_a_sentence": 0}
-        spent, frames_done, load_s = 0.0, 0, 0.0
+        spent, frames_done, load_s, slowest = 0.0, 0, 0.0, 0.0
         for w, spec in enumerate(specs):
             if not Path(spec["out"]).exists():        # a worker died: its utterances are not counted, and the block says so
                 tail = (wd / f"ref_worker{w}.err").read_bytes()[-400:].decode("utf-8", "replace")
@@ -634,6 +738,7 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
                 continue
             z = np.load(spec["out"])
             load_s = max(load_s, float(z["load_s"]))
+            slowest = max(slowest, sum(float(z[f"sec_{u}"]) for u in spec["utts"]))
             for u in spec["utts"]:
                 rtr = {k[len(f"tr_{u}_"):]: z[k] for k in z.files if k.startswith(f"tr_{u}_")}
                 rw, rs = z[f"w_{u}"], float(z[f"s_{u}"])
@@ -658,6 +763,18 @@ def e2e_parity(bm, d_sc, NS, off, uniq, nuniq, res_exact, jargs, wd, ref_built, 
                "cores": 1, "kind": "reference", "rtf_inv": frames_done / 100.0 / spent,
                "sample": f"{what} on {vs['utts']} utterances = {frames_done} frames, {spent:.1f} core-seconds over {nproc} worker processes of "
                          f"one core each ({wall:.1f} s wall, {os.cpu_count()} host cores; model load {load_s:.1f} s not counted)"}
+        if slowest > 0:     # the same workers read as ONE N-process job: all frames / the slowest worker's recognition time
+            cpu["multi"] = {"cores": nproc, "rtf_inv": frames_done / 100.0 / slowest, "value": frames_done * NS / slowest,
+                            "note": f"{nproc} julius -1pass processes side by side, one core each: frames of all / recognition time of the slowest"}
+        sec2, fr2, n2done = 0.0, 0, 0
+        for spec in specs2:
+            if Path(spec["out"]).exists():
+                z = np.load(spec["out"])
+                for u in spec["utts"]:
+                    sec2 += float(z[f"sec_{u}"]); fr2 += len(uniq[u]); n2done += 1
+        if sec2 > 0:
+            cpu["two_pass"] = {"cores": 1, "rtf_inv": fr2 / 100.0 / sec2, "utts": n2done,
+                               "note": "the full recogniser (first pass + stack decoding, no -1pass) on the same files, one core"}
     return par, cpu
 
 
@@ -704,6 +821,8 @@ def main():
                     help="utterances per GPU per step (gmm/dnn: x1000 frames, default 64 = one GPU's share of the "
                          "512-utterance batch of configs[4]; e2e: default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="e2e: skip the jamd_batch (product serving loop) run of the same task")
+    ap.add_argument("--batch-launches", type=int, default=None, help="e2e: launches of the jamd_batch run (default 4, DNN 2)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="e2e: scoring and first pass of every step on ONE stream (default: two streams, the scoring of step k+1 "
                          "overlaps the first pass of step k)")

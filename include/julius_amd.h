@@ -435,12 +435,20 @@ int  jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out);
  * the cross-word LM table is built from them; the tree half -- nodes, factoring values, word -> N-gram ids, class
  * probabilities -- stays PREFIX.lex's, which is the output of libjulius/src/wchmm.c over the dictionary and not a file
  * format.  The two must share their vocabulary (names in N-gram id order: PREFIX.lex records it; refused otherwise).
- * With the N-gram the tree was built from the result equals jamd_lexicon_load()'s; a retrained N-gram over the same
- * vocabulary keeps the tree's 1-gram factoring values (re-export to refresh them). */
+ * With the N-gram the tree was built from the result equals jamd_lexicon_load()'s.  A RETRAINED N-gram over the same
+ * vocabulary: the tree depends on the 1-gram in two places -- which words wchmm.c keeps out of the tree (the -sepnum most
+ * frequent ones, libjulius/src/wchmm.c:1470, :1882) and the 1-gram factoring value of every shared node
+ * (libjulius/src/factoring_sub.c:429-463).  The loader recomputes the factoring values from the file's 1-gram (the best
+ * uni_prob + class probability over the words below the node) when the same words stay out of the tree -- the result is
+ * then the lexicon a fresh jamd_export with that N-gram writes -- and refuses (JAMD_EINVAL, "export the lexicon again")
+ * when the tree itself would differ or PREFIX.lex does not record -sepnum (written before this check existed). */
 int  jamd_lexicon_load_ngram(jamd_engine *e, const char *path, const char *bingram_path, jamd_lexicon **out);
 /* Host only: do PREFIX.lex and a binary N-gram share their vocabulary (JAMD_OK, else JAMD_EINVAL with the reason), and
  * -- *same_tables, may be NULL -- are the file's first-pass tables byte for byte the ones PREFIX.lex holds? */
 int  jamd_bingram_check(const char *lex_path, const char *bingram_path, int *same_tables);
+/* Host only: the 1-gram factoring values jamd_lexicon_load_ngram() would use -- fscore[0..*nfscore) (at most `cap` are
+ * written; index 0 is unused, as in WCHMM_INFO.fscore) -- with the same acceptance rules and errors. */
+int  jamd_bingram_fscore(const char *lex_path, const char *bingram_path, float *fscore, int cap, int *nfscore);
 void jamd_lexicon_destroy(jamd_lexicon *l);
 
 /* First-pass status of one utterance */

@@ -45,6 +45,9 @@ def _parity(par):
                "ref_sentences": vs.get("reference_found_a_sentence")}
         if out["wanted"] != out["utts"]:
             out["incomplete"] = True
+    rl = par.get("result_lines_vs_in_process")
+    if isinstance(rl, dict):
+        out = {"utts": rl.get("utts"), "identical": rl.get("identical"), "against": "in-process"}
     for k, v in par.items():
         if k.startswith("fast_kernel_vs_") and isinstance(v, dict):
             out["fast_kernel_identical"] = v.get("trellis_identical")
@@ -85,9 +88,14 @@ def _nested(r):
     p1 = r.get("pass1")
     if isinstance(p1, dict):
         out["pass1"] = {"ok": p1.get("ok"), "utts": p1.get("utts")}
+    tm = r.get("timing")
+    if isinstance(tm, dict):         # the product's serving loop (jamd_batch -time)
+        out["timing"] = {k: _num(tm[k], 4) for k in ("decode_s", "models_s", "host_read_s", "host_wait_s") if k in tm}
+        if "vs_e2e_same_task" in r:
+            out["vs_e2e_same_task"] = _num(r["vs_e2e_same_task"], 4)
     cfg = r.get("config") or {}
     c2 = {}
-    for k in ("beam", "utts_per_gpu", "utts_total", "order_mode"):
+    for k in ("beam", "utts_per_gpu", "utts_total", "order_mode", "launch"):
         if k in cfg:
             c2[k] = cfg[k]
     if "workgroup_shape" in cfg:

@@ -15,6 +15,7 @@
 // 2 uint8), int32 count, payload padded to 4 bytes; scalars travel in the records "ints"/"floats".
 // Host-only code; the kernels are in the other translation units.
 #include "jamd_internal.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -220,11 +221,76 @@ static bool ngram_matches(const Blob &b, const char *path, const JamdNgramTables
   return true;
 }
 
-static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, jamd_lexicon **out) {
-  *out = nullptr;
-  Blob b;
+// ---- a retrained N-gram under an exported tree ---------------------------------------------------------------------
+// What wchmm.c derives from the 1-gram when it builds the tree (libjulius/src/wchmm.c:1749-1900, factoring_sub.c:345-468):
+//  (1) WHICH words stay out of the tree: those whose p(w) = uni_prob(wton[w]) + cprob[w] reaches the separate_wnum-th best
+//      value (get_nbest_uniprob(), wchmm.c:1470), taken in the builder's word order until separate_wnum are out
+//      (:1882) -- for the same candidate set the builder makes the same tree;
+//  (2) the 1-gram factoring value of every shared node: the best p(w) over the words that pass through it (:429-463).
+// candidates() restates (1); refresh_fscore() restates (2) over the flattened tree -- a word passes through a node iff
+// its word-end node lies in the node's subtree (self loops aside the arcs form a tree).
+static float uni_of(const float *uni, int unk_id, float unk_num_log, int w) {      // ngram_access.c:229-236
+  return w != unk_id ? uni[w] : uni[w] - unk_num_log;
+}
+
+static std::vector<unsigned char> candidates(const jamd_lexicon_desc &d, const float *uni, int sepnum) {
+  const int W = d.nword;
+  std::vector<float> p((size_t)W);
+  for (int w = 0; w < W; w++) p[(size_t)w] = uni_of(uni, d.ng_unk_id, d.ng_unk_num_log, d.wton[w]) + d.cprob[w];
+  std::vector<float> sorted(p);
+  std::sort(sorted.begin(), sorted.end(), [](float a, float b) { return a > b; });
+  int n = sepnum < 1 ? 1 : sepnum;
+  if (n > W) n = W;
+  const float thres = sorted[(size_t)n - 1];
+  std::vector<unsigned char> c((size_t)W, 0);
+  if (sepnum > 0)
+    for (int w = 0; w < W; w++) c[(size_t)w] = (w != d.head_silwid && w != d.tail_silwid && p[(size_t)w] >= thres) ? 1 : 0;
+  return c;
+}
+
+static bool refresh_fscore(const jamd_lexicon_desc &d, const float *uni, std::vector<float> &fs) {
+  const int N = d.nnode;
+  std::vector<float> best((size_t)N, JAMD_LOG_ZERO);
+  std::vector<unsigned char> state((size_t)N, 0);             // 0 = new, 1 = on the stack, 2 = done
+  std::vector<int> stack, child_at((size_t)N, 0);
+  auto nchild = [&](int n) { return (d.next_a[n] != JAMD_LOG_ZERO && n + 1 < N ? 1 : 0) + (d.ac_off[n + 1] - d.ac_off[n]); };
+  auto child = [&](int n, int k) {
+    const int hasnext = (d.next_a[n] != JAMD_LOG_ZERO && n + 1 < N) ? 1 : 0;
+    return (hasnext && k == 0) ? n + 1 : d.ac_to[d.ac_off[n] + k - hasnext];
+  };
+  fs.assign((size_t)(d.nfscore > 0 ? d.nfscore : 1), JAMD_LOG_ZERO);
+  for (int root = 0; root < N; root++) {
+    if (d.scid[root] >= 0 || state[(size_t)root] == 2) continue;
+    stack.push_back(root); state[(size_t)root] = 1;
+    while (!stack.empty()) {
+      const int n = stack.back();
+      if (child_at[(size_t)n] < nchild(n)) {
+        const int c = child(n, child_at[(size_t)n]++);
+        if (c == n || c < 0 || c >= N) continue;
+        if (state[(size_t)c] == 1) return false;               // a cycle beyond self loops: not the tree this restatement assumes
+        if (state[(size_t)c] == 0) { state[(size_t)c] = 1; stack.push_back(c); }
+        continue;
+      }
+      float b = JAMD_LOG_ZERO;
+      if (d.stend[n] >= 0 && d.stend[n] < d.nword)
+        b = uni_of(uni, d.ng_unk_id, d.ng_unk_num_log, d.wton[d.stend[n]]) + d.cprob[d.stend[n]];
+      for (int k = 0; k < nchild(n); k++) { const int c = child(n, k); if (c != n && c >= 0 && c < N && best[(size_t)c] > b) b = best[(size_t)c]; }
+      best[(size_t)n] = b; state[(size_t)n] = 2; stack.pop_back();
+    }
+  }
+  for (int n = 0; n < N; n++)
+    if (d.scid[n] < 0) {
+      if (-d.scid[n] >= d.nfscore) return false;
+      fs[(size_t)(-d.scid[n])] = best[(size_t)n];
+    }
+  return true;
+}
+
+// PREFIX.lex -> descriptor (views into the blob `b`); with `bingram` the N-gram half comes from that binary N-gram (`ng`
+// holds its tables, `fscore_new` the factoring values recomputed for a retrained 1-gram).
+static int lexicon_desc_from_file(Blob &b, const char *path, const char *bingram, JamdNgramTables &ng, std::vector<float> &fscore_new,
+                                  jamd_lexicon_desc &d) {
   if (!read_blob(path, "JAMDLEX1", b)) return JAMD_EINVAL;
-  JamdNgramTables ng;
   if (bingram) {
     if (!jamd_read_bingram_tables(bingram, ng)) return JAMD_EINVAL;
     if (!ngram_matches(b, path, ng, bingram, nullptr)) return JAMD_EINVAL;
@@ -236,7 +302,6 @@ static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, j
   }
   const int *I = reinterpret_cast<const int *>(ir->second.data.data());
   const float *F = reinterpret_cast<const float *>(fr->second.data.data());
-  jamd_lexicon_desc d;
   memset(&d, 0, sizeof(d));
   d.nnode = I[0]; d.nword = I[1]; d.startnum = I[2]; d.isolatenum = I[3]; d.nlc = I[4]; d.nlcrow = I[5]; d.nset = I[6];
   d.cdset_method = I[7]; d.cdmax_num = I[8]; d.head_silwid = I[9]; d.tail_silwid = I[10]; d.nfscore = I[11]; d.nscword = I[12];
@@ -273,10 +338,45 @@ static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, j
     // tables, which 2-gram the first pass reads; the cross-word LM table is built from them when the lexicon is created.
     // The tree half -- nodes, word -> N-gram ids, class probabilities, factoring values -- stays the file's.
     if ((d.lm_type & 0xff) != JAMD_LM_NGRAM) { jamd_set_error("%s is a grammar lexicon: no N-gram to replace", path); return JAMD_EINVAL; }
+    if (ng.nword != d.ng_nword) { jamd_set_error("%s: %d N-gram words, %s has %d", path, d.ng_nword, bingram, ng.nword); return JAMD_EINVAL; }
+    if (memcmp(ng.uni_prob.data(), d.ng_uni_prob, sizeof(float) * (size_t)d.ng_nword) != 0) {
+      // a RETRAINED 1-gram: the tree half depends on it in two places (see candidates() / refresh_fscore() above)
+      auto sp = b.find("sep_wnum");
+      if (sp == b.end() || sp->second.dtype != 0 || sp->second.count < 1) {
+        jamd_set_error("%s does not record -sepnum (written by an older jamd_export): a retrained N-gram needs it, export the lexicon again", path);
+        return JAMD_EINVAL;
+      }
+      const int sepnum = *reinterpret_cast<const int *>(sp->second.data.data());
+      if (candidates(d, d.ng_uni_prob, sepnum) != candidates(d, ng.uni_prob.data(), sepnum)) {
+        jamd_set_error("%s: under the 1-gram of %s other words are the %d most frequent ones, which wchmm.c keeps out of the tree "
+                       "(-sepnum): the tree itself would differ, export the lexicon again", path, bingram, sepnum);
+        return JAMD_EINVAL;
+      }
+      std::vector<float> check;
+      if (!refresh_fscore(d, d.ng_uni_prob, check) || (size_t)d.nfscore > check.size() ||
+          memcmp(check.data() + 1, d.fscore + 1, sizeof(float) * (size_t)(d.nfscore > 1 ? d.nfscore - 1 : 0)) != 0) {
+        jamd_set_error("%s: the factoring values of this tree are not the subtree maxima of its own 1-gram (a lexicon form the "
+                       "refresh does not cover): export the lexicon again with the new N-gram", path);
+        return JAMD_EINVAL;
+      }
+      if (!refresh_fscore(d, ng.uni_prob.data(), fscore_new)) { jamd_set_error("%s: factoring refresh failed", path); return JAMD_EINVAL; }
+      d.fscore = fscore_new.data();
+    }
     d.ng_mode = ng.mode; d.ng_nword = ng.nword; d.ng_nbigram = ng.nbigram;
     d.ng_uni_prob = ng.uni_prob.data(); d.ng_uni_bo = ng.uni_bo.data();
     d.ng_bi_bgn = ng.bi_bgn.data(); d.ng_bi_num = ng.bi_num.data(); d.ng_bi_wid = ng.bi_wid.data(); d.ng_bi_prob = ng.bi_prob.data();
   }
+  return JAMD_OK;
+}
+
+static int load_lexicon(jamd_engine *e, const char *path, const char *bingram, jamd_lexicon **out) {
+  *out = nullptr;
+  Blob b;
+  JamdNgramTables ng;
+  std::vector<float> fscore_new;
+  jamd_lexicon_desc d;
+  const int rc = lexicon_desc_from_file(b, path, bingram, ng, fscore_new, d);
+  if (rc != JAMD_OK) return rc;
   return jamd_lexicon_create(e, &d, out);
 }
 
@@ -288,6 +388,19 @@ int jamd_lexicon_load(jamd_engine *e, const char *path, jamd_lexicon **out) {
 int jamd_lexicon_load_ngram(jamd_engine *e, const char *path, const char *bingram_path, jamd_lexicon **out) {
   if (!e || !path || !bingram_path || !out) { jamd_set_error("jamd_lexicon_load_ngram: NULL argument"); return JAMD_EINVAL; }
   return load_lexicon(e, path, bingram_path, out);
+}
+
+int jamd_bingram_fscore(const char *lex_path, const char *bingram_path, float *fscore, int cap, int *nfscore) {
+  if (!lex_path || !bingram_path || !nfscore || (cap > 0 && !fscore)) { jamd_set_error("jamd_bingram_fscore: NULL argument"); return JAMD_EINVAL; }
+  Blob b;
+  JamdNgramTables ng;
+  std::vector<float> fscore_new;
+  jamd_lexicon_desc d;
+  const int rc = lexicon_desc_from_file(b, lex_path, bingram_path, ng, fscore_new, d);
+  if (rc != JAMD_OK) return rc;
+  *nfscore = d.nfscore;
+  for (int i = 0; i < d.nfscore && i < cap; i++) fscore[i] = d.fscore[i];
+  return JAMD_OK;
 }
 
 int jamd_bingram_check(const char *lex_path, const char *bingram_path, int *same_tables) {

@@ -2,7 +2,7 @@
  * jamd_batch -- batch-of-utterances first pass over the C ABI, no Julius process.
  *
  *   jamd_batch [-d device | -devices 0,1,..|0-7] [-b beam] [-bs score_width] [-gprune none|safe N|heu N|beam N]
- *              [-order exact|fast|strict] [-shard R N] [-rej verification.blob]
+ *              [-order exact|fast|strict] [-shard R N] [-rej verification.blob] [-launch N] [-time]
  *              (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list.txt
  *
  * -shard R N: this process takes the utterances u with u % N == R (one process per GPU, e.g.
@@ -40,56 +40,92 @@ static void die(const char *what)
 
 static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-/* one HTK parameter file -> frames appended to *buf; returns the frame count or -1 */
-static int read_htk(const char *path, int veclen, float **buf, size_t *used, size_t *cap)
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* header of an HTK parameter file: the frame count, or -1 when it is not `veclen`-dim float vectors */
+static int htk_frames(const char *path, int veclen)
 {
   FILE *f = fopen(path, "rb");
-  unsigned char h[12], *raw;
-  int n, size, i;
+  unsigned char h[12];
+  int n, size;
   if (f == NULL) return -1;
   if (fread(h, 1, 12, f) != 12) { fclose(f); return -1; }
-  n = (int)be32(h); size = (h[8] << 8) | h[9];
-  if (n <= 0 || size != 4 * veclen) { fclose(f); return -1; }
-  raw = (unsigned char *)malloc((size_t)n * size);
-  if (raw == NULL || fread(raw, (size_t)size, (size_t)n, f) != (size_t)n) { free(raw); fclose(f); return -1; }
   fclose(f);
-  if (*used + (size_t)n * veclen > *cap) {
-    *cap = 2 * (*used + (size_t)n * veclen);
-    *buf = (float *)realloc(*buf, sizeof(float) * *cap);
-  }
-  for (i = 0; i < n * veclen; i++) {
-    uint32_t v = be32(raw + 4 * (size_t)i);
-    memcpy(*buf + *used + i, &v, 4);
-  }
-  *used += (size_t)n * veclen;
-  free(raw);
+  n = (int)be32(h); size = (h[8] << 8) | h[9];
+  if (n <= 0 || size != 4 * veclen) return -1;
   return n;
+}
+
+/* the n vectors of the file straight into `dst` (pinned staging memory), byte-swapped in place */
+static int htk_read_into(const char *path, float *dst, size_t nfloat)
+{
+  FILE *f = fopen(path, "rb");
+  uint32_t *w = (uint32_t *)dst;
+  size_t i;
+  if (f == NULL) return -1;
+  if (fseek(f, 12, SEEK_SET) != 0 || fread(dst, sizeof(float), nfloat, f) != nfloat) { fclose(f); return -1; }
+  fclose(f);
+  for (i = 0; i < nfloat; i++) w[i] = __builtin_bswap32(w[i]);
+  return 0;
 }
 
 /* One launch: up to LAUNCH utterances, their frames on the host and on the device, their score rows.  512 = two per CU
  * of an MI355X: the exact-order first pass then runs in its half shape (jamd_beam_set_workgroup_shape(), automatic),
- * the one with the most frames per second; beams too wide for it run the same launch one utterance per CU. */
+ * the one with the most frames per second; beams too wide for it run the same launch one utterance per CU.
+ * The two chunks of a device are its double buffer: PINNED host staging (jamd_host_alloc(): the upload is a true
+ * asynchronous DMA, the host goes on reading the next files) and the device buffers, all kept from launch to launch and
+ * grown only when a launch needs more (no allocation -- which would synchronise the device -- in the steady state). */
 #define LAUNCH 512
-typedef struct { float *frames, *d_frames, *d_scores; int off[LAUNCH + 1], n; } chunk;
+typedef struct {
+  float *frames, *d_frames, *d_scores;      /* pinned staging, device frames, device score rows */
+  size_t cap_frames, cap_scores;            /* their capacities in bytes */
+  int off[LAUNCH + 1], n;
+} chunk;
 
-/* reads the files of the launch that starts at files[first] and queues the upload of the frames on `stream` (nothing
- * is waited for) */
 static int launch = LAUNCH;      /* -launch N: utterances per device launch (1 .. LAUNCH) */
+static int want_time = 0;        /* -time: one JSON line per device on stderr (model load, decode wall time, host read time) */
 
-static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream)
+typedef struct { double read_s, sync_s; size_t h2d_bytes; int launches; } hosttime;
+
+/* reads the files of the launch that starts at files[first] into the chunk's pinned buffer and queues the upload of
+ * the frames on `stream` (nothing is waited for) */
+static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream, hosttime *ht)
 {
-  size_t used = 0, cap = 0;
+  const double t0 = now_s();
+  size_t need_fr, need_sc;
   int u;
   c->n = nfile - first < launch ? nfile - first : launch;
-  c->frames = NULL; c->off[0] = 0;
+  c->off[0] = 0;
   for (u = 0; u < c->n; u++) {
-    const int t = read_htk(files[first + u], veclen, &c->frames, &used, &cap);
+    const int t = htk_frames(files[first + u], veclen);
     if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first + u], veclen); exit(1); }
     c->off[u + 1] = c->off[u] + t;
   }
-  if (jamd_malloc(e, sizeof(float) * used, (void **)&c->d_frames) != JAMD_OK ||
-      jamd_malloc(e, sizeof(float) * (size_t)c->off[c->n] * nstate, (void **)&c->d_scores) != JAMD_OK ||
-      jamd_memcpy_h2d_async(e, c->d_frames, c->frames, sizeof(float) * used, stream) != JAMD_OK) die("device buffers");
+  need_fr = sizeof(float) * (size_t)c->off[c->n] * (size_t)veclen;
+  need_sc = sizeof(float) * (size_t)c->off[c->n] * (size_t)nstate;
+  if (need_fr > c->cap_frames) {
+    if (c->frames) jamd_host_free(e, c->frames);
+    if (c->d_frames) jamd_free(e, c->d_frames);
+    c->cap_frames = need_fr + need_fr / 4;
+    if (jamd_host_alloc(e, c->cap_frames, (void **)&c->frames) != JAMD_OK ||
+        jamd_malloc(e, c->cap_frames, (void **)&c->d_frames) != JAMD_OK) die("frame buffers");
+  }
+  if (need_sc > c->cap_scores) {
+    if (c->d_scores) jamd_free(e, c->d_scores);
+    c->cap_scores = need_sc + need_sc / 4;
+    if (jamd_malloc(e, c->cap_scores, (void **)&c->d_scores) != JAMD_OK) die("score buffer");
+  }
+  for (u = 0; u < c->n; u++)
+    if (htk_read_into(files[first + u], c->frames + (size_t)c->off[u] * veclen, (size_t)(c->off[u + 1] - c->off[u]) * veclen) != 0) {
+      fprintf(stderr, "jamd_batch: %s is shorter than its header says\n", files[first + u]); exit(1);
+    }
+  if (jamd_memcpy_h2d_async(e, c->d_frames, c->frames, need_fr, stream) != JAMD_OK) die("upload");
+  ht->read_s += now_s() - t0; ht->h2d_bytes += need_fr; ht->launches++;
 }
 
 /* queues the scoring kernels of a loaded launch on `stream` */
@@ -124,6 +160,9 @@ static void *run_device(void *arg)
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   int veclen, nstate, first, k;
   chunk ck[2];
+  hosttime ht = {0.0, 0.0, 0, 0};
+  double t_start = now_s(), t_models, t_done;
+  long frames_total = 0;
   void *s_copy = NULL, *s_beam = NULL;
   size_t linecap = 1 << 16;
   char *text = (char *)malloc(linecap);
@@ -154,7 +193,10 @@ static void *run_device(void *arg)
    * wants for its second utterance per CU and it takes twice as long) -- queues their scoring, which fills the CUs
    * that the shorter utterances of launch k leave. */
   if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
-  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy); score(&ck[0], nstate, gm, dn, gs, s_copy); }
+  memset(ck, 0, sizeof(ck));
+  if (jamd_engine_sync(e) != JAMD_OK) die("model upload");
+  t_models = now_s();                                  /* engine + models + work area are up: the decode clock starts */
+  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy); }
   for (first = 0, k = 0; first < nfile; first += launch, k++) {
     chunk *c = &ck[k & 1];
     const int n = c->n;
@@ -167,11 +209,13 @@ static void *run_device(void *arg)
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
     if (first + launch < nfile) {
       chunk *nx = &ck[(k + 1) & 1];
-      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy);
+      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy, &ht);
       if (jamd_beam_stream_wait_resident(bm, s_copy) != JAMD_OK) die("first pass");   /* s_copy goes on once the first pass holds its CUs */
       score(nx, nstate, gm, dn, gs, s_copy);
     }
-    if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+    { const double tw = now_s();
+      if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
+      ht.sync_s += now_s() - tw; frames_total += off[n]; }
     if (rj != NULL) {                                  /* gmm_proceed() over every frame, gmm_end() per input */
       const int nm = jamd_rejgmm_nmodel(rj);
       float *d_fs = NULL, *d_us = NULL;
@@ -199,8 +243,17 @@ static void *run_device(void *arg)
       emit(j, first + u, text);
     }
     free(us); free(res);
-    jamd_free(e, c->d_frames); jamd_free(e, c->d_scores); free(c->frames);
-    c->d_frames = c->d_scores = NULL; c->frames = NULL;
+  }
+  t_done = now_s();
+  if (want_time)       /* decode_s: first file read -> last result line, everything in between (reads, uploads, scoring, first pass, result copies) */
+    fprintf(stderr, "{\"jamd_batch_time\": {\"device\": %d, \"utts\": %d, \"frames\": %ld, \"launches\": %d, \"models_s\": %.6f, "
+                    "\"decode_s\": %.6f, \"host_read_s\": %.6f, \"host_wait_s\": %.6f, \"h2d_bytes\": %zu, \"rtf_inv\": %.3f}}\n",
+            j->device, nfile, frames_total, ht.launches, t_models - t_start, t_done - t_models, ht.read_s, ht.sync_s, ht.h2d_bytes,
+            t_done > t_models ? (double)frames_total / 100.0 / (t_done - t_models) : 0.0);
+  for (k = 0; k < 2; k++) {
+    if (ck[k].frames) jamd_host_free(e, ck[k].frames);
+    if (ck[k].d_frames) jamd_free(e, ck[k].d_frames);
+    if (ck[k].d_scores) jamd_free(e, ck[k].d_scores);
   }
   jamd_stream_destroy(e, s_copy); jamd_stream_destroy(e, s_beam);
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
@@ -263,6 +316,7 @@ int main(int argc, char **argv)
     }
     else if (!strcmp(argv[i], "-shard") && i + 2 < argc) { shard_r = atoi(argv[++i]); shard_n = atoi(argv[++i]); }
     else if (!strcmp(argv[i], "-launch") && i + 1 < argc) launch = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-time")) want_time = 1;
     else if (!strcmp(argv[i], "-am") && i + 1 < argc) am = argv[++i];
     else if (!strcmp(argv[i], "-gms") && i + 1 < argc) gmsp = argv[++i];
     else if (!strcmp(argv[i], "-rej") && i + 1 < argc) rejp = argv[++i];
@@ -274,7 +328,7 @@ int main(int argc, char **argv)
   if (devspec != NULL) ndev = parse_devices(devspec, devs, 64); else { devs[0] = device; ndev = 1; }
   if ((am == NULL) == (dnnconf == NULL) || (gmsp != NULL && am == NULL) || lexp == NULL || list == NULL || shard_n < 1 || shard_r < 0 || shard_r >= shard_n || launch < 1 || launch > LAUNCH || ndev < 1) {
     fprintf(stderr, "usage: jamd_batch (-am model.blob [-gms selection.blob] | -dnnconf dnn.conf) -lex lexicon.blob -filelist list "
-                    "[-d dev | -devices 0,1,..|0-7] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512]\n");
+                    "[-d dev | -devices 0,1,..|0-7] [-b beam] [-bs width] [-gprune safe|heu|beam N] [-order exact|fast|strict] [-shard R N] [-launch utterances per launch, 1..512] [-time]\n");
     return 2;
   }
   setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* the upload/scoring stream and the first-pass stream must not share a hardware queue */

@@ -99,6 +99,7 @@ def load():
         "jamd_lexicon_load": (ci, [vp, C.c_char_p, P(vp)]),
         "jamd_lexicon_load_ngram": (ci, [vp, C.c_char_p, C.c_char_p, P(vp)]),
         "jamd_bingram_check": (ci, [C.c_char_p, C.c_char_p, P(ci)]),
+        "jamd_bingram_fscore": (ci, [C.c_char_p, C.c_char_p, vp, ci, P(ci)]),
         "jamd_gmm_destroy": (None, [vp]),
         "jamd_gmm_nstate": (ci, [vp]),
         "jamd_gmm_veclen": (ci, [vp]),

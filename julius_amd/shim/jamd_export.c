@@ -95,6 +95,7 @@ int main(int argc, char **argv)
     snprintf(path, sizeof(path), "%s.lex", prefix);
     rc = jamd_lexicon_save(&fl.desc, path);
     if (rc == JAMD_OK && r->lmtype == LM_PROB && r->lm != NULL) rc = jamd_lexicon_append_ngram_names(path, r->lm->ngram);
+    if (rc == JAMD_OK && r->lmtype == LM_PROB && r->lm != NULL) rc = jamd_lexicon_append_separation(path, r->lm->config->separate_wnum);
     if (rc == JAMD_OK)
       printf("wrote %s (%d nodes, %d words, beam width %d, gprune %s)\n", path, fl.desc.nnode, fl.desc.nword,
              r->trellis_beam_width, r->am->config->gprune_method == GPRUNE_SEL_SAFE ? "safe" : "none/other");

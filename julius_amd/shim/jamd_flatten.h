@@ -95,6 +95,7 @@ void jamd_flat_lexicon_free(jamd_flat_lexicon *f);
  * julius_amd/lexblob.py and jamd_lexicon_load() (include/julius_amd.h) read). */
 int  jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path);
 int  jamd_lexicon_append_ngram_names(const char *path, const NGRAM_INFO *ng);
+int  jamd_lexicon_append_separation(const char *path, int separate_wnum);
 
 /* ---- batch of buffered inputs through the first-pass shim (jamd_pass1_shim.c) ----------------
  * Replaces the one-launch-per-utterance pattern of get_back_trellis() / decode_proceed()

@@ -387,6 +387,21 @@ int jamd_lexicon_append_ngram_names(const char *path, const NGRAM_INFO *ng)
   return fclose(f) == 0 ? JAMD_OK : JAMD_EINVAL;
 }
 
+/* Appends "sep_wnum" (-sepnum: how many of the most frequent words wchmm.c keeps out of the tree, wchmm.c:1782, :1882) so
+ * that jamd_lexicon_load_ngram() can tell whether a retrained N-gram would have produced ANOTHER tree (then it refuses)
+ * before it recomputes the 1-gram factoring values of this one. */
+int jamd_lexicon_append_separation(const char *path, int separate_wnum)
+{
+  FILE *f = fopen(path, "r+b");
+  int nrec = 0;
+  if (f == NULL) return JAMD_EINVAL;
+  if (fseek(f, 8, SEEK_SET) != 0 || fread(&nrec, 4, 1, f) != 1) { fclose(f); return JAMD_EINVAL; }
+  nrec++;
+  if (fseek(f, 8, SEEK_SET) != 0 || fwrite(&nrec, 4, 1, f) != 1 || fseek(f, 0, SEEK_END) != 0 ||
+      put_rec(f, "sep_wnum", 0, 1, &separate_wnum) != 0) { fclose(f); return JAMD_EINVAL; }
+  return fclose(f) == 0 ? JAMD_OK : JAMD_EINVAL;
+}
+
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");

@@ -122,6 +122,15 @@ def test_standalone_c_driver(oracle, tmp_path):
                                 str(tmp_path / "list"), "-b", str(g["beam_width"]), "-launch", per_launch],
                                check=True, capture_output=True, text=True).stdout.strip().splitlines()
         assert again == out
+    # -time: the same lines on stdout, and one JSON record per device on stderr (the product's own clock: models up ->
+    # last result line; what bench.py's `batch` entries report); launches grow the pinned staging buffers (1 then 2 files)
+    tm = subprocess.run([str(exe), "-am", str(tmp_path / "am.blob"), "-lex", str(tmp_path / "lex.blob"), "-filelist",
+                         str(tmp_path / "list"), "-b", str(g["beam_width"]), "-launch", "2", "-time"], check=True, capture_output=True, text=True)
+    assert tm.stdout.strip().splitlines() == out
+    import json
+    rec = [json.loads(x)["jamd_batch_time"] for x in tm.stderr.splitlines() if x.startswith('{"jamd_batch_time"')]
+    assert len(rec) == 1 and rec[0]["utts"] == len(names) and rec[0]["launches"] == (len(names) + 1) // 2
+    assert rec[0]["frames"] == sum(len(u["frames"]) for u in g["utts"]) and rec[0]["decode_s"] > 0 and rec[0]["h2d_bytes"] == 4 * 39 * rec[0]["frames"]
     # BASELINE configs[4] inside one process: one host thread + engine + work area per listed device (here the same
     # device twice and three times), utterances dealt round-robin, result lines merged in file-list order
     for devices in ("0,0", "0-0,0,0"):

