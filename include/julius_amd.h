@@ -302,7 +302,13 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * reference's default "fast" setup), DFA grammar with per-category trees, or isolated word list; multipath models
  * through jamd_flatten_lexicon_multipath() (JAMD_LM_MULTIPATH below).  All indices are
  * 32-bit; WORD_INVALID is -1 here.  Built by jamd_flatten_lexicon()
- * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess. */
+ * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess.
+ * NOT SERVED -- the flattener returns JAMD_EINVAL, the shim's get_back_trellis_init() logs the reason and returns FALSE
+ * (there is no CPU first pass behind this library):
+ *   - a grammar decoded with a FORWARD DFA beside the reversed one (a `.dfa.forward` file: tokens and trellis words then
+ *     carry a DFA state, libjulius/src/beam.c:1740-1748, :2413-2422);
+ *   - a grammar without per-category trees, and user-defined LM functions (LM_NGRAM_USER);
+ *   - N-gram lexicons built without 1-gram factoring (a non-default ./configure of the reference). */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
 #define JAMD_AS_LSET  1   /* AS_LSET   wchmm.h:106: out_id = state-set id                */
 #define JAMD_AS_RSET  2   /* AS_RSET   wchmm.h:107: out_id = row of lc_tab               */

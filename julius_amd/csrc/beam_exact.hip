@@ -76,6 +76,7 @@ struct XShared {
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used
   int df_prof[4];                                // down_finish(): load, dependencies, sifts, output (100 MHz ticks; development)
   unsigned emaxbits;                             // multipath frame: best score among the tokens on emitting nodes (the score-pruning envelope)
+  unsigned long long ph[8];                      // phase clocks of the instrumented instantiation (JAMD_BEAM_TIMING=1)
 };
 
 struct XCells {
@@ -84,6 +85,15 @@ struct XCells {
   int nslot;
 };
 constexpr int kXProbes = 24;
+// The probe loop of a cell insert: fully unrolled into 24 nested conditionals (0: the compiler's choice and the default) or
+// kept as ONE loop (1).  Unrolled, every level saves an execution mask and a condition mask, eight call sites deep -- 370
+// of the kernel's remaining scalar spill slots and a sixth of its code -- but those levels only RUN for the rare lane
+// that probes that far, while the rolled loop pays its mask bookkeeping on every insert: measured on one box, round 5
+// (profiles/r05b_ab_register_diet.txt), rolled is 2.5 - 3 % slower on every configuration (C3 512 utterances 208.0 vs
+// 203.0 ms, C4 946.6 vs 930.7 ms), as its round-3 predecessor was.  Static spill counts are not run time.
+#ifndef JAMD_XPROBE_ROLLED
+#define JAMD_XPROBE_ROLLED 0
+#endif
 
 // The thread index as a value the optimiser cannot carry from one frame to the next.  Everything derived from it (lane
 // and wave numbers, per-thread addresses into a dozen arrays) is loop-invariant over the frame loop; hoisted, those
@@ -160,6 +170,9 @@ __device__ __forceinline__ void xpush_key(XShared &sh, const XCells &cl, int nod
   int slot = -1;
   if (cl.nslot > 0) {
     unsigned h = __umulhi((unsigned)node * 2654435761u, (unsigned)cl.nslot);
+#if JAMD_XPROBE_ROLLED
+#pragma nounroll
+#endif
     for (int pr = 0; pr < kXProbes; pr++) {
       const int o = atomicCAS((int *)&cl.lnode[h], -1, node);
       if (o == -1 || o == node) { slot = (int)h; first = (o == -1); break; }
@@ -1111,22 +1124,88 @@ template <> struct XSv<true> {
   }
 };
 
+// ---- the kernel's arguments, read where they are used ------------------------------------------------------------
+// LexDev + XWork are some 150 dwords of launch constants, and the frame loop derives another forty uniform addresses
+// from them.  Taken as by-value parameters they are all loaded at the kernel's entry and stay live across the frame
+// loop: the hardware has ~100 SGPRs, so the compiler parked a thousand of them in VGPR lanes (sgpr_spill_count 1 047 in
+// round 4) and a sixth of the instruction stream was v_readlane / v_writelane.  They are constants of the KERNARG
+// segment, which a wave can read at any time with a scalar load (scalar data cache): the first two parameters are one
+// struct at offset 0 of that segment, and every frame re-derives its view of it from an address the compiler cannot see
+// through (xargs_now(): the same device as tid_now() for the thread index), so that a value is loaded in the phase that
+// uses it and dies there.  JAMD_XARGS_RELOAD=0 builds the round-4 form (everything live from the kernel's entry).
+#ifndef JAMD_XARGS_RELOAD
+#define JAMD_XARGS_RELOAD 1
+#endif
+struct XKArgs { LexDev lx; XWork xw; };
+__device__ __forceinline__ const XKArgs &xargs_now() {
+  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return *(const XKArgs *)(const __attribute__((address_space(4))) XKArgs *)a;    // constant address space: scalar loads
+}
+
+// everything the frame loop derives from the launch constants (declares lx, xw, wk and the LDS / slice views)
+#define XBEAM_VIEWS(KA)                                                                                              \
+  const LexDev &lx = (KA).lx; const XWork &xw = (KA).xw; const Work &wk = xw.w;                                        \
+  XSv<WIDE> sv;                                            /* Tok[beam], two quads each */                           \
+  if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + wk.o_sv); else sv.p = (lds_v4 *)dyn_lds;                    \
+  lds_i32 *sv_atom = (lds_i32 *)(dyn_lds + xw.off_atom);                                                               \
+  lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      /* word ends of the frame; the pruning step returns its order here */ \
+  lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);    /* [beam + 2] first dense visiting index of each source */ \
+  lds_u32 *tpre = (lds_u32 *)(dyn_lds + xw.off_tpre);                                                                  \
+  XCells cl;                                                                                                          \
+  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;               \
+  cl.nslot = xw.nslot;                                                                                                \
+  cl.lkey = (lds_u64 *)(dyn_lds + xw.off_cells);                                                                       \
+  cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);                                                                      \
+  cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);                                                                    \
+  lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);                                                                   \
+  PruneMem pm;                                                                                                        \
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;                                      \
+  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);                                                                       \
+  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);                                                                           \
+  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);                                                                          \
+  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);                                                                        \
+  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);                                                                    \
+  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);                                                      \
+  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;                        \
+  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);                                                                \
+  pm.b_cap = xw.b_cap;                                                                                                \
+  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;             \
+  pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;                                                                 \
+  pm.pstat = xw.o_sweep ? sh.pst : nullptr;               /* (a generic pointer to LDS: a handful of accesses per frame) */ \
+  lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);                                                                  \
+  unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);                                  \
+  u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);                                                          \
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;                                                                 \
+  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;                                                                        \
+  const bool wordmode = lx.lm_type == JAMD_LM_WORD;                                                                    \
+  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);                                \
+  const int s1 = xw.s1, XW = xw.xw;                                                                                    \
+  const unsigned submask = (1u << s1) - 1u;                                                                            \
+  const int nroot_x = wordmode ? 0 : (dfa ? lx.startnum : lx.isolatenum);                                              \
+  (void)sv_atom; (void)welist; (void)dbase; (void)tpre; (void)rowc; (void)Hlds; (void)Hglob; (void)Gcol; (void)lmw; (void)pen; \
+  (void)memo; (void)XW; (void)submask; (void)nroot_x
+
 template <bool TIMED, bool WIDE, int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
-beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
+beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  const Work &wk = xw.w;
-  if (threadIdx.x == 0 && wk.resident) __hip_atomic_fetch_add(wk.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this workgroup holds its share of a CU now
+#if JAMD_XARGS_RELOAD
+  const XKArgs &ka0 = xargs_now();
+#else
+  const XKArgs &ka0 = ka_;
+#endif
+  if (threadIdx.x == 0 && ka0.xw.w.resident) __hip_atomic_fetch_add(ka0.xw.w.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this workgroup holds its share of a CU now
   const int u = min(max(utt_off[gridDim.x + 1 + blockIdx.x], 0), (int)gridDim.x - 1);   // longest utterance first (upload_utt_off()); clamped: never outside the launch's slices
   int tid = threadIdx.x;                                                     // refreshed every frame: see tid_now()
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
-  StreamState *ss = smode ? wk.stream + u : nullptr;
+  StreamState *ss = smode ? ka0.xw.w.stream + u : nullptr;
   const bool resume = smode && ss->started;
   const int base = resume ? ss->frames_done : 0;
   const int T = base + nrows;
   const bool finish = smode != 1;
-  unsigned char *const ub = wk.slices + (size_t)u * wk.utt_stride;
+  unsigned char *const ub = ka0.xw.w.slices + (size_t)u * ka0.xw.w.utt_stride;
 #define SLICE(T, off, i) (*reinterpret_cast<T *>(ub + (unsigned)((off) + (unsigned)sizeof(T) * (unsigned)(i))))
 #define NODEKEY(i) SLICE(unsigned long long, wk.o_nodekey, i)
 #define NODEFIRST(i) SLICE(unsigned, xw.o_nodefirst, i)
@@ -1135,48 +1214,12 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
 #define TOUCHED(i) SLICE(int2, wk.o_touched, i)
 #define ARCQ(i) SLICE(int2, wk.o_arcq, i)
 #define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
-  jamd_pass1_result *res = wk.res + u;
+  jamd_pass1_result *res = ka0.xw.w.res + u;
   // LDS image: survivors in VISITING ORDER (no node hash: a candidate names its source by position)
-  XSv<WIDE> sv;                                            // Tok[beam], two quads each
-  if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + wk.o_sv); else sv.p = (lds_v4 *)dyn_lds;
-  lds_i32 *sv_atom = (lds_i32 *)(dyn_lds + xw.off_atom);
-  lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      // word ends of the frame; the pruning step returns its order here
-  lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);    // [beam + 2] first dense visiting index of each source
-  lds_u32 *tpre = (lds_u32 *)(dyn_lds + xw.off_tpre);
-  XCells cl;
-  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;
-  cl.nslot = xw.nslot;
-  cl.lkey = (lds_u64 *)(dyn_lds + xw.off_cells);
-  cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);
-  cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);
-  lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);
-  PruneMem pm;
-  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
-  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
-  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
-  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);
-  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
-  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
-  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
-  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
-  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
-  pm.b_cap = xw.b_cap;
-  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
-  pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;
-  pm.pstat = xw.o_sweep ? sh.pst : nullptr;               // (a generic pointer to LDS: a handful of accesses per frame)
+  XBEAM_VIEWS(ka0);
   int *const pstat_glob = xw.o_sweep ? reinterpret_cast<int *>(ub + xw.o_pstat) : nullptr;
   if (tid == 0) for (int i = 0; i < 16; i++) sh.pst[i] = 0;
-  lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
-  unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
-  u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
   for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
-  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
-  const bool dfa = lx.lm_type != JAMD_LM_NGRAM;
-  const bool wordmode = lx.lm_type == JAMD_LM_WORD;
-  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);
-  const int s1 = xw.s1, XW = xw.xw;
-  const unsigned submask = (1u << s1) - 1u;
-  const int nroot_x = wordmode ? 0 : (dfa ? lx.startnum : lx.isolatenum);
 
   if (resume) {
     if (!ss->active) return;
@@ -1216,7 +1259,11 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
     }
   }
   float thr = resume ? ss->thr : JAMD_LOG_ZERO;
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tc2 = tc;
+  // the phase clocks of the instrumented instantiation live in LDS (thread 0 adds to them): eight 64-bit counters in
+  // registers cost the kernel 16 VGPRs it does not have
+  unsigned long long *const ph = sh.ph;
+  if (TIMED && threadIdx.x == 0) for (int i = 0; i < 8; i++) sh.ph[i] = 0ull;
+  unsigned long long tc = wall_clock64(), tc2 = tc;
   (void)tc2;
 #ifdef JAMD_DEV
   const unsigned long long cyc0 = clock64(), wall0 = tc;   // JAMD_XBEAM_PROBE == 4: shader clock under this kernel
@@ -1243,6 +1290,9 @@ beam_exact_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, 
   row_request(resume ? base : (dfa ? 0 : 1));
   for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
     tid = tid_now();
+#if JAMD_XARGS_RELOAD
+    XBEAM_VIEWS(xargs_now());                              // this frame's view of the launch constants (see xargs_now())
+#endif
     const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
@@ -1997,16 +2047,16 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
   const dim3 grid(nutt), block(xw.nt);
 #define JAMD_XLAUNCH(W, N)                                                                                                   \
   do {                                                                                                                       \
-    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode); \
-    else hipLaunchKernelGGL((beam_exact_kernel<false, W, N>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);      \
+    if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, W, N>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode); \
+    else hipLaunchKernelGGL((beam_exact_kernel<false, W, N>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);      \
   } while (0)
   if (xw.mp) {                                         // multipath lexicons: their own frame (beam_exact_mp.h), full shape only
     if (xw.wide) {
-      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, true, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, true, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, true, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
+      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, true, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
     } else {
-      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, false, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
-      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, false, NT>), grid, block, lds, st, lx, xw, scores, nstate, d_utt_off, smode);
+      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, false, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
+      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, false, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
     }
   }
   else if (xw.nt == kHalfNT) JAMD_XLAUNCH(true, kHalfNT);

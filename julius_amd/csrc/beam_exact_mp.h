@@ -60,67 +60,80 @@ __device__ __forceinline__ void literal_sort(const unsigned *keys, int n, int k,
   if (n <= heap_cap) run(Hl); else run(Hg);
 }
 
+// the multipath kernel's per-frame view of the launch constants (see xargs_now() in beam_exact.hip)
+#define XBEAM_MP_VIEWS(KA)                                                                                           \
+  const LexDev &lx = (KA).lx; const XWork &xw = (KA).xw; const Work &wk = xw.w;                                        \
+  XSv<WIDE> sv;                                                                                                       \
+  if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + wk.o_sv); else sv.p = (lds_v4 *)dyn_lds;                    \
+  lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      /* token ids of the frame's word ends; the final cut returns its order here */ \
+  lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);                                                                \
+  lds_u32 *tpre = (lds_u32 *)(dyn_lds + xw.off_tpre);                                                                  \
+  XCells cl;                                                                                                          \
+  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;               \
+  cl.nslot = xw.nslot;                                                                                                \
+  cl.lkey = (lds_u64 *)(dyn_lds + xw.off_cells);                                                                       \
+  cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);                                                                      \
+  cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);                                                                    \
+  lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);                                                                   \
+  PruneMem pm;                                                                                                        \
+  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;                                      \
+  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);                                                                       \
+  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);                                                                           \
+  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);                                                                          \
+  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);                                                                        \
+  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);                                                                    \
+  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);                                                      \
+  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;                        \
+  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);                                                                \
+  pm.b_cap = xw.b_cap;                                                                                                \
+  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;             \
+  pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;                                                                 \
+  pm.pstat = xw.o_sweep ? sh.pst : nullptr;                                                                           \
+  lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);                                                                  \
+  unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);                                  \
+  u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);                                                          \
+  auto clear_cells = [&]() { for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; } }; \
+  const float lmw = lx.lm_weight, pen = lx.lm_penalty;                                                                 \
+  const int lmt = lx.lm_type & 0xff;                                                                                  \
+  const bool dfa = lmt != JAMD_LM_NGRAM;                                                                               \
+  const bool wordmode = lmt == JAMD_LM_WORD;                                                                           \
+  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);                                \
+  const int s1 = xw.s1, XW = xw.xw;                                                                                    \
+  const unsigned submask = (1u << s1) - 1u;                                                                            \
+  const int nroot_x = wordmode ? 0 : (dfa ? lx.startnum : lx.isolatenum);                                              \
+  const int slots2 = nroot_x * XW;                         /* visiting indices a word end owns in the second half */ \
+  lds_u32 *bm_l = (lds_u32 *)(dyn_lds + xw.off_bm);                                                                    \
+  unsigned *bm_g = reinterpret_cast<unsigned *>(ub + xw.o_bitmap);                                                     \
+  (void)welist; (void)dbase; (void)tpre; (void)rowc; (void)Hlds; (void)Hglob; (void)Gcol; (void)lmw; (void)pen; (void)memo; \
+  (void)XW; (void)submask; (void)slots2; (void)bm_l; (void)bm_g; (void)clear_cells
+
 template <bool TIMED, bool WIDE, int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
-beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
+beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
-  const Work &wk = xw.w;
-  if (threadIdx.x == 0 && wk.resident) __hip_atomic_fetch_add(wk.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#if JAMD_XARGS_RELOAD
+  const XKArgs &ka0 = xargs_now();
+#else
+  const XKArgs &ka0 = ka_;
+#endif
+  if (threadIdx.x == 0 && ka0.xw.w.resident) __hip_atomic_fetch_add(ka0.xw.w.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int u = min(max(utt_off[gridDim.x + 1 + blockIdx.x], 0), (int)gridDim.x - 1);
   int tid = threadIdx.x;
   const int t_begin = utt_off[u], nrows = utt_off[u + 1] - t_begin;
-  StreamState *ss = smode ? wk.stream + u : nullptr;
+  StreamState *ss = smode ? ka0.xw.w.stream + u : nullptr;
   const bool resume = smode && ss->started;
   const int base = resume ? ss->frames_done : 0;
   const int T = base + nrows;
   const bool finish = smode != 1;
-  unsigned char *const ub = wk.slices + (size_t)u * wk.utt_stride;
+  unsigned char *const ub = ka0.xw.w.slices + (size_t)u * ka0.xw.w.utt_stride;
 #define NODETOK(i) SLICE(unsigned, xw.o_nodetok, i)
 #define ARR(i) SLICE(int, xw.o_arr, i)
 #define KEY2(i) SLICE(unsigned, xw.o_key2, i)
-  jamd_pass1_result *res = wk.res + u;
-  XSv<WIDE> sv;
-  if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + wk.o_sv); else sv.p = (lds_v4 *)dyn_lds;
-  lds_i32 *welist = (lds_i32 *)(dyn_lds + xw.off_we);      // token ids of the frame's word ends; the final cut returns its order here
-  lds_i32 *dbase = (lds_i32 *)(dyn_lds + xw.off_dbase);
-  lds_u32 *tpre = (lds_u32 *)(dyn_lds + xw.off_tpre);
-  XCells cl;
-  cl.ub = ub; cl.o_nodekey = wk.o_nodekey; cl.o_nodefirst = xw.o_nodefirst; cl.o_touched = wk.o_touched;
-  cl.nslot = xw.nslot;
-  cl.lkey = (lds_u64 *)(dyn_lds + xw.off_cells);
-  cl.lnode = (lds_i32 *)(dyn_lds + xw.off_lnode);
-  cl.lfirst = (lds_u32 *)(dyn_lds + xw.off_lfirst);
-  lds_f32 *rowc = (lds_f32 *)(dyn_lds + xw.off_row);
-  PruneMem pm;
-  pm.compR = (lds_u64 *)(dyn_lds + xw.off_compr); pm.compT = pm.compR + xw.b_cap;
-  pm.vposR = (lds_u32 *)(dyn_lds + xw.off_vpos);
-  pm.idR = (lds_u32 *)(dyn_lds + xw.off_id);
-  pm.idT = (lds_u32 *)(dyn_lds + xw.off_idt);
-  pm.hist = (lds_u32 *)(dyn_lds + xw.off_hist);
-  pm.tailmask = (lds_u32 *)(dyn_lds + xw.off_tail);
-  pm.cand = (lds_i32 *)(pm.tailmask + (xw.w.beam + 31) / 32 + 2);
-  pm.occ = pm.cand + kMaxCand; pm.need = pm.occ + kMaxCand; pm.takers = pm.need + kMaxCand + 4;
-  pm.ordv = pm.takers + (kMaxCand + 1) * (kTakers + 1);
-  pm.b_cap = xw.b_cap;
-  pm.sw_region = (unsigned char JAMD_LDS *)(dyn_lds + xw.off_dov); pm.sw_bytes = xw.off_row - xw.off_dov;
-  pm.sw_glob = xw.o_sweep ? ub + xw.o_sweep : nullptr;
-  pm.pstat = xw.o_sweep ? sh.pst : nullptr;
+  jamd_pass1_result *res = ka0.xw.w.res + u;
+  XBEAM_MP_VIEWS(ka0);
   int *const pstat_glob = xw.o_sweep ? reinterpret_cast<int *>(ub + xw.o_pstat) : nullptr;
   if (tid == 0) for (int i = 0; i < 16; i++) sh.pst[i] = 0;
-  lds_u64 *Hlds = (lds_u64 *)(dyn_lds + xw.off_heap);
-  unsigned long long *Hglob = reinterpret_cast<unsigned long long *>(ub + xw.o_heap);
-  u32x4 *Gcol = reinterpret_cast<u32x4 *>(ub + xw.o_collect);
-  auto clear_cells = [&]() { for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; } };
-  const float lmw = lx.lm_weight, pen = lx.lm_penalty;
-  const int lmt = lx.lm_type & 0xff;
-  const bool dfa = lmt != JAMD_LM_NGRAM;
-  const bool wordmode = lmt == JAMD_LM_WORD;
-  unsigned long long *memo = reinterpret_cast<unsigned long long *>(ub + wk.o_lmcache);
-  const int s1 = xw.s1, XW = xw.xw;
-  const unsigned submask = (1u << s1) - 1u;
-  const int nroot_x = wordmode ? 0 : (dfa ? lx.startnum : lx.isolatenum);
-  const int slots2 = nroot_x * XW;                         // visiting indices a word end owns in the second half
   const int head_root = dfa ? -1 : lx.word_head(lx.head_silwid);
 
   if (resume) {
@@ -199,7 +212,11 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
     }
   }
   float thr = resume ? ss->thr : JAMD_LOG_ZERO;
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = wall_clock64(), tc2 = tc;
+  // the phase clocks of the instrumented instantiation live in LDS (thread 0 adds to them): eight 64-bit counters in
+  // registers cost the kernel 16 VGPRs it does not have
+  unsigned long long *const ph = sh.ph;
+  if (TIMED && threadIdx.x == 0) for (int i = 0; i < 8; i++) sh.ph[i] = 0ull;
+  unsigned long long tc = wall_clock64(), tc2 = tc;
   (void)tc2;
   int max_tokens = resume ? ss->max_tokens : 1;
   bool stopped = false;
@@ -213,11 +230,12 @@ beam_exact_mp_kernel(LexDev lx, XWork xw, const float *__restrict__ scores, int 
       if (b + ln < S) __builtin_amdgcn_global_load_lds((glb_void *)(rg + b + ln), (lds_void *)(rowc + b), 4, 0, 0);
   };
   row_request(base);
-  lds_u32 *bm_l = (lds_u32 *)(dyn_lds + xw.off_bm);
-  unsigned *bm_g = reinterpret_cast<unsigned *>(ub + xw.o_bitmap);
 
   for (int t = base; t <= (finish ? T : T - 1); t++) {
     tid = tid_now();
+#if JAMD_XARGS_RELOAD
+    XBEAM_MP_VIEWS(xargs_now());                           // this frame's view of the launch constants
+#endif
     const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) {

@@ -62,6 +62,7 @@ struct jamd_gmm {
   int ntied = 0;
   int maxbook = 0;                // largest codebook
   int tm_cap = 0;                 // slots per (frame, book) in the codebook cache
+  bool has_null = false;          // some mixture entry names no density (NULL density): K1 keeps its LOG_ZERO selects
   int hist_method = 0;            // JAMD_GPRUNE_HEU / _BEAM over tied-mixture codebooks (history pruning), else 0
   int *d_cur_utt_off = nullptr;   // [cur_nutt + 1] utterance boundaries of the running call (history pruning restarts
   int cur_nutt = 0; size_t utt_off_cap = 0;   //   at every utterance's first frame)

@@ -488,6 +488,8 @@ int jref_engine_save_lexicon(void *h, const char *path)
   rc = jamd_lexicon_save(&fl.desc, path);
   if (rc == 0 && e->recog->process_list->lmtype == LM_PROB && e->recog->process_list->lm != NULL)
     rc = jamd_lexicon_append_ngram_names(path, e->recog->process_list->lm->ngram);     /* as jamd_export does */
+  if (rc == 0 && e->recog->process_list->lmtype == LM_PROB && e->recog->process_list->lm != NULL)
+    rc = jamd_lexicon_append_separation(path, e->recog->process_list->lm->config->separate_wnum);
   jamd_flat_lexicon_free(&fl);
   return rc;
 }
