@@ -377,6 +377,23 @@ def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None, multipa
     return task, jargs, prefix
 
 
+def first_pass_traffic(use_dnn, multipath, flat, nutt, beam, shape):
+    """HBM bytes of ONE first-pass launch of this configuration as the PMC passes measured them (profiles/traffic_first_pass.json:
+    rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, MI355X_MICROARCH.md "HBM" corrections), or None when this
+    exact launch (scorer, -multipath, utterances per launch, beam, workgroup shape) was not measured."""
+    f = ROOT / "profiles" / "traffic_first_pass.json"
+    if not f.exists():
+        return None
+    try:
+        for e in json.loads(f.read_text()).get("entries", []):
+            if (bool(e.get("dnn")) == bool(use_dnn) and bool(e.get("multipath")) == bool(multipath) and bool(e.get("flat")) == bool(flat)
+                    and e.get("utts") == nutt and e.get("beam") == beam and e.get("shape") == shape):
+                return e.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
 def first_pass_roofline(work, beam_ms, nutt, shape, sc_ms):
     """SURVEY 8d's substitute figures for the first pass (irregular gather / scatter: no algorithmic-bytes roofline): the
     work of one step counted by the kernel -- tokens created, survivors visited, word ends -- and the bytes that work
@@ -584,6 +601,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         d_sc = d_scs[(count[0] - 1) % nbuf]                      # the scores of the last step (parity leg)
         sc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         beam_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        beam_ms_steps = [round(float(e[2].elapsed_time(e[3])), 3) for e in ev]       # the spread over the timed steps (detail output)
         res_local = bm.results()
         # per-step counters of the exact-order kernel: the paths of utterance 0's pruning steps, the work of all utterances
         nlaunch = max(1, steps + warmup)
@@ -624,12 +642,14 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                             "workgroup_shape": bm.workgroup_shape(nutt) + (" (two utterances per CU)" if bm.workgroup_shape(nutt) == "half" else " (one utterance per CU)"),
                             "pipelined": ("scoring of step k+1 on a second stream, released once the first pass of step k is running (it fills the CUs "
                                           "the first pass leaves)" if pipelined else "no")},
-                 "roofline": first_pass_roofline(work, beam_ms, nutt, bm.workgroup_shape(nutt), sc_ms),
+                 "roofline": dict(first_pass_roofline(work, beam_ms, nutt, bm.workgroup_shape(nutt), sc_ms),
+                                  traffic=first_pass_traffic(use_dnn, multipath, flat, nutt, beam, bm.workgroup_shape(nutt))),
                  "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,
                            "mean_peak_tokens": float(np.mean([x.max_tokens for x in res_local])),
                            "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us),
                            "prune_paths_utt0": dict(zip(("frames_pruned", "up_closed_form", "up_wave_replay", "up_sweep", "up_sweep_gave_up",
                                                          "down_closed_form", "extraction_loop", "sweep_rounds"), pstats))}}
+            r["roofline"]["beam_kernel_ms_steps"] = beam_ms_steps
             if multipath:      # frames whose new tokens exceeded the beam (the mid-frame sort really sorted)
                 r["pass1"]["multipath_frames"] = {"mid_frame_sorted": mpstat[0], "all": int(work[3])}
             if ri == 0 and dd.world == 1 and not args.no_cpu_baseline:
@@ -886,15 +906,15 @@ def main():
         strong_total = args.batch_total or C5_TOTAL_UTTS
         runs = []
         if wl == "all" or not (args.strong or args.multipath):
-            runs.append(("e2e", per_gpu, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
+            runs.append(("e2e", per_gpu, pick(args.steps, 10), pick(args.warmup, 1), "weak"))
         if wl == "all" or (args.strong and not args.multipath):
-            runs.append(("e2e_strong", max(1, strong_total // dd.world), pick(args.steps, 4), pick(args.warmup, 1), "strong"))
+            runs.append(("e2e_strong", max(1, strong_total // dd.world), pick(args.steps, 8), pick(args.warmup, 1), "strong"))
         if not args.strong and not args.multipath and args.utts is None:
-            runs.append(("e2e_256", 256, pick(args.steps, 6), pick(args.warmup, 1), "weak"))
+            runs.append(("e2e_256", 256, pick(args.steps, 10), pick(args.warmup, 1), "weak"))
         r = run_e2e(args, dd, runs, use_dnn=False) if runs else {}
         if wl == "all" or args.multipath:
             # the same task decoded with -multipath: one utterance per CU (the multipath frame has the full shape only)
-            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
+            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
                              use_dnn=False, multipath=True))
         if dd.rank == 0:
             if nested:
@@ -911,16 +931,16 @@ def main():
         strong_total = args.batch_total or C5_TOTAL_UTTS
         runs = []
         if wl == "all" or not (args.strong or args.flat or args.multipath):
-            runs.append(("e2e_dnn", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak"))
+            runs.append(("e2e_dnn", pick(args.utts, 256), pick(args.steps, 5), pick(args.warmup, 1), "weak"))
         if wl == "all" or (args.strong and not args.flat and not args.multipath):
-            runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 2), pick(args.warmup, 1), "strong"))
+            runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 3), pick(args.warmup, 1), "strong"))
         r = run_e2e(args, dd, runs, use_dnn=True) if runs else {}
         if wl == "all" or args.multipath:
             # the reference's DNN recipe as its README gives it: -b 4000 WITH -multipath (the multipath frame, wide layout)
-            r.update(run_e2e(args, dd, [("e2e_dnn_mp", pick(args.utts, 256), pick(args.steps, 1), pick(args.warmup, 1), "weak")],
+            r.update(run_e2e(args, dd, [("e2e_dnn_mp", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
                              use_dnn=True, multipath=True))
         if wl == "all" or (args.flat and not args.multipath):
-            r.update(run_e2e(args, dd, [("e2e_dnn_flat", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
+            r.update(run_e2e(args, dd, [("e2e_dnn_flat", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
                              use_dnn=True, flat=True))
         if dd.rank == 0:
             if nested:
