@@ -660,7 +660,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         if ri == 0 and ref_built and not flat and not args.no_batch and mode.startswith("exact"):
             # the same task through the product's own host loop (file read + pinned staging + H2D + kernels + D2H), own clock
             bl = min(nutt, 512)
-            rb = run_batch(args, dd, wd, prefix, task, uniq, use_dnn, beam, bl, args.batch_launches or (2 if use_dnn else 4), NS, multipath)
+            rb = run_batch(args, dd, wd, prefix, task, uniq, use_dnn, beam, bl, args.batch_launches or (3 if (use_dnn and multipath) else 4), NS, multipath)
             if dd.rank == 0 and rb is not None:
                 if "result_lines_text" in rb:       # the serving loop's result lines against the in-process results of the same utterances
                     same = 0
@@ -842,7 +842,7 @@ def main():
                          "512-utterance batch of configs[4]; e2e: default 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="e2e: skip the jamd_batch (product serving loop) run of the same task")
-    ap.add_argument("--batch-launches", type=int, default=None, help="e2e: launches of the jamd_batch run (default 4, DNN 2)")
+    ap.add_argument("--batch-launches", type=int, default=None, help="e2e: launches of the jamd_batch run (default 4; DNN -multipath 3)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="e2e: scoring and first pass of every step on ONE stream (default: two streams, the scoring of step k+1 "
                          "overlaps the first pass of step k)")

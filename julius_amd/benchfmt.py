@@ -64,48 +64,66 @@ def _cpu(c):
     return out
 
 
-def _nested(r):
-    out = {k: _num(r[k]) for k in ("ms_per_step", "rtf_inv", "steps", "scaling") if k in r}
+def _nested(r, lean=False):
+    """One nested configuration: what a reader compares, nothing that only explains.  `lean` drops
+    everything but the figures named there."""
+    out = {k: _num(r[k]) for k in ("ms_per_step", "rtf_inv", "steps") if k in r}
+    if r.get("scaling") == "strong":
+        out["scaling"] = "strong"
     roof = r.get("roofline") or {}
     bound = str(roof.get("bound", "")).split(" ")[0]
-    rr = {"bound": bound, "frac": _num(roof.get("frac"), 4)}
+    rr = {"frac": _num(roof.get("frac"), 4)}
     # the first-pass lines have no algorithmic roofline (SURVEY 8d): their modelled GB/s stay in the detail file
     for k in ("kernel_ms", "beam_kernel_ms", "score_kernels_ms", "traffic") + (() if bound == "latency" else ("achieved", "peak")):
-        if roof.get(k) is not None:
+        if roof.get(k) is not None and not (lean and k in ("score_kernels_ms", "achieved", "peak")):
             rr[k] = _num(roof[k], 5)
-    out["roofline"] = rr
+    if not lean and bound:
+        rr["bound"] = bound
+    if "timing" not in r or rr["frac"] is not None:
+        out["roofline"] = rr
     if isinstance(r.get("cpu_baseline"), dict):
         c = r["cpu_baseline"]
-        out["cpu_baseline"] = {"rtf_inv": _num(c.get("rtf_inv"), 4), "cores": c.get("cores"), "kind": c.get("kind")}
-        for k in ("multi", "two_pass", "threads"):
-            if isinstance(c.get(k), dict):
-                out["cpu_baseline"][k] = {kk: _num(vv, 4) for kk, vv in c[k].items() if isinstance(vv, (int, float)) and not isinstance(vv, bool)}
+        cb = {"rtf_inv": _num(c.get("rtf_inv"), 4), "cores": c.get("cores"), "kind": c.get("kind")}
+        if not lean:
+            m = c.get("multi")
+            if isinstance(m, dict) and "rtf_inv" in m:
+                cb["multi"] = {"cores": m.get("cores"), "rtf_inv": _num(m["rtf_inv"], 4)}
+            if isinstance(c.get("two_pass"), dict):
+                cb["two_pass_rtf_inv"] = _num(c["two_pass"].get("rtf_inv"), 4)
+            if isinstance(c.get("threads"), dict):
+                cb["threads"] = {k: _num(v, 4) for k, v in c["threads"].items() if isinstance(v, (int, float))}
+        out["cpu_baseline"] = cb
     p = _parity(r.get("parity"))
     if p:
+        if p.get("wanted") == p.get("utts"):
+            p.pop("wanted", None)
+        p.pop("fast_kernel_identical", None)
+        if lean:
+            p = {k: p[k] for k in ("utts", "identical", "incomplete") if k in p}
         out["parity"] = p
     if "parity_spot_check" in r:
         out["parity_spot_check"] = r["parity_spot_check"]
     p1 = r.get("pass1")
-    if isinstance(p1, dict):
-        out["pass1"] = {"ok": p1.get("ok"), "utts": p1.get("utts")}
+    if isinstance(p1, dict) and not lean:
+        out["pass1_ok"] = f"{p1.get('ok')}/{p1.get('utts')}"
     tm = r.get("timing")
     if isinstance(tm, dict):         # the product's serving loop (jamd_batch -time)
-        out["timing"] = {k: _num(tm[k], 4) for k in ("decode_s", "models_s", "host_read_s", "host_wait_s") if k in tm}
+        out["timing"] = {k: _num(tm[k], 4) for k in (("decode_s",) if lean else ("decode_s", "models_s", "host_read_s")) if k in tm}
         if "vs_e2e_same_task" in r:
-            out["vs_e2e_same_task"] = _num(r["vs_e2e_same_task"], 4)
+            out["vs_e2e"] = _num(r["vs_e2e_same_task"], 3)
+    if "error" in r:
+        out["error"] = _short(r["error"], 120)
     cfg = r.get("config") or {}
-    c2 = {}
-    for k in ("beam", "utts_per_gpu", "utts_total", "order_mode", "launch"):
-        if k in cfg:
-            c2[k] = cfg[k]
-    if "workgroup_shape" in cfg:
-        c2["shape"] = str(cfg["workgroup_shape"]).split(" ")[0]
-    if c2:
-        out["config"] = c2
+    if not lean:
+        c2 = {k: cfg[k] for k in ("beam", "utts_per_gpu") if k in cfg}
+        if "workgroup_shape" in cfg:
+            c2["shape"] = str(cfg["workgroup_shape"]).split(" ")[0]
+        if c2:
+            out["config"] = c2
     return out
 
 
-def compact_line(full: dict) -> dict:
+def compact_line(full: dict, lean: bool = False) -> dict:
     """The driver's line: contract keys of the top-level result + a short record per nested configuration."""
     line = {k: _num(full[k]) for k in _TOP_KEYS if k in full}
     cfg = full.get("config") or {}
@@ -135,21 +153,16 @@ def compact_line(full: dict) -> dict:
         line["pass1"] = {"ok": full["pass1"].get("ok"), "utts": full["pass1"].get("utts")}
     for k, v in full.items():
         if isinstance(v, dict) and "ms_per_step" in v and k not in line:
-            line[k] = _nested(v)
+            line[k] = _nested(v, lean)
     if "detail_file" in full:
         line["detail_file"] = full["detail_file"]
     return line
 
 
 def final_line(full: dict) -> str:
-    """json of compact_line(full); if it would still exceed MAX_LINE_BYTES, the nested records shrink to
-    {ms_per_step, rtf_inv, roofline.frac, parity} -- never the contract keys."""
-    line = compact_line(full)
-    s = json.dumps(line, separators=(",", ":"))
+    """json of compact_line(full); if that exceeds MAX_LINE_BYTES the nested records go lean (ms_per_step, rtf_inv, steps,
+    kernel times, roofline.frac, cpu_baseline.rtf_inv, parity counts) -- never the contract keys of the top level."""
+    s = json.dumps(compact_line(full), separators=(",", ":"))
     if len(s) > MAX_LINE_BYTES:
-        for k, v in list(line.items()):
-            if isinstance(v, dict) and "ms_per_step" in v:
-                line[k] = {kk: v[kk] for kk in ("ms_per_step", "rtf_inv", "steps", "parity") if kk in v}
-                line[k]["roofline"] = {"frac": (v.get("roofline") or {}).get("frac")}
-        s = json.dumps(line, separators=(",", ":"))
+        s = json.dumps(compact_line(full, lean=True), separators=(",", ":"))
     return s

@@ -19,7 +19,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 @pytest.mark.parametrize("path", RECORDED, ids=lambda p: p.name)
 def test_final_line_is_small_and_round_trips(path):
     full = json.loads(path.read_text())
-    if "roofline" not in full or "hbm" not in full["roofline"]:
+    if "roofline" not in full or "note" not in full["roofline"]:
         pytest.skip("already a compact record")
     s = benchfmt.final_line(full)
     assert "\n" not in s and len(s) < 6000, len(s)
@@ -38,7 +38,13 @@ def test_final_line_is_small_and_round_trips(path):
     assert nested
     for k in nested:
         assert line[k]["ms_per_step"] == pytest.approx(full[k]["ms_per_step"], rel=1e-5)
+        if "timing" in full[k]:                                   # the product's serving loop: its own clock instead of a roofline
+            assert line[k]["timing"]["decode_s"] == pytest.approx(full[k]["timing"]["decode_s"], rel=1e-3)
+            assert line[k]["parity"]["identical"] == full[k]["parity"]["result_lines_vs_in_process"]["identical"]
+            continue
         assert "frac" in line[k]["roofline"]
+        if "cpu_baseline" in full[k]:
+            assert line[k]["cpu_baseline"]["rtf_inv"] == pytest.approx(full[k]["cpu_baseline"]["rtf_inv"], rel=1e-3)
         if "parity" in full[k] and "device_vs_compiled_reference" in full[k]["parity"]:
             vs = full[k]["parity"]["device_vs_compiled_reference"]
             assert line[k]["parity"]["utts"] == vs["utts"]
@@ -54,7 +60,7 @@ def test_oversized_tree_still_fits():
     line = json.loads(s)
     for k in CONTRACT:
         assert k in line
-    assert len(s) < 12000
+    assert len(s) < 16000
     assert "hbm" in line["roofline"]
 
 
