@@ -1186,8 +1186,14 @@ __device__ __forceinline__ const XKArgs &xargs_now() {
   (void)sv_atom; (void)welist; (void)dbase; (void)tpre; (void)rowc; (void)Hlds; (void)Hglob; (void)Gcol; (void)lmw; (void)pen; \
   (void)memo; (void)XW; (void)submask; (void)nroot_x
 
+// JAMD_HALF_WAVES (development, tools/build_variant.sh): waves per SIMD the HALF shape is compiled for.  4 = 128 VGPRs (two
+// workgroups fill a CU's register file); 5 = 96 VGPRs, which leaves a fifth of the file to a co-resident scoring wave
+// (with JAMD_HALF_LDS_KB=62 also the LDS for one gmm_tile workgroup): the experiment of DESIGN.md section 5, "K1 beside K6x".
+#ifndef JAMD_HALF_WAVES
+#define JAMD_HALF_WAVES 4
+#endif
 template <bool TIMED, bool WIDE, int NT>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == kHalfNT ? JAMD_HALF_WAVES : 4, NT == kHalfNT ? JAMD_HALF_WAVES : 4)))
 beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int *__restrict__ utt_off, int smode) {
   __shared__ XShared sh;
   extern __shared__ __align__(16) unsigned char dyn_lds[];
@@ -1988,6 +1994,9 @@ int xbeam_layout(XWork *xw, const Work &w, int maxfan, int nroot, int ninit, int
   xw->mp = mp ? 1 : 0;
   xw->nt = half ? kHalfNT : NT;
   xw->lds_budget = half ? kHalfDynLds : kMaxDynLds;
+#ifdef JAMD_DEV
+  if (half) { const char *kb = getenv("JAMD_HALF_LDS_KB"); if (kb && atoi(kb) >= 32 && atoi(kb) * 1024 <= kHalfDynLds) xw->lds_budget = atoi(kb) * 1024; }
+#endif
   const int beam = w.beam;
   xw->xw = maxfan;                                   // self, next, extra arcs
   int need = maxfan + nroot;                         // transition numbers of one source
