@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JAMD_ABI_VERSION 3
+#define JAMD_ABI_VERSION 4
 
 #define JAMD_OK        0
 #define JAMD_EINVAL   -1   /* bad argument / unsupported model feature        */
@@ -305,8 +305,7 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess.
  * NOT SERVED -- the flattener returns JAMD_EINVAL, the shim's get_back_trellis_init() logs the reason and returns FALSE
  * (there is no CPU first pass behind this library):
- *   - a grammar decoded with a FORWARD DFA beside the reversed one (a `.dfa.forward` file: tokens and trellis words then
- *     carry a DFA state, libjulius/src/beam.c:1740-1748, :2413-2422);
+ *   - a MULTIPATH grammar with a forward DFA (`.dfa.forward`; the non-multipath form is served, see nfwd below);
  *   - a grammar without per-category trees, and user-defined LM functions (LM_NGRAM_USER);
  *   - N-gram lexicons built without 1-gram factoring (a non-default ./configure of the reference). */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
@@ -398,6 +397,18 @@ typedef struct {
   const int   *init_node;              /* [ninit] distinct word-head nodes in creation order       */
   const float *init_lscore;            /* [ninit] penalty1 + cprob of the first word reaching it   */
   float penalty1;                      /* r->config->lmp.penalty1                                  */
+  /* ---- a FORWARD DFA beside the reversed one (the `.dfa.forward` file recent mkdfa.pl writes next to `.dfa`,
+   * libjulius/src/multi-gram.c:868-880).  Tokens then carry a state of it (TOKEN2.to_state): an initial token of
+   * category t takes the arc labelled t out of the grammar's first state (libjulius/src/beam.c:1739-1747), a cross-word
+   * transition to a root of category c takes the arc labelled c out of the token's state and is dropped when there is
+   * none (:2412-2422), word-internal transitions inherit it (:2120).  nfwd = 0: no forward DFA (all pointers may be NULL).
+   * Served by the exact-order kernel (JAMD_ORDER_EXACT, the default) and the strict-order kernel on non-multipath
+   * lexicons; jamd_beam_create() refuses the other combinations. */
+  int nfwd;                            /* states of wchmm->dfa_forward                              */
+  const int   *fwd_off;                /* [nfwd+1] arcs of a state, in the order of its arc list     */
+  const int   *fwd_label;              /*          arc label = word category                         */
+  const int   *fwd_to;                 /*          next state                                        */
+  const int   *init_to_state;          /* [ninit] to_state of initial token e (-1: no such arc)      */
 } jamd_lexicon_desc;
 
 /* One emitted word-trellis record (TRELLIS_ATOM, libjulius/include/julius/

@@ -801,7 +801,7 @@ beam_pass1_kernel(LexDev lx, Work wk, const float *__restrict__ scores, int S,
 // utterances of a batch).  It is two to three orders of magnitude slower per utterance
 // than beam_pass1_kernel and exists so that the word trellis can be checked bit for bit
 // against the reference in every case, ties included.  Same inputs, same result records.
-struct STok { int last_tre, last_cword; float last_lscore, score; int node; };
+struct STok { int last_tre, last_cword; float last_lscore, score; int node; int to_state; };   // to_state: forward-DFA state (TOKEN2.to_state), 0 without one
 
 struct StrictWork {
   STok *tl[2];     // [utt][cap]   tlist[2]
@@ -866,17 +866,17 @@ __device__ void s_sort_no_order(SBeam &b, int neednum) {         // sort_token_n
 }
 
 __device__ void s_propagate(SBeam &b, int next_node, float next_score, int last_tre, int last_cword,
-                            float last_lscore) {                 // propagate_token() :1945
+                            float last_lscore, int to_state = 0) {   // propagate_token() :1945
   if (next_score <= JAMD_LOG_ZERO) return;
   int id = b.token[next_node];
   if (id >= 0) {
     STok &tk = b.tl[b.tn][id];
-    if (tk.score < next_score) { tk.last_tre = last_tre; tk.last_cword = last_cword; tk.last_lscore = last_lscore; tk.score = next_score; }
+    if (tk.score < next_score) { tk.last_tre = last_tre; tk.last_cword = last_cword; tk.last_lscore = last_lscore; tk.score = next_score; tk.to_state = to_state; }
   } else {
     id = s_create_token(b);
     STok &tk = b.tl[b.tn][id];
     tk.last_tre = last_tre; tk.last_cword = last_cword; tk.last_lscore = last_lscore; tk.score = next_score;
-    tk.node = next_node; b.token[next_node] = id;
+    tk.node = next_node; tk.to_state = to_state; b.token[next_node] = id;
   }
 }
 
@@ -890,7 +890,7 @@ __device__ void s_intra_core(SBeam &b, const STok &tk, int next_node, float next
     tmpsum += ng;
   }
   if (ng == JAMD_LOG_ZERO) ng = tk.last_lscore;
-  s_propagate(b, next_node, tmpsum, tk.last_tre, tk.last_cword, ng);
+  s_propagate(b, next_node, tmpsum, tk.last_tre, tk.last_cword, ng, tk.to_state);     // :2120
 }
 
 __device__ int s_save_trellis(SBeam &b, const STok &tk, int sword, int t) {            // :2209
@@ -934,7 +934,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
       const int4 nr = lx.node_b(node);
       nw.last_lscore = lx.init_lscore(e); nw.last_tre = -1; nw.last_cword = -1;
       nw.score = node_outprob(lx, b.sc, nr.w, nr.z, -1) + nw.last_lscore;
-      nw.node = node; b.token[node] = id;
+      nw.node = node; nw.to_state = lx.nfwd ? lx.init_to_state(e) : 0; b.token[node] = id;       // :1739-1747
     }
   } else {                                                           // init_nodescore() :1622-1665
     const int id = s_create_token(b);
@@ -945,7 +945,7 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
     ls = ls * lmw + pen;
     nw.last_lscore = ls; nw.last_tre = -1; nw.last_cword = -1;
     nw.score = node_outprob(lx, b.sc, nr.w, nr.z, -1) + ls;
-    nw.node = node; b.token[node] = id;
+    nw.node = node; nw.to_state = 0; b.token[node] = id;
   }
   s_sort_no_order(b, wk.beam);
   b.thr = JAMD_LOG_ZERO;
@@ -973,12 +973,14 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
           const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
           for (int stid = lx.startnum - 1; stid >= 0; stid--) {
             if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(stid))) continue;      // :2404-2412
+            int next_state = 0;
+            if (lx.nfwd) { next_state = fwd_next(lx, tk.to_state, lx.root_cat(stid)); if (next_state < 0) continue; }   // :2412-2422
             float tmpsum = tk.score;
             tmpsum += lx.wordend_a(sword);
             float ng = lx.penalty1;                                             // :2452-2461
             ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
             tmpsum += ng;
-            s_propagate(b, lx.startnode(stid), tmpsum, tre, last_word, ng);
+            s_propagate(b, lx.startnode(stid), tmpsum, tre, last_word, ng, next_state);
           }
         } else if (sword != lx.tail_silwid) {                                   // beam_inter_word() :2271
           const bool tr = lx.is_transparent(sword) != 0;
@@ -1117,7 +1119,7 @@ beam_strict_mp_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict
       const int node = lx.init_node(e);
       nw.last_lscore = lx.init_lscore(e); nw.last_tre = -1; nw.last_cword = -1;
       nw.score = nw.last_lscore;
-      nw.node = node; b.token[node] = id;
+      nw.node = node; nw.to_state = 0; b.token[node] = id;
     }
   } else {                                                           // :1635-1663
     const int id = s_create_token(b);
@@ -1577,6 +1579,24 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
       if (h->init_node[e] < 0 || h->init_node[e] >= h->nnode) { jamd_set_error("jamd_lexicon_create: bad initial node"); rc = JAMD_EINVAL; }
     UP(cat_pair, h->cat_pair, wordmode ? 0 : (size_t)h->ncat * h->ncat); UP(root_cat, root_cat.data(), root_cat.size());
     UP(init_node, h->init_node, h->ninit); UP(init_lscore, h->init_lscore, h->ninit);
+    if (h->nfwd > 0 && rc == JAMD_OK) {
+      // forward DFA: every index the kernels will follow is checked here
+      if (wordmode || multipath || !h->fwd_off || !h->fwd_label || !h->fwd_to || !h->init_to_state || h->fwd_off[0] != 0) {
+        jamd_set_error(multipath ? "jamd_lexicon_create: a forward DFA with a multipath lexicon is not served"
+                                 : "jamd_lexicon_create: forward DFA descriptor incomplete"); rc = JAMD_EINVAL;
+      }
+      for (int s2 = 0; s2 < h->nfwd && rc == JAMD_OK; s2++)
+        if (h->fwd_off[s2 + 1] < h->fwd_off[s2]) { jamd_set_error("jamd_lexicon_create: forward DFA offsets not monotone"); rc = JAMD_EINVAL; }
+      for (int a = 0; rc == JAMD_OK && a < h->fwd_off[h->nfwd]; a++)
+        if (h->fwd_to[a] < 0 || h->fwd_to[a] >= h->nfwd) { jamd_set_error("jamd_lexicon_create: forward DFA arc %d leaves the automaton", a); rc = JAMD_EINVAL; }
+      for (int e2 = 0; rc == JAMD_OK && e2 < h->ninit; e2++)
+        if (h->init_to_state[e2] < -1 || h->init_to_state[e2] >= h->nfwd) { jamd_set_error("jamd_lexicon_create: bad initial forward-DFA state"); rc = JAMD_EINVAL; }
+      if (rc == JAMD_OK) {
+        UP(fwd_off, h->fwd_off, (size_t)h->nfwd + 1); UP(fwd_label, h->fwd_label, (size_t)h->fwd_off[h->nfwd]);
+        UP(fwd_to, h->fwd_to, (size_t)h->fwd_off[h->nfwd]); UP(init_to_state, h->init_to_state, h->ninit);
+        d.nfwd = h->nfwd;
+      }
+    }
   }
 #undef UP
   if (rc == JAMD_OK && arena.size() >= ((size_t)1 << 32)) { jamd_set_error("jamd_lexicon_create: lexicon image exceeds 4 GB"); rc = JAMD_EINVAL; }
@@ -1749,6 +1769,11 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   }
   // default order mode: the exact-order kernel where it can serve the work area, else the frame-parallel one
   b->exact = b->exact_status == 0;
+  if (rc == JAMD_OK && l->d.nfwd > 0 && !b->exact) {     // the canonical-tie kernel carries no forward-DFA state
+    jamd_set_error("jamd_beam_create: a grammar with a forward DFA is decoded by the exact-order kernel (or the strict-order one), which "
+                   "cannot serve beam %d on this lexicon", w.beam);
+    rc = JAMD_ESTATE;
+  }
   if (rc != JAMD_OK) { jamd_beam_destroy(b); return rc; }
   *out = b;
   return JAMD_OK;
@@ -1900,7 +1925,9 @@ int jamd_beam_set_order_mode(jamd_beam *b, int mode) {
   if (!b) { jamd_set_error("jamd_beam_set_order_mode: NULL"); return JAMD_EINVAL; }
   if (b->streaming > 0) { jamd_set_error("jamd_beam_set_order_mode: a streaming session is open"); return JAMD_ESTATE; }
   switch (mode) {
-    case JAMD_ORDER_FAST: { const int rc = jamd_beam_set_strict_order(b, 0); b->exact = false; return rc; }
+    case JAMD_ORDER_FAST:
+      if (b->lex->d.nfwd > 0) { jamd_set_error("jamd_beam_set_order_mode: the canonical-tie kernel does not carry a forward DFA's state"); return JAMD_ESTATE; }
+      { const int rc = jamd_beam_set_strict_order(b, 0); b->exact = false; return rc; }
     case JAMD_ORDER_STRICT: b->exact = false; return jamd_beam_set_strict_order(b, 1);
     case JAMD_ORDER_EXACT:
     case JAMD_ORDER_EXACT_SERIAL:

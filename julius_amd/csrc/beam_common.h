@@ -36,13 +36,16 @@ constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its spa
   X(float, ng_uni_prob) X(float, ng_uni_bo) X(int, ng_bi_bgn) X(int, ng_bi_num) X(int, ng_bi_wid) X(float, ng_bi_prob) \
   /* grammar (per-category trees): category-pair matrix [ncat][ncat] (dfa_cp()), each root's category         \
      wton[start2wid[root]], the initial tokens [ninit] */                                                      \
-  X(unsigned char, cat_pair) X(int, root_cat) X(int, init_node) X(float, init_lscore)
+  X(unsigned char, cat_pair) X(int, root_cat) X(int, init_node) X(float, init_lscore)                         \
+  /* forward DFA (nfwd > 0; libjulius/src/beam.c:1739-1747, :2412-2422): arcs of a state in list order, the initial tokens' states */ \
+  X(int, fwd_off) X(int, fwd_label) X(int, fwd_to) X(int, init_to_state)
 
 struct LexDev {
   int nnode, nword, startnum, isolatenum, nshared, nlc, cdset_method, cdmax_num;
   int head_silwid, tail_silwid, ng_mode, ng_unk_id;
   float ng_unk_num_log, lm_weight, lm_penalty, lm_penalty_trans;
   int lm_type, ncat, ninit; float penalty1;
+  int nfwd;                           // states of the forward DFA, 0 = none (grammars only)
   const unsigned char *base;          // the arena
   // Cross-word LM table (N-gram lexicons): iwtab[ctx * isolatenum + i] = bigram_prob(ctx, wton(w_i)) + cprob(w_i) for the
   // word w_i behind isolated root i -- every entry max_successor_prob_iw() (factoring_sub.c:1049-1143) can ever put
@@ -109,6 +112,16 @@ __device__ __forceinline__ unsigned ord(float f) {
 }
 __device__ __forceinline__ float unord(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// The arc of forward-DFA state `st` labelled `cat` (first match in list order, libjulius/src/beam.c:1741-1746, :2415-2420):
+// its target state, or -1.  A token whose own state is -1 (no arc matched when it was created) finds nothing: the reference
+// would index st[-1] there -- such a token cannot arise from a consistent pair of automata.
+__device__ __forceinline__ int fwd_next(const LexDev &lx, int st, int cat) {
+  if (st < 0 || st >= lx.nfwd) return -1;
+  const int a0 = lx.fwd_off(st), a1 = lx.fwd_off(st + 1);
+  for (int a = a0; a < a1; a++) if (lx.fwd_label(a) == cat) return lx.fwd_to(a);
+  return -1;
 }
 
 // search_bigram(), ngram_access.c:225-247

@@ -1412,6 +1412,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
         const Tok tk = sv.load(j);
         const int sword = tk.pad0;
         if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(r))) continue;
+        if (lx.nfwd && fwd_next(lx, tk.pad1, lx.root_cat(r)) < 0) continue;     // forward DFA: no arc for this category (:2412-2422)
         const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
         float tmpsum = tk.score;
         tmpsum += lx.wordend_a(sword);
@@ -1550,7 +1551,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
       constexpr int CB = JAMD_XBEAM_CB;
       for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
         bool ok[CB]; int node[CB], slot[CB], tokid[CB]; int4 nr[CB]; unsigned long long key[CB]; unsigned fvis[CB];
-        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB];
+        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB], l_to[CB];       // l_to: forward-DFA state (TOKEN2.to_state), 0 without one
         float l_ls[CB];
 #pragma unroll
         for (int k = 0; k < CB; k++) {
@@ -1589,15 +1590,16 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
 #pragma unroll
         for (int k = 0; k < CB; k++) {
           const unsigned vis = ~(unsigned)key[k];
-          lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f;
+          lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f; l_to[k] = 0;
           if (!ok[k]) continue;
           int j = (int)(vis >> s1);
           const int sub = (int)(vis & submask);
           if (dfa && t == 0) {                                 // an initial token of the grammar
             l_ls[k] = lx.init_lscore(sub);
+            if (lx.nfwd) l_to[k] = lx.init_to_state(sub);      // :1739-1747
           } else if (j < n_surv && sub < XW) {                 // intra-word
             const Tok tk = sv.load(j);
-            l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid;
+            l_tre[k] = tk.last_tre; l_cword[k] = tk.last_cword; l_wid[k] = tk.last_wid; l_to[k] = tk.pad1;   // (:2120: the state is inherited)
             if (node[k] != tk.node && nr[k].y != 0) lmreq[k] = nr[k].y;   // beam_intra_word_core() :2069-2082
             else l_ls[k] = tk.last_lscore;
           } else {
@@ -1611,6 +1613,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
               float ng = lx.penalty1;
               ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
               l_ls[k] = ng;
+              if (lx.nfwd) l_to[k] = fwd_next(lx, tk.pad1, lx.root_cat(lx.startnum - 1 - (sub - XW)));   // the arc step B found (:2415-2420)
             } else if (iso) {                                // beam_inter_word() :2430-2438
               float p = 0.0f;
               if (last_word >= 0) {
@@ -1668,7 +1671,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
           const int s = tokid[k];
           const float score = unord((unsigned)(key[k] >> 32));
           Tok nw;
-          nw.node = node[k]; nw.pad0 = nr[k].x; nw.pad1 = 0;
+          nw.node = node[k]; nw.pad0 = nr[k].x; nw.pad1 = l_to[k];
           nw.last_tre = l_tre[k]; nw.last_cword = l_cword[k]; nw.last_wid = l_wid[k]; nw.last_lscore = l_ls[k];
           if (ent[k] >= 0) {
             nw.score = score + ac[k];

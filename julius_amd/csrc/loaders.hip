@@ -307,6 +307,7 @@ static int lexicon_desc_from_file(Blob &b, const char *path, const char *bingram
   d.cdset_method = I[7]; d.cdmax_num = I[8]; d.head_silwid = I[9]; d.tail_silwid = I[10]; d.nfscore = I[11]; d.nscword = I[12];
   d.ng_mode = I[13]; d.ng_nword = I[14]; d.ng_nbigram = I[15]; d.ng_unk_id = I[16];
   if (ir->second.count >= 21) { d.lm_type = I[18]; d.ncat = I[19]; d.ninit = I[20]; }      // files written before grammar support stop at 18
+  if (ir->second.count >= 22) d.nfwd = I[21];                                                // forward DFA (round 5)
   d.ng_unk_num_log = F[0]; d.lm_weight = F[1]; d.lm_penalty = F[2]; d.lm_penalty_trans = F[3];
   if (fr->second.count >= 5) d.penalty1 = F[4];
   if (d.nnode <= 0 || d.nword <= 0 || d.startnum < 0 || d.nset < 0 || d.nlc < 0 || d.nlcrow < 0) { jamd_set_error("%s: bad sizes", path); return JAMD_EINVAL; }
@@ -331,7 +332,13 @@ static int lexicon_desc_from_file(Blob &b, const char *path, const char *bingram
     d.cat_pair = view<unsigned char>(b, "cat_pair", 2, (long long)d.ncat * d.ncat, ok);
     d.start2wid = view<int>(b, "start2wid", 0, d.startnum, ok);
     d.init_node = view<int>(b, "init_node", 0, d.ninit, ok); d.init_lscore = view<float>(b, "init_lscore", 1, d.ninit, ok);
-  }
+    if (d.nfwd > 0) {
+      d.fwd_off = view<int>(b, "fwd_off", 0, (long long)d.nfwd + 1, ok);
+      const long long nfa = ok ? d.fwd_off[d.nfwd] : 0;
+      d.fwd_label = view<int>(b, "fwd_label", 0, nfa, ok); d.fwd_to = view<int>(b, "fwd_to", 0, nfa, ok);
+      d.init_to_state = view<int>(b, "init_to_state", 0, d.ninit, ok);
+    }
+  } else d.nfwd = 0;
   if (!ok) return JAMD_EINVAL;
   if (bingram) {
     // the N-gram half from the binary N-gram itself (libsent/src/ngram/ngram_read_bin.c:240-365): 1-gram and 2-gram

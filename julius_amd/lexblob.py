@@ -14,9 +14,10 @@ import numpy as np
 _DT = {0: np.int32, 1: np.float32, 2: np.uint8}
 _INTS = ["nnode", "nword", "startnum", "isolatenum", "nlc", "nlcrow", "nset", "cdset_method", "cdmax_num",
          "head_silwid", "tail_silwid", "nfscore", "nscword", "ng_mode", "ng_nword", "ng_nbigram", "ng_unk_id",
-         "_reserved", "lm_type", "ncat", "ninit"]
+         "_reserved", "lm_type", "ncat", "ninit", "nfwd"]
 _FLOATS = ["ng_unk_num_log", "lm_weight", "lm_penalty", "lm_penalty_trans", "penalty1"]
 DFA_ARRAYS = ["cat_pair", "start2wid", "init_node", "init_lscore"]
+FWD_ARRAYS = ["fwd_off", "fwd_label", "fwd_to", "init_to_state"]      # only with a forward DFA (nfwd > 0)
 ARRAYS = ["self_a", "next_a", "ac_off", "ac_to", "ac_a", "stend", "scid", "out_kind", "out_id", "lc_tab",
           "word_lc", "set_off", "set_states", "startnode", "start2isolate", "wordend_a", "wton", "cprob",
           "is_transparent", "word_head", "fscore", "scword", "ng_uni_prob", "ng_uni_bo", "ng_bi_bgn",
@@ -91,7 +92,9 @@ def save_gmm(model: dict, path, state2gs=None, nbest: int = 0) -> None:
 
 def save(lex: dict, path) -> None:
     """Same format as jamd_lexicon_save() (used to commit small golden fixtures)."""
-    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if lex.get("lm_type", 0) & 0xff != 0 else 0))]
+    isdfa = lex.get("lm_type", 0) & 0xff != 0
+    out = [b"JAMDLEX1", struct.pack("<i", 2 + len(ARRAYS) + (len(DFA_ARRAYS) if isdfa else 0) +
+                                    (len(FWD_ARRAYS) if isdfa and lex.get("nfwd", 0) > 0 else 0))]
 
     def put(name, arr):
         arr = np.ascontiguousarray(arr)
@@ -106,6 +109,9 @@ def save(lex: dict, path) -> None:
     if lex.get("lm_type", 0) & 0xff != 0:
         for k in DFA_ARRAYS:
             put(k, lex[k])
+        if lex.get("nfwd", 0) > 0:
+            for k in FWD_ARRAYS:
+                put(k, lex[k])
     Path(path).write_bytes(b"".join(out))
 
 
@@ -132,6 +138,7 @@ class LexiconDesc(_C.Structure):
         ("lm_weight", _cf), ("lm_penalty", _cf), ("lm_penalty_trans", _cf),
         ("lm_type", _ci), ("ncat", _ci), ("cat_pair", _vp), ("start2wid", _vp),
         ("ninit", _ci), ("init_node", _vp), ("init_lscore", _vp), ("penalty1", _cf),
+        ("nfwd", _ci), ("fwd_off", _vp), ("fwd_label", _vp), ("fwd_to", _vp), ("init_to_state", _vp),
     ]
 
 
@@ -151,7 +158,9 @@ def make_desc(lex: dict):
     d = LexiconDesc()
     scalars = {n for n, t in LexiconDesc._fields_ if t is not _vp}
     dflt = {"lm_type": 0, "ncat": 0, "ninit": 0, "penalty1": 0.0, "cat_pair": np.zeros(1, np.uint8),
-            "start2wid": np.zeros(1, np.int32), "init_node": np.zeros(1, np.int32), "init_lscore": np.zeros(1, np.float32)}
+            "start2wid": np.zeros(1, np.int32), "init_node": np.zeros(1, np.int32), "init_lscore": np.zeros(1, np.float32),
+            "nfwd": 0, "fwd_off": np.zeros(1, np.int32), "fwd_label": np.zeros(1, np.int32), "fwd_to": np.zeros(1, np.int32),
+            "init_to_state": np.zeros(1, np.int32)}
     for name, ctype in LexiconDesc._fields_:
         val = lex.get(name, dflt.get(name))           # fixtures written before grammar mode lack the DFA fields
         if name in scalars:

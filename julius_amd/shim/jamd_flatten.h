@@ -80,11 +80,12 @@ typedef struct {
   float *fscore; int *scword;
   float *ng_uni_prob, *ng_uni_bo; int *ng_bi_bgn, *ng_bi_num, *ng_bi_wid; float *ng_bi_prob;
   unsigned char *cat_pair; int *start2wid, *init_node; float *init_lscore;
+  int *fwd_off, *fwd_label, *fwd_to, *init_to_state;      /* forward DFA (NULL without one) */
 } jamd_flat_lexicon;
 
 /* Walk r->wchmm (after j_final_fusion()) and fill `out`.  JAMD_EINVAL for the
- * configurations the device beam does not cover (grammars with a
- * forward DFA or without per-category trees, multipath models, user LM plugin, 24-bit
+ * configurations the device beam does not cover (grammars
+ * without per-category trees, a forward DFA together with a multipath model, user LM plugin, 24-bit
  * compacted 2-gram index). */
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
 /* The same for a multipath acoustic model (lm_type | JAMD_LM_MULTIPATH); not yet accepted by

@@ -114,8 +114,8 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   if (multipath && !g_allow_multipath) return JAMD_EINVAL;
   if (word_mode) {
     if (!wchmm->category_tree) return JAMD_EINVAL;
-  } else if (dfa_mode) {              /* grammar: per-category trees, no forward DFA */
-    if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL || wchmm->dfa_forward != NULL)
+  } else if (dfa_mode) {              /* grammar: per-category trees; a forward DFA only without multipath */
+    if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL || (wchmm->dfa_forward != NULL && multipath))
       return JAMD_EINVAL;
   } else {
     if (r->lmtype != LM_PROB || ng == NULL) return JAMD_EINVAL;
@@ -280,6 +280,22 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
     out->start2wid = NEW(int, wchmm->startnum);
     for (i = 0; i < wchmm->startnum; i++) out->start2wid[i] = wchmm->start2wid[i];
     out->init_node = NEW(int, W); out->init_lscore = NEW(float, W);
+    if (!word_mode && wchmm->dfa_forward != NULL) {
+      /* the forward DFA as CSR, arcs in list order (the reference takes the first arc whose label matches, beam.c:1741, :2415) */
+      DFA_INFO *fw = wchmm->dfa_forward;
+      DFA_ARC *ac;
+      int s2, na = 0;
+      for (s2 = 0; s2 < fw->state_num; s2++) for (ac = fw->st[s2].arc; ac; ac = ac->next) na++;
+      out->fwd_off = NEW(int, fw->state_num + 1); out->fwd_label = NEW(int, na + 1); out->fwd_to = NEW(int, na + 1);
+      out->init_to_state = NEW(int, W);
+      na = 0;
+      for (s2 = 0; s2 < fw->state_num; s2++) {
+        out->fwd_off[s2] = na;
+        for (ac = fw->st[s2].arc; ac; ac = ac->next) { out->fwd_label[na] = ac->label; out->fwd_to[na] = ac->to_state; na++; }
+      }
+      out->fwd_off[fw->state_num] = na;
+      d->nfwd = fw->state_num;
+    }
     for (m = r->lm->grammars; m; m = m->next) {
       if (!m->active) continue;
       if (word_mode) {                                 /* every word of the active lists, beam.c:1762-1788 */
@@ -301,6 +317,13 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
           seen[node] = 1;
           out->init_node[ninit] = node;
           out->init_lscore[ninit] = r->config->lmp.penalty1 + winfo->cprob[wid];   /* beam.c:1724-1727 */
+          if (out->init_to_state != NULL) {            /* beam.c:1739-1747: from boslist[gram].dfa_state = m->state_begin (:1694) */
+            int a2, ts = -1;
+            if (m->state_begin >= 0 && m->state_begin < d->nfwd)
+              for (a2 = out->fwd_off[m->state_begin]; a2 < out->fwd_off[m->state_begin + 1]; a2++)
+                if (out->fwd_label[a2] == t) { ts = out->fwd_to[a2]; break; }
+            out->init_to_state[ninit] = ts;
+          }
           ninit++;
         }
       }
@@ -308,6 +331,7 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
     free(seen);
     d->lm_type = word_mode ? JAMD_LM_WORD : JAMD_LM_DFA; d->ncat = C; d->ninit = ninit; d->penalty1 = r->config->lmp.penalty1;
     d->cat_pair = out->cat_pair; d->start2wid = out->start2wid; d->init_node = out->init_node; d->init_lscore = out->init_lscore;
+    d->fwd_off = out->fwd_off; d->fwd_label = out->fwd_label; d->fwd_to = out->fwd_to; d->init_to_state = out->init_to_state;
     d->ng_unk_id = -1;
   }
 
@@ -346,6 +370,7 @@ void jamd_flat_lexicon_free(jamd_flat_lexicon *f)
   free(f->cprob); free(f->is_transparent); free(f->word_head); free(f->fscore); free(f->scword);
   free(f->ng_uni_prob); free(f->ng_uni_bo); free(f->ng_bi_bgn); free(f->ng_bi_num); free(f->ng_bi_wid);
   free(f->ng_bi_prob); free(f->cat_pair); free(f->start2wid); free(f->init_node); free(f->init_lscore);
+  free(f->fwd_off); free(f->fwd_label); free(f->fwd_to); free(f->init_to_state);
   memset(f, 0, sizeof(*f));
 }
 
@@ -405,20 +430,20 @@ int jamd_lexicon_append_separation(const char *path, int separate_wnum)
 int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
 {
   FILE *f = fopen(path, "wb");
-  int nrec = 30 + ((d->lm_type & 0xff) != JAMD_LM_NGRAM ? 4 : 0), rc = 0;
-  int ints[21]; float floats[5];
+  int nrec = 30 + ((d->lm_type & 0xff) != JAMD_LM_NGRAM ? 4 : 0) + (d->nfwd > 0 ? 4 : 0), rc = 0;
+  int ints[22]; float floats[5];
   if (f == NULL) return JAMD_EINVAL;
   ints[0] = d->nnode; ints[1] = d->nword; ints[2] = d->startnum; ints[3] = d->isolatenum;
   ints[4] = d->nlc; ints[5] = d->nlcrow; ints[6] = d->nset; ints[7] = d->cdset_method; ints[8] = d->cdmax_num;
   ints[9] = d->head_silwid; ints[10] = d->tail_silwid; ints[11] = d->nfscore; ints[12] = d->nscword;
   ints[13] = d->ng_mode; ints[14] = d->ng_nword; ints[15] = d->ng_nbigram; ints[16] = d->ng_unk_id; ints[17] = 0;
-  ints[18] = d->lm_type; ints[19] = d->ncat; ints[20] = d->ninit; floats[4] = d->penalty1;
+  ints[18] = d->lm_type; ints[19] = d->ncat; ints[20] = d->ninit; ints[21] = d->nfwd; floats[4] = d->penalty1;
   floats[0] = d->ng_unk_num_log; floats[1] = d->lm_weight; floats[2] = d->lm_penalty; floats[3] = d->lm_penalty_trans;
   fwrite("JAMDLEX1", 1, 8, f); fwrite(&nrec, 4, 1, f);
 #define I32(nm, p, n) rc |= put_rec(f, nm, 0, (n), (p))
 #define F32(nm, p, n) rc |= put_rec(f, nm, 1, (n), (p))
 #define U8(nm, p, n)  rc |= put_rec(f, nm, 2, (n), (p))
-  I32("ints", ints, 21); F32("floats", floats, 5);
+  I32("ints", ints, 22); F32("floats", floats, 5);
   F32("self_a", d->self_a, d->nnode); F32("next_a", d->next_a, d->nnode);
   I32("ac_off", d->ac_off, d->nnode + 1); I32("ac_to", d->ac_to, d->ac_off[d->nnode]); F32("ac_a", d->ac_a, d->ac_off[d->nnode]);
   I32("stend", d->stend, d->nnode); I32("scid", d->scid, d->nnode);
@@ -435,6 +460,10 @@ int jamd_lexicon_save(const jamd_lexicon_desc *d, const char *path)
   if ((d->lm_type & 0xff) != JAMD_LM_NGRAM) {
     U8("cat_pair", d->cat_pair, d->ncat * d->ncat); I32("start2wid", d->start2wid, d->startnum);
     I32("init_node", d->init_node, d->ninit); F32("init_lscore", d->init_lscore, d->ninit);
+    if (d->nfwd > 0) {
+      I32("fwd_off", d->fwd_off, d->nfwd + 1); I32("fwd_label", d->fwd_label, d->fwd_off[d->nfwd]);
+      I32("fwd_to", d->fwd_to, d->fwd_off[d->nfwd]); I32("init_to_state", d->init_to_state, d->ninit);
+    }
   }
 #undef I32
 #undef F32

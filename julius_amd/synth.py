@@ -1001,3 +1001,87 @@ def make_rejection_gmm(workdir, centre, names=("speech", "noise", "music", "coug
     path = Path(workdir) / "rejgmm"
     path.write_text("\n".join(L) + "\n")
     return path, model, list(names)
+
+
+def make_forward_grammar(task, ncat=3, maxwords=4, seed=0):
+    """A DFA grammar over the words of a triphone task WITH the forward automaton recent mkdfa.pl writes next to the
+    reversed one (`g.dfa.forward`, read by libjulius/src/multi-gram.c:868-880): sentences <s> W{2..maxwords} </s> where a
+    word of category c is followed by one of category c+1 or c+2 (mod ncat).  The length bound is what the category-pair
+    constraint of the first pass (dfa_cp(), from the reversed automaton) cannot express, so the forward automaton's
+    states really prune cross-word transitions (libjulius/src/beam.c:2412-2422).  The reversed automaton g.dfa is derived
+    from the forward one (NFA reversal + subset construction), so both describe the same language.
+    Categories: 0 = </s>, 1 = <s>, 2.. = words.  Returns make_triphone_grammar()'s dict + `fwd` = (arcs, accepting)."""
+    rng = np.random.default_rng(seed + 177)
+    workdir = Path(task["dir"])
+    words = task["words"]
+    cat = [int(rng.integers(0, ncat)) for _ in words]
+    dl = ["0 [</s>] silE", "1 [<s>] silB"] + [f"{2 + c} [{w}] " + " ".join(ph) for (w, ph), c in zip(words, cat)]
+    (workdir / "g.dict").write_text("\n".join(dl) + "\n")
+    # forward automaton: 0 --<s>--> 1 (no word yet); (p words, last category c) = state 2 + (p - 1) * ncat + c; final F
+    arcs = {(0, 1): 1}
+    F = 2 + maxwords * ncat
+    st = lambda p, c: 2 + (p - 1) * ncat + c
+    for c in range(ncat):
+        arcs[(1, 2 + c)] = st(1, c)
+    for p in range(1, maxwords + 1):
+        for c in range(ncat):
+            if p < maxwords:
+                for c2 in ((c + 1) % ncat, (c + 2) % ncat):
+                    arcs[(st(p, c), 2 + c2)] = st(p + 1, c2)
+            if p >= 2:
+                arcs[(st(p, c), 0)] = F
+    accept = {F}
+    fl = [f"{s} {l} {n} {1 if s in accept else 0} 0" for (s, l), n in sorted(arcs.items())] + [f"{F} -1 -1 1 0"]
+    (workdir / "g.dfa.forward").write_text("\n".join(fl) + "\n")
+    # reversed automaton by subset construction: start = accepting states, accept = subsets holding the forward start
+    rev = {}
+    for (s, l), n in arcs.items():
+        rev.setdefault((n, l), set()).add(s)
+    start = frozenset(accept)
+    ids, order, lines = {start: 0}, [start], []
+    i = 0
+    while i < len(order):
+        cur = order[i]
+        labels = sorted({l for (n, l) in rev if n in cur})
+        out_any = False
+        for l in labels:
+            nxt = frozenset(s for n in cur for s in rev.get((n, l), ()))
+            if nxt not in ids:
+                ids[nxt] = len(order); order.append(nxt)
+            lines.append(f"{ids[cur]} {l} {ids[nxt]} {1 if 0 in cur else 0} 0")
+            out_any = True
+        if not out_any:
+            lines.append(f"{ids[cur]} -1 -1 {1 if 0 in cur else 0} 0")
+        i += 1
+    (workdir / "g.dfa").write_text("\n".join(lines) + "\n")
+    g = dict(task)
+    g.update(dfa=workdir / "g.dfa", gdict=workdir / "g.dict", word_cat=cat, ncat=ncat, wrap=True, fwd=(arcs, accept), maxwords=maxwords)
+    return g
+
+
+def make_forward_grammar_utterance(g, seed=0, frames_per_state=3, noise=0.7, nwords=None):
+    """Frames along a random sentence of make_forward_grammar()'s language -- or, nwords > maxwords, along a category chain
+    that is TOO LONG for it (every adjacent pair allowed, the length not): what the forward automaton is there to cut."""
+    rng = np.random.default_rng(seed)
+    ncat = g["ncat"]
+    by_cat = [[i for i, c in enumerate(g["word_cat"]) if c == k] for k in range(ncat)]
+    n = int(rng.integers(2, g["maxwords"] + 1)) if nwords is None else nwords
+    c = int(rng.integers(0, ncat))
+    ids = []
+    for _ in range(n):
+        while not by_cat[c]:
+            c = (c + 1) % ncat
+        ids.append(int(rng.choice(by_cat[c])))
+        c = (c + int(rng.integers(1, 3))) % ncat
+    model = g["model"]
+    S = len(model["st_off"]) - 1
+    per = (S - 6) // len(g["phones"])
+    seq = [S - 6, S - 5, S - 4]
+    for i in ids:
+        for p in g["words"][i][1]:
+            base = g["phones"].index(p) * per
+            seq += [int(base + rng.integers(0, per)) for _ in range(3)]
+    seq += [S - 3, S - 2, S - 1]
+    st = np.repeat(np.array(seq), frames_per_state)
+    fr = model["centre"][st] + rng.normal(0, noise, size=(len(st), model["mean"].shape[1]))
+    return fr.astype(np.float32), [g["words"][i][0] for i in ids]

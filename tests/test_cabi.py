@@ -13,7 +13,7 @@ def test_library_loads_and_exports_declared_symbols():
     l = lib.load()
     missing = [s for s in lib.declared_symbols() if not hasattr(l, s)]
     assert not missing, f"declared in include/julius_amd.h but not exported: {missing}"
-    assert l.jamd_abi_version() == 3
+    assert l.jamd_abi_version() == 4
 
 
 def test_header_is_plain_c(tmp_path):

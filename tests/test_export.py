@@ -13,7 +13,7 @@ from oracle import pyoracle
 EXPORT = pyoracle.HERE.parent / "julius_amd" / "jamd_export"
 
 
-@pytest.mark.parametrize("lm", ["ngram", "grammar"])
+@pytest.mark.parametrize("lm", ["ngram", "grammar", "grammar_forward_dfa"])
 def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
     if not EXPORT.exists():
         pytest.skip("julius_amd/jamd_export not built")
@@ -22,7 +22,7 @@ def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
         args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"],
                 "-input", "htkparam", "-gprune", "none", "-b", "120", "-sepnum", "4"]
     else:
-        task = synth.make_triphone_grammar(task, ncat=3, seed=91)
+        task = synth.make_triphone_grammar(task, ncat=3, seed=91) if lm == "grammar" else synth.make_forward_grammar(task, ncat=3, maxwords=3, seed=91)
         args = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
                 "-input", "htkparam", "-gprune", "none", "-b", "120", "-penalty1", "-2.0"]
     args = [str(a) for a in args]
@@ -34,6 +34,18 @@ def test_export_program_matches_in_process_flattening(ref, tmp_path, lm):
     assert a.keys() == b.keys()
     for k in a:
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    if lm == "grammar_forward_dfa":
+        # the forward automaton of g.dfa.forward as CSR (arcs of a state in the reference's list order = reverse file order),
+        # the initial tokens' states (beam.c:1739-1747), and the python writer reproduces the file byte for byte
+        arcs, accept = task["fwd"]
+        assert a["nfwd"] == 1 + max(max(s for s, _ in arcs), max(arcs.values()))
+        got = {(s, int(a["fwd_label"][e])): int(a["fwd_to"][e]) for s in range(a["nfwd"]) for e in range(a["fwd_off"][s], a["fwd_off"][s + 1])}
+        assert got == {k: v for k, v in arcs.items()}
+        assert list(a["init_to_state"]) == [arcs[(0, 1)]] * a["ninit"]      # every sentence starts with <s> (category 1)
+        lexblob.save(a, tmp_path / "again.lex")
+        assert (tmp_path / "again.lex").read_bytes() == (tmp_path / "m.lex").read_bytes()
+    else:
+        assert a.get("nfwd", 0) == 0
     am = ref.am_load(task["hmmdefs"], task["hmmlist"])
     want, got = am.export(), lexblob.load_gmm(tmp_path / "m.am")
     for k in ("mean", "ivar", "gconst", "st_off", "ent_dens", "ent_logw"):
