@@ -116,3 +116,25 @@ def test_progout_interim_results(tmp_path, interval):
     want, got = pick(w), pick(g)
     assert sum(1 for ln in want if ln.startswith("pass1_best:")) > 3 * 3      # several interim lines per input
     assert got == want
+
+
+def test_julius_over_device_first_pass_grammar_with_forward_dfa(tmp_path):
+    """The real program on a grammar compiled WITH a forward DFA (`g.dfa.forward` next to `g.dfa`, what recent mkdfa.pl
+    writes): bin/julius_amd -- device scoring + device first pass carrying the automaton's state, then the reference's
+    own second pass -- prints what the plain bin/julius prints, on sentences of the language and on chains too long for it."""
+    _need("julius", "julius_amd")
+    task = synth.make_forward_grammar(synth.make_triphone_task(tmp_path, seed=41, nword=120, nphone=10, S=160), ncat=3, maxwords=3, seed=41)
+    files = []
+    for u in range(5):
+        fr, _ = synth.make_forward_grammar_utterance(task, seed=4100 + u, nwords=None if u < 3 else 3 + u)
+        synth.write_htk_param(tmp_path / f"u{u}.mfc", fr)
+        files.append(str(tmp_path / f"u{u}.mfc"))
+    (tmp_path / "list").write_text("\n".join(files) + "\n")
+    args = [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"], "-input", "htkparam",
+                             "-b", "200", "-b2", "30", "-n", "1", "-s", "500", "-gprune", "none", "-filelist", tmp_path / "list"]]
+    plain = _run("julius", args)
+    assert "reading additional forward dfa" in plain
+    want = _results(plain)
+    got = _results(_run("julius_amd", args))
+    assert len([x for x in want if x.startswith("sentence1")]) >= 3
+    assert got == want
