@@ -159,7 +159,7 @@ static void *run_device(void *arg)
   const int nfile = j->nfile;
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   int veclen, nstate, first, k;
-  chunk ck[2];
+  chunk ck[3];
   hosttime ht = {0.0, 0.0, 0, 0};
   double t_start = now_s(), t_models, t_done;
   long frames_total = 0;
@@ -187,32 +187,39 @@ static void *run_device(void *arg)
   if (strict && jamd_beam_set_strict_order(bm, 1) != JAMD_OK) die("strict order");
   if (!strict && order >= 0 && jamd_beam_set_order_mode(bm, order) != JAMD_OK) die("order mode");
 
-  /* Launches of up to LAUNCH utterances over two streams: `s_copy` uploads and scores, `s_beam` searches.  While the
-   * first pass of launch k runs, the host reads the files of launch k+1, uploads them and -- once that first pass is
-   * on the device (jamd_beam_wait_started(): queued any earlier, the scoring workgroups take the LDS the first pass
-   * wants for its second utterance per CU and it takes twice as long) -- queues their scoring, which fills the CUs
-   * that the shorter utterances of launch k leave. */
+  /* Launches of up to LAUNCH utterances over two streams: `s_copy` uploads and scores, `s_beam` searches; THREE chunks in
+   * flight: while the first pass of launch k runs, launch k+1 (read and uploaded one iteration earlier) is scored -- queued
+   * at once behind jamd_beam_stream_wait_resident(): the scoring starts when that first pass holds its CUs (queued any
+   * earlier, the scoring workgroups take the LDS the first pass wants for its second utterance per CU and it takes twice
+   * as long) and fills the CUs that the shorter utterances of launch k leave -- and the host reads the files of launch
+   * k+2.  File reading is then off the device's critical path whatever the file system does (round 5: with two chunks a
+   * box with slow reads delayed the QUEUEING of the next scoring by the read time: 442 instead of 300 ms per launch). */
   if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
   memset(ck, 0, sizeof(ck));
   if (jamd_engine_sync(e) != JAMD_OK) die("model upload");
   t_models = now_s();                                  /* engine + models + work area are up: the decode clock starts */
-  if (nfile > 0) { load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy); }
+  if (nfile > 0) {
+    load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy);
+    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch 0 */
+    if (launch < nfile) load(e, &ck[1], files, launch, nfile, veclen, nstate, s_copy, &ht);
+  }
   for (first = 0, k = 0; first < nfile; first += launch, k++) {
-    chunk *c = &ck[k & 1];
+    chunk *c = &ck[k % 3];
     const int n = c->n;
     const int *off = c->off;
     int u;
     float *us = NULL;
     jamd_pass1_result *res = (jamd_pass1_result *)malloc(sizeof(jamd_pass1_result) * LAUNCH);
     if (res == NULL) die("out of memory");
-    if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch k */
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
-    if (first + launch < nfile) {
-      chunk *nx = &ck[(k + 1) & 1];
-      load(e, nx, files, first + launch, nfile, veclen, nstate, s_copy, &ht);
+    if (first + launch < nfile) {                      /* launch k+1: its frames are on their way or there already */
+      chunk *nx = &ck[(k + 1) % 3];
       if (jamd_beam_stream_wait_resident(bm, s_copy) != JAMD_OK) die("first pass");   /* s_copy goes on once the first pass holds its CUs */
       score(nx, nstate, gm, dn, gs, s_copy);
+      if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");        /* the next first pass waits for exactly these scores */
     }
+    if (first + 2 * launch < nfile)                    /* launch k+2: read and upload while the device is busy with k and k+1 */
+      load(e, &ck[(k + 2) % 3], files, first + 2 * launch, nfile, veclen, nstate, s_copy, &ht);
     { const double tw = now_s();
       if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
       ht.sync_s += now_s() - tw; frames_total += off[n]; }
@@ -250,7 +257,7 @@ static void *run_device(void *arg)
                     "\"decode_s\": %.6f, \"host_read_s\": %.6f, \"host_wait_s\": %.6f, \"h2d_bytes\": %zu, \"rtf_inv\": %.3f}}\n",
             j->device, nfile, frames_total, ht.launches, t_models - t_start, t_done - t_models, ht.read_s, ht.sync_s, ht.h2d_bytes,
             t_done > t_models ? (double)frames_total / 100.0 / (t_done - t_models) : 0.0);
-  for (k = 0; k < 2; k++) {
+  for (k = 0; k < 3; k++) {
     if (ck[k].frames) jamd_host_free(e, ck[k].frames);
     if (ck[k].d_frames) jamd_free(e, ck[k].d_frames);
     if (ck[k].d_scores) jamd_free(e, ck[k].d_scores);
