@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X (driver contract, see README).
 
-One JSON line per run.  Top level = BASELINE.json configs[1] ("C2"): tied-state
+stdout: every nested result in full as its own line ({"bench_detail": key, ...}), then -- LAST -- one compact JSON line
+(julius_amd/benchfmt.py: the contract keys of the top-level workload + a short record per nested configuration, < 6 KB;
+the whole tree also goes to bench_detail.json).  Top level = BASELINE.json configs[1] ("C2"): tied-state
 triphone-sized GMM, S=3000 states x M=16 mixtures x D=39, outprob kernel only.  One "step" = one
 pass of the GMM outprob path over `--utts` (default 64) synthetic utterances x 1000 frames already
 resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
@@ -31,9 +33,14 @@ resident in HBM: [T][39] floats in, [T][3000] log10 likelihoods out.
              -b 4000 -multipath): the lexicon is the reference's multipath lexicon, the first pass is the multipath
              frame of the exact-order kernel (csrc/beam_exact_mp.h); `parity` against julius -1pass [-dnnconf]
              -multipath utterance by utterance (`--workload e2e|e2e-dnn --multipath` runs them alone).
+  batch, batch_mp, batch_dnn, batch_dnn_mp = the same four tasks through the PRODUCT's serving loop: `jamd_batch -time` (C over
+             the C ABI) over HTK parameter files on tmpfs -- file read, pinned staging, H2D, scoring, first pass, D2H of the
+             results, result lines -- on the process's own clock (model load excluded); `vs_e2e_same_task` = its RTF^-1 over
+             the e2e entry's, `parity` = its result lines against the in-process results.
   dnn      = nested result for the configs[3] scoring half ("C4"): MFMA fp32 DNN.
   cpu_baseline (top level and nested) = the COMPILED REFERENCE (oracle/_ref, kind "reference") on a
-             bounded sample of the same workload: one host core, plus an N-process figure for C2.
+             bounded sample of the same workload: one host core, an N-process figure (C2: eager scoring; C3 / C4: 16 julius
+             -1pass processes side by side), the full two-pass recogniser on a few of the same files, DNN num_threads 2 / half the cores.
 
 Multi-GPU: one process per GPU; utterances are sharded, no data-path collective ("weak" scaling:
 per-GPU batch fixed; `e2e_strong` / `--workload e2e --strong` = the fixed 512-utterance batch).  RCCL is used for the barrier, the max-over-ranks clock and the gather of the

@@ -18,8 +18,9 @@
  * Every line of the file list names an HTK parameter file (what Julius reads with
  * `-input htkparam`: 12-byte big-endian header nSamples, sampPeriod, sampSize, parmKind, then
  * big-endian float vectors -- libsent/src/anlz/rdparam.c).  All utterances are scored and
- * decoded in device launches of up to 512 utterances (reading, uploading and -- in the CUs its shorter
- * utterances leave -- scoring launch k+1 overlap the first pass of launch k); one result line per utterance:
+ * decoded in device launches of up to 512 utterances, three launches in flight: while the first pass of launch k runs,
+ * launch k+1 is scored (in the CUs the shorter utterances of launch k leave) and the files of launch k+2 are read into
+ * pinned staging memory and uploaded; -time reports the process's own clock.  One result line per utterance:
  *   <file> status=<0 ok|1 no result|2 beam died|3 trellis overflow> score=<pass-1 score> words=<id id ...>
  * which is what get_back_trellis_end() leaves in r->pass1_wseq / pass1_score.
  */
