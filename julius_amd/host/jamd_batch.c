@@ -31,6 +31,10 @@
 #include <string.h>
 #include <pthread.h>
 #include <time.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/types.h>
+#include <sys/stat.h>
 #include "julius_amd.h"
 
 static void die(const char *what)
@@ -48,31 +52,52 @@ static double now_s(void)
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* header of an HTK parameter file: the frame count, or -1 when it is not `veclen`-dim float vectors */
+/* frames of an HTK parameter file of `veclen`-dim float vectors, from its SIZE (one stat() instead of open + read + close:
+ * on a box whose file system makes an open cost 0.2 ms, two opens per 220 KB file were most of a launch's host time); the
+ * header is checked when the file is read.  -1: not there / not a whole number of vectors. */
 static int htk_frames(const char *path, int veclen)
 {
-  FILE *f = fopen(path, "rb");
-  unsigned char h[12];
-  int n, size;
-  if (f == NULL) return -1;
-  if (fread(h, 1, 12, f) != 12) { fclose(f); return -1; }
-  fclose(f);
-  n = (int)be32(h); size = (h[8] << 8) | h[9];
-  if (n <= 0 || size != 4 * veclen) return -1;
-  return n;
+  struct stat st;
+  long body;
+  if (stat(path, &st) != 0 || st.st_size < 12 + 4 * (long)veclen) return -1;
+  body = (long)st.st_size - 12;
+  if (body % (4 * (long)veclen) != 0 || body / (4 * (long)veclen) > 0x7fffffffL) return -1;
+  return (int)(body / (4 * (long)veclen));
 }
 
-/* the n vectors of the file straight into `dst` (pinned staging memory), byte-swapped in place */
-static int htk_read_into(const char *path, float *dst, size_t nfloat)
+/* One reader: files [u0, u1) of a launch -> their slots of the pinned staging buffer.  A file is read whole (header and
+ * vectors, one open) into an ordinary cached bounce buffer, its header checked against what its size promised, and the
+ * byte swap WRITES the pinned buffer once, front to back: pinned host memory may be mapped uncached for the CPU, and an
+ * in-place swap would read it back at a few hundred MB/s. */
+typedef struct {
+  char **files; const int *off; float *frames; int veclen, u0, u1, rc;
+  unsigned char *bounce; size_t bounce_cap;
+} reader;
+
+static void *reader_main(void *arg)
 {
-  FILE *f = fopen(path, "rb");
-  uint32_t *w = (uint32_t *)dst;
-  size_t i;
-  if (f == NULL) return -1;
-  if (fseek(f, 12, SEEK_SET) != 0 || fread(dst, sizeof(float), nfloat, f) != nfloat) { fclose(f); return -1; }
-  fclose(f);
-  for (i = 0; i < nfloat; i++) w[i] = __builtin_bswap32(w[i]);
-  return 0;
+  reader *r = (reader *)arg;
+  int u;
+  r->rc = 0;
+  for (u = r->u0; u < r->u1 && r->rc == 0; u++) {
+    const int n = r->off[u + 1] - r->off[u];
+    const size_t nfloat = (size_t)n * (size_t)r->veclen, bytes = 12 + 4 * nfloat;
+    uint32_t *w = (uint32_t *)(r->frames + (size_t)r->off[u] * r->veclen);
+    size_t got = 0, i;
+    int fd;
+    if (bytes > r->bounce_cap) {
+      free(r->bounce);
+      r->bounce_cap = bytes + bytes / 4 + 4096;
+      r->bounce = (unsigned char *)malloc(r->bounce_cap);
+      if (r->bounce == NULL) { r->bounce_cap = 0; r->rc = -1 - u; break; }
+    }
+    if ((fd = open(r->files[u], O_RDONLY)) < 0) { r->rc = -1 - u; break; }
+    while (got < bytes) { const ssize_t k = read(fd, r->bounce + got, bytes - got); if (k <= 0) break; got += (size_t)k; }
+    close(fd);
+    if (got != bytes || (int)be32(r->bounce) != n || (((int)r->bounce[8] << 8) | r->bounce[9]) != 4 * r->veclen) { r->rc = -1 - u; break; }
+    for (i = 0; i < nfloat; i++) { uint32_t v; memcpy(&v, r->bounce + 12 + 4 * i, 4); w[i] = __builtin_bswap32(v); }
+  }
+  return NULL;
 }
 
 /* One launch: up to LAUNCH utterances, their frames on the host and on the device, their score rows.  512 = two per CU
@@ -91,10 +116,29 @@ typedef struct {
 static int launch = LAUNCH;      /* -launch N: utterances per device launch (1 .. LAUNCH) */
 static int want_time = 0;        /* -time: one JSON line per device on stderr (model load, decode wall time, host read time) */
 
-typedef struct { double read_s, sync_s; size_t h2d_bytes; int launches; } hosttime;
+#define READERS 4                 /* host threads that read and byte-swap the files of a launch side by side */
+typedef struct { double read_s, sync_s; size_t h2d_bytes; int launches; reader rd[READERS]; } hosttime;
 
 /* reads the files of the launch that starts at files[first] into the chunk's pinned buffer and queues the upload of
  * the frames on `stream` (nothing is waited for) */
+/* the chunk's buffers for a launch of need_fr bytes of frames and need_sc bytes of scores (pinning 100+ MB and a multi-GB
+ * hipMalloc take 0.1 - 0.3 s: run_device() does it for the largest launch of the list before the decode clock starts) */
+static void reserve(jamd_engine *e, chunk *c, size_t need_fr, size_t need_sc)
+{
+  if (need_fr > c->cap_frames) {
+    if (c->frames) jamd_host_free(e, c->frames);
+    if (c->d_frames) jamd_free(e, c->d_frames);
+    c->cap_frames = need_fr + need_fr / 16;
+    if (jamd_host_alloc(e, c->cap_frames, (void **)&c->frames) != JAMD_OK ||
+        jamd_malloc(e, c->cap_frames, (void **)&c->d_frames) != JAMD_OK) die("frame buffers");
+  }
+  if (need_sc > c->cap_scores) {
+    if (c->d_scores) jamd_free(e, c->d_scores);
+    c->cap_scores = need_sc + need_sc / 16;
+    if (jamd_malloc(e, c->cap_scores, (void **)&c->d_scores) != JAMD_OK) die("score buffer");
+  }
+}
+
 static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream, hosttime *ht)
 {
   const double t0 = now_s();
@@ -109,22 +153,21 @@ static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, i
   }
   need_fr = sizeof(float) * (size_t)c->off[c->n] * (size_t)veclen;
   need_sc = sizeof(float) * (size_t)c->off[c->n] * (size_t)nstate;
-  if (need_fr > c->cap_frames) {
-    if (c->frames) jamd_host_free(e, c->frames);
-    if (c->d_frames) jamd_free(e, c->d_frames);
-    c->cap_frames = need_fr + need_fr / 4;
-    if (jamd_host_alloc(e, c->cap_frames, (void **)&c->frames) != JAMD_OK ||
-        jamd_malloc(e, c->cap_frames, (void **)&c->d_frames) != JAMD_OK) die("frame buffers");
-  }
-  if (need_sc > c->cap_scores) {
-    if (c->d_scores) jamd_free(e, c->d_scores);
-    c->cap_scores = need_sc + need_sc / 4;
-    if (jamd_malloc(e, c->cap_scores, (void **)&c->d_scores) != JAMD_OK) die("score buffer");
-  }
-  for (u = 0; u < c->n; u++)
-    if (htk_read_into(files[first + u], c->frames + (size_t)c->off[u] * veclen, (size_t)(c->off[u + 1] - c->off[u]) * veclen) != 0) {
-      fprintf(stderr, "jamd_batch: %s is shorter than its header says\n", files[first + u]); exit(1);
+  reserve(e, c, need_fr, need_sc);                     /* (sized before the clock starts, run_device(): a no-op here unless files changed) */
+  {
+    pthread_t th[READERS];
+    int r, started = 0;
+    for (r = 0; r < READERS; r++) {
+      reader *rd = &ht->rd[r];
+      rd->files = files + first; rd->off = c->off; rd->frames = c->frames; rd->veclen = veclen;
+      rd->u0 = (int)((long)c->n * r / READERS); rd->u1 = (int)((long)c->n * (r + 1) / READERS);
+      if (r + 1 < READERS && pthread_create(&th[r], NULL, reader_main, rd) == 0) started |= 1 << r;
+      else reader_main(rd);                            /* the last share (and any share whose thread did not start) on this thread */
     }
+    for (r = 0; r < READERS; r++) if (started & (1 << r)) pthread_join(th[r], NULL);
+    for (r = 0; r < READERS; r++)
+      if (ht->rd[r].rc != 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first - 1 - ht->rd[r].rc], veclen); exit(1); }
+  }
   if (jamd_memcpy_h2d_async(e, c->d_frames, c->frames, need_fr, stream) != JAMD_OK) die("upload");
   ht->read_s += now_s() - t0; ht->h2d_bytes += need_fr; ht->launches++;
 }
@@ -161,7 +204,7 @@ static void *run_device(void *arg)
   jamd_engine *e; jamd_gmm *gm = NULL; jamd_dnn *dn = NULL; jamd_gms *gs = NULL; jamd_rejgmm *rj = NULL; jamd_lexicon *lx; jamd_beam *bm;
   int veclen, nstate, first, k;
   chunk ck[3];
-  hosttime ht = {0.0, 0.0, 0, 0};
+  hosttime ht;
   double t_start = now_s(), t_models, t_done;
   long frames_total = 0;
   void *s_copy = NULL, *s_beam = NULL;
@@ -169,6 +212,7 @@ static void *run_device(void *arg)
   char *text = (char *)malloc(linecap);
 
   if (text == NULL) die("out of memory");
+  memset(&ht, 0, sizeof(ht));
   if (jamd_engine_create(j->device, &e) != JAMD_OK) die("engine");
   if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }
   else if (jamd_dnn_load(e, dnnconf, &dn) != JAMD_OK) die("DNN");
@@ -197,12 +241,28 @@ static void *run_device(void *arg)
    * box with slow reads delayed the QUEUEING of the next scoring by the read time: 442 instead of 300 ms per launch). */
   if (jamd_stream_create(e, &s_copy) != JAMD_OK || jamd_stream_create(e, &s_beam) != JAMD_OK) die("streams");
   memset(ck, 0, sizeof(ck));
+  {
+    /* the staging and device buffers of the (at most three) launches in flight, sized for the largest launch of the list
+     * (one stat() per file): set-up, like the models -- the steady state allocates nothing */
+    size_t most = 0;
+    int nl = 0, f0;
+    for (f0 = 0; f0 < nfile; f0 += launch, nl++) {
+      size_t fr = 0;
+      int u2;
+      for (u2 = f0; u2 < nfile && u2 < f0 + launch; u2++) {
+        const int t = htk_frames(files[u2], veclen);
+        if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[u2], veclen); exit(1); }
+        fr += (size_t)t;
+      }
+      if (fr > most) most = fr;
+    }
+    for (f0 = 0; f0 < 3 && f0 < nl; f0++) reserve(e, &ck[f0], sizeof(float) * most * (size_t)veclen, sizeof(float) * most * (size_t)nstate);
+  }
   if (jamd_engine_sync(e) != JAMD_OK) die("model upload");
   t_models = now_s();                                  /* engine + models + work area are up: the decode clock starts */
   if (nfile > 0) {
     load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy);
     if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch 0 */
-    if (launch < nfile) load(e, &ck[1], files, launch, nfile, veclen, nstate, s_copy, &ht);
   }
   for (first = 0, k = 0; first < nfile; first += launch, k++) {
     chunk *c = &ck[k % 3];
@@ -215,6 +275,7 @@ static void *run_device(void *arg)
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
     if (first + launch < nfile) {                      /* launch k+1: its frames are on their way or there already */
       chunk *nx = &ck[(k + 1) % 3];
+      if (k == 0) load(e, nx, files, launch, nfile, veclen, nstate, s_copy, &ht);   /* (the first pass of launch 0 is queued: now read launch 1) */
       if (jamd_beam_stream_wait_resident(bm, s_copy) != JAMD_OK) die("first pass");   /* s_copy goes on once the first pass holds its CUs */
       score(nx, nstate, gm, dn, gs, s_copy);
       if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");        /* the next first pass waits for exactly these scores */
@@ -263,6 +324,7 @@ static void *run_device(void *arg)
     if (ck[k].d_frames) jamd_free(e, ck[k].d_frames);
     if (ck[k].d_scores) jamd_free(e, ck[k].d_scores);
   }
+  { int r; for (r = 0; r < READERS; r++) free(ht.rd[r].bounce); }
   jamd_stream_destroy(e, s_copy); jamd_stream_destroy(e, s_beam);
   jamd_beam_destroy(bm); jamd_lexicon_destroy(lx);
   if (rj) jamd_rejgmm_destroy(rj);
