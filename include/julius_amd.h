@@ -305,7 +305,6 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess.
  * NOT SERVED -- the flattener returns JAMD_EINVAL, the shim's get_back_trellis_init() logs the reason and returns FALSE
  * (there is no CPU first pass behind this library):
- *   - a MULTIPATH grammar with a forward DFA (`.dfa.forward`; the non-multipath form is served, see nfwd below);
  *   - a grammar without per-category trees, and user-defined LM functions (LM_NGRAM_USER);
  *   - N-gram lexicons built without 1-gram factoring (a non-default ./configure of the reference). */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
@@ -402,8 +401,8 @@ typedef struct {
    * category t takes the arc labelled t out of the grammar's first state (libjulius/src/beam.c:1739-1747), a cross-word
    * transition to a root of category c takes the arc labelled c out of the token's state and is dropped when there is
    * none (:2412-2422), word-internal transitions inherit it (:2120).  nfwd = 0: no forward DFA (all pointers may be NULL).
-   * Served by the exact-order kernel (JAMD_ORDER_EXACT, the default) and the strict-order kernel on non-multipath
-   * lexicons; jamd_beam_create() refuses the other combinations. */
+   * Served by the exact-order kernels (JAMD_ORDER_EXACT, the default; multipath lexicons included) and the strict-order
+   * kernels; the canonical-tie kernel (JAMD_ORDER_FAST) carries no such state and is refused for these lexicons. */
   int nfwd;                            /* states of wchmm->dfa_forward                              */
   const int   *fwd_off;                /* [nfwd+1] arcs of a state, in the order of its arc list     */
   const int   *fwd_label;              /*          arc label = word category                         */

@@ -1081,12 +1081,12 @@ beam_strict_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict__ 
 // input (:3066-3073).  Kept as its own kernel beside beam_strict_kernel: same helpers, same records.
 // Exact by construction like its parent; the CPU restatement of the same frame is pinned to the reference on
 // multipath tasks (tests/test_beam_oracle.py), the kernel against both (tests/test_beam_gpu.py::test_multipath_*).
-__device__ void s_enter_word_mp(SBeam &b, const LexDev &lx, int root, float tmpsum, int tre, int last_word, float ng) {
+__device__ void s_enter_word_mp(SBeam &b, const LexDev &lx, int root, float tmpsum, int tre, int last_word, float ng, int to_state = 0) {
   const int4 na = lx.node_a(root);
   const float a_self = __int_as_float(na.x), a_next = __int_as_float(na.y);
-  if (a_self != JAMD_LOG_ZERO) s_propagate(b, root, tmpsum + a_self, tre, last_word, ng);
-  if (a_next != JAMD_LOG_ZERO) s_propagate(b, root + 1, tmpsum + a_next, tre, last_word, ng);
-  for (int e = na.z; e < na.w; e++) s_propagate(b, lx.ac_to(e), tmpsum + lx.ac_a(e), tre, last_word, ng);
+  if (a_self != JAMD_LOG_ZERO) s_propagate(b, root, tmpsum + a_self, tre, last_word, ng, to_state);
+  if (a_next != JAMD_LOG_ZERO) s_propagate(b, root + 1, tmpsum + a_next, tre, last_word, ng, to_state);
+  for (int e = na.z; e < na.w; e++) s_propagate(b, lx.ac_to(e), tmpsum + lx.ac_a(e), tre, last_word, ng, to_state);
 }
 
 __global__ void __launch_bounds__(64)
@@ -1119,7 +1119,7 @@ beam_strict_mp_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict
       const int node = lx.init_node(e);
       nw.last_lscore = lx.init_lscore(e); nw.last_tre = -1; nw.last_cword = -1;
       nw.score = nw.last_lscore;
-      nw.node = node; nw.to_state = 0; b.token[node] = id;
+      nw.node = node; nw.to_state = lx.nfwd ? lx.init_to_state(e) : 0; b.token[node] = id;
     }
   } else {                                                           // :1635-1663
     const int id = s_create_token(b);
@@ -1164,11 +1164,13 @@ beam_strict_mp_kernel(LexDev lx, Work wk, StrictWork sw, const float *__restrict
         const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
         for (int stid = lx.startnum - 1; stid >= 0; stid--) {
           if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(stid))) continue;
+          int next_state = 0;
+          if (lx.nfwd) { next_state = fwd_next(lx, tk.to_state, lx.root_cat(stid)); if (next_state < 0) continue; }   // :2412-2422
           float tmpsum = tk.score;
           float ng = lx.penalty1;
           ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
           tmpsum += ng;
-          s_enter_word_mp(b, lx, lx.startnode(stid), tmpsum, tre, last_word, ng);
+          s_enter_word_mp(b, lx, lx.startnode(stid), tmpsum, tre, last_word, ng, next_state);
         }
       } else if (sword != lx.tail_silwid) {
         const bool tr = lx.is_transparent(sword) != 0;
@@ -1581,9 +1583,8 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     UP(init_node, h->init_node, h->ninit); UP(init_lscore, h->init_lscore, h->ninit);
     if (h->nfwd > 0 && rc == JAMD_OK) {
       // forward DFA: every index the kernels will follow is checked here
-      if (wordmode || multipath || !h->fwd_off || !h->fwd_label || !h->fwd_to || !h->init_to_state || h->fwd_off[0] != 0) {
-        jamd_set_error(multipath ? "jamd_lexicon_create: a forward DFA with a multipath lexicon is not served"
-                                 : "jamd_lexicon_create: forward DFA descriptor incomplete"); rc = JAMD_EINVAL;
+      if (wordmode || !h->fwd_off || !h->fwd_label || !h->fwd_to || !h->init_to_state || h->fwd_off[0] != 0) {
+        jamd_set_error("jamd_lexicon_create: forward DFA descriptor incomplete"); rc = JAMD_EINVAL;
       }
       for (int s2 = 0; s2 < h->nfwd && rc == JAMD_OK; s2++)
         if (h->fwd_off[s2 + 1] < h->fwd_off[s2]) { jamd_set_error("jamd_lexicon_create: forward DFA offsets not monotone"); rc = JAMD_EINVAL; }

@@ -185,7 +185,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
         const int node = lx.init_node(e);
         Tok nw;
         nw.node = node; nw.last_tre = -1; nw.last_cword = -1; nw.last_wid = -1; nw.last_lscore = lx.init_lscore(e);
-        nw.score = nw.last_lscore; nw.pad0 = lx.node_b(node).x; nw.pad1 = 0;
+        nw.score = nw.last_lscore; nw.pad0 = lx.node_b(node).x; nw.pad1 = lx.nfwd ? lx.init_to_state(e) : 0;   // forward-DFA state (:1739-1747)
         CUR(e) = nw;
         const unsigned b = ordz(nw.score);
         CURKEY(e) = b;
@@ -363,7 +363,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
         const Tok tk = sv.load(j);
         const int4 nr = lx.node_b(node);
         Tok nw;
-        nw.node = node; nw.pad0 = nr.x; nw.pad1 = 0;
+        nw.node = node; nw.pad0 = nr.x; nw.pad1 = tk.pad1;                 // (the forward-DFA state is inherited, :2120)
         nw.last_tre = tk.last_tre; nw.last_cword = tk.last_cword; nw.last_wid = tk.last_wid;
         nw.last_lscore = tk.last_lscore;
         if (!dfa && node != tk.node && nr.y != 0)                       // beam_intra_word_core() :2069-2082
@@ -451,6 +451,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
           const Tok tk = CUR(welist[w]);
           const int sword = tk.pad0;
           if (!lx.cat_pair(lx.wton(sword) * lx.ncat + lx.root_cat(ent.w))) continue;
+          if (lx.nfwd && fwd_next(lx, tk.pad1, lx.root_cat(ent.w)) < 0) continue;      // forward DFA: no arc for this category (:2412-2422)
           const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
           float tmpsum = tk.score;
           float ng = lx.penalty1;
@@ -605,7 +606,8 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
           ls = lx.shared_root(ri).y * lmw + pen;
         }
         Tok nw;
-        nw.node = node; nw.pad0 = lx.node_b(node).x; nw.pad1 = 0;
+        nw.node = node; nw.pad0 = lx.node_b(node).x;
+        nw.pad1 = (dfa && lx.nfwd) ? fwd_next(lx, src.pad1, lx.root_cat(lx.startnum - 1 - ri)) : 0;   // the arc step B' found (:2415-2420; roots are numbered from startnum-1 down)
         nw.last_tre = atom_base + (fact ? (int)(~(unsigned)sh.we_best) : w); nw.last_cword = last_word; nw.last_wid = sword;
         nw.last_lscore = ls; nw.score = cand;
         CUR(id) = nw;

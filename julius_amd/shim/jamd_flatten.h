@@ -85,7 +85,7 @@ typedef struct {
 
 /* Walk r->wchmm (after j_final_fusion()) and fill `out`.  JAMD_EINVAL for the
  * configurations the device beam does not cover (grammars
- * without per-category trees, a forward DFA together with a multipath model, user LM plugin, 24-bit
+ * without per-category trees, user LM plugin, 24-bit
  * compacted 2-gram index). */
 int  jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out);
 /* The same for a multipath acoustic model (lm_type | JAMD_LM_MULTIPATH); not yet accepted by

@@ -114,8 +114,8 @@ int jamd_flatten_lexicon(RecogProcess *r, jamd_flat_lexicon *out)
   if (multipath && !g_allow_multipath) return JAMD_EINVAL;
   if (word_mode) {
     if (!wchmm->category_tree) return JAMD_EINVAL;
-  } else if (dfa_mode) {              /* grammar: per-category trees; a forward DFA only without multipath */
-    if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL || (wchmm->dfa_forward != NULL && multipath))
+  } else if (dfa_mode) {              /* grammar: per-category trees (with or without a forward DFA) */
+    if (r->lmvar != LM_DFA_GRAMMAR || !wchmm->category_tree || wchmm->dfa == NULL)
       return JAMD_EINVAL;
   } else {
     if (r->lmtype != LM_PROB || ng == NULL) return JAMD_EINVAL;

@@ -202,8 +202,7 @@ static boolean ctx_prepare(pass1_ctx *c, RecogProcess *r)
     jamd_flat_lexicon fl;
     if ((r->am->hmminfo->multipath ? jamd_flatten_lexicon_multipath(r, &fl) : jamd_flatten_lexicon(r, &fl)) != JAMD_OK) {
       jlog("ERROR: jamd: this lexicon / LM configuration is not served by the device first pass (include/julius_amd.h, "
-           "\"NOT SERVED\": a forward DFA, a grammar without category trees, a user-defined LM, no 1-gram factoring)%s\n",
-           (r->lmtype == LM_DFA && r->wchmm->dfa_forward != NULL) ? ": this grammar has a forward DFA" : "");
+           "\"NOT SERVED\": a grammar without category trees, a user-defined LM, no 1-gram factoring)\n");
       return FALSE;
     }
     rc = jamd_lexicon_create(g_eng, &fl.desc, &c->lex);

@@ -5,7 +5,7 @@ there is none (:2412-2422), word-internal transitions inherit the state (:2120).
 
 The grammar of synth.make_forward_grammar() bounds the sentence length -- something the category-pair test of the first pass
 cannot see -- so the forward automaton really cuts transitions.  The device's first pass (exact-order kernel, and the
-strict-order kernel as the second implementation) must give the compiled reference's word trellis, sentence and score on
+strict-order kernel as the second implementation; multipath lexicons -- `-multipath` -- through their own frame) must give the compiled reference's word trellis, sentence and score on
 sentences inside the language and on category chains that are too long for it; the canonical-tie kernel refuses such a lexicon."""
 import numpy as np
 import pytest
@@ -17,19 +17,21 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
-def _task(ref, tmp_path, seed, beam, nword=80, maxwords=3):
+def _task(ref, tmp_path, seed, beam, nword=80, maxwords=3, multipath=False):
     task = synth.make_forward_grammar(synth.make_triphone_task(tmp_path, seed=seed, nword=nword), ncat=3, maxwords=maxwords, seed=seed)
     eng = pyoracle.RefEngine(ref, [str(a) for a in ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-dfa", task["dfa"], "-v", task["gdict"],
-                                                      "-input", "htkparam", "-1pass", "-gprune", "none", "-b", beam]])
+                                                      "-input", "htkparam", "-1pass", "-gprune", "none", "-b", beam]] + (["-multipath"] if multipath else []))
     eng.save_lexicon(tmp_path / "lex.blob")
     lex = lexblob.load(tmp_path / "lex.blob")
     am = ref.am_load(task["hmmdefs"], task["hmmlist"]).export()
     return eng, lex, am, task
 
 
+@pytest.mark.parametrize("multipath", [False, True], ids=["plain", "multipath"])
 @pytest.mark.parametrize("seed,beam", [(11, 200), (12, 40), (13, 12)])
-def test_forward_dfa_first_pass_equals_compiled_reference(engine, oracle, ref, tmp_path, seed, beam):
-    eng, lex, am, task = _task(ref, tmp_path, seed, beam)
+def test_forward_dfa_first_pass_equals_compiled_reference(engine, oracle, ref, tmp_path, seed, beam, multipath):
+    eng, lex, am, task = _task(ref, tmp_path, seed, beam, multipath=multipath)
+    assert bool(lex["lm_type"] & 0x100) == multipath
     assert lex["nfwd"] > 5 and len(lex["fwd_to"]) == lex["fwd_off"][-1] and len(lex["init_to_state"]) == lex["ninit"]
     utts = [synth.make_forward_grammar_utterance(task, seed=100 * seed + u, nwords=None if u < 3 else 4 + u)[0] for u in range(6)]
     scores = [oracle.gmm_outprob(am, fr) for fr in utts]
