@@ -9,6 +9,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $REPO/bench.py "$@" > $OUT/bench.log 2>&1
 grep "^{\"metric\"" $OUT/bench.log | tail -1 > $OUT/bench_line.json
-python $REPO/tools/rocpd_summary.py $OUT "" > $OUT/summary.json 2>/dev/null
+JAMD_BY_GRID=1 python $REPO/tools/rocpd_summary.py $OUT "" > $OUT/summary.json 2>/dev/null
 find $OUT -name "*.db" -delete
 ls $OUT

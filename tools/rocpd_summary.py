@@ -14,6 +14,19 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         out[name]["kernels"] = [{"name": r[0][:90], "calls": r[1], "avg_us": r[2] / 1e3, "min_us": r[3] / 1e3, "max_us": r[4] / 1e3, "total_us": r[5] / 1e3} for r in rows[:8]]
     except Exception as e:
         out[name]["kernels_error"] = str(e)
+    if os.environ.get("JAMD_BY_GRID"):
+        # the same per (kernel, grid size): one kernel name can cover launches of very different sizes in one process
+        # (the default bench line: gmm_tile at 64 000 frames for C2 and at 360 000 - 727 000 frames inside the e2e steps)
+        try:
+            cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+            gcol = next((c for c in cols if "grid" in c.lower() and c.lower().endswith("x")), None) or next((c for c in cols if "grid" in c.lower()), None)
+            if gcol:
+                rows = con.execute(f"select name, {gcol}, count(*), avg(end-start), min(end-start), max(end-start) from kernels group by name, {gcol} order by sum(end-start) desc").fetchall()
+                out[name]["kernels_by_grid"] = [{"name": r[0][:90], "grid": r[1], "calls": r[2], "avg_us": r[3] / 1e3, "min_us": r[4] / 1e3, "max_us": r[5] / 1e3} for r in rows[:24] if sub in r[0]]
+            else:
+                out[name]["kernels_by_grid_error"] = "no grid column among " + ",".join(cols)
+        except Exception as e:
+            out[name]["kernels_by_grid_error"] = str(e)
     try:
         cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
         pm = {}
