@@ -1697,7 +1697,9 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     const int mp_roots = (l->d.lm_type == JAMD_LM_NGRAM) ? l->d.isolatenum : l->d.startnum;   // roots a word end is followed by
     b->exact_status = (mp && !l->mp_parallel) ? -4
                       : xbeam_layout(&xw, w, l->maxfan, mp ? mp_roots : l->d.startnum, l->d.ninit, l->d.nshared, false, mp);
-    b->half_status = (b->exact_status != 0 || mp) ? -2 : xbeam_layout(&b->xw_half, w, l->maxfan, l->d.startnum, l->d.ninit, l->d.nshared, true);
+    b->half_status = b->exact_status != 0 ? -2
+                     : xbeam_layout(&b->xw_half, w, l->maxfan, mp ? mp_roots : l->d.startnum, l->d.ninit, l->d.nshared, true, mp);
+    if (mp && getenv("JAMD_MP_HALF_OFF") != nullptr) b->half_status = -2;    // (development: the multipath frame in the full shape only, as in round 4)
     size_t sv_max = (size_t)w.sv_bytes;
     if (b->exact_status == 0 && (size_t)xw.w.sv_bytes > sv_max) sv_max = (size_t)xw.w.sv_bytes;
     if (b->half_status == 0 && (size_t)b->xw_half.w.sv_bytes > sv_max) sv_max = (size_t)b->xw_half.w.sv_bytes;
@@ -1765,6 +1767,9 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       const int svh = xh.w.sv_bytes;
       xh.w = w; xh.w.sv_bytes = svh;
       xh.o_nodefirst = b->xw.o_nodefirst; xh.o_bitmap = b->xw.o_bitmap; xh.o_heap = b->xw.o_heap; xh.o_collect = b->xw.o_collect; xh.o_sweep = b->xw.o_sweep; xh.o_pstat = b->xw.o_pstat;
+      xh.o_nodetok = b->xw.o_nodetok; xh.o_arr = b->xw.o_arr; xh.o_key2 = b->xw.o_key2;
+      xh.o_mp_iso = b->xw.o_mp_iso; xh.o_mp_shared = b->xw.o_mp_shared; xh.o_mp_start = b->xw.o_mp_start;
+      xh.n_mp_iso = b->xw.n_mp_iso; xh.n_mp_shared = b->xw.n_mp_shared; xh.n_mp_start = b->xw.n_mp_start;
     }
     if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
   }

@@ -708,7 +708,9 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
     bool down_ok = false;
     // (wide layout, full shape only: the narrow layout's beams have a handful of tail candidates, and the mere presence of
     // this code in the kernel costs its steps 0-C 2.5 us each per frame at beam 800 -- profiles/r04_ab_sweep_code_presence.txt)
-    if constexpr (kLdsHeap && (WIDE || FULL) && NT == jamdb::NT) down_ok = (FULL || !upward) && pm.sw_glob != nullptr;
+    // (round 5: the whole-array form also in the half shape -- the multipath frame's mid-frame sort needs it there; what does
+    // not fit half a CU's LDS falls back to the extraction loop at run time)
+    if constexpr (kLdsHeap && (WIDE || FULL) && (NT == jamdb::NT || FULL)) down_ok = (FULL || !upward) && pm.sw_glob != nullptr;
     // (FULL: down_ok = "the whole array can come out of the closed form", either direction)
     const int cnt = upward ? k : n - k;                            // extractions
     const unsigned xm = upward ? 0u : 0xffffffffu;
@@ -830,7 +832,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
         if (FULL || !upward) {
           // the residual heap: every event matters (the survivors stay in heap layout), so the sweep runs over all turns
           bool ok = false;
-          if constexpr (kLdsHeap && (WIDE || FULL) && NT == jamdb::NT) {
+          if constexpr (kLdsHeap && (WIDE || FULL) && (NT == jamdb::NT || FULL)) {
             const int tailb = sweep_down_bytes(cnt);
             // (the sift replay holds the whole heap in LDS, 8 bytes a token: a frame too large for it goes to the extraction loop at once)
             if (pm.sw_bytes > tailb + 1024 && 8 * (n + 2) + cnt + 80 <= ((pm.sw_bytes - tailb) & ~15) && n < 0xffff) {
@@ -2043,6 +2045,7 @@ hipError_t xbeam_prepare() {
   }
   // the half shape is always the wide layout (xbeam_layout())
   const void *fh[] = {(const void *)beam_exact_kernel<false, true, kHalfNT>, (const void *)beam_exact_kernel<true, true, kHalfNT>,
+                      (const void *)beam_exact_mp_kernel<false, true, kHalfNT>, (const void *)beam_exact_mp_kernel<true, true, kHalfNT>,
                       (const void *)prune_order_kernel<true, kHalfNT, false>};
   for (const void *f : fh) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfDynLds);
@@ -2062,8 +2065,11 @@ void xbeam_launch(const LexDev &lx, const XWork &xw0, const float *scores, int n
     if (timed) hipLaunchKernelGGL((beam_exact_kernel<true, W, N>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode); \
     else hipLaunchKernelGGL((beam_exact_kernel<false, W, N>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);      \
   } while (0)
-  if (xw.mp) {                                         // multipath lexicons: their own frame (beam_exact_mp.h), full shape only
-    if (xw.wide) {
+  if (xw.mp) {                                         // multipath lexicons: their own frame (beam_exact_mp.h)
+    if (xw.nt == kHalfNT) {                              // half shape (round 5): always the wide layout
+      if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, true, kHalfNT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
+      else hipLaunchKernelGGL((beam_exact_mp_kernel<false, true, kHalfNT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
+    } else if (xw.wide) {
       if (timed) hipLaunchKernelGGL((beam_exact_mp_kernel<true, true, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
       else hipLaunchKernelGGL((beam_exact_mp_kernel<false, true, NT>), grid, block, lds, st, XKArgs{lx, xw}, scores, nstate, d_utt_off, smode);
     } else {

@@ -200,3 +200,120 @@ def test_wait_started(engine, oracle):
         assert r.status == 0 and r.score == g["utts"][u]["score"]
         assert_trellis_equal(bm.trellis(u), g["utts"][u]["trellis"])
     d.free()
+
+
+# ---------------------------------------------------------------- the multipath frame (csrc/beam_exact_mp.h) in the half shape
+def test_multipath_golden_half(engine, oracle):
+    """The compiled reference's golden multipath trellises, decoded two utterances per CU (round 5)."""
+    g = load_beam_golden("beam_multipath.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    for mode in ("exact", "exact_serial"):
+        bm = _half(lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(scores)).set_order_mode(mode))
+        assert bm.exact_layout() == "wide"                      # (the half shape is always the wide layout)
+        res, tre = bm.pass1_host(scores)
+        for r, atoms, u in zip(res, tre, g["utts"]):
+            assert r.status == 0
+            assert_trellis_equal(atoms, u["trellis"])
+            assert np.array_equal(np.array(r.wseq[:r.wnum]), u["wseq"]) and r.score == u["score"]
+        bm.close()
+
+
+@pytest.mark.parametrize("chunks", [[7] * 60, [0, 25, 0, 3, 1000]])
+def test_multipath_streaming_half(engine, oracle, chunks):
+    g = load_beam_golden("beam_multipath.npz")
+    lx = lib.Lexicon(engine, g["lex"])
+    scores = [oracle.gmm_outprob(g["am"], u["frames"]) for u in g["utts"]]
+    S = scores[0].shape[1]
+    bm = _half(lib.Beam(engine, lx, g["beam_width"], g["score_pruning_width"], max_utts=len(scores)))
+    bm.stream_begin(len(scores))
+    pos = [0] * len(scores)
+    for ci, c in enumerate(chunks):
+        part, off = [], [0]
+        for u, sc in enumerate(scores):
+            n = min(len(sc) - pos[u], (c + u) if c else 0)
+            part.append(sc[pos[u]:pos[u] + n]); pos[u] += n; off.append(off[-1] + n)
+        rows = np.concatenate(part) if off[-1] else np.zeros((1, S), np.float32)
+        d = lib.DevBuf(engine, rows.nbytes).upload(rows)
+        bm.stream_push_dev(d.ptr, S, np.array(off, np.int32), final=ci == len(chunks) - 1)
+        bm.results(len(scores))
+        d.free()
+    for u, r in enumerate(bm.results(len(scores))):
+        gu = g["utts"][u]
+        assert r.status == 0 and r.score == gu["score"]
+        assert_trellis_equal(bm.trellis(u), gu["trellis"])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_multipath_tie_heavy_fuzz_half(engine, oracle, ref, tmp_path, seed):
+    """The tie-heavy fuzz of tests/test_multipath_exact_gpu.py (reference-built multipath lexicons: plain, state skips, two
+    entry arcs, -iwsp, grammar; quantised random scores) in the half shape: the mid-frame sort's whole array comes out of
+    exact_prune<FULL> on 512 threads and half a CU's LDS, or of the extraction loop where that does not fit."""
+    from beamutil import ref_grammar_task
+    from test_multipath_exact_gpu import SKIP_TRANS, SPLIT_TRANS
+    rng = np.random.default_rng(5200 + seed)
+    kind = ["plain", "skip", "split", "iwsp", "grammar"][seed % 5]
+    nword = int(rng.choice([80, 200, 400]))
+    sep = str(int(rng.choice([0, 3, 20])))
+    if kind == "grammar":
+        eng, lex, am, task = ref_grammar_task(ref, tmp_path, 500 + seed, 50, ["-penalty1", "-1.5", "-multipath"], wrap=bool(seed & 1), nword=max(nword, 70))
+    elif kind == "iwsp":
+        eng, lex, am, task = ref_task(ref, tmp_path, 500 + seed, 50, ["-sepnum", sep, "-multipath", "-iwsp", "-spmodel", "sp"], sp=True, nword=nword)
+    elif kind in ("skip", "split"):
+        eng, lex, am, task = ref_task(ref, tmp_path, 500 + seed, 50, ["-sepnum", sep], nword=nword, trans=SKIP_TRANS if kind == "skip" else SPLIT_TRANS)
+    else:
+        eng, lex, am, task = ref_task(ref, tmp_path, 500 + seed, 50, ["-sepnum", sep, "-multipath"], nword=nword)
+    assert lex["lm_type"] & 0x100
+    S = len(am["st_off"]) - 1
+    lx = lib.Lexicon(engine, lex)
+    T = int(rng.integers(25, 70))
+    step = float(rng.choice([0.5, 2.0, 8.0]))
+    scores = [(-np.round(rng.random((T, S)) * 40.0 / step) * step - 20.0).astype(np.float32) for _ in range(3)]
+    sorted_frames = 0
+    for beam in (2, int(rng.integers(5, 40)), int(rng.integers(40, 300))):
+        for width in (-1.0, float(rng.choice([30.0, 80.0]))):
+            bm = _half(lib.Beam(engine, lx, beam, width, max_utts=len(scores), atoms_per_utt=1 << 16))
+            res, tre = bm.pass1_host(scores)
+            for sc, r, atoms in zip(scores, res, tre):
+                oatoms, owseq, oscore, rc, died = oracle.beam_pass1(lex, sc, beam, width)
+                assert r.status == rc, (seed, kind, beam, width)
+                assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+                if rc == 0:
+                    assert list(r.wseq[:r.wnum]) == list(owseq) and r.score == oscore
+                sorted_frames += int(r.max_tokens > beam)
+            bm.close()
+    assert sorted_frames > 0
+
+
+def test_multipath_larger_task_half_and_auto_choice(engine, oracle, ref, tmp_path):
+    """A 400-word multipath lexicon whose every frame really sorts (tokens > beam), half shape against the CPU restatement;
+    then a batch large enough for the automatic choice to pick the half shape, against the full shape on the same work area."""
+    beam = 300
+    eng, lex, am, task = ref_task(ref, tmp_path, 71, beam, ["-sepnum", "10", "-multipath"], nword=400)
+    utts = [synth.make_utterance(task, nwords=4 + u, seed=7100 + u)[0] for u in range(3)]
+    scores = [oracle.gmm_outprob(am, fr) for fr in utts]
+    lx = lib.Lexicon(engine, lex)
+    probe = lib.Beam(engine, lx, beam, -1.0, max_utts=1).set_workgroup_shape("auto")
+    nbig = next(n for n in range(1, 1 << 14) if probe.workgroup_shape(n) == "half")
+    probe.close()
+    bm = lib.Beam(engine, lx, beam, -1.0, max_utts=nbig, atoms_per_utt=1 << 16)
+    _half(bm)
+    res, tre = bm.pass1_host(scores)
+    for sc, r, atoms in zip(scores, res, tre):
+        oatoms, wseq, score, rc, died = oracle.beam_pass1(lex, sc, beam, -1.0)
+        assert_trellis_equal(atoms, lexblob.canonical_trellis(oatoms))
+        assert (r.status == 0) == (rc == 0) and r.max_tokens > beam
+        if rc == 0:
+            assert list(r.wseq[:r.wnum]) == list(wseq) and r.score == score
+    short = [scores[u % 3][:30 + (u * 7) % 40] for u in range(nbig)]
+    bm.set_workgroup_shape("auto")
+    assert bm.workgroup_shape(nbig) == "half"
+    res_a, tre_a = bm.pass1_host(short)
+    bm.set_workgroup_shape("full")
+    res_f, tre_f = bm.pass1_host(short)
+    for u in range(nbig):
+        a, f = res_a[u], res_f[u]
+        assert (a.status, a.natom, a.wnum, a.score, a.frames) == (f.status, f.natom, f.wnum, f.score, f.frames)
+        if u % 16 == 0:
+            assert tre_a[u].tobytes() == tre_f[u].tobytes()
+    bm.close()
