@@ -925,8 +925,8 @@ def main():
             runs.append(("e2e_256", 256, pick(args.steps, 10), pick(args.warmup, 1), "weak"))
         r = run_e2e(args, dd, runs, use_dnn=False) if runs else {}
         if wl == "all" or args.multipath:
-            # the same task decoded with -multipath: one utterance per CU (the multipath frame has the full shape only)
-            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
+            # the same task decoded with -multipath: 512 utterances per step, two per CU (the multipath frame in its half shape, round 5)
+            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 512), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
                              use_dnn=False, multipath=True))
         if dd.rank == 0:
             if nested:
