@@ -325,7 +325,7 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * the frame loop of beam.c:2747-2836: word-internal transitions, the beam over the NEW tokens, cross-word transitions
  * from the word ends among them with the root expanded along its own arcs inside the frame, output probabilities on
  * emitting nodes, the final cut).  Decoded by the exact-order kernel's multipath frame (csrc/beam_exact_mp.h: one
- * workgroup per utterance, full shape, streaming included) in the reference's own tie order, or by the strict-order
+ * workgroup per utterance, either workgroup shape, streaming included) in the reference's own tie order, or by the strict-order
  * kernel (JAMD_ORDER_STRICT); JAMD_ORDER_FAST does not take them.  One kind of lexicon is strict-order only: a root
  * that reaches a word-end node along its own arcs (a word made of tee models only) -- jamd_beam_order_mode() then
  * reports JAMD_ORDER_FAST for the new work area and jamd_beam_set_order_mode(b, JAMD_ORDER_EXACT) says why. */

@@ -51,6 +51,7 @@ for name, sub, dnn, mp, utts, beam, shape, frames in (
         ("e2e_256", "beam_exact_kernel", False, False, 256, 800, "full", 363600),
         ("e2e_dnn_256", "beam_exact_kernel", True, False, 256, 4000, "full", 358848),
         ("e2e_mp_256", "beam_exact_mp_kernel", False, True, 256, 800, "full", 363600),
+        ("e2e_mp_512", "beam_exact_mp_kernel", False, True, 512, 800, "half", 727200),
         ("e2e_dnn_mp_256", "beam_exact_mp_kernel", True, True, 256, 4000, "full", 358848)):
     c = counters(name, sub)
     fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
