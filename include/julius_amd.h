@@ -328,7 +328,10 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * workgroup per utterance, either workgroup shape, streaming included) in the reference's own tie order, or by the strict-order
  * kernel (JAMD_ORDER_STRICT); JAMD_ORDER_FAST does not take them.  One kind of lexicon is strict-order only: a root
  * that reaches a word-end node along its own arcs (a word made of tee models only) -- jamd_beam_order_mode() then
- * reports JAMD_ORDER_FAST for the new work area and jamd_beam_set_order_mode(b, JAMD_ORDER_EXACT) says why. */
+ * reports JAMD_ORDER_FAST for the new work area and jamd_beam_set_order_mode(b, JAMD_ORDER_EXACT) says why.  The reference
+ * never builds such a lexicon (wchmm_add_word() rejects the word: "WORD SKIPPING TRANSITION NOT ALLOWED", wchmm.c:1345-1362;
+ * tests/test_beam_oracle.py shows it for a grammar and for an N-gram), so jamd_export / the shim cannot produce one: the
+ * restriction concerns hand-written descriptors only. */
 #define JAMD_LM_MULTIPATH 0x100
 
 #define JAMD_NG_NORMAL         0  /* bi_prob_normal()            ngram_access.c:288 */

@@ -34,7 +34,8 @@
 // One restriction, checked when the lexicon is loaded (jamd_lexicon::mp_parallel): no root may reach a word-end node
 // along its own arcs (a word made of tee models only).  There a cross-word transition would improve a word end that the
 // loop of step 3 has yet to visit -- or has visited already -- and the outcome depends on the loop's position; such
-// lexicons stay on the strict-order kernel.
+// lexicons stay on the strict-order kernel.  (The reference builds none: wchmm_add_word() refuses a word whose models can
+// all be skipped, wchmm.c:1345-1362 -- only a hand-written descriptor gets here.)
 
 // sort_token_no_order() (beam.c:1492 over :1342-1480) carried out literally on (score bits << 32 | index) entries:
 // H[1..n] ends as tindex[0..n-1].  The heap in LDS when it fits (pipelined extraction), else in the slice (one lane).

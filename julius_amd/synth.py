@@ -338,7 +338,8 @@ def write_dnnconf(workdir, dnn, feature_len=None, context_len=1, num_threads=1):
 
 # ---------------------------------------------------- triphone task (beam tests)
 def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, seed=0,
-                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None, sp=False):
+                       maxlen=5, nbigram_per_word=6, defined_frac=0.8, with_rl3=False, ntransparent=0, nunk=0, trans=None, sp=False,
+                       ntee=0):
     """Write a complete synthetic recognition task the reference can load:
     tied-state triphone hmmdefs + HMMList, HTK dictionary with <s>/</s>, ARPA
     forward 2-gram (optionally a backward 3-gram).  Returns a dict of paths plus
@@ -396,12 +397,18 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
     # the LM context skips them
     dl = ["<s> [] silB", "</s> [] silE"] + [
         (f"{w} {{{w}}} " if i < ntransparent else f"{w} [{w}] ") + " ".join(ph) for i, (w, ph) in enumerate(words)]
+    # `ntee` words made of the short-pause model only (the dictation kits' punctuation words, "sp"): with a tee `sp` the
+    # word's head node reaches its tail along its own arcs (multipath lexicons; beam.c:2467-2510)
+    tee_words = [f"T{i:02d}" for i in range(ntee)]
+    assert not ntee or sp, "tee-only words need the sp model"
+    dl += [f"{w} [{w}] sp" for w in tee_words]
     (workdir / "dict").write_text("\n".join(dl) + "\n")
     # forward 2-gram ARPA (log10), entries in 1-gram order.  With nunk > 0 the last `nunk`
     # dictionary words are left out of the LM and an <unk> entry is added: the reference maps
     # them to it and divides its probability among them (unk_num_log,
     # libsent/src/ngram/init_ngram.c; used by libsent/src/ngram/ngram_access.c:296-306)
     lm_words = [w for w, _ in words][:len(words) - nunk] if nunk > 0 else [w for w, _ in words]
+    lm_words = lm_words + tee_words
     vocab = ["<s>", "</s>"] + (["<unk>"] if nunk > 0 else []) + lm_words
     V = len(vocab)
     uni = rng.dirichlet(np.full(V, 1.0))
@@ -454,7 +461,7 @@ def make_triphone_task(workdir, nphone=8, S=120, M=4, D=39, nword=60, nvar=3, se
             f.write("\n\\end\\\n")
     return dict(dir=workdir, hmmdefs=workdir / "hmmdefs", hmmlist=workdir / "hmmlist", dict=workdir / "dict",
                 arpa=workdir / "lm.arpa", arpa_rl=rl, model=model, words=words, vocab=vocab, phones=phones,
-                phys=dict(phys), logical=dict(ln.split() for ln in lines))
+                phys=dict(phys), logical=dict(ln.split() for ln in lines), tee_words=tee_words)
 
 
 def make_utterance(task, nwords=6, seed=0, frames_per_state=3, noise=0.7):
@@ -857,6 +864,10 @@ def make_triphone_grammar(task, ncat=3, seed=0, wrap=True):
     words = task["words"]
     cat = [int(rng.integers(0, ncat)) for _ in words]
     dl = ["0 [</s>] silE", "1 [<s>] silB"] + [f"{2 + c} [{w}] " + " ".join(ph) for (w, ph), c in zip(words, cat)]
+    # the task's tee-only words (make_triphone_task(ntee=...)): a pause category that may stand between any two words,
+    # once (states P_j = F + 1 + j below)
+    tee = task.get("tee_words") or []
+    dl += [f"{2 + ncat} [{w}] sp" for w in tee]
     (workdir / "g.dict").write_text("\n".join(dl) + "\n")
     # reversed automaton: 0 --</s>--> E(1); E --cat j--> R_j (2+j); R_j --cat i (i may precede j)--> R_i;
     # R_j --<s>--> F; F accepts
@@ -868,6 +879,10 @@ def make_triphone_grammar(task, ncat=3, seed=0, wrap=True):
         for i in range(ncat):
             if (i + 1) % ncat == j or (i + 2) % ncat == j:
                 lines.append(f"{2 + j} {2 + i} {2 + i} 0 0")
+                if tee:                                                # ... or with one pause word between the two
+                    lines.append(f"{F + 1 + j} {2 + i} {2 + i} 0 0")
+        if tee:
+            lines.append(f"{2 + j} {2 + ncat} {F + 1 + j} 0 0")          # (mkcpair.c:79-101: not first, not last, not twice)
         lines.append(f"{2 + j} 1 {F} 0 0" if wrap else f"{2 + j} -1 -1 1 0")
     if wrap:
         lines.append(f"{F} -1 -1 1 0")
@@ -877,8 +892,9 @@ def make_triphone_grammar(task, ncat=3, seed=0, wrap=True):
     return g
 
 
-def make_triphone_grammar_utterance(g, nwords=4, seed=0, frames_per_state=3, noise=0.7):
-    """Frames following a random sentence the grammar of make_triphone_grammar() accepts."""
+def make_triphone_grammar_utterance(g, nwords=4, seed=0, frames_per_state=3, noise=0.7, pause_prob=0.0):
+    """Frames following a random sentence the grammar of make_triphone_grammar() accepts; with pause_prob > 0 a short
+    pause (the sp model's state; the grammar's tee-only pause word) stands between some of the words."""
     rng = np.random.default_rng(seed)
     ncat = g["ncat"]
     by_cat = [[i for i, c in enumerate(g["word_cat"]) if c == k] for k in range(ncat)]
@@ -894,7 +910,9 @@ def make_triphone_grammar_utterance(g, nwords=4, seed=0, frames_per_state=3, noi
     S = len(model["st_off"]) - 1
     per = (S - 6) // len(g["phones"])
     seq = [S - 6, S - 5, S - 4] if g.get("wrap", True) else []
-    for i in ids:
+    for n, i in enumerate(ids):
+        if n > 0 and pause_prob > 0 and rng.random() < pause_prob:
+            seq.append(S - 5)
         for p in g["words"][i][1]:
             base = g["phones"].index(p) * per
             seq += [int(base + rng.integers(0, per)) for _ in range(3)]
@@ -1016,6 +1034,10 @@ def make_forward_grammar(task, ncat=3, maxwords=4, seed=0):
     words = task["words"]
     cat = [int(rng.integers(0, ncat)) for _ in words]
     dl = ["0 [</s>] silE", "1 [<s>] silB"] + [f"{2 + c} [{w}] " + " ".join(ph) for (w, ph), c in zip(words, cat)]
+    # the task's tee-only words (make_triphone_task(ntee=...)): a pause category that may stand between any two words,
+    # once (states P_j = F + 1 + j below)
+    tee = task.get("tee_words") or []
+    dl += [f"{2 + ncat} [{w}] sp" for w in tee]
     (workdir / "g.dict").write_text("\n".join(dl) + "\n")
     # forward automaton: 0 --<s>--> 1 (no word yet); (p words, last category c) = state 2 + (p - 1) * ncat + c; final F
     arcs = {(0, 1): 1}

@@ -441,7 +441,8 @@ class RefEngine:
         if not self.h:
             raise RuntimeError("reference engine failed to start: " + " ".join(args))
         info = np.zeros(16, np.int32)
-        lib.jref_engine_info(self.h, _p(info))
+        if lib.jref_engine_info(self.h, _p(info)) != 0:
+            raise RuntimeError("the reference built no lexicon tree for: " + " ".join(args))
         (self.nnode, self.nword, self.startnum, self.isolatenum, self.beam_width, self.nstate,
          self.lmtype, self.multipath, self.ccd) = [int(x) for x in info[:9]]
 

@@ -468,6 +468,7 @@ int jref_engine_info(void *h, int *info)
 {
   jref_eng *e = (jref_eng *)h;
   RecogProcess *r = e->recog->process_list;
+  if (r == NULL || r->wchmm == NULL || r->wchmm->winfo == NULL) return -1;   /* e.g. a grammar the reference purged */
   info[0] = r->wchmm->n; info[1] = r->wchmm->winfo->num; info[2] = r->wchmm->startnum;
   info[3] = r->wchmm->isolatenum; info[4] = r->trellis_beam_width; info[5] = r->wchmm->hmminfo->totalstatenum;
   info[6] = r->lmtype; info[7] = r->wchmm->hmminfo->multipath; info[8] = r->ccd_flag;

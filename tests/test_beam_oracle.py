@@ -205,3 +205,36 @@ def test_oracle_matches_reference_multipath_grammar(oracle, ref, tmp_path, seed,
         assert rc == 0
         assert_trellis_equal(atoms, rtr)
         assert np.array_equal(wseq, rwseq) and score == rscore
+
+
+@pytest.mark.parametrize("lm", ["grammar", "ngram"])
+def test_reference_refuses_words_made_of_tee_models_only(tmp_path, lm):
+    """The one lexicon kind the frame-parallel multipath frame leaves to the strict-order kernel -- a root that reaches a
+    word-end node along its own arcs, i.e. a word made of tee models only (csrc/beam_exact_mp.h, jamd_lexicon::mp_parallel)
+    -- is a lexicon the reference itself never builds: wchmm_add_word() rejects the word ("WORD SKIPPING TRANSITION NOT
+    ALLOWED ... This type of word skipping is not supported", libjulius/src/wchmm.c:1345-1362), the tree is not built
+    (m_fusion.c "error in bulding wchmm" with an N-gram; a grammar is left without its tree and a beam width of 0).
+    Shown on the dictation kits' form of such a word: a pause word pronounced `sp`, with an `sp` model that has the
+    entry -> exit skip."""
+    import shutil
+    import subprocess
+    from oracle import pyoracle
+    julius = pyoracle.HERE / "_ref" / "bin" / "julius"
+    if not julius.exists() or shutil.which("stdbuf") is None:
+        pytest.skip("oracle/_ref/bin/julius not built (or no stdbuf: the N-gram case ends in a crash that loses buffered output)")
+    task = synth.make_triphone_task(tmp_path, seed=5, sp=True, nword=40, ntee=1)
+    (tmp_path / "empty.list").write_text("")
+    args = ["stdbuf", "-o0", "-e0", julius, "-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-input", "htkparam",
+            "-filelist", tmp_path / "empty.list", "-1pass", "-b", "50", "-multipath"]
+    if lm == "grammar":
+        g = synth.make_triphone_grammar(task, ncat=3, seed=5)
+        args += ["-dfa", g["dfa"], "-v", g["gdict"]]
+    else:
+        args += ["-nlr", task["arpa"], "-v", task["dict"]]
+    out = subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=120)
+    log = out.stdout + out.stderr
+    assert "WORD SKIPPING TRANSITION NOT ALLOWED" in log and "[T00])" in log and "failed to add word" in log
+    if lm == "grammar":
+        assert "trellis beam width = 0" in log                       # multigram_build() gave up before set_beam_width()
+    else:
+        assert "error in bulding wchmm" in log and out.returncode != 0

@@ -209,7 +209,8 @@ def test_multipath_streaming_equals_one_shot(engine, oracle, chunks):
 def test_root_that_reaches_a_word_end_stays_on_the_strict_kernel(engine, oracle):
     """A word made of tee models only: its root reaches the word-end node along its own arcs, a cross-word transition would
     improve a word end inside the loop that visits the word ends (beam.c:2779-2825) -- such a lexicon is refused by the
-    frame-parallel multipath frame (jamd_lexicon::mp_parallel) and decoded in strict order."""
+    frame-parallel multipath frame (jamd_lexicon::mp_parallel) and decoded in strict order.  Hand-made: the reference
+    refuses such a word when it builds the tree (wchmm.c:1345-1362; tests/test_beam_oracle.py)."""
     g = load_beam_golden("beam_multipath.npz")
     lex = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in g["lex"].items()}
     root = int(lex["startnode"][0])
