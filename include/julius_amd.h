@@ -305,7 +305,8 @@ int  jamd_dnn_outprob_host(jamd_dnn *n, const float *host_frames, int T, float *
  * (julius_amd/shim/jamd_flatten_lex.c) from an unmodified RecogProcess.
  * NOT SERVED -- the flattener returns JAMD_EINVAL, the shim's get_back_trellis_init() logs the reason and returns FALSE
  * (there is no CPU first pass behind this library):
- *   - a grammar without per-category trees, and user-defined LM functions (LM_NGRAM_USER);
+ *   - a grammar without per-category trees (not a runtime choice of the reference: multigram_build() sets
+ *     wchmm->category_tree = TRUE for every grammar, multi-gram.c:101), and user-defined LM functions (LM_NGRAM_USER);
  *   - N-gram lexicons built without 1-gram factoring (a non-default ./configure of the reference). */
 #define JAMD_AS_STATE 0   /* AS_STATE  wchmm.h:105: out_id = state id                   */
 #define JAMD_AS_LSET  1   /* AS_LSET   wchmm.h:106: out_id = state-set id                */
