@@ -1286,6 +1286,12 @@ struct jamd_lexicon {
   // in visiting order; byte offsets into the lexicon arena + entry counts (XWork carries them to the kernel)
   unsigned o_mp_iso = 0, o_mp_shared = 0, o_mp_start = 0;
   int n_mp_iso = 0, n_mp_shared = 0, n_mp_start = 0;
+  // ... and the nodes those transitions lead to, numbered densely: int [nnode], -1 = never entered from a root.  Only such a
+  // node can meet a token of the frame's second half, so the per-utterance "which token sits on this node" table of the
+  // multipath frame (XWork::o_nodetok) has n_mp_tgt entries instead of nnode (a few KB that stay in L2 instead of a
+  // megabyte per utterance written four bytes at a time).
+  unsigned o_mp_tgt = 0;
+  int n_mp_tgt = 0;
   std::vector<void *> owned;
 };
 
@@ -1555,6 +1561,16 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
       *off = (unsigned)at; *cnt = (int)v.size();
     };
     put(e_iso, &l->o_mp_iso, &l->n_mp_iso); put(e_shared, &l->o_mp_shared, &l->n_mp_shared); put(e_start, &l->o_mp_start, &l->n_mp_start);
+    {
+      std::vector<int> tgt((size_t)h->nnode, -1);
+      int ntgt = 0;
+      for (const std::vector<int4> *v : {&e_iso, &e_shared, &e_start})
+        for (const int4 &ent : *v) if (tgt[(size_t)ent.x] < 0) tgt[(size_t)ent.x] = ntgt++;
+      const size_t at = (arena.size() + 15) & ~(size_t)15;
+      arena.resize(at + tgt.size() * sizeof(int));
+      memcpy(arena.data() + at, tgt.data(), tgt.size() * sizeof(int));
+      l->o_mp_tgt = (unsigned)at; l->n_mp_tgt = ntgt;
+    }
   }
   UP(startnode, h->startnode, h->startnum); UP(start2isolate, h->start2isolate, h->startnum);
   UP(lc_tab, h->lc_tab, (size_t)h->nlcrow * (h->nlc + 1)); UP(word_lc, h->word_lc, h->nword);
@@ -1717,8 +1733,9 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       xw.o_nodetok = xw.o_arr = xw.o_key2 = 0;
       xw.o_mp_iso = l->o_mp_iso; xw.o_mp_shared = l->o_mp_shared; xw.o_mp_start = l->o_mp_start;
       xw.n_mp_iso = l->n_mp_iso; xw.n_mp_shared = l->n_mp_shared; xw.n_mp_start = l->n_mp_start;
+      xw.o_mp_tgt = l->o_mp_tgt; xw.n_mp_tgt = l->n_mp_tgt;
       if (mp) {
-        place(&xw.o_nodetok, (size_t)w.nnode * sizeof(unsigned));
+        place(&xw.o_nodetok, (size_t)(l->n_mp_tgt > 0 ? l->n_mp_tgt : 1) * sizeof(unsigned));
         place(&xw.o_arr, (size_t)w.tok_cap * sizeof(int));
         place(&xw.o_key2, (size_t)w.tok_cap * sizeof(unsigned));
       }
@@ -1770,6 +1787,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
       xh.o_nodetok = b->xw.o_nodetok; xh.o_arr = b->xw.o_arr; xh.o_key2 = b->xw.o_key2;
       xh.o_mp_iso = b->xw.o_mp_iso; xh.o_mp_shared = b->xw.o_mp_shared; xh.o_mp_start = b->xw.o_mp_start;
       xh.n_mp_iso = b->xw.n_mp_iso; xh.n_mp_shared = b->xw.n_mp_shared; xh.n_mp_start = b->xw.n_mp_start;
+      xh.o_mp_tgt = b->xw.o_mp_tgt; xh.n_mp_tgt = b->xw.n_mp_tgt;
     }
     if (xbeam_prepare() != hipSuccess) b->exact_status = -5;
   }

@@ -14,12 +14,14 @@ struct XWork {
   unsigned o_sweep;            // xbeam_sweep_bytes(beam): scratch of the sweep replay (beam_sweep.h), 0 = none
   unsigned o_pstat;            // int [8]: how this utterance's pruning steps were resolved (jamd_beam_prune_stats())
   // multipath lexicons (beam_exact_mp.h)
-  unsigned o_nodetok;          // u32 [nnode]   token id + 1 of the node's token of the frame's first half (0 = none)
+  unsigned o_nodetok;          // u32 [n_mp_tgt] token id + 1 of the token a node holds, by the node's number among the nodes a root leads to (0 = none)
   unsigned o_arr;              // int [tok_cap] tindex[]: the frame's tokens as the mid-frame sort left them + the appended ones
   unsigned o_key2;             // u32 [tok_cap] their score bits in that arrangement (input of the frame's final cut)
   int mp;                      // 1 = multipath lexicon: beam_exact_mp_kernel
   unsigned o_mp_iso, o_mp_shared, o_mp_start;   // the roots' own transitions (int4 lists in the lexicon arena, jamd_lexicon)
   int n_mp_iso, n_mp_shared, n_mp_start;
+  unsigned o_mp_tgt;           // int [nnode] in the lexicon arena: that number, -1 = no root leads to the node
+  int n_mp_tgt;
   int nt, lds_budget;          // workgroup shape: threads, dynamic LDS it may use (full: NT / kMaxDynLds; half: kHalfNT / kHalfDynLds)
   int wide;                    // 1 = wide-beam layout: survivors in the utterance's slice (o_sv), the pruning step overlays
                                //     the whole LDS image but welist[] (see xbeam_layout())

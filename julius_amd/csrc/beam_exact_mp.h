@@ -29,7 +29,10 @@
 // Visiting indices.  First half: (survivor position << s1) | transition number, as in the ordinary kernel.  Second
 // half: (rank of the word end among the frame's word ends << s1) | (root number * XW + transition number of the root);
 // the factoring pass (beam_inter_word_factoring(), one source: the best word end) uses rank = number of word ends.
-// A node that holds a token of the first half is found through nodetok[] (token id + 1 per node, cleared in step O).
+// A node that holds a token of the first half is found through nodetok[] (token id + 1, cleared in step O) -- one entry
+// per node A ROOT LEADS TO (jamd_lexicon::o_mp_tgt numbers them; no other node meets a token of the second half): a few
+// thousand words that stay in L2, where a table over all nodes was a megabyte per utterance written four bytes at a time
+// (half of the frame's memory-side traffic, profiles/traffic_first_pass.json).
 //
 // One restriction, checked when the lexicon is loaded (jamd_lexicon::mp_parallel): no root may reach a word-end node
 // along its own arcs (a word made of tee models only).  There a cross-word transition would improve a word end that the
@@ -128,7 +131,8 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
   const int T = base + nrows;
   const bool finish = smode != 1;
   unsigned char *const ub = ka0.xw.w.slices + (size_t)u * ka0.xw.w.utt_stride;
-#define NODETOK(i) SLICE(unsigned, xw.o_nodetok, i)
+#define NODETOK(i) SLICE(unsigned, xw.o_nodetok, i)       /* i = TGT(node) >= 0 */
+#define TGT(node) lx.at<int>(xw.o_mp_tgt, node)
 #define ARR(i) SLICE(int, xw.o_arr, i)
 #define KEY2(i) SLICE(unsigned, xw.o_key2, i)
   jamd_pass1_result *res = ka0.xw.w.res + u;
@@ -156,7 +160,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
     }
     for (int i = tid; i < wk.nscword; i += NT) memo[i] = 0xffffffff00000000ull;
     // (an utterance can end between steps C1 and O -- the transition-only last call, an overflow -- and leave entries behind)
-    for (int i = tid; i < wk.nnode; i += NT) NODETOK(i) = 0u;
+    for (int i = tid; i < xw.n_mp_tgt; i += NT) NODETOK(i) = 0u;
     __syncthreads();
     if (nrows <= 0) {
       if (tid == 0) { if (smode != 1) res->status = JAMD_PASS1_FAIL; if (ss) { ss->started = 0; ss->active = 1; } }
@@ -374,7 +378,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
         const unsigned kb = (unsigned)(key >> 32);
         CURKEY(id) = kb;
         mymax1 = max(mymax1, kb); mymin1 = min(mymin1, kb);
-        NODETOK(node) = (unsigned)id + 1u;
+        { const int ti = TGT(node); if (ti >= 0) NODETOK(ti) = (unsigned)id + 1u; }
         ARR(id) = id;
       }
       atomicMax(&sh.maxbits, mymax1); atomicMin(&sh.minbits, mymin1);      // (the mid-frame sort's bins span them)
@@ -562,7 +566,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
       }
       const int nbits2 = (n_we + 1) * slots2 + (dfa ? 0 : lx.nshared * XW);
       auto dense2 = [&](unsigned fv) -> int { return (int)(fv >> s1) * slots2 + (int)(fv & submask); };
-      const int Wsh = rank_setup(nbits2, n2, dense2, [&](int node) { return NODETOK(node) == 0u; });
+      const int Wsh = rank_setup(nbits2, n2, dense2, [&](int node) { return NODETOK(TGT(node)) == 0u; });
       if (tid == 0) sh.n_arc = 0;
       __syncthreads();
       for (int s = tid; s < n2; s += NT) {
@@ -576,7 +580,8 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
           key = atomicExch(&NODEKEY(node), 0ull);
           fvis = ~atomicExch(&NODEFIRST(node), 0u);
         }
-        const unsigned have = NODETOK(node);
+        const int ti = TGT(node);                          // (>= 0: the candidates of the second half come from the roots' lists)
+        const unsigned have = NODETOK(ti);
         const float cand = unord((unsigned)(key >> 32));
         int id;
         if (have != 0u) {
@@ -612,7 +617,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
         nw.last_tre = atom_base + (fact ? (int)(~(unsigned)sh.we_best) : w); nw.last_cword = last_word; nw.last_wid = sword;
         nw.last_lscore = ls; nw.score = cand;
         CUR(id) = nw;
-        if (have == 0u) { NODETOK(node) = (unsigned)id + 1u; ARR(id) = id; }
+        if (have == 0u) { NODETOK(ti) = (unsigned)id + 1u; ARR(id) = id; }
       }
       __syncthreads();
       n_tot = n1 + uni(sh.n_arc);
@@ -629,7 +634,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
       unsigned mymax = ord(JAMD_LOG_ZERO), mymin = 0xffffffffu, myemax = ord(JAMD_LOG_ZERO);
       for (int i = tid; i < n_tot; i += NT) {
         const Tok tk = CUR(i);
-        NODETOK(tk.node) = 0u;
+        { const int ti = TGT(tk.node); if (ti >= 0) NODETOK(ti) = 0u; }
         const int4 nr = lx.node_b(tk.node);
         float sc = tk.score;
         if (nr.w != JAMD_AS_NONE) {
@@ -745,6 +750,7 @@ beam_exact_mp_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const 
     }
   }
 #undef NODETOK
+#undef TGT
 #undef ARR
 #undef KEY2
 }
