@@ -243,6 +243,7 @@ def run_gmm(args, dd: Dist, steps, warmup):
         compulsory = E * (2 * D + 2) * 4 + T * D * 4 + T * S * 4      # model once + frames in + scores out
         valu_ops = T * E * D * 4.0
         traffic = None
+        traffic_source = None
         tfile = ROOT / "profiles" / "traffic_gmm_tile.json"
         if tfile.exists():
             try:
@@ -250,6 +251,7 @@ def run_gmm(args, dd: Dist, steps, warmup):
                 # only a measurement of THIS kernel instantiation at THIS launch size counts
                 if tj.get("frames_per_launch") == T and tj.get("kernel") == gmm.last_kernel():
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "replayed from profiles/traffic_gmm_tile.json (a separate rocprofv3 --pmc pass of this kernel instantiation and launch size, not measured in this run)"
             except Exception:
                 traffic = None
         tops = valu_ops / (kern_ms * 1e-3) / 1e12
@@ -266,7 +268,7 @@ def run_gmm(args, dd: Dist, steps, warmup):
                        "frames_per_step_per_gpu": L * T, "frames_per_launch": T, "launches_per_step": L,
                        "parallelism": f"utterance-sharded x{dd.world}", "kernel": gmm.last_kernel()},
             "roofline": {"bound": "valu", "achieved": tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (fp32, unfused)",
-                         "frac": tops / VALU_PEAK_TOPS, "traffic": traffic, "kernel_ms": kern_ms,
+                         "frac": tops / VALU_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms,
                          "ops_per_launch": valu_ops,
                          "note": "4 separately rounded fp32 operations per (frame, Gaussian, dim) -- the reference's "
                                  "arithmetic, no FMA -- against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
@@ -390,15 +392,16 @@ def first_pass_traffic(use_dnn, multipath, flat, nutt, beam, shape):
     exact launch (scorer, -multipath, utterances per launch, beam, workgroup shape) was not measured."""
     f = ROOT / "profiles" / "traffic_first_pass.json"
     if not f.exists():
-        return None
+        return None, None
     try:
         for e in json.loads(f.read_text()).get("entries", []):
             if (bool(e.get("dnn")) == bool(use_dnn) and bool(e.get("multipath")) == bool(multipath) and bool(e.get("flat")) == bool(flat)
                     and e.get("utts") == nutt and e.get("beam") == beam and e.get("shape") == shape):
-                return e.get("hbm_bytes_per_launch")
+                return e.get("hbm_bytes_per_launch"), ("replayed from profiles/traffic_first_pass.json <- " + str(e.get("source"))
+                                                        + " (a separate rocprofv3 --pmc pass of this launch shape, not measured in this run)")
     except Exception:
-        return None
-    return None
+        return None, None
+    return None, None
 
 
 def first_pass_roofline(work, beam_ms, nutt, shape, sc_ms):
@@ -650,7 +653,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                             "pipelined": ("scoring of step k+1 on a second stream, released once the first pass of step k is running (it fills the CUs "
                                           "the first pass leaves)" if pipelined else "no")},
                  "roofline": dict(first_pass_roofline(work, beam_ms, nutt, bm.workgroup_shape(nutt), sc_ms),
-                                  traffic=first_pass_traffic(use_dnn, multipath, flat, nutt, beam, bm.workgroup_shape(nutt))),
+                                  **dict(zip(("traffic", "traffic_source"), first_pass_traffic(use_dnn, multipath, flat, nutt, beam, bm.workgroup_shape(nutt))))),
                  "pass1": {"ok": int((st == 0).sum()), "no_sentence": int((st == 1).sum()), "utts": nutt_all,
                            "mean_peak_tokens": float(np.mean([x.max_tokens for x in res_local])),
                            "ties_counted": int(sum(x.ties for x in res_local)), "phase_us_utt0": list(res_local[0].phase_us),

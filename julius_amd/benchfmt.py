@@ -79,6 +79,8 @@ def _nested(r, lean=False):
             rr[k] = _num(roof[k], 5)
     if not lean and bound:
         rr["bound"] = bound
+    if rr.get("traffic") is not None and not lean:
+        rr["traffic_source"] = "profiles/" if str(roof.get("traffic_source", "")).startswith("replayed") else "this run"
     if "timing" not in r or rr["frac"] is not None:
         out["roofline"] = rr
     if isinstance(r.get("cpu_baseline"), dict):
@@ -134,6 +136,8 @@ def compact_line(full: dict, lean: bool = False) -> dict:
             line["config"][k] = _short(cfg[k], 80) if isinstance(cfg[k], str) else cfg[k]
     roof = full.get("roofline") or {}
     line["roofline"] = {k: (_num(roof.get(k)) if k not in ("bound", "unit") else _short(roof.get(k, ""), 40)) for k in _ROOF_KEYS}
+    if roof.get("traffic") is not None:     # where the figure comes from: "measured" in this run, or replayed from profiles/ 
+        line["roofline"]["traffic_source"] = _short(roof.get("traffic_source") or "measured in this run", 90)
     for k in ("beam_kernel_ms", "score_kernels_ms"):
         if roof.get(k) is not None:
             line["roofline"][k] = _num(roof[k])

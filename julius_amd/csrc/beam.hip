@@ -1793,10 +1793,14 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
   }
   // default order mode: the exact-order kernel where it can serve the work area, else the frame-parallel one
   b->exact = b->exact_status == 0;
-  if (rc == JAMD_OK && l->d.nfwd > 0 && !b->exact) {     // the canonical-tie kernel carries no forward-DFA state
-    jamd_set_error("jamd_beam_create: a grammar with a forward DFA is decoded by the exact-order kernel (or the strict-order one), which "
-                   "cannot serve beam %d on this lexicon", w.beam);
-    rc = JAMD_ESTATE;
+  if (rc == JAMD_OK && l->d.nfwd > 0 && !b->exact) {
+    // The canonical-tie kernel carries no forward-DFA state; the strict-order kernels do.  A work area the exact-order
+    // kernel cannot serve (beam too wide for the LDS image, a root that reaches a word end, no LDS) therefore starts in
+    // strict order instead of being refused: the caller has no beam to call jamd_beam_set_strict_order() on
+    // when create fails.
+    rc = jamd_beam_set_strict_order(b, 1);
+    if (rc != JAMD_OK) jamd_set_error("jamd_beam_create: a grammar with a forward DFA needs the exact-order or the strict-order kernel; "
+                                      "neither can serve beam %d on this lexicon", w.beam);
   }
   if (rc != JAMD_OK) { jamd_beam_destroy(b); return rc; }
   *out = b;

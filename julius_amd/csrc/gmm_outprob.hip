@@ -87,7 +87,12 @@ gmm_tile_kernel(const float *__restrict__ rec, const int *__restrict__ st_off,
     for (int d = 0; d < D; d++) { v[p][d].x = fa[d]; v[p][d].y = fb_[d]; }
   }
 
-  // addlog table as a raw buffer (gfx9 dword 3: 32-bit data format); offsets past its JAMD_TBLSIZE + 1 entries read 0
+  // addlog table as a raw buffer (gfx9 dword 3: 32-bit data format); offsets past its JAMD_TBLSIZE + 1 entries read 0.
+  // NaN inputs: a NaN |s - y| selects slot TBLSIZE (0.0f) and v_max_f32 drops a NaN operand -- scores are finite or
+  // LOG_ZERO on this path (NULL densities are marked in gconst and handled before the log-sum), so no NaN reaches it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "gmm_tile: the raw buffer descriptor below is the gfx9 (CDNA) format; this library is written for gfx950 only"
+#endif
   const __amdgpu_buffer_rsrc_t tbl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tbl, 0, 4 * (JAMD_TBLSIZE + 1), 0x00020000);
   const int s_begin = sb * nsb;
   const int s_end = min(S, s_begin + nsb);

@@ -57,12 +57,23 @@ static double now_s(void)
  * header is checked when the file is read.  -1: not there / not a whole number of vectors. */
 static int htk_frames(const char *path, int veclen)
 {
+  /* nSamples and sampSize come from the 12-byte HTK header (nSamples, sampPeriod: 4 bytes each; sampSize, parmKind: 2 each,
+   * big endian); the body must hold at least nSamples vectors -- trailing bytes (a CRC word of _K files) are accepted, as
+   * by the reference's reader (the size alone used to decide, and such files were refused). */
+  unsigned char h[12];
   struct stat st;
-  long body;
-  if (stat(path, &st) != 0 || st.st_size < 12 + 4 * (long)veclen) return -1;
-  body = (long)st.st_size - 12;
-  if (body % (4 * (long)veclen) != 0 || body / (4 * (long)veclen) > 0x7fffffffL) return -1;
-  return (int)(body / (4 * (long)veclen));
+  long n, size;
+  int fd = open(path, O_RDONLY);
+  ssize_t got;
+  if (fd < 0) return -1;
+  got = read(fd, h, 12);
+  if (got != 12 || fstat(fd, &st) != 0) { close(fd); return -1; }
+  close(fd);
+  n = (long)be32(h);
+  size = ((long)h[8] << 8) | (long)h[9];
+  if (size != 4 * (long)veclen || n < 1 || n > 0x7fffffffL) return -1;
+  if ((long)st.st_size - 12 < n * size) return -1;
+  return (int)n;
 }
 
 /* One reader: files [u0, u1) of a launch -> their slots of the pinned staging buffer.  A file is read whole (header and
@@ -139,7 +150,7 @@ static void reserve(jamd_engine *e, chunk *c, size_t need_fr, size_t need_sc)
   }
 }
 
-static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, int veclen, int nstate, void *stream, hosttime *ht)
+static void load(jamd_engine *e, chunk *c, char **files, const int *nfr, int first, int nfile, int veclen, int nstate, void *stream, hosttime *ht)
 {
   const double t0 = now_s();
   size_t need_fr, need_sc;
@@ -147,7 +158,7 @@ static void load(jamd_engine *e, chunk *c, char **files, int first, int nfile, i
   c->n = nfile - first < launch ? nfile - first : launch;
   c->off[0] = 0;
   for (u = 0; u < c->n; u++) {
-    const int t = htk_frames(files[first + u], veclen);
+    const int t = nfr[first + u] >= 0 ? nfr[first + u] : htk_frames(files[first + u], veclen);   /* (counted once, in the pre-sizing pass) */
     if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[first + u], veclen); exit(1); }
     c->off[u + 1] = c->off[u] + t;
   }
@@ -210,8 +221,10 @@ static void *run_device(void *arg)
   void *s_copy = NULL, *s_beam = NULL;
   size_t linecap = 1 << 16;
   char *text = (char *)malloc(linecap);
+  int *nfr = (int *)malloc(sizeof(int) * (size_t)(nfile > 0 ? nfile : 1));   /* frames per file, counted once */
 
-  if (text == NULL) die("out of memory");
+  if (text == NULL || nfr == NULL) die("out of memory");
+  for (k = 0; k < nfile; k++) nfr[k] = -1;
   memset(&ht, 0, sizeof(ht));
   if (jamd_engine_create(j->device, &e) != JAMD_OK) die("engine");
   if (am != NULL) { if (jamd_gmm_load(e, am, gprune, gnum, &gm) != JAMD_OK) die("acoustic model"); }
@@ -250,7 +263,7 @@ static void *run_device(void *arg)
       size_t fr = 0;
       int u2;
       for (u2 = f0; u2 < nfile && u2 < f0 + launch; u2++) {
-        const int t = htk_frames(files[u2], veclen);
+        const int t = nfr[u2] = htk_frames(files[u2], veclen);
         if (t < 0) { fprintf(stderr, "jamd_batch: cannot read %s as %d-dim HTK parameters\n", files[u2], veclen); exit(1); }
         fr += (size_t)t;
       }
@@ -261,7 +274,7 @@ static void *run_device(void *arg)
   if (jamd_engine_sync(e) != JAMD_OK) die("model upload");
   t_models = now_s();                                  /* engine + models + work area are up: the decode clock starts */
   if (nfile > 0) {
-    load(e, &ck[0], files, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy);
+    load(e, &ck[0], files, nfr, 0, nfile, veclen, nstate, s_copy, &ht); score(&ck[0], nstate, gm, dn, gs, s_copy);
     if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");                   /* the scores of launch 0 */
   }
   for (first = 0, k = 0; first < nfile; first += launch, k++) {
@@ -275,13 +288,13 @@ static void *run_device(void *arg)
     if (jamd_beam_pass1_dev(bm, c->d_scores, nstate, off, n, s_beam) != JAMD_OK) die("first pass");
     if (first + launch < nfile) {                      /* launch k+1: its frames are on their way or there already */
       chunk *nx = &ck[(k + 1) % 3];
-      if (k == 0) load(e, nx, files, launch, nfile, veclen, nstate, s_copy, &ht);   /* (the first pass of launch 0 is queued: now read launch 1) */
+      if (k == 0) load(e, nx, files, nfr, launch, nfile, veclen, nstate, s_copy, &ht);   /* (the first pass of launch 0 is queued: now read launch 1) */
       if (jamd_beam_stream_wait_resident(bm, s_copy) != JAMD_OK) die("first pass");   /* s_copy goes on once the first pass holds its CUs */
       score(nx, nstate, gm, dn, gs, s_copy);
       if (jamd_stream_wait(e, s_beam, s_copy) != JAMD_OK) die("stream order");        /* the next first pass waits for exactly these scores */
     }
     if (first + 2 * launch < nfile)                    /* launch k+2: read and upload while the device is busy with k and k+1 */
-      load(e, &ck[(k + 2) % 3], files, first + 2 * launch, nfile, veclen, nstate, s_copy, &ht);
+      load(e, &ck[(k + 2) % 3], files, nfr, first + 2 * launch, nfile, veclen, nstate, s_copy, &ht);
     { const double tw = now_s();
       if (jamd_stream_sync(e, s_beam) != JAMD_OK || jamd_beam_results(bm, res, n) != JAMD_OK) die("first pass");
       ht.sync_s += now_s() - tw; frames_total += off[n]; }
@@ -332,7 +345,7 @@ static void *run_device(void *arg)
   if (gm) jamd_gmm_destroy(gm);
   if (dn) jamd_dnn_destroy(dn);
   jamd_engine_destroy(e);
-  free(text);
+  free(text); free(nfr);
   return NULL;
 }
 
