@@ -70,7 +70,7 @@ struct XShared {
   unsigned sel_digit, sel_need, sel_count;
   unsigned wsum[NT / 64], wsum2[NT / 64];
   int scan_total, scan_total2;
-  int sw_nev, sw_limit, sw_fail, sw_changed;     // the sweep replay (beam_sweep.h)
+  int sw_nev, sw_limit, sw_fail, sw_changed, sw_ncl;     // the sweep replay (beam_sweep.h)
   int sw_ticks, sw_nev_out, sw_prof[8];
   int pst[16];                                   // this launch's share of jamd_beam_prune_stats(): kept here, added to the slice once at the end                      // its duration (100 MHz ticks), events held at the end
   int sw_info;                                   // last pruning step: rounds of the sweep replay, -1 = it gave up, 0 = not used

@@ -52,10 +52,17 @@ constexpr int kSwRounds = 24;
 constexpr int kSwPerThread = 8;          // list entries per thread in a pass
 
 typedef JAMD_LDS unsigned short lds_u16;
+// the sweep's global scratch is addressed as GLOBAL memory (a generic pointer makes flat_store / flat_load, which also count
+// against lgkmcnt: the LDS-only barrier of a level pass would then wait for the path rows' stores after all)
+typedef __attribute__((address_space(1))) unsigned short glb_u16;
+typedef __attribute__((address_space(1))) unsigned glb_u32;
+typedef __attribute__((address_space(1))) u32x4 glb_u32x4;
 constexpr unsigned kSwPos = 0x3fffffu;   // heap position (< 2^(kMaxL+1))
 constexpr unsigned kSwProbe = 0x80000000u, kSwLanded = 0x40000000u;
 // a list entry: entry number (13 bits) | landed << 14 | probe << 15 | T << 16
 constexpr unsigned kSwX = 0x1fffu, kSwXLanded = 0x4000u, kSwXProbe = 0x8000u;
+constexpr unsigned kSwTV = 0x1fffu;     // the turn itself in the T field (T <= M <= kSwX)
+constexpr unsigned kSwTC = 0x8000u;     // T field: this turn is a candidate turn (its tail position holds a top element) up to the limit
 constexpr unsigned kSwXF = 0x2000u;     // (inside a level pass) the T field of this probe / landed entry holds what the entry BEHIND it reads
 
 // What sort_token_downward() needs from the sweep beside the chains (all in LDS, behind the sweep's own image):
@@ -82,9 +89,9 @@ struct SweepMem {
   lds_u32 *wsum;                 // [2][NT / 64] wave sums of a level's scan, double buffered
   const lds_u32 *cur_evq;        // the event table in use (a landed element's birth = the turn of its last event)
   int n;
-  unsigned short *path;          // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
-  unsigned *ids;                 // global [nB] token ids
-  unsigned *chain;               // global [nB][kSwChainRec] new chain of an element: its landings, word kSwChain = its first position
+  glb_u16 *path;                 // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
+  glb_u32 *ids;                  // global [nB] token ids
+  glb_u32 *chain;                // global [nB][kSwChainRec] new chain of an element: its landings, word kSwChain = its first position
 };
 
 // LDS and global scratch the sweep needs for a top list of nB entries
@@ -227,10 +234,10 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
   // ---- the lists leave the region through the global scratch, then it is laid out afresh
   SweepMem m;
   m.n = n;
-  m.path = reinterpret_cast<unsigned short *>(gs);
-  m.ids = sweep_ids(gs);
+  m.path = (glb_u16 *)gs;
+  m.ids = (glb_u32 *)sweep_ids(gs);
   m.chain = m.ids + ((nB + 3) & ~3);
-  unsigned *const stage = m.chain;      // [nB] positions, [nB] score bits, the tail mask
+  glb_u32 *const stage = m.chain;      // [nB] positions, [nB] score bits, the tail mask
   for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
   for (int w = tid; w < nwords; w += NT) stage[2 * nB + w] = tailmask[w];
   __syncthreads();
@@ -326,7 +333,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     }
     const int nrows = min((int)m.tpre[nwords], kSwCandMax);
     {
-      unsigned *p32 = reinterpret_cast<unsigned *>(m.path);
+      glb_u32 *p32 = (glb_u32 *)m.path;
       for (int i = tid; i < (nrows * kSwDepth + 1) / 2; i += NT) p32[i] = 0xffffffffu;
     }
     SWTICK(1);
@@ -354,55 +361,71 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     const lds_u32 *const l_evq = evq, *const l_evp = m.evp, *const l_tail = m.tailmask;
     const lds_u16 *const l_tpre = m.tpre;
     lds_u16 *const l_TDx = m.TDx;
-    unsigned short *const l_path = m.path;
+    glb_u16 *const l_path = m.path;
     lds_u32 *const l_wsum = m.wsum, *const l_ent0 = m.ent[0], *const l_ent1 = m.ent[1];
     lds_u32 *const l_fd = down ? down->fd : nullptr, *const l_posend = down ? down->posend : nullptr;
     const int lane = tid & 63, wv = tid >> 6;
-    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;      // the lanes in front of mine
+    // A turn's flag (bit kSwTC of the T field: "this is a candidate turn up to `limit`": its path row is wanted) is looked
+    // up ONCE, where the value enters the table, and rides along with it -- not once per entry and level (round 6).
+    auto tflag = [&](unsigned T) -> unsigned {
+      if (T - 1u < (unsigned)limit) { const unsigned tw = l_tail[(T - 1u) >> 5]; if ((tw >> ((T - 1u) & 31u)) & 1u) return T | kSwTC; }
+      return T;
+    };
     for (int d = 0; L > 0; d++) {
       if (d >= kSwDepth - 1) return false;
       lds_u32 *A = pp ? l_ent1 : l_ent0;
       lds_u32 *B = pp ? l_ent0 : l_ent1;
       // a wave takes 64 * C consecutive entries, row by row (row i: entries wbase + 64 i + lane): the lanes of a wave read
-      // consecutive words, and an entry's place among the left- / right-goers of its wave is a ballot and a popcount
+      // consecutive words, and an entry's place among the left- / right-goers of its wave is a ballot and a popcount.
+      // The rows are unrolled (C <= kSwPerThread, uniform): an entry's word stays in a register between the two halves of
+      // the pass.
       const int C = (L + NT - 1) / NT;
       if (C > kSwPerThread) return false;
       const int wbase = wv * 64 * C;
+      lds_u32 *const Ar = A + wbase + lane;
       int nl = 0, nr = 0;                                              // the wave's totals (uniform)
       unsigned kind = 0u;                                              // 2 bits a row: 1 = goes left, 2 = goes right
       unsigned spec = 0u;                                              // rows in which my entry is a probe or a landed entry
+      unsigned wr[kSwPerThread];
       // What the entry behind reads is the T of the entry in front -- except behind a probe (looked through: it delays
       // nobody) and behind a landed entry born in turn b (looked through while the value in front of it is < b).  Those
       // few entries put that value into their own slot here (bit kSwXF: a slot is read whole, old or new), so that the
       // second half of the pass reads one word per entry.
-      for (int i = 0; i < C; i++) {
-        const int idx = wbase + 64 * i + lane;
-        unsigned kd = 0u;
-        if (idx < L) {
-          const unsigned w = A[idx], x = w & kSwX, T = w >> 16;
-          const unsigned ev = l_evp[x], vp = ev & kSwPos;
-          const int dep = sw_depth(vp);
-          if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << i;
-          if (d >= 1 && !(ev & kSwProbe) && (int)T <= limit) {         // who moves in a candidate turn
-            const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
-            if (tw & bit) {
+#pragma unroll
+      for (int i = 0; i < kSwPerThread; i++) {
+        wr[i] = 0u;
+        if (i < C) {
+          const int idx = wbase + 64 * i + lane;
+          unsigned kd = 0u;
+          if (idx < L) {
+            unsigned w = Ar[64 * i];
+            const unsigned x = w & kSwX;
+            const unsigned vp = l_evp[x] & kSwPos;
+            const int dep = sw_depth(vp);
+            if (d == 0) { w = (w & 0xffffu) | (tflag(w >> 16) << 16); Ar[64 * i] = w; }
+            wr[i] = w;
+            if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << i;
+            if (d >= 1 && (int)w < 0 && !(w & kSwXProbe)) {             // who moves in a candidate turn
+              const unsigned T = (w >> 16) & kSwTV;
+              const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
               const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
               if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
             }
-          }
-          if (l_fd && !(ev & kSwProbe)) {                              // sorting downward: where the hole leaves the extracted region,
-            const unsigned anc = vp >> (dep - d);                      // and where the elements that stay end up
-            if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
-            else {
-              const int li = (int)x - (nB - kSwLeft);
-              if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
+            if (l_fd && !(w & kSwXProbe)) {                            // sorting downward: where the hole leaves the extracted region,
+              const unsigned anc = vp >> (dep - d);                    // and where the elements that stay end up
+              const unsigned T = (w >> 16) & kSwTV;
+              if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
+              else {
+                const int li = (int)x - (nB - kSwLeft);
+                if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
+              }
             }
+            if (dep == d) l_TDx[x] = (unsigned short)(w >> 16);
+            else kd = ((vp >> (dep - d - 1)) & 1u) + 1u;
           }
-          if (dep == d) l_TDx[x] = (unsigned short)T;
-          else kd = ((vp >> (dep - d - 1)) & 1u) ? 2u : 1u;
+          kind |= kd << (2 * i);
+          nl += __popcll(__ballot(kd == 1u)); nr += __popcll(__ballot(kd == 2u));
         }
-        kind |= kd << (2 * i);
-        nl += __popcll(__ballot(kd == 1u)); nr += __popcll(__ballot(kd == 2u));
       }
       while (spec) {                                                   // (a wave runs this once or twice, not once per row)
         const int idx = wbase + 64 * (__ffs((int)spec) - 1) + lane;
@@ -411,16 +434,17 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         int j = idx - 1;
         unsigned wj = j >= 0 ? A[j] : 0u;
         while (j >= 0 && (wj & (kSwXProbe | kSwXLanded)) && !(wj & kSwXF)) { j--; wj = j >= 0 ? A[j] : 0u; }
-        unsigned v = wj >> 16;
+        unsigned v = (wj >> 16) & kSwTV;
         for (int s = j + 1; s <= idx; s++) {
           const unsigned ws = s == idx ? w : A[s];
-          if (ws & kSwXF) { v = ws >> 16; continue; }
+          if (ws & kSwXF) { v = (ws >> 16) & kSwTV; continue; }
           if (ws & kSwXProbe) continue;
           const unsigned b = (unsigned)(n - (int)l_evq[(int)l_ep[(ws & kSwX) + 1u] - 1] + 1);
           if (v < b) continue;
-          v = (ws >> 16) > b ? (ws >> 16) : b;
+          const unsigned ts = (ws >> 16) & kSwTV;
+          v = ts > b ? ts : b;
         }
-        A[idx] = (w & 0xffffu) | kSwXF | (v << 16);
+        A[idx] = (w & 0xffffu) | kSwXF | (tflag(v) << 16);
       }
       SWTICK(6);
       // the waves' totals -> where each wave's left- and right-goers start (one barrier: the totals alternate between two buffers)
@@ -435,16 +459,21 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         el = (int)(base & 0xffffu); er = (int)(base >> 16);
         totl = uni((int)(tot & 0xffffu)); totr = uni((int)(tot >> 16));
       }
-      for (int i = 0; i < C; i++) {
-        const int idx = wbase + 64 * i + lane;
-        const unsigned kd = (kind >> (2 * i)) & 3u;
-        const unsigned long long ml = __ballot(kd == 1u), mr = __ballot(kd == 2u);
-        if (kd) {
-          const unsigned v = idx > 0 ? (A[idx - 1] >> 16) : 0u;
-          const int at = kd == 1u ? el + __popcll(ml & lt_mask) : totl + er + __popcll(mr & lt_mask);
-          B[at] = (A[idx] & (0xffffu & ~kSwXF)) | (v << 16);
+#pragma unroll
+      for (int i = 0; i < kSwPerThread; i++) {
+        if (i < C) {
+          const unsigned kd = (kind >> (2 * i)) & 3u;
+          const unsigned long long ml = __ballot(kd == 1u), mr = __ballot(kd == 2u);
+          if (kd) {
+            const int idx = wbase + 64 * i + lane;
+            const unsigned pv = idx > 0 ? Ar[64 * i - 1] : 0u;         // the T of the entry in front (its flag rides along)
+            const unsigned long long mm = kd == 1u ? ml : mr;
+            const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+            const int at = (kd == 1u ? el : totl + er) + rk;
+            B[at] = (wr[i] & 0xffffu) | (pv & 0xffff0000u);           // (a register copy never carries kSwXF)
+          }
+          el += __popcll(ml); er += __popcll(mr);
         }
-        el += __popcll(ml); er += __popcll(mr);
       }
       lds_barrier();
       SWTICK(7);
@@ -456,11 +485,29 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     if (tid == 0) { sh.sw_changed = 0; }
     lds_u32 *ncnt = m.ent[0];                                          // new events per element (then their prefix)
     for (int r = tid; r <= nB; r += NT) ncnt[r] = 0u;
+    if (tid == 0) sh.sw_ncl = 0;
     __syncthreads();
-    for (int r = tid; r < nB; r += NT) {
+    // Only an element that STARTS on a tail position can have a chain (a tenth of the list): they are gathered first, so
+    // that the chain walk below runs on a few full waves instead of on every wave with a tenth of its lanes (round 6:
+    // 14.5 -> 6.5 us a round).
+    lds_u32 *const cl = m.ent[1];
+    for (int r0 = 0; r0 < nB; r0 += NT) {
+      const int r = r0 + tid;
+      bool has = false;
+      if (r < nB) {
+        const int c0 = m.ep[r];
+        const unsigned q0 = (int)m.ep[r + 1] != c0 ? evq[c0] : (m.evp[r] & kSwPos);
+        has = q0 >= (unsigned)(n - k + 1);
+      }
+      const int slot = wave_alloc(&sh.sw_ncl, has);
+      if (has) cl[slot] = (unsigned)r;
+    }
+    __syncthreads();
+    const int ncl = uni(sh.sw_ncl);
+    for (int ci = tid; ci < ncl; ci += NT) {
+      const int r = (int)cl[ci];
       const int c0 = m.ep[r], oc = (int)m.ep[r + 1] - c0;
       const unsigned q0 = oc ? evq[c0] : (m.evp[r] & kSwPos);
-      if (q0 < (unsigned)(n - k + 1)) continue;                       // never on a tail position at first: no chain
       int g0, len;
       group_of(r, g0, len);
       unsigned nh[kSwChain];
@@ -473,12 +520,12 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         if (turn > limit) break;
         if (t > oc || (t > 0 && nh[t - 1] != evh[c0 + t - 1])) break;   // this incarnation was not in the sweep: next round
         const unsigned x = t < oc ? (unsigned)(nB + c0 + t) : (unsigned)r;
-        if ((int)m.TDx[x] < turn) break;                                // it left the leaf before its turn
+        if ((int)(m.TDx[x] & kSwTV) < turn) break;                      // it left the leaf before its turn
         // landing: past the elements that move in this turn while they are strictly better
         const unsigned tw = m.tailmask[(turn - 1) >> 5], bit = 1u << ((turn - 1) & 31);
         const int ci = (int)m.tpre[(turn - 1) >> 5] + __popc(tw & (bit - 1u));
         if (!(tw & bit) || ci >= kSwCandMax) { sh.sw_fail = 1; break; }
-        const u32x4 *row = reinterpret_cast<const u32x4 *>(m.path + (size_t)ci * kSwDepth);
+        const glb_u32x4 *row = (const glb_u32x4 *)(m.path + (size_t)ci * kSwDepth);
         const u32x4 r0 = row[0], r1 = row[1], r2 = row[2];
         const unsigned rw[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         unsigned h = 1u;
@@ -510,7 +557,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       if (changed) sh.sw_changed = 1;
       ncnt[r] = (unsigned)nn;
       {
-        unsigned *rec = m.chain + (size_t)r * kSwChainRec;
+        glb_u32 *rec = m.chain + (size_t)r * kSwChainRec;
         for (int t = 0; t < nn; t++) rec[t] = nh[t];
         rec[kSwChain] = q0;
       }
@@ -534,7 +581,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const int nn = (int)ncnt[r];
         const int oc = (int)m.ep[r + 1] - (int)m.ep[r];
         if (nn == 0 && oc == 0) continue;
-        const unsigned *rec = m.chain + (size_t)r * kSwChainRec;
+        const glb_u32 *rec = m.chain + (size_t)r * kSwChainRec;
         unsigned q = rec[kSwChain];
         for (int t = 0; t < nn; t++) { const unsigned h = rec[t]; nq[ex + t] = q; nhh[ex + t] = h; nel[ex + t] = (unsigned short)r; q = h; }
         m.evp[r] = q | (nn ? kSwLanded : 0u);
