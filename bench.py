@@ -81,14 +81,18 @@ MFMA_F32_PEAK = 157.3          # TFLOP/s, dense fp32 MFMA
 
 # ------------------------------------------------------------------------------------------------ dist
 class Dist:
-    """torch.distributed (backend nccl = RCCL) when there is more than one rank."""
+    """torch.distributed (backend nccl = RCCL) when there is more than one rank.  `backend` "gloo" + `share_device` (every
+    rank on cuda:0) is the form in which the N > 1 orchestration -- rank spawn, strong split, barrier, max-over-ranks clock,
+    gather of the result records -- runs on a ONE-GPU box (RCCL refuses two ranks on one device): tests/test_bench_ranks_gpu.py."""
 
-    def __init__(self, gpus):
+    def __init__(self, gpus, backend="nccl", share_device=False):
         import torch
         self.torch = torch
         self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank = 0 if share_device else int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = backend
+        self.coll_device = "cuda" if backend == "nccl" else "cpu"      # where the (tiny) collectives' tensors live
         if gpus > 1 and self.world != gpus:
             raise SystemExit(f"--gpus {gpus}: WORLD_SIZE={self.world}")
         torch.cuda.set_device(self.local_rank)
@@ -97,8 +101,11 @@ class Dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             self.dist = dist
 
     def fence(self):
@@ -110,9 +117,16 @@ class Dist:
     def max_over_ranks(self, x: float) -> float:
         if self.dist is None:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(self, x: int) -> int:
+        if self.dist is None:
+            return int(x)
+        t = self.torch.tensor([int(x)], dtype=self.torch.int64, device=self.coll_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
 
     def close(self):
         if self.dist is not None:
@@ -282,6 +296,28 @@ def run_gmm(args, dd: Dist, steps, warmup):
                                          "512 frames per model sweep, so that figure exceeds the HBM peak by construction "
                                          "and is not a roofline; real traffic is the measured / compulsory bytes"}},
         }
+        # The small-T regime: one call scores T frames and the 15.4 MB model is streamed for them alone --
+        # the regime (live input, JAMD_STREAM_CHUNK = 25) in which north_star's "fraction of the HBM roofline" is the bound
+        # that could bind.  One lane = one frame, a wave = 128 frame slots: a call of T < 128 frames fills T of them.
+        small = []
+        model_bytes = E * (2 * D + 2) * 4
+        for Ts in (1, 25, 100, 1000):
+            ncall = 200
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(10):
+                gmm.outprob_dev(fr_ptr, Ts, out_ptr, stream.cuda_stream)
+            e0.record(stream)
+            for _ in range(ncall):
+                gmm.outprob_dev(fr_ptr, Ts, out_ptr, stream.cuda_stream)
+            e1.record(stream)
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / ncall
+            small.append({"frames_per_call": Ts, "us_per_call": us, "model_GBs": model_bytes / (us * 1e-6) / 1e9,
+                          "frac_of_hbm_peak": model_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": gmm.last_kernel()})
+        res["k1_small_T"] = {"calls": small, "model_bytes": model_bytes,
+                             "note": "back-to-back calls on one stream (launch overhead included); model_GBs = the model's bytes per call / "
+                                     "time per call: what a frame-synchronous caller streams; the model stays in L2 / Infinity Cache between "
+                                     "calls, so this is a rate, not measured HBM traffic"}
         if dd.world == 1 and not args.no_cpu_baseline:
             rng = np.random.default_rng(0)
             ss = np.sort(rng.choice(S, 16, replace=False))
@@ -377,6 +413,22 @@ def build_reference_task(workdir: Path, nword: int, beam: int, dnn=None, multipa
         am = ["-dnnconf", task["dnnconf"], "-notypecheck"]
     jargs = ["-h", task["hmmdefs"], "-hlist", task["hmmlist"], "-v", task["dict"], "-nlr", task["arpa"]] + am + [
         "-input", "htkparam", "-1pass", "-b", str(beam)] + (["-multipath"] if multipath else [])
+    export = ROOT / "julius_amd" / "jamd_export"
+    if not export.exists():
+        return task, jargs, None
+    prefix = workdir / "task"
+    subprocess.run([str(export)] + [str(a) for a in jargs] + ["-jamdout", str(prefix)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return task, jargs, prefix
+
+
+def build_c1_task(workdir: Path, beam: int):
+    """BASELINE configs[0] in the reference's own formats: tied-mixture monophone GMM-HMM (HTK ascii, <TMix> codebooks) + a
+    100-word loop grammar (.dfa / .dict), exported through Julius' loaders and wchmm.c by jamd_export like C3 / C4."""
+    from julius_amd import synth
+    task = synth.make_grammar_task(workdir, seed=0)
+    jargs = ["-h", task["hmmdefs"], "-dfa", task["dfa"], "-v", task["dict"], "-input", "htkparam", "-gprune", "safe", "-tmix", "2",
+             "-1pass", "-b", str(beam), "-penalty1", "-1.0"]
     export = ROOT / "julius_amd" / "jamd_export"
     if not export.exists():
         return task, jargs, None
@@ -506,7 +558,7 @@ def run_batch(args, dd: Dist, wd: Path, prefix, task, uniq, use_dnn, beam, launc
         shutil.rmtree(fd, ignore_errors=True)
 
 
-def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
+def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False, c1=False):
     """configs[2] (GMM) / configs[3] (DNN) end to end on the device: acoustic scores -> exact-order first pass.
     `runs` = list of (key, utterances per GPU, steps, warmup, scaling): every run shares the models, the lexicon and the
     distinct utterances; the FIRST run carries the parity block and the CPU baseline.  Returns {key: result}."""
@@ -515,26 +567,28 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
     eng = lib.Engine(dd.local_rank)
     tmp = tempfile.TemporaryDirectory(prefix="jamd_e2e_")
     wd = Path(tmp.name)
-    beam = args.beam if args.beam else (4000 if use_dnn else 800)
+    beam = args.beam if args.beam else (4000 if use_dnn else (200 if c1 else 800))
     # C4: a network whose posteriors are peaked on the state a frame was drawn from (synth.make_decodable_dnn: the first
     # pass ends in a sentence), or -- flat=True, the worst case for the rank pruning step -- random-init weights over noise
     dnn = (synth.make_dnn(seed=0) if flat else synth.make_decodable_dnn(seed=0)) if use_dnn else None
     NS = int(dnn["dims"][-1]) if use_dnn else S
-    task, jargs, prefix = build_reference_task(wd, args.nword, beam, dnn, multipath)
+    task, jargs, prefix = build_c1_task(wd, beam) if c1 else build_reference_task(wd, args.nword, beam, dnn, multipath)
+    if c1 and prefix is None:
+        return {}      # (no Julius tree to build jamd_export from: the C1 line needs the reference's grammar loader)
     if multipath and prefix is None:
         raise SystemExit("bench.py: the multipath workload needs julius_amd/jamd_export (the multipath lexicon is the reference's)")
     ref_built = prefix is not None
     if ref_built:
         lx = lib.Lexicon.from_file(eng, str(prefix) + ".lex")
         info = lexblob.load(str(prefix) + ".lex")
-        lexwhat = (f"{args.nword}-word tree lexicon built by the reference (wchmm.c via jamd_export: {info['nnode']} nodes, "
-                   f"{info['startnum']} roots, {info['isolatenum']} isolated) + 2-gram")
+        lexwhat = (f"{len(task['words']) if c1 else args.nword}-word tree lexicon built by the reference (wchmm.c via jamd_export: {info['nnode']} nodes, "
+                   f"{info['startnum']} roots, {info['isolatenum']} isolated) + " + ("loop grammar (DFA, per-category trees)" if c1 else "2-gram"))
     else:           # no Julius tree on this box to build jamd_export from: python-made lexicon over the same state inventory
         lex = synth.make_lexicon(nword=args.nword, nphone=40, S=NS, seed=0)
         lx = lib.Lexicon(eng, lex)
         lexwhat = f"{args.nword}-word synthetic tree lexicon ({lex['nnode']} nodes, {lex['startnum']} roots) + 2-gram"
     maxu = max(r[1] for r in runs)
-    ndist = max(1, min(maxu, args.distinct))
+    ndist = max(1, min(maxu * dd.world, args.distinct))      # distinct utterances of the GLOBAL batch: the same list for every N
     if use_dnn:
         scorer = lib.Dnn.from_dnnconf(eng, task["dnnconf"]) if ref_built else lib.Dnn(eng, dnn)
         if flat:    # random-init weights over noise: the scores carry no sentence, every frame saturates the beam
@@ -545,12 +599,22 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         what = (f"DNN {[int(x) for x in dnn['dims']]} (MFMA fp32) outprob, "
                 + ("random-init weights over noise frames (flat scores: no sentence, worst case of the rank pruning step)" if flat
                    else "nearest-centroid output layer over random hidden layers (peaked posteriors), frames drawn along word sequences"))
+    elif c1:
+        # BASELINE configs[0]: tied-mixture monophones (codebook top-N cache + per-state re-weighting, calc_tied_mix.c:162),
+        # -gprune safe -tmix 2 as in the C1 tests; 100-word loop grammar
+        scorer = lib.Gmm.from_file(eng, str(prefix) + ".am", lib.GPRUNE_SAFE, 2)
+        NS = scorer.S
+        uniq = [synth.make_grammar_utterance(task, nwords=6, seed=u)[0] for u in range(ndist)]
+        what = (f"tied-mixture GMM S={NS} states over {task['model']['nbook']} codebooks x {task['model']['mean'].shape[0] // max(1, task['model']['nbook'])} "
+                f"Gaussians x D={D}, -gprune safe -tmix 2 (K2 tmix_book + tmix_state)")
     else:
         scorer = lib.Gmm.from_file(eng, str(prefix) + ".am") if ref_built else lib.Gmm(eng, task["model"])
         uniq = [synth.make_utterance(task, nwords=30, seed=u)[0] for u in range(ndist)]
         what = f"GMM S={S} x M={M} x D={D} outprob"
     nuniq = len(uniq)
-    bm = lib.Beam(eng, lx, beam, -1.0, max_utts=maxu, atoms_per_utt=1 << (18 if beam > 1600 else 17))
+    # (C3 at -b 4000 saves 160 000 - 340 000 trellis words per utterance: a work area of 2^18 atoms reports JAMD_PASS1_OVERFLOW
+    # for half of them -- loudly, status != 0 -- so that run gets 2^19)
+    bm = lib.Beam(eng, lx, beam, -1.0, max_utts=maxu, atoms_per_utt=1 << ((19 if not use_dnn else 18) if beam > 1600 else 17))
     if args.order:
         bm.set_order_mode(args.order)
     mode = bm.order_mode()
@@ -625,13 +689,17 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         nutt_all = nutt * dd.world
         if dd.world > 1:
             # round-robin table: utterance g lives on rank g % world; this rank's u-th utterance is g = rank + u * world
-            table = shard.gather_results(shard.pack_results(res_local), nutt_all, dd.rank, dd.world, device="cuda")
+            table = shard.gather_results(shard.pack_results(res_local), nutt_all, dd.rank, dd.world, device=dd.coll_device)
         else:
             table = shard.pack_results(res_local)
+        frames_all = dd.sum_over_ranks(T)                       # the ranks' shares differ in length: the job's frames are their sum
+        if dd.rank == 0 and ri == 0 and args.dump_results:
+            np.savez(args.dump_results, table=np.asarray(table, np.int32), world=dd.world, utts_per_rank=nutt, frames_all=frames_all,
+                     rank0_utts=np.arange(dd.rank, nutt_all, dd.world))
         if dd.rank == 0:
             st = np.asarray(table)[:, 0]
-            total_frames = T * dd.world * steps
-            cfg = "C4 (BASELINE.json configs[3])" if use_dnn else "C3 (BASELINE.json configs[2])"
+            total_frames = frames_all * steps
+            cfg = "C4 (BASELINE.json configs[3])" if use_dnn else ("C1 (BASELINE.json configs[0])" if c1 else "C3 (BASELINE.json configs[2])")
             if multipath:
                 cfg += " decoded with -multipath (non-emitting word-begin / word-end nodes, the reference's two-half frame: beam.c:2747-2836)"
             if scaling == "strong":
@@ -640,9 +708,10 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
                  "unit": "frame*states/s", "n_gpus": dd.world, "steps": steps, "warmup": warmup, "scaling": scaling,
                  "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "rtf_inv": total_frames / 100.0 / elapsed,
                  "frames_per_s": total_frames / elapsed, "frames_per_s_per_gpu": total_frames / elapsed / dd.world,
-                 "config": {"workload": (f"{'C4' if use_dnn else 'C3'} = configs[{3 if use_dnn else 2}]"
+                 "config": {"workload": (f"{'C4' if use_dnn else ('C1' if c1 else 'C3')} = configs[{3 if use_dnn else (0 if c1 else 2)}]"
                                          + (" as configs[4] (fixed batch)" if scaling == "strong" else "")
-                                         + f": {'DNN' if use_dnn else 'GMM'} scores + HIP first pass, {args.nword} words, beam {beam}"
+                                         + f": {'DNN' if use_dnn else ('tied-mixture GMM' if c1 else 'GMM')} scores + HIP first pass, "
+                                         + f"{len(task['words']) if c1 else args.nword} words{' (grammar)' if c1 else ''}, beam {beam}"
                                          + (", -multipath" if multipath else "") + (", flat scores" if flat else "")
                                          + f", {nutt} utts/GPU/step"),
                             "detail": f"{cfg}: {what} + HIP first pass ({mode} tie order), {lexwhat}, beam {beam}, "
@@ -670,7 +739,7 @@ def run_e2e(args, dd: Dist, runs, use_dnn=False, flat=False, multipath=False):
         if ri == 0:
             first_key, first_nutt, first_res = key, nutt, res_local
         del d_fr, d_sc, d_scs
-    if runs and ref_built and not flat and not args.no_batch and mode.startswith("exact"):
+    if runs and ref_built and not flat and not c1 and not args.no_batch and mode.startswith("exact"):
         # the same task through the product's own host loop (file read + pinned staging + H2D + kernels + D2H), own clock.
         # AFTER the in-process runs: the exit of a process that held 30 GB of device and pinned memory disturbs the next
         # second of this process's kernels (round 5: one 360 - 440 ms step among e2e_strong's 205 ms steps when it ran between them)
@@ -882,6 +951,13 @@ def main():
     ap.add_argument("--distinct", type=int, default=32, help="e2e: distinct utterances in the batch")
     ap.add_argument("--order", default=None, choices=["fast", "strict", "exact", "exact_serial"],
                     help="e2e: first-pass tie order mode (default: the work area's default = exact)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of an N > 1 run (nccl = RCCL over xGMI; gloo: barrier / clock / gather over the host, "
+                         "with --share-device the way the N > 1 orchestration runs on a one-GPU box)")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (one-GPU box; needs --dist-backend gloo)")
+    ap.add_argument("--dump-results", default=None,
+                    help="e2e: rank 0 writes the gathered per-utterance result table of the first run (int32 [utts][4 + 150]: status, "
+                         "words, frames, score bits, word ids) and each rank's utterance ids to this .npz")
     ap.add_argument("--cpu-worker", nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ref-e2e-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -894,7 +970,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
-    dd = Dist(args.gpus)
+    dd = Dist(args.gpus, args.dist_backend, args.share_device)
     wl = args.workload
     nested = wl == "all"
 
@@ -927,6 +1003,12 @@ def main():
         if not args.strong and not args.multipath and args.utts is None:
             runs.append(("e2e_256", 256, pick(args.steps, 10), pick(args.warmup, 1), "weak"))
         r = run_e2e(args, dd, runs, use_dnn=False) if runs else {}
+        if wl == "all":
+            # SURVEY 8d's table lists C3 at -b 800 AND -b 4000: 256 utterances, wide layout, parity vs julius -1pass -b 4000
+            a4 = argparse.Namespace(**vars(args)); a4.beam = 4000; a4.no_batch = True
+            r.update(run_e2e(a4, dd, [("e2e_b4000", 256, 2, 1, "weak")], use_dnn=False))
+            # BASELINE configs[0] (the reference's CPU-runnable plumbing case) on the device: tied-mixture scoring + grammar first pass
+            r.update(run_e2e(args, dd, [("c1", 512, 5, 1, "weak")], c1=True))
         if wl == "all" or args.multipath:
             # the same task decoded with -multipath: 512 utterances per step, two per CU (the multipath frame in its half shape, round 5)
             r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 512), pick(args.steps, 4), pick(args.warmup, 1), "weak")],

@@ -601,6 +601,14 @@ int  jamd_beam_wait_started(jamd_beam *b);
  * and the scoring launches of batch k+1 (jamd_batch.c, bench.py): no event wait, no sleep, nothing to time.  Devices
  * without wait-on-memory fall back to jamd_beam_wait_started() plus a millisecond's pause inside this call. */
 int  jamd_beam_stream_wait_resident(jamd_beam *b, void *stream);
+/* Test entry: sets the resident counter (the device word the first-pass workgroups bump, and the host's bookkeeping of
+ * it) to `count`, as if that many workgroups had been launched since the work area was created.  The counter is 32 bits
+ * wide and drained back to zero before it could wrap (csrc/beam.hip mark_started()); a test starts it just below that
+ * point instead of launching 2^31 workgroups.  The device is synchronised first. */
+int  jamd_beam_debug_preset_resident(jamd_beam *b, unsigned count);
+/* Test entry: workgroups accounted since the last drain (*launched) and the value the next
+ * jamd_beam_stream_wait_resident() waits for (*target). */
+int  jamd_beam_debug_resident(const jamd_beam *b, unsigned *launched, unsigned *target);
 /* The rank-pruning step alone (sort_token_no_order(), beam.c:1492): given the scores of the n tokens of
  * a frame in creation order (host array), writes the token indices the next frame visits, in visiting
  * order (tindex[n_start..n_end]), for the work area's beam width; *nkeep = how many.  Runs the

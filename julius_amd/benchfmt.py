@@ -145,6 +145,9 @@ def compact_line(full: dict, lean: bool = False) -> dict:
     if isinstance(hbm, dict):
         line["roofline"]["hbm"] = {k: _num(hbm.get(k)) for k in ("algorithmic_GBs", "algorithmic_frac_of_peak", "compulsory_GBs",
                                                                   "measured_bytes_per_launch", "peak_GBs") if k in hbm}
+    sm = full.get("k1_small_T")
+    if isinstance(sm, dict):      # K1 called with a handful of frames: [frames per call, us per call, fraction of the HBM peak the model streams at]
+        line["k1_small_T"] = [[c.get("frames_per_call"), _num(c.get("us_per_call"), 4), _num(c.get("frac_of_hbm_peak"), 3)] for c in sm.get("calls", [])]
     c = _cpu(full.get("cpu_baseline"))
     if c:
         line["cpu_baseline"] = c

@@ -2013,6 +2013,22 @@ int jamd_beam_stream_wait_resident(jamd_beam *b, void *stream) {
   return JAMD_OK;
 }
 
+int jamd_beam_debug_preset_resident(jamd_beam *b, unsigned count) {
+  if (!b) { jamd_set_error("jamd_beam_debug_preset_resident: NULL"); return JAMD_EINVAL; }
+  JAMD_HIP(hipSetDevice(b->eng->device));
+  JAMD_HIP(hipDeviceSynchronize());
+  if (b->d_resident) JAMD_HIP(hipMemcpy(b->d_resident, &count, sizeof(unsigned), hipMemcpyHostToDevice));
+  b->launched_wg = count; b->resident_target = count;
+  return JAMD_OK;
+}
+
+int jamd_beam_debug_resident(const jamd_beam *b, unsigned *launched, unsigned *target) {
+  if (!b) { jamd_set_error("jamd_beam_debug_resident: NULL"); return JAMD_EINVAL; }
+  if (launched) *launched = b->launched_wg;
+  if (target) *target = b->resident_target;
+  return JAMD_OK;
+}
+
 int jamd_beam_workgroup_shape(const jamd_beam *b, int nutt) {
   if (!b) return -1;
   return use_half_shape(b, nutt) ? JAMD_SHAPE_HALF : JAMD_SHAPE_FULL;

@@ -35,6 +35,7 @@ using namespace jamd;
 #define JAMD_GMM_LOGSUM_R4 0
 #endif
 constexpr int kWaves = 4;  // waves per workgroup
+int ensure(float **p, size_t *cap, size_t need);
 
 // XCD-aware block decode: the dispatcher places block b on XCD b % 8
 // (MI355X_MICROARCH.md "Workgroup dispatch"); all frame-blocks of one state
@@ -316,6 +317,101 @@ int launch_tile_generic(jamd_gmm *g, const float *frames, int T, float *out, hip
 }
 
 // ---------------------------------------------------------------------------------------
+// K1n, the NARROW form of K1 (round 6): a call of a handful of frames -- live input, a streaming chunk
+// (JAMD_STREAM_CHUNK = 25), the calcmix slot of a frame-synchronous caller.  K1 maps one lane to one frame (128 frame
+// slots per wave): a 25-frame call fills a fifth of ONE wave per 16-state block, and every block still walks its 256
+// Gaussians one after the other -- 250 us per call whatever T is, the 15.4 MB model streamed at 60 GB/s.  Here the
+// mapping is turned round: one lane = one MIXTURE ENTRY (its record in 2 D + 2 registers, read once per call), the
+// frames are wave-uniform and arrive by scalar load, two at a time as the packed pair of the D-loop; the weighted
+// Gaussian scores go to a [T][E] scratch (coalesced), and a second kernel -- one lane per (frame, state) -- runs the
+// table log-sum from the last mixture to the first (addlog_array(), addlog.c:103) and calc_mix()'s tail.  Same four
+// separately rounded fp32 operations per dimension, same scan order: bit-identical to K1 (tests/test_gmm_gpu.py).
+constexpr int kNarrowT = 256;      // calls of at most this many frames (the scratch is kNarrowT x E floats)
+constexpr int kNarrowFB = 8;       // frames per block of the first kernel
+template <int D, bool HAS_NULL>
+__global__ void __launch_bounds__(64)
+gmm_narrow_dens_kernel(const float *__restrict__ rec, const float *__restrict__ frames, float *__restrict__ dens, int T, int E,
+                       int nfb, int neb) {
+  constexpr int REC = (2 * D + 2 + 3) & ~3;
+  // the frame blocks of one range of 64 entries run on ONE XCD (block b is placed on XCD b % 8): the range's records
+  // come from HBM / Infinity Cache once and from that XCD's L2 for the other frame blocks (decode_block(), as K1)
+  int fbk, ebk;
+  if (!decode_block(nfb, neb, fbk, ebk)) return;
+  const int e = ebk * 64 + threadIdx.x;
+  const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(rec + (size_t)(e < E ? e : E - 1) * REC);
+  float r[REC];
+#pragma unroll
+  for (int q = 0; q < REC / 4; q++) { const float4 v = r4[q]; r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
+  const float gc = r[2 * D], lw = r[2 * D + 1];
+  const bool nulld = HAS_NULL && (gc != gc);      // NULL density marker (gprune_none.c:67)
+  // a block takes kNarrowFB frames: with one wave per SIMD the scalar loads of a frame pair (a microsecond) were not
+  // covered by anything (25 frames: 26 us); three or four waves per SIMD cover them (the record is read once per block: L2)
+  const int t_end = min(T, (fbk + 1) * kNarrowFB);
+  for (int t = fbk * kNarrowFB; t < t_end; t += 2) {
+    const float *__restrict__ fa = frames + (size_t)t * D;
+    const float *__restrict__ fb = frames + (size_t)(t + 1 < T ? t + 1 : t) * D;
+    f2 acc = {gc, gc};
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      f2 x = f2{fa[d], fb[d]} - f2{r[d], r[d]};
+      x = x * x;
+      x = x * f2{r[D + d], r[D + d]};
+      acc = acc + x;
+    }
+    f2 s2 = acc * f2{-0.5f, -0.5f};
+    if (nulld) s2 = f2{JAMD_LOG_ZERO, JAMD_LOG_ZERO};
+    s2 = s2 + f2{lw, lw};
+    if (e < E) {
+      dens[(size_t)t * E + e] = s2.x;
+      if (t + 1 < T) dens[(size_t)(t + 1) * E + e] = s2.y;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gmm_narrow_lse_kernel(const float *__restrict__ dens, const int *__restrict__ st_off, const float *__restrict__ tbl,
+                      float *__restrict__ out, int T, int S, int E, float addmin_f) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * S) return;
+  const int t = i / S, s = i - t * S;
+  const int e0 = st_off[s], e1 = st_off[s + 1];
+  const float *__restrict__ dr = dens + (size_t)t * E;
+  float y = JAMD_LOG_ZERO;
+  int e = e1 - 1;
+  for (; e - 7 >= e0; e -= 8) {                    // eight terms in flight in front of the serial table scan
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = dr[e - q];
+#pragma unroll
+    for (int q = 0; q < 8; q++) y = addlog_step(y, v[q], tbl, addmin_f);
+  }
+  for (; e >= e0; e--) y = addlog_step(y, dr[e], tbl, addmin_f);
+  out[(size_t)t * S + s] = finish_state(y);
+}
+
+// JAMD_GMM_NARROW=0: every call through K1 (A/B switch; read once)
+bool narrow_enabled() {
+  static const bool on = [] { const char *v = getenv("JAMD_GMM_NARROW"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
+template <int D>
+int launch_narrow(jamd_gmm *g, const float *frames, int T, float *out, hipStream_t st) {
+  const int E = g->E_plain;
+  int rc = ensure(&g->d_narrow, &g->narrow_cap, sizeof(float) * (size_t)kNarrowT * (size_t)E);   // (first narrow call only)
+  if (rc != JAMD_OK) return rc;
+  const int grid = (E + 63) / 64;
+  const int nfb = (T + kNarrowFB - 1) / kNarrowFB;
+  const dim3 gr(8 * ((grid + 7) / 8) * nfb);
+  if (g->has_null) hipLaunchKernelGGL((gmm_narrow_dens_kernel<D, true>), gr, dim3(64), 0, st, g->d_rec, frames, g->d_narrow, T, E, nfb, grid);
+  else hipLaunchKernelGGL((gmm_narrow_dens_kernel<D, false>), gr, dim3(64), 0, st, g->d_rec, frames, g->d_narrow, T, E, nfb, grid);
+  hipLaunchKernelGGL(gmm_narrow_lse_kernel, dim3((T * g->S + 255) / 256), dim3(256), 0, st, g->d_narrow, g->d_st_off_plain,
+                     g->eng->d_addlog, out, T, g->S, E, g->eng->addmin_f);
+  snprintf(g->last_kernel, sizeof(g->last_kernel), "gmm_narrow<D=%d> grid=%d + lse", D, grid);
+  return JAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Per-Gaussian scores for the reference's plugin slot (compute_gaussset / calcmix,
 // plugin/calcmix.c:86-323): dens[t][e] = compute_g_base() of mixture entry e at frame t,
 // (gconst + sum_d (o_d - mu_d)^2 * ivar_d) * -0.5, the same four fp32 operations per dimension as
@@ -540,7 +636,7 @@ void jamd_gmm_destroy(jamd_gmm *g) {
   if (!g) return;
   (void)hipSetDevice(g->eng->device);
   void *ptrs[] = { g->d_rec, g->d_cur_utt_off, g->d_st_off, g->d_st_off_plain, g->d_tied_states, g->d_st_book, g->d_book_off, g->d_book_rec,
-                   g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num };
+                   g->d_ent_logw, g->d_frames, g->d_out, g->d_tm_score, g->d_tm_id, g->d_tm_num, g->d_narrow };
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (g->h_utt_off) (void)hipHostFree(g->h_utt_off);
   if (g->ev_utt_off) (void)hipEventDestroy(g->ev_utt_off);
@@ -667,6 +763,15 @@ int jamd_gmm_outprob_utts_dev(jamd_gmm *g, const float *dev_frames, const int *u
   // table log-sum, so it also goes through the sorted kernel
   if (g->gprune == JAMD_GPRUNE_SAFE) {
     rc = jamd_gmm_launch_safe(g, dev_frames, T, dev_out, st);
+  } else
+  if (T <= kNarrowT && narrow_enabled() && (g->D == 39 || g->D == 38 || g->D == 26 || g->D == 25)) {
+    // a handful of frames: one lane per mixture entry instead of one lane per frame (K1n above)
+    switch (g->D) {
+      case 39: rc = launch_narrow<39>(g, dev_frames, T, dev_out, st); break;
+      case 38: rc = launch_narrow<38>(g, dev_frames, T, dev_out, st); break;
+      case 26: rc = launch_narrow<26>(g, dev_frames, T, dev_out, st); break;
+      default: rc = launch_narrow<25>(g, dev_frames, T, dev_out, st); break;
+    }
   } else
   switch (g->D) {
     case 39: rc = launch_tile<39, 2, 16>(g, dev_frames, T, dev_out, st); break;

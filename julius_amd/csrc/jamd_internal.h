@@ -70,6 +70,7 @@ struct jamd_gmm {
   float *d_frames = nullptr; size_t frames_cap = 0;
   float *d_out = nullptr; size_t out_cap = 0;
   float *d_tm_score = nullptr; int *d_tm_id = nullptr; int *d_tm_num = nullptr;
+  float *d_narrow = nullptr; size_t narrow_cap = 0;   // [kNarrowT][E_plain] weighted Gaussian scores of a narrow call (K1n, gmm_outprob.hip)
   size_t tm_cap_bytes = 0, tm_id_bytes = 0, tm_num_bytes = 0;
   char last_kernel[64] = {0};
   // pinned staging copy of the running call's utterance boundaries (history pruning only) and the event behind its

@@ -139,6 +139,8 @@ def load():
         "jamd_beam_exact_layout": (ci, [vp]),
         "jamd_beam_wait_started": (ci, [vp]),
         "jamd_beam_stream_wait_resident": (ci, [vp, vp]),
+        "jamd_beam_debug_preset_resident": (ci, [vp, C.c_uint]),
+        "jamd_beam_debug_resident": (ci, [vp, P(C.c_uint), P(C.c_uint)]),
         "jamd_beam_prune_order": (ci, [vp, vp, ci, vp, P(ci)]),
         "jamd_beam_prune_arrange": (ci, [vp, vp, ci, vp, P(ci), vp]),
         "jamd_beam_prune_info": (ci, [vp, P(ci), P(ci), P(ci)]),
@@ -658,6 +660,14 @@ class Beam:
         """Work queued on `stream` behind this call starts once the latest first-pass launch holds its CUs
         (jamd_beam_stream_wait_resident: a wait on device memory, no host involvement)."""
         _check(load().jamd_beam_stream_wait_resident(self.h, stream), "jamd_beam_stream_wait_resident")
+
+    def debug_preset_resident(self, count: int):
+        _check(load().jamd_beam_debug_preset_resident(self.h, count), "jamd_beam_debug_preset_resident")
+
+    def debug_resident(self):
+        a, b = C.c_uint(), C.c_uint()
+        _check(load().jamd_beam_debug_resident(self.h, C.byref(a), C.byref(b)), "jamd_beam_debug_resident")
+        return int(a.value), int(b.value)
 
     def exact_layout(self) -> str:
         """'narrow' / 'wide' LDS image of the exact-order kernel for this work area, or 'none' (jamd_beam_exact_layout)."""

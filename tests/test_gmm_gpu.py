@@ -22,11 +22,36 @@ def load(name):
 
 
 def test_golden_plain(engine):
+    """Both forms of K1 against the compiled reference's golden scores: the narrow form (calls of <= 256 frames: one lane per
+    mixture entry, csrc/gmm_outprob.hip K1n) and the tile kernel (one lane per frame) on the same frames repeated."""
     g = load("gmm_plain_none.npz")
     gm = lib.Gmm(engine, g)
+    T = len(g["frames"])
     out = gm.outprob_host(g["frames"])
-    assert "gmm_tile<D=39" in gm.last_kernel()
+    assert ("gmm_narrow<D=39" if T <= 256 else "gmm_tile<D=39") in gm.last_kernel()
     assert np.array_equal(out, g["out"])
+    reps = 256 // T + 2
+    big = gm.outprob_host(np.tile(g["frames"], (reps, 1)))
+    assert "gmm_tile<D=39" in gm.last_kernel()
+    for r in range(reps):
+        assert np.array_equal(big[r * T:(r + 1) * T], g["out"])
+
+
+@pytest.mark.parametrize("D,ragged,T", [(39, False, 1), (39, False, 25), (39, True, 2), (39, True, 255), (39, True, 256),
+                                          (26, True, 33), (38, False, 100), (25, True, 7)])
+def test_narrow_call_equals_tile_kernel(engine, oracle, D, ragged, T):
+    """A call of a handful of frames (live input, a streaming chunk) takes the narrow form of K1; the same frames inside a
+    long call take the tile kernel: the scores are the same floats, and the oracle's."""
+    m = synth.make_gmm(S=70, M=11, D=D, seed=900 + T, ragged=ragged, null_frac=0.08 if ragged else 0.0)
+    fr = synth.make_frames(m, T=600, seed=T)
+    gm = lib.Gmm(engine, m)
+    wide = gm.outprob_host(fr)
+    assert "gmm_tile<D=" in gm.last_kernel()
+    for start in (0, 300):
+        narrow = gm.outprob_host(fr[start:start + T])
+        assert "gmm_narrow<D=" in gm.last_kernel()
+        assert np.array_equal(narrow, wide[start:start + T])
+    assert np.array_equal(gm.outprob_host(fr[:T]), oracle.gmm_outprob(m, fr[:T]))
 
 
 def test_golden_ragged_null_densities(engine):
