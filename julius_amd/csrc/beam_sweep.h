@@ -37,13 +37,13 @@
 // tools/prune_lab2.py restates all of this in numpy and checks it against the sequential loop (3 600 tie-heavy random
 // arrays, frames of the C4 task); tests/test_prune_order.py does it for this code through jamd_beam_prune_order().
 //
-// Cost: a round is ~14 level passes over <= 5 000 entries by the whole workgroup; whatever the sweep cannot hold
+// Cost: a round is ~14 level passes over <= 5 000 entries by the whole workgroup (sweep_replay(): each lane takes a run of
+// consecutive entries, ~35 instructions an entry and level); whatever the sweep cannot hold
 // (more than kSwEvMax events, a tie group with events and more than kSwGroup entries, no convergence) falls back to the
 // pipelined extraction loop.
 #pragma once
 
 constexpr int kSwEvMax = 1024;           // events (probe entries) held
-constexpr int kSwCandMax = 1024;         // candidate turns with a path row
 constexpr int kSwDepth = kMaxL + 4;      // path row: one slot per depth, three 16-byte words
 constexpr int kSwChain = 8;              // events per element (an element can bounce from tail leaf to tail leaf: five in real frames)
 constexpr int kSwChainRec = 12;          // words of an element's new chain in the global scratch: landings, then the first position
@@ -57,13 +57,17 @@ typedef JAMD_LDS unsigned short lds_u16;
 typedef __attribute__((address_space(1))) unsigned short glb_u16;
 typedef __attribute__((address_space(1))) unsigned glb_u32;
 typedef __attribute__((address_space(1))) u32x4 glb_u32x4;
-constexpr unsigned kSwPos = 0x3fffffu;   // heap position (< 2^(kMaxL+1))
+constexpr unsigned kSwPos = 0xffffu;     // evp[]: heap position (the sweep holds heaps of < 2^16 tokens); bits 16..29 of a landed element's
+constexpr int kSwBirthSh = 16;           // word: the turn in which it took that position (13 bits), then that turn's kSwTC flag
 constexpr unsigned kSwProbe = 0x80000000u, kSwLanded = 0x40000000u;
 // a list entry: entry number (13 bits) | landed << 14 | probe << 15 | T << 16
 constexpr unsigned kSwX = 0x1fffu, kSwXLanded = 0x4000u, kSwXProbe = 0x8000u;
 constexpr unsigned kSwTV = 0x1fffu;     // the turn itself in the T field (T <= M <= kSwX)
 constexpr unsigned kSwTC = 0x8000u;     // T field: this turn is a candidate turn (its tail position holds a top element) up to the limit
-constexpr unsigned kSwXF = 0x2000u;     // (inside a level pass) the T field of this probe / landed entry holds what the entry BEHIND it reads
+// Inside the level passes an entry is TWO slots that move together: a 32-bit word (entry number | landed << 14 | probe << 15 |
+// ROUTE << 16) and a 16-bit T field.  ROUTE = the path bits of the entry's position BELOW the level at hand, left-aligned, then a
+// terminating 1: 0x8000 = the entry lies at this level's depth, < 0x8000 = it goes left, > 0x8000 = right; the next level's route
+// is one shift.  (So a level needs neither the position nor its depth: heaps of < 2^16 tokens.)
 
 // What sort_token_downward() needs from the sweep beside the chains (all in LDS, behind the sweep's own image):
 struct SweepDown {
@@ -80,16 +84,17 @@ struct SweepMem {
   lds_u32 *evp;                  // [M] position | flags, per entry (x < nB: the element's current incarnation; nB + c: the probe of event c)
   lds_u16 *gid;                  // [nB] tie group: 0x8000 | length at the group's first rank, else that rank
   lds_u16 *ep;                   // [nB + 1] events of the elements in front (the event table is sorted by element)
-  lds_u32 *ent[2];               // [M] the list of a level, ping-pong: entry | T << 16
+  lds_u32 *ent[2];               // [M] ent[1]: the list of a level, entry | route << 16, rewritten in place (a pass holds its entries in
+                                 //     registers between its two barriers); ent[0]: level 0 as it is built (entry | T << 16), scratch
+  lds_u16 *tl;                   // [M] the T fields of the list
   lds_u32 *evq[2], *evh[2];      // [kSwEvMax] event table, double buffered: tail position left, landing
   lds_u16 *evel[2];              // [kSwEvMax] element
-  lds_u16 *tpre;                 // [words + 1] prefix popcount of the tail mask
   lds_u32 *tailmask;
-  lds_u16 *TDx;                  // [M] T at the entry's own depth
+  lds_u16 *TDx;                  // [M] T at the entry's own depth (lies over ent[0], which the level passes do not use)
   lds_u32 *wsum;                 // [2][NT / 64] wave sums of a level's scan, double buffered
   const lds_u32 *cur_evq;        // the event table in use (a landed element's birth = the turn of its last event)
   int n;
-  glb_u16 *path;                 // global [kSwCandMax][kSwDepth] who moves in a candidate turn, by depth
+  glb_u16 *path;                 // global [k + 1][kSwDepth] who moves in a candidate turn, by turn and depth
   glb_u32 *ids;                  // global [nB] token ids
   glb_u32 *chain;                // global [nB][kSwChainRec] new chain of an element: its landings, word kSwChain = its first position
 };
@@ -97,7 +102,7 @@ struct SweepMem {
 // LDS and global scratch the sweep needs for a top list of nB entries
 __host__ __device__ inline int sweep_lds_bytes(int nB, int k, int evmax) {
   const int M = nB + evmax;
-  return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * evmax + 6 * ((k + 31) / 32 + 4) + 512;
+  return 4 * M + 2 * M + 2 * nB + 2 * (nB + 2) + 8 * M + 2 * (4 + 4 + 2) * evmax + 4 * ((k + 31) / 32 + 4) + 512;
 }
 // the most events (a multiple of 64, at most kSwEvMax) whose image fits `avail` bytes of LDS; 0 = none
 __host__ __device__ inline int sweep_pick_evmax(int nB, int k, int avail) {
@@ -106,17 +111,41 @@ __host__ __device__ inline int sweep_pick_evmax(int nB, int k, int avail) {
   return ev >= 64 ? ev : 0;
 }
 __host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
-  return 2 * (size_t)kSwCandMax * kSwDepth + 4 * (size_t)b_cap + 4 * (size_t)kSwChainRec * (size_t)b_cap + 64;
+  return 2 * (size_t)(b_cap + 2) * kSwDepth + 4 * (size_t)b_cap + 4 * (size_t)kSwChainRec * (size_t)b_cap + 64;
 }
 
 __device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
 // token ids of the top list in the sweep's global scratch (rank order of the list handed to sweep_replay())
-__device__ __forceinline__ unsigned *sweep_ids(unsigned char *gs) { return reinterpret_cast<unsigned *>(gs + 2 * (size_t)kSwCandMax * kSwDepth); }
+__device__ __forceinline__ unsigned *sweep_ids(unsigned char *gs) { return reinterpret_cast<unsigned *>(gs); }
 // workgroup barrier that orders LDS traffic only: the global stores of a level pass (who moves when: consumed after the
 // whole sweep) stay in flight instead of being waited for at every barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // turn in which landed element x (kSwLanded set) took its present position
 __device__ __forceinline__ int sw_birth(const SweepMem &m, unsigned x) { return m.n - (int)m.cur_evq[(int)m.ep[x + 1] - 1] + 1; }
+
+// T field of a turn as it enters the table: bit kSwTC marks a candidate turn (its tail position holds a top element) up to `limit`
+__device__ __forceinline__ unsigned sweep_tflag(const lds_u32 *tail, int limit, unsigned T) {
+  if (T - 1u < (unsigned)limit) { const unsigned tw = tail[(T - 1u) >> 5]; if ((tw >> ((T - 1u) & 31u)) & 1u) return T | kSwTC; }
+  return T;
+}
+// T field (turn | flag) of the turn in which landed element x took its present position, out of its evp[] word
+__device__ __forceinline__ unsigned sweep_birth_field(unsigned e) { const unsigned b = e >> kSwBirthSh; return (b & kSwTV) | ((b << 2) & kSwTC); }
+// route of heap position p (depth <= 15) at level 0
+__device__ __forceinline__ unsigned sweep_route(unsigned p) { return (((p << 1) | 1u) << (15 - sw_depth(p))) & 0xffffu; }
+// inclusive prefix sums over the lanes of a wave / over each row of 16 lanes, on the DPP path (no LDS round trips)
+__device__ __forceinline__ unsigned dpp_row_scan(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  return v;
+}
+__device__ __forceinline__ unsigned dpp_wave_scan(unsigned v) {
+  v = dpp_row_scan(v);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
 
 // block-wide exclusive scan with max (one unsigned per thread, identity 0)
 template <int NT>
@@ -228,15 +257,20 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
   const unsigned long long clk0 = wall_clock64();
   unsigned long long clk = clk0;
 #define SWTICK(i) do { if (tid == 0) { const unsigned long long c_ = wall_clock64(); sh.sw_prof[i] += (int)(c_ - clk); clk = c_; } } while (0)
+#ifdef JAMD_SWEEP_LEVEL_TICKS                                          // development: the clock of thread JAMD_SWEEP_LEVEL_TICKS's wave inside a level pass (slots 6, 7, and 4, 5 borrowed)
+#define SWTICK2(i) do { if (tid == JAMD_SWEEP_LEVEL_TICKS) { const unsigned long long c_ = wall_clock64(); sh.sw_prof[i] += (int)(c_ - clk2); clk2 = c_; } } while (0)
+#else
+#define SWTICK2(i) do { } while (0)
+#endif
   const int M = nB + evmax;
   const int nwords = (k + 31) / 32 + 1;
-  if (nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k, evmax) > region_bytes || 4 * (2 * nB + nwords) > 4 * kSwChainRec * nB) return false;
+  if (n >= 0x10000 || nB > kSwPerThread * NT || M > (int)kSwX || nB >= 0x8000 || sweep_lds_bytes(nB, k, evmax) > region_bytes || 4 * (2 * nB + nwords) > 4 * kSwChainRec * nB) return false;
   // ---- the lists leave the region through the global scratch, then it is laid out afresh
   SweepMem m;
   m.n = n;
-  m.path = (glb_u16 *)gs;
   m.ids = (glb_u32 *)sweep_ids(gs);
   m.chain = m.ids + ((nB + 3) & ~3);
+  m.path = (glb_u16 *)(m.chain + (size_t)kSwChainRec * nB);            // (16-byte aligned: rows are read as three 16-byte words)
   glb_u32 *const stage = m.chain;      // [nB] positions, [nB] score bits, the tail mask
   for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
   for (int w = tid; w < nwords; w += NT) stage[2 * nB + w] = tailmask[w];
@@ -247,12 +281,12 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     m.evp = (lds_u32 *)take(4 * M);
     m.ent[0] = (lds_u32 *)take(4 * M);
     m.ent[1] = (lds_u32 *)take(4 * M);
-    m.TDx = (lds_u16 *)take(2 * M);
+    m.tl = (lds_u16 *)take(2 * M);
+    m.TDx = (lds_u16 *)m.ent[0];
     m.gid = (lds_u16 *)take(2 * nB);
     m.ep = (lds_u16 *)take(2 * (nB + 2));
     for (int b = 0; b < 2; b++) { m.evq[b] = (lds_u32 *)take(4 * evmax); m.evh[b] = (lds_u32 *)take(4 * evmax); m.evel[b] = (lds_u16 *)take(2 * evmax); }
     m.tailmask = (lds_u32 *)take(4 * (nwords + 1));
-    m.tpre = (lds_u16 *)take(2 * (nwords + 2));
     m.wsum = (lds_u32 *)take(4 * 2 * (NT / 64));
   }
   lds_u32 *score = m.ent[1];                                           // (until the groups are known)
@@ -299,7 +333,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     lds_u32 *const evq = m.evq[cur], *const evh = m.evh[cur];
     m.cur_evq = evq;
     lds_u16 *const evel = m.evel[cur];
-    // ---- ep[r] = events of the elements in front of r; prefix popcount of the tail mask; path rows cleared
+    // ---- ep[r] = events of the elements in front of r; the path rows of the candidate turns cleared
     {
       lds_u32 *cntv = m.ent[1];
       for (int r = tid; r <= nB; r += NT) cntv[r] = 0u;
@@ -312,29 +346,22 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       for (int r = lo; r < hi; r++) tot += (int)cntv[r];
       int ex = block_excl_scan<NT>(sh, tot);
       for (int r = lo; r < hi; r++) { const int c = (int)cntv[r]; m.ep[r] = (unsigned short)ex; ex += c; }
-      if (tid < 64) {
-        int run = 0;
-        for (int w0 = 0; w0 < nwords; w0 += 64) {
-          const int w = w0 + tid;
-          const int c = w < nwords ? __popc(m.tailmask[w]) : 0;
-          int incl = c;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (tid >= off) incl += o; }
-          if (w < nwords) m.tpre[w] = (unsigned short)(run + incl - c);
-          run += __shfl(incl, 63, 64);
-        }
-        if (tid == 0) m.tpre[nwords] = (unsigned short)run;
-      }
       __syncthreads();
     }
     if (down) {
       for (int i = tid; i <= k; i += NT) down->fd[i] = 0u;
       for (int i = tid; i < kSwLeft; i += NT) down->posend[i] = 0u;
     }
-    const int nrows = min((int)m.tpre[nwords], kSwCandMax);
-    {
-      glb_u32 *p32 = (glb_u32 *)m.path;
-      for (int i = tid; i < (nrows * kSwDepth + 1) / 2; i += NT) p32[i] = 0xffffffffu;
+    for (int w = tid; w < nwords; w += NT) {                             // (a row is written and read in the same round, for the turns flagged below)
+      unsigned tw = m.tailmask[w];
+      while (tw) {
+        const int T = 32 * w + __ffs((int)tw);
+        tw &= tw - 1u;
+        if (T > limit) break;
+        glb_u32x4 *row = (glb_u32x4 *)(m.path + (size_t)T * kSwDepth);
+        const u32x4 ff = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        row[0] = ff; row[1] = ff; row[2] = ff;
+      }
     }
     SWTICK(1);
     // ---- level 0: the entries in extraction order.  A group without events keeps the order of the sorted list.
@@ -356,141 +383,204 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     }
     SWTICK(2);
     // ---- the sweep: level d -> d + 1
-    int L = L0, pp = 0;
     const lds_u16 *const l_ep = m.ep;                                   // (locals: `m` itself may live in scratch memory)
     const lds_u32 *const l_evq = evq, *const l_evp = m.evp, *const l_tail = m.tailmask;
-    const lds_u16 *const l_tpre = m.tpre;
     lds_u16 *const l_TDx = m.TDx;
+    lds_u32 *const l_evpw = m.evp;
     glb_u16 *const l_path = m.path;
     lds_u32 *const l_wsum = m.wsum, *const l_ent0 = m.ent[0], *const l_ent1 = m.ent[1];
+    lds_u16 *const l_t1 = m.tl;
     lds_u32 *const l_fd = down ? down->fd : nullptr, *const l_posend = down ? down->posend : nullptr;
     const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / 64;
     // A turn's flag (bit kSwTC of the T field: "this is a candidate turn up to `limit`": its path row is wanted) is looked
-    // up ONCE, where the value enters the table, and rides along with it -- not once per entry and level (round 6).
-    auto tflag = [&](unsigned T) -> unsigned {
-      if (T - 1u < (unsigned)limit) { const unsigned tw = l_tail[(T - 1u) >> 5]; if ((tw >> ((T - 1u) & 31u)) & 1u) return T | kSwTC; }
-      return T;
-    };
+    // up ONCE, where the value enters the table, and rides along with it.
+    auto tflag = [&](unsigned T) -> unsigned { return sweep_tflag(l_tail, limit, T); };
+    // level 0 as the passes want it: entry | route in list 1, the T fields beside it; a landed entry's birth with its flag
+    for (int i = tid; i < L0; i += NT) {
+      const unsigned w = l_ent0[i];
+      const unsigned x = w & kSwX;
+      l_ent1[i] = (w & 0xdfffu) | (sweep_route(l_evp[x] & kSwPos) << 16);
+      l_t1[i] = (unsigned short)tflag(w >> 16);
+      if (w & kSwXLanded) {
+        const unsigned bf = tflag((unsigned)(n - (int)l_evq[(int)l_ep[x + 1u] - 1] + 1));
+        l_evpw[x] = (l_evpw[x] & (kSwPos | kSwProbe | kSwLanded)) | (((bf & kSwTV) | ((bf & kSwTC) >> 2)) << kSwBirthSh);
+      }
+    }
+    lds_barrier();
+    int L = L0;
+    unsigned long long clk2 = wall_clock64(); (void)clk2;
     for (int d = 0; L > 0; d++) {
       if (d >= kSwDepth - 1) return false;
-      lds_u32 *A = pp ? l_ent1 : l_ent0;
-      lds_u32 *B = pp ? l_ent0 : l_ent1;
-      // a wave takes 64 * C consecutive entries, row by row (row i: entries wbase + 64 i + lane): the lanes of a wave read
-      // consecutive words, and an entry's place among the left- / right-goers of its wave is a ballot and a popcount.
-      // The rows are unrolled (C <= kSwPerThread, uniform): an entry's word stays in a register between the two halves of
-      // the pass.
-      const int C = (L + NT - 1) / NT;
-      if (C > kSwPerThread) return false;
-      const int wbase = wv * 64 * C;
-      lds_u32 *const Ar = A + wbase + lane;
-      int nl = 0, nr = 0;                                              // the wave's totals (uniform)
-      unsigned kind = 0u;                                              // 2 bits a row: 1 = goes left, 2 = goes right
-      unsigned spec = 0u;                                              // rows in which my entry is a probe or a landed entry
-      unsigned wr[kSwPerThread];
-      // What the entry behind reads is the T of the entry in front -- except behind a probe (looked through: it delays
-      // nobody) and behind a landed entry born in turn b (looked through while the value in front of it is < b).  Those
-      // few entries put that value into their own slot here (bit kSwXF: a slot is read whole, old or new), so that the
-      // second half of the pass reads one word per entry.
+      // Lane-runs: a thread takes CH consecutive entries of the list, so the entry in front of all but its first is its own,
+      // its place among the left- / right-goers is a count inside the thread plus ONE prefix sum per wave (DPP), and every
+      // quantity of an entry comes out of its two slots by a compare (round 6; the round-4 form gave every lane one entry of a
+      // 64-entry row and paid ~100 instructions an entry and level for ballots, position look-ups and nested branches).
+      // A lane's run is 4 or 8 entries: one or two 16-byte reads of the list, 8-byte reads of the T fields (a run that starts
+      // anywhere makes the lanes' 4-byte reads collide in the LDS banks).  The list falls into units of 256 entries; every wave
+      // takes one, the first `nb` waves a second one.
+      const int nunits = (L + 255) >> 8, nb = max(nunits - NW, 0);
+      if (nb > NW) return false;
+      const int wvu = uni(wv);
+      const int CH = wvu < nb ? 8 : 4;
+      const int wavebase = wvu < nb ? wvu * 512 : nb * 512 + (wvu - nb) * 256;
+      lds_u32 *const Wa = l_ent1, *const Wb = l_ent1;                  // (in place: every entry is in a register between the two barriers)
+      lds_u16 *const Ta = l_t1, *const Tb = l_t1;
+      const int base = wavebase + lane * CH;
+      const int nval = min(max(L - base, 0), CH);
+      const lds_u32 *const wp = Wa + base;
+      const lds_u16 *const tp = Ta + base;
+      unsigned w[kSwPerThread], f[kSwPerThread];                       // f: the T field an entry takes to the next level
+      unsigned cl = 0u, cr = 0u, accw = 0u, acct = 0u;
 #pragma unroll
-      for (int i = 0; i < kSwPerThread; i++) {
-        wr[i] = 0u;
-        if (i < C) {
-          const int idx = wbase + 64 * i + lane;
-          unsigned kd = 0u;
-          if (idx < L) {
-            unsigned w = Ar[64 * i];
-            const unsigned x = w & kSwX;
-            const unsigned vp = l_evp[x] & kSwPos;
-            const int dep = sw_depth(vp);
-            if (d == 0) { w = (w & 0xffffu) | (tflag(w >> 16) << 16); Ar[64 * i] = w; }
-            wr[i] = w;
-            if (w & (kSwXProbe | kSwXLanded)) spec |= 1u << i;
-            if (d >= 1 && (int)w < 0 && !(w & kSwXProbe)) {             // who moves in a candidate turn
-              const unsigned T = (w >> 16) & kSwTV;
-              const unsigned tw = l_tail[(T - 1u) >> 5], bit = 1u << ((T - 1u) & 31u);
-              const int ci = (int)l_tpre[(T - 1u) >> 5] + __popc(tw & (bit - 1u));
-              if (ci < kSwCandMax) l_path[(size_t)ci * kSwDepth + d] = (unsigned short)x;
+      for (int i = 0; i < kSwPerThread; i++) { w[i] = 0u; f[i] = 0u; }
+      const bool active = wavebase < L;                                 // (a wave behind the end of a short list only joins the barriers)
+      if (active) {
+        unsigned t[kSwPerThread];
+        unsigned wq = wp[-1], v = tp[-1];                               // the entry in front of the run
+        if (base == 0 || nval == 0) { wq = 0u; v = 0u; }
+        {
+          typedef JAMD_LDS unsigned long long lds_u64x;
+          const u32x4 a0 = *(const lds_v4 *)wp;
+          const unsigned long long b0 = *(const lds_u64x *)tp;
+          u32x4 a1 = {0u, 0u, 0u, 0u};
+          unsigned long long b1 = 0ull;
+          if (CH == 8) { a1 = *(const lds_v4 *)(wp + 4); b1 = *(const lds_u64x *)(tp + 4); }
+          const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (int i = 0; i < kSwPerThread; i++) {
+            const unsigned b = (unsigned)((i < 4 ? b0 : b1) >> (16 * (i & 3))) & 0xffffu;
+            w[i] = i < nval ? aw[i] : 0u; t[i] = i < nval ? b : 0u;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kSwPerThread; i++) {
+          if (i < CH) {
+            cl += (int)w[i] > 0xffff ? 1u : 0u;                         // 0 < route < 0x8000
+            cr += w[i] >= 0x80010000u ? 1u : 0u;                        // route > 0x8000
+            accw |= w[i]; acct |= t[i];
+            if ((w[i] >> 16) == 0x8000u) l_TDx[w[i] & kSwX] = (unsigned short)t[i];   // T at the entry's own depth
+          }
+        }
+        SWTICK2(6);
+        if (d >= 1 && __any((int)(acct & kSwTC))) {                     // who moves in a candidate turn
+#pragma unroll
+          for (int i = 0; i < kSwPerThread; i++) {
+            if (i < CH) {
+              if ((t[i] & kSwTC) && !(w[i] & kSwXProbe)) l_path[(t[i] & kSwTV) * (unsigned)kSwDepth + (unsigned)d] = (unsigned short)(w[i] & kSwX);
             }
-            if (l_fd && !(w & kSwXProbe)) {                            // sorting downward: where the hole leaves the extracted region,
-              const unsigned anc = vp >> (dep - d);                    // and where the elements that stay end up
-              const unsigned T = (w >> 16) & kSwTV;
-              if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | anc); }
-              else {
-                const int li = (int)x - (nB - kSwLeft);
-                if (li >= 0) l_posend[li] = anc; else sh.sw_fail = 1;
+          }
+        }
+        SWTICK2(0);
+        if (l_fd) {                                                    // sorting downward: where the hole leaves the extracted region
+#pragma unroll                                                         // (the deepest mover of a turn: entry number here, its position after the last round),
+          for (int i = 0; i < kSwPerThread; i++) {                     // and where the elements that stay end up
+            if (i < CH) {
+              if (w[i] != 0u && !(w[i] & kSwXProbe)) {
+                const unsigned T = t[i] & kSwTV, x = w[i] & kSwX;
+                if ((int)T <= k) { if (d >= 1) atomicMax((unsigned *)&l_fd[T], ((unsigned)d << 21) | x); }
+                else {
+                  const int li = (int)x - (nB - kSwLeft);
+                  const unsigned vp = l_evp[x] & kSwPos;
+                  if (li >= 0) l_posend[li] = vp >> (sw_depth(vp) - d); else sh.sw_fail = 1;
+                }
               }
             }
-            if (dep == d) l_TDx[x] = (unsigned short)(w >> 16);
-            else kd = ((vp >> (dep - d - 1)) & 1u) + 1u;
           }
-          kind |= kd << (2 * i);
-          nl += __popcll(__ballot(kd == 1u)); nr += __popcll(__ballot(kd == 2u));
         }
-      }
-      while (spec) {                                                   // (a wave runs this once or twice, not once per row)
-        const int idx = wbase + 64 * (__ffs((int)spec) - 1) + lane;
-        spec &= spec - 1u;
-        const unsigned w = A[idx];
-        int j = idx - 1;
-        unsigned wj = j >= 0 ? A[j] : 0u;
-        while (j >= 0 && (wj & (kSwXProbe | kSwXLanded)) && !(wj & kSwXF)) { j--; wj = j >= 0 ? A[j] : 0u; }
-        unsigned v = (wj >> 16) & kSwTV;
-        for (int s = j + 1; s <= idx; s++) {
-          const unsigned ws = s == idx ? w : A[s];
-          if (ws & kSwXF) { v = (ws >> 16) & kSwTV; continue; }
-          if (ws & kSwXProbe) continue;
-          const unsigned b = (unsigned)(n - (int)l_evq[(int)l_ep[(ws & kSwX) + 1u] - 1] + 1);
-          if (v < b) continue;
-          const unsigned ts = (ws >> 16) & kSwTV;
-          v = ts > b ? ts : b;
-        }
-        A[idx] = (w & 0xffffu) | kSwXF | (tflag(v) << 16);
-      }
-      SWTICK(6);
-      // the waves' totals -> where each wave's left- and right-goers start (one barrier: the totals alternate between two buffers)
-      int el, er, totl, totr;
-      {
-        lds_u32 *ws = l_wsum + (d & 1) * (NT / 64);
-        if (lane == 0) ws[wv] = (unsigned)nl | ((unsigned)nr << 16);
-        lds_barrier();
-        unsigned base = 0u, tot = 0u;
+        // What the entry behind reads is the T of the entry in front -- except behind a probe (looked through: it delays
+        // nobody) and behind a landed entry born in turn b (looked through while the value in front of it is < b).  The
+        // value runs along the thread's entries in registers; only a thread whose run begins behind such an entry walks
+        // back through the list.  (The round-4 form had these entries rewrite their slots before a barrier: 2.5 of a
+        // level's 4.3 us were that walk and the wait for the slowest wave's.)
+        if (__any((int)((accw | wq) & (kSwXProbe | kSwXLanded)))) {
+          // (all look-ups first, the two entries in front of the run among them: the walk below is for the thread whose run
+          // begins behind two or more such entries)
+          unsigned wq2 = wp[-2], tq2 = tp[-2];
+          if (base <= 1 || nval == 0) { wq2 = 0u; tq2 = 0u; }
+          unsigned bq = 0xffffu, bb[kSwPerThread];                      // (a probe: as if born after every turn)
+          if (wq & kSwXLanded) bq = sweep_birth_field(l_evp[wq & kSwX]);
 #pragma unroll
-        for (int w = 0; w < NT / 64; w++) { const unsigned v = ws[w]; tot += v; base += w < wv ? v : 0u; }
-        el = (int)(base & 0xffffu); er = (int)(base >> 16);
-        totl = uni((int)(tot & 0xffffu)); totr = uni((int)(tot >> 16));
+          for (int i = 0; i < kSwPerThread; i++) { bb[i] = 0xffffu; if (i < CH) { if (w[i] & kSwXLanded) bb[i] = sweep_birth_field(l_evp[w[i] & kSwX]); } }
+          if (wq & (kSwXProbe | kSwXLanded)) {
+            unsigned in = tq2;                                          // what stands in front of the entry in front
+            if (wq2 & (kSwXProbe | kSwXLanded)) {
+              int j = base - 2;
+              while (j >= 0 && (Wa[j] & (kSwXProbe | kSwXLanded))) j--;
+              in = j >= 0 ? (unsigned)Ta[j] : 0u;
+              for (int s = j + 1; s < base - 1; s++) {
+                const unsigned ws = Wa[s];
+                if (ws & kSwXProbe) continue;
+                const unsigned b = sweep_birth_field(l_evp[ws & kSwX]);
+                if ((in & kSwTV) < (b & kSwTV)) continue;
+                const unsigned ts = Ta[s];
+                in = (ts & kSwTV) > (b & kSwTV) ? ts : b;
+              }
+            }
+            const unsigned late = (v & kSwTV) > (bq & kSwTV) ? v : bq;  // (v: the T field of the entry in front)
+            v = (in & kSwTV) < (bq & kSwTV) ? in : late;
+          }
+#pragma unroll
+          for (int i = 0; i < kSwPerThread; i++) {
+            f[i] = 0u;
+            if (i < CH) {
+              f[i] = v;
+              const unsigned b = bb[i];
+              const unsigned late = (t[i] & kSwTV) > (b & kSwTV) ? t[i] : b;
+              const unsigned thru = (v & kSwTV) < (b & kSwTV) ? v : late;
+              v = (w[i] & (kSwXProbe | kSwXLanded)) ? thru : t[i];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < kSwPerThread; i++) { f[i] = 0u; if (i < CH) { f[i] = v; v = t[i]; } }
+        }
       }
+      SWTICK2(1);
+      // where this thread's left- and right-goers start: prefix over the wave, then over the waves' totals
+      const unsigned c = cl | (cr << 16);
+      const unsigned incl = dpp_wave_scan(c);
+      lds_u32 *ws = l_wsum + (d & 1) * NW;                              // (one barrier: the totals alternate between two buffers)
+      if (lane == 63) ws[wv] = incl;
+      lds_barrier();
+      SWTICK2(7);
+      const unsigned wsc = dpp_row_scan(lane < NW ? ws[lane] : 0u);
+      const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wsc, NW - 1);
+      const unsigned wbase = wvu ? (unsigned)__builtin_amdgcn_readlane((int)wsc, wvu - 1) : 0u;
+      const int totl = (int)(tot & 0xffffu), totr = (int)(tot >> 16);
+      const unsigned ex = wbase + incl - c;
+      unsigned el = ex & 0xffffu, er = (unsigned)totl + (ex >> 16);
+      if (active) {
 #pragma unroll
       for (int i = 0; i < kSwPerThread; i++) {
-        if (i < C) {
-          const unsigned kd = (kind >> (2 * i)) & 3u;
-          const unsigned long long ml = __ballot(kd == 1u), mr = __ballot(kd == 2u);
-          if (kd) {
-            const int idx = wbase + 64 * i + lane;
-            const unsigned pv = idx > 0 ? Ar[64 * i - 1] : 0u;         // the T of the entry in front (its flag rides along)
-            const unsigned long long mm = kd == 1u ? ml : mr;
-            const int rk = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-            const int at = (kd == 1u ? el : totl + er) + rk;
-            B[at] = (wr[i] & 0xffffu) | (pv & 0xffff0000u);           // (a register copy never carries kSwXF)
+        if (i < CH) {
+          const bool left = (int)w[i] > 0xffff, right = w[i] >= 0x80010000u;
+          if (left || right) {
+            const unsigned at = left ? el : er;
+            Wb[at] = (w[i] & 0xffffu) | ((w[i] & 0x7fff0000u) << 1);
+            Tb[at] = (unsigned short)f[i];
           }
-          el += __popcll(ml); er += __popcll(mr);
+          el += left ? 1u : 0u; er += right ? 1u : 0u;
         }
       }
+      }
+      SWTICK2(4);
       lds_barrier();
-      SWTICK(7);
-      L = totl + totr; pp ^= 1;
+      SWTICK2(5);
+      L = totl + totr;
     }
     __syncthreads();                                                   // (the moves written to global memory)
     SWTICK(3);
     // ---- every chain again from the table
     if (tid == 0) { sh.sw_changed = 0; }
-    lds_u32 *ncnt = m.ent[0];                                          // new events per element (then their prefix)
-    for (int r = tid; r <= nB; r += NT) ncnt[r] = 0u;
+    lds_u16 *const cl = (lds_u16 *)m.ent[1];                           // (the list is done with; ent[0] holds TDx[])
+    lds_u16 *const ncnt = cl + ((nB + 8) & ~7);                        // new events per element
+    for (int r = tid; r <= nB; r += NT) ncnt[r] = 0;
     if (tid == 0) sh.sw_ncl = 0;
     __syncthreads();
     // Only an element that STARTS on a tail position can have a chain (a tenth of the list): they are gathered first, so
     // that the chain walk below runs on a few full waves instead of on every wave with a tenth of its lanes (round 6:
     // 14.5 -> 6.5 us a round).
-    lds_u32 *const cl = m.ent[1];
     for (int r0 = 0; r0 < nB; r0 += NT) {
       const int r = r0 + tid;
       bool has = false;
@@ -500,7 +590,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         has = q0 >= (unsigned)(n - k + 1);
       }
       const int slot = wave_alloc(&sh.sw_ncl, has);
-      if (has) cl[slot] = (unsigned)r;
+      if (has) cl[slot] = (unsigned short)r;
     }
     __syncthreads();
     const int ncl = uni(sh.sw_ncl);
@@ -523,9 +613,8 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         if ((int)(m.TDx[x] & kSwTV) < turn) break;                      // it left the leaf before its turn
         // landing: past the elements that move in this turn while they are strictly better
         const unsigned tw = m.tailmask[(turn - 1) >> 5], bit = 1u << ((turn - 1) & 31);
-        const int ci = (int)m.tpre[(turn - 1) >> 5] + __popc(tw & (bit - 1u));
-        if (!(tw & bit) || ci >= kSwCandMax) { sh.sw_fail = 1; break; }
-        const glb_u32x4 *row = (const glb_u32x4 *)(m.path + (size_t)ci * kSwDepth);
+        if (!(tw & bit)) { sh.sw_fail = 1; break; }
+        const glb_u32x4 *row = (const glb_u32x4 *)(m.path + (size_t)turn * kSwDepth);
         const u32x4 r0 = row[0], r1 = row[1], r2 = row[2];
         const unsigned rw[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         unsigned h = 1u;
@@ -555,7 +644,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         if (nh[t] >= (unsigned)(n - k + 1)) { const int b = n - (int)nh[t]; atomicOr((unsigned *)&m.tailmask[b >> 5], 1u << (b & 31)); }
       }
       if (changed) sh.sw_changed = 1;
-      ncnt[r] = (unsigned)nn;
+      ncnt[r] = (unsigned short)nn;
       {
         glb_u32 *rec = m.chain + (size_t)r * kSwChainRec;
         for (int t = 0; t < nn; t++) rec[t] = nh[t];
@@ -600,12 +689,17 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     for (int i = tid; i < (k + 31) / 32 + 1; i += NT) down->evbits[i] = 0u;
     __syncthreads();
     for (int c = tid; c < nev; c += NT) { const int b = n - (int)m.evq[cur][c]; atomicOr((unsigned *)&down->evbits[b >> 5], 1u << (b & 31)); }
+    for (int i = tid; i <= k; i += NT) {                                 // fd[]: the deepest mover of a turn -> the position it left
+      const unsigned w = down->fd[i];
+      if (w) { const unsigned dd = w >> 21, vp = m.evp[w & kSwX] & kSwPos; down->fd[i] = (dd << 21) | (vp >> (sw_depth(vp) - (int)dd)); }
+    }
     if (uni(sh.sw_fail)) return false;
   }
   if (tid == 0) { sh.sw_info = round; sh.sw_ticks = (int)(wall_clock64() - clk0); sh.sw_nev_out = sh.sw_nev; }   // diagnostic: jamd_beam_prune_info()
   __syncthreads();
   return true;
 #undef SWTICK
+#undef SWTICK2
 }
 
 // sort_token_downward() (beam.c:1414-1457), the part the sweep does not give: the residual heap.  Every turn i takes the
