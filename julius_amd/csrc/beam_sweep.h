@@ -97,6 +97,7 @@ struct SweepMem {
   glb_u16 *path;                 // global [k + 1][kSwDepth] who moves in a candidate turn, by turn and depth
   glb_u32 *ids;                  // global [nB] token ids
   glb_u32 *chain;                // global [nB][kSwChainRec] new chain of an element: its landings, word kSwChain = its first position
+  glb_u16 *cand;                 // global [nB] the elements that start on a tail position (only they can have a chain)
 };
 
 // LDS and global scratch the sweep needs for a top list of nB entries
@@ -111,7 +112,7 @@ __host__ __device__ inline int sweep_pick_evmax(int nB, int k, int avail) {
   return ev >= 64 ? ev : 0;
 }
 __host__ __device__ inline size_t sweep_global_bytes(int b_cap) {
-  return 2 * (size_t)(b_cap + 2) * kSwDepth + 4 * (size_t)b_cap + 4 * (size_t)kSwChainRec * (size_t)b_cap + 64;
+  return 2 * (size_t)(b_cap + 2) * kSwDepth + 4 * (size_t)b_cap + 4 * (size_t)kSwChainRec * (size_t)b_cap + 2 * (size_t)(b_cap + 8) + 64;
 }
 
 __device__ __forceinline__ int sw_depth(unsigned p) { return 31 - __clz((int)p); }
@@ -270,7 +271,8 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
   m.n = n;
   m.ids = (glb_u32 *)sweep_ids(gs);
   m.chain = m.ids + ((nB + 3) & ~3);
-  m.path = (glb_u16 *)(m.chain + (size_t)kSwChainRec * nB);            // (16-byte aligned: rows are read as three 16-byte words)
+  m.cand = (glb_u16 *)(m.chain + (size_t)kSwChainRec * nB);
+  m.path = m.cand + ((nB + 7) & ~7);                                   // (16-byte aligned: rows are read as three 16-byte words)
   glb_u32 *const stage = m.chain;      // [nB] positions, [nB] score bits, the tail mask
   for (int r = tid; r < nB; r += NT) { stage[r] = vposR[r]; stage[nB + r] = (unsigned)(compR[r] >> 32); m.ids[r] = idR[r]; }
   for (int w = tid; w < nwords; w += NT) stage[2 * nB + w] = tailmask[w];
@@ -320,7 +322,17 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     g0 = (g & 0x8000u) ? r : (int)g;
     len = (int)(m.gid[g0] & 0x7fffu);
   };
-  if (tid == 0) { sh.sw_nev = 0; sh.sw_limit = ilast; sh.sw_fail = 0; }
+  if (tid == 0) { sh.sw_nev = 0; sh.sw_limit = ilast; sh.sw_fail = 0; sh.sw_ncl = 0; }
+  for (int r = tid; r <= nB + 1; r += NT) m.ep[r] = 0;                  // (kept up to date where the event table is rebuilt)
+  __syncthreads();
+  // Only an element that STARTS on a tail position can have a chain (a tenth of the list): they are gathered once, so that
+  // the chain walk of a round runs on a few full waves instead of on every wave with a tenth of its lanes.
+  for (int r0 = 0; r0 < nB; r0 += NT) {
+    const int r = r0 + tid;
+    const bool has = r < nB && (m.evp[r] & kSwPos) >= (unsigned)(n - k + 1);
+    const int slot = wave_alloc(&sh.sw_ncl, has);
+    if (has) m.cand[slot] = (unsigned short)r;
+  }
   __syncthreads();
   SWTICK(0);
   int cur = 0;                                                         // event table in use
@@ -332,22 +344,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     const int L0 = nB + nev;
     lds_u32 *const evq = m.evq[cur], *const evh = m.evh[cur];
     m.cur_evq = evq;
-    lds_u16 *const evel = m.evel[cur];
-    // ---- ep[r] = events of the elements in front of r; the path rows of the candidate turns cleared
-    {
-      lds_u32 *cntv = m.ent[1];
-      for (int r = tid; r <= nB; r += NT) cntv[r] = 0u;
-      __syncthreads();
-      for (int c = tid; c < nev; c += NT) atomicAdd((unsigned *)&cntv[evel[c]], 1u);
-      __syncthreads();
-      const int C = (nB + 1 + NT - 1) / NT;
-      const int lo = tid * C, hi = min(nB + 1, lo + C);
-      int tot = 0;
-      for (int r = lo; r < hi; r++) tot += (int)cntv[r];
-      int ex = block_excl_scan<NT>(sh, tot);
-      for (int r = lo; r < hi; r++) { const int c = (int)cntv[r]; m.ep[r] = (unsigned short)ex; ex += c; }
-      __syncthreads();
-    }
+    // ---- the path rows of the candidate turns cleared (ep[r] = events of the elements in front of r: from the rebuild below)
     if (down) {
       for (int i = tid; i <= k; i += NT) down->fd[i] = 0u;
       for (int i = tid; i < kSwLeft; i += NT) down->posend[i] = 0u;
@@ -364,25 +361,8 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       }
     }
     SWTICK(1);
-    // ---- level 0: the entries in extraction order.  A group without events keeps the order of the sorted list.
-    {
-      lds_u32 *A = m.ent[0];
-      for (int r = tid; r < nB; r += NT) {
-        int g0, len;
-        group_of(r, g0, len);
-        const int c0 = m.ep[g0], c1 = m.ep[g0 + len];
-        if (c0 == c1) {
-          A[r + c0] = (unsigned)r | ((unsigned)(r + 1) << 16);
-          if ((!down || down->want_order) && r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
-        } else if (r == g0) {
-          if (!sweep_order_group(m, nB, g0, len, c0, c1, A + g0 + c0, m.ent[1] + g0 + c0, (down && !down->want_order) ? 0 : k, svid)) sh.sw_fail = 1;
-        }
-      }
-      __syncthreads();
-      if (uni(sh.sw_fail)) return false;
-    }
-    SWTICK(2);
-    // ---- the sweep: level d -> d + 1
+    // ---- level 0: the entries in extraction order, as the passes want them: entry | route in the list, the T fields beside
+    // it, a landed entry's birth with its flag in its evp[] word.  A group without events keeps the order of the sorted list.
     const lds_u16 *const l_ep = m.ep;                                   // (locals: `m` itself may live in scratch memory)
     const lds_u32 *const l_evq = evq, *const l_evp = m.evp, *const l_tail = m.tailmask;
     lds_u16 *const l_TDx = m.TDx;
@@ -396,18 +376,35 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     // A turn's flag (bit kSwTC of the T field: "this is a candidate turn up to `limit`": its path row is wanted) is looked
     // up ONCE, where the value enters the table, and rides along with it.
     auto tflag = [&](unsigned T) -> unsigned { return sweep_tflag(l_tail, limit, T); };
-    // level 0 as the passes want it: entry | route in list 1, the T fields beside it; a landed entry's birth with its flag
-    for (int i = tid; i < L0; i += NT) {
-      const unsigned w = l_ent0[i];
-      const unsigned x = w & kSwX;
-      l_ent1[i] = (w & 0xdfffu) | (sweep_route(l_evp[x] & kSwPos) << 16);
-      l_t1[i] = (unsigned short)tflag(w >> 16);
-      if (w & kSwXLanded) {
-        const unsigned bf = tflag((unsigned)(n - (int)l_evq[(int)l_ep[x + 1u] - 1] + 1));
-        l_evpw[x] = (l_evpw[x] & (kSwPos | kSwProbe | kSwLanded)) | (((bf & kSwTV) | ((bf & kSwTC) >> 2)) << kSwBirthSh);
+    for (int r = tid; r < nB; r += NT) {
+      int g0, len;
+      group_of(r, g0, len);
+      const int c0 = l_ep[g0], c1 = l_ep[g0 + len];
+      if (c0 == c1) {
+        l_ent1[r + c0] = (unsigned)r | (sweep_route(l_evp[r] & kSwPos) << 16);
+        l_t1[r + c0] = (unsigned short)tflag((unsigned)(r + 1));
+        if ((!down || down->want_order) && r + 1 <= k) svid[k - (r + 1)] = (int)m.ids[r];
+      } else if (r == g0) {
+        lds_u32 *const dst = l_ent0 + g0 + c0;                          // (ordered as entry | T << 16, scratch in the list's own place)
+        if (!sweep_order_group(m, nB, g0, len, c0, c1, dst, l_ent1 + g0 + c0, (down && !down->want_order) ? 0 : k, svid)) sh.sw_fail = 1;
+        else {
+          for (int i = 0; i < len + (c1 - c0); i++) {
+            const unsigned w = dst[i];
+            const unsigned x = w & kSwX;
+            l_ent1[g0 + c0 + i] = (w & 0xdfffu) | (sweep_route(l_evp[x] & kSwPos) << 16);
+            l_t1[g0 + c0 + i] = (unsigned short)tflag(w >> 16);
+            if (w & kSwXLanded) {
+              const unsigned bf = tflag((unsigned)(n - (int)l_evq[(int)l_ep[x + 1u] - 1] + 1));
+              l_evpw[x] = (l_evpw[x] & (kSwPos | kSwProbe | kSwLanded)) | (((bf & kSwTV) | ((bf & kSwTC) >> 2)) << kSwBirthSh);
+            }
+          }
+        }
       }
     }
-    lds_barrier();
+    __syncthreads();
+    if (uni(sh.sw_fail)) return false;
+    SWTICK(2);
+    // ---- the sweep: level d -> d + 1
     int L = L0;
     unsigned long long clk2 = wall_clock64(); (void)clk2;
     for (int d = 0; L > 0; d++) {
@@ -573,29 +570,13 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     SWTICK(3);
     // ---- every chain again from the table
     if (tid == 0) { sh.sw_changed = 0; }
-    lds_u16 *const cl = (lds_u16 *)m.ent[1];                           // (the list is done with; ent[0] holds TDx[])
-    lds_u16 *const ncnt = cl + ((nB + 8) & ~7);                        // new events per element
+    lds_u16 *const ncnt = (lds_u16 *)m.ent[1];                         // new events per element (the list is done with; ent[0] holds TDx[])
+    lds_u16 *const nep = ncnt + ((nB + 9) & ~7);                       // ep[] of the next round
     for (int r = tid; r <= nB; r += NT) ncnt[r] = 0;
-    if (tid == 0) sh.sw_ncl = 0;
-    __syncthreads();
-    // Only an element that STARTS on a tail position can have a chain (a tenth of the list): they are gathered first, so
-    // that the chain walk below runs on a few full waves instead of on every wave with a tenth of its lanes (round 6:
-    // 14.5 -> 6.5 us a round).
-    for (int r0 = 0; r0 < nB; r0 += NT) {
-      const int r = r0 + tid;
-      bool has = false;
-      if (r < nB) {
-        const int c0 = m.ep[r];
-        const unsigned q0 = (int)m.ep[r + 1] != c0 ? evq[c0] : (m.evp[r] & kSwPos);
-        has = q0 >= (unsigned)(n - k + 1);
-      }
-      const int slot = wave_alloc(&sh.sw_ncl, has);
-      if (has) cl[slot] = (unsigned short)r;
-    }
     __syncthreads();
     const int ncl = uni(sh.sw_ncl);
     for (int ci = tid; ci < ncl; ci += NT) {
-      const int r = (int)cl[ci];
+      const int r = (int)m.cand[ci];
       const int c0 = m.ep[r], oc = (int)m.ep[r + 1] - c0;
       const unsigned q0 = oc ? evq[c0] : (m.evp[r] & kSwPos);
       int g0, len;
@@ -669,6 +650,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
       for (int r = lo; r < hi && r < nB; r++) {
         const int nn = (int)ncnt[r];
         const int oc = (int)m.ep[r + 1] - (int)m.ep[r];
+        nep[r] = (unsigned short)ex;
         if (nn == 0 && oc == 0) continue;
         const glb_u32 *rec = m.chain + (size_t)r * kSwChainRec;
         unsigned q = rec[kSwChain];
@@ -677,6 +659,8 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         ex += nn;
       }
       __syncthreads();
+      for (int r = tid; r < nB; r += NT) m.ep[r] = nep[r];
+      if (tid == 0) m.ep[nB] = (unsigned short)total;
       for (int c = tid; c < total; c += NT) m.evp[nB + c] = nq[c] | kSwProbe;
       if (tid == 0) sh.sw_nev = total;
       cur ^= 1;
