@@ -1701,7 +1701,7 @@ int jamd_beam_create(jamd_engine *e, jamd_lexicon *l, int beam_width, float scor
     size_t at = 0;
     auto place = [&](unsigned *off, size_t bytes) { *off = (unsigned)at; at = (at + bytes + 255) & ~(size_t)255; };
     place(&w.o_nodekey, (size_t)w.nnode * sizeof(unsigned long long));
-    place(&w.o_cur, (size_t)w.tok_cap * sizeof(Tok));
+    place(&w.o_cur, (size_t)w.tok_cap * (sizeof(Tok) + 16));   // + the exact-order kernel's 16-byte records of a frame's tokens (REC())
     place(&w.o_cur_key, (size_t)w.tok_cap * sizeof(unsigned));
     place(&w.o_touched, (size_t)w.tok_cap * sizeof(int2));
     place(&w.o_arcq, (size_t)w.tok_cap * sizeof(int2));

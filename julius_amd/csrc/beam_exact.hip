@@ -1219,6 +1219,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
 #define NODEFIRST(i) SLICE(unsigned, xw.o_nodefirst, i)
 #define CUR(i) SLICE(Tok, wk.o_cur, i)
 #define CURKEY(i) SLICE(unsigned, wk.o_cur_key, i)
+#define REC(i) SLICE(u32x4, wk.o_cur + (unsigned)sizeof(Tok) * (unsigned)wk.tok_cap, i)   /* {node, visiting index of the winner, trellis word or -2, score bits} */
 #define TOUCHED(i) SLICE(int2, wk.o_touched, i)
 #define ARCQ(i) SLICE(int2, wk.o_arcq, i)
 #define ATOM(i) SLICE(jamd_trellis_atom, wk.o_atoms, i)
@@ -1553,8 +1554,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
       constexpr int CB = JAMD_XBEAM_CB;
       for (int s0 = tid; s0 < n_new; s0 += CB * NT) {
         bool ok[CB]; int node[CB], slot[CB], tokid[CB]; int4 nr[CB]; unsigned long long key[CB]; unsigned fvis[CB];
-        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], ent[CB], l_to[CB];       // l_to: forward-DFA state (TOKEN2.to_state), 0 without one
-        float l_ls[CB];
+        int l_tre[CB], l_wid[CB], ent[CB];
 #pragma unroll
         for (int k = 0; k < CB; k++) {
           const int s = s0 + k * NT;
@@ -1588,10 +1588,148 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
           r += __popc(bm_get(w) & ((1u << (dense & 31)) - 1u));
           tokid[k] = r;
         }
-        // winner's payload from its visiting index
+        // of the winner's payload only what the score needs (the word whose last phone selects the state of a word-head
+        // node) and what the pruning step overwrites (the trellis word a cross-word winner comes from); the rest is built
+        // for the SURVIVORS after the pruning step, from the record {node, visiting index, trellis word, score} (round 6)
 #pragma unroll
         for (int k = 0; k < CB; k++) {
           const unsigned vis = ~(unsigned)key[k];
+          l_tre[k] = -2; l_wid[k] = -1;
+          if (!ok[k]) continue;
+          int j = (int)(vis >> s1);
+          const int sub = (int)(vis & submask);
+          if (dfa && t == 0) { l_tre[k] = -1; continue; }
+          if (j < n_surv && sub < XW) {                          // intra-word: inherited
+            if (nr[k].w >= JAMD_AS_RSET) l_wid[k] = sv.load(j).last_wid;
+          } else {
+            if (!(j < n_surv)) j = (int)(~(unsigned)sh.we_best);  // the factoring pass: from the best word end
+            l_tre[k] = sv_atom[j];
+            if (nr[k].w >= JAMD_AS_RSET) l_wid[k] = sv.load(j).pad0;
+          }
+        }
+        {
+          int col[CB];
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            col[k] = lx.nlc;
+            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc(l_wid[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < CB; k++) {
+            if (nr[k].w == JAMD_AS_STATE) ent[k] = nr[k].z;
+            else if (nr[k].w == JAMD_AS_LSET) ent[k] = ~nr[k].z;
+            else ent[k] = ok[k] ? lx.lc_tab((size_t)nr[k].z * (lx.nlc + 1) + col[k]) : 0;
+          }
+        }
+        float ac[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) ac[k] = (ok[k] && ent[k] >= 0) ? row[ent[k]] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          if (!ok[k]) continue;
+          const int s = tokid[k];
+          const float score = unord((unsigned)(key[k] >> 32));
+          float sc = score;
+          if (ent[k] >= 0) {
+            sc = score + ac[k];
+            const unsigned b = ordz(sc);
+            CURKEY(s) = b;
+            if (b > mymax) mymax = b;
+            if (b < mymin) mymin = b;
+          } else {
+            ARCQ(atomicAdd(&sh.n_arc, 1)) = make_int2(s, ~ent[k]);
+          }
+          REC(s) = u32x4{(unsigned)node[k], ~(unsigned)key[k], (unsigned)l_tre[k], __float_as_uint(sc)};
+        }
+      }
+      __syncthreads();
+      PROBE(2, 6);
+      // state-set reductions (outprob_cd(), outprob.c:287-400): four, two or one lane per (token, set), so that the
+      // frame's sets go through in one round when they can; eight member loads in flight per lane
+      const int n_set = uni(sh.n_arc);
+      const int lps = n_set <= NT / 4 ? 4 : (n_set <= NT / 2 ? 2 : 1), lsh = lps == 4 ? 2 : (lps == 2 ? 1 : 0);
+      const int sub = tid & (lps - 1), lane = tid & 63;
+      for (int q0 = 0; q0 < n_set; q0 += NT >> lsh) {
+        const int q = q0 + (tid >> lsh);
+        const bool act = q < n_set;
+        const int2 it = act ? ARCQ(q) : make_int2(0, 0);
+        const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
+        const float sc0 = (act && sub == 0) ? __uint_as_float(REC(it.x).w) : 0.0f;      // in flight beside the member loads
+        float r;
+        if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
+          r = lx.cdmax_num <= 3 ? nbest_of_set<3>(lx, row, a, bnd, sub, lps) : nbest_of_set<4>(lx, row, a, bnd, sub, lps);
+        } else if (lx.cdset_method == JAMD_IWCD_MAX) {
+          float m_ = JAMD_LOG_ZERO;
+          for (int m = a + sub; m < bnd; m += 8 * lps) {
+            int ix[8]; float pv[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) if (m_ < pv[jj]) m_ = pv[jj];
+          }
+          for (int src = 1; src < lps; src++) { const float c = __shfl(m_, (lane & ~(lps - 1)) + src, 64); if (m_ < c) m_ = c; }
+          r = m_;
+        } else {
+          r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
+        }
+        if (act && sub == 0) {
+          const float sc = sc0 + r;
+          REC(it.x).w = __float_as_uint(sc);
+          const unsigned b = ordz(sc);
+          CURKEY(it.x) = b;
+          if (b > mymax) mymax = b;
+          if (b < mymin) mymin = b;
+        }
+      }
+      atomicMax(&sh.maxbits, mymax);
+      atomicMin(&sh.minbits, mymin);
+    }
+    __syncthreads();
+    row_request(t + 1);
+    PHASE(2);
+    {
+      const float mx = unord(sh.maxbits);
+      thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;
+      if (t == 0) thr = JAMD_LOG_ZERO;
+    }
+    if (n_new == 0) {
+      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }
+      stopped = true;
+      __syncthreads();
+      break;
+    }
+    if (sh.n_atom > wk.atom_cap) {
+      if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
+      stopped = true;
+      __syncthreads();
+      break;
+    }
+    // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
+    const int n_keep = exact_prune<WIDE, NT>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
+    // ---- E: the survivors' records (create_token() / propagate_token(): TOKEN2's last_tre, last_cword, last_lscore ...).
+    //         Only the <= beam tokens that are kept get one: step C left {node, visiting index, trellis word, score} for every
+    //         token (16 bytes instead of 32), and the sources' records and the LM look-ups are read for the survivors only.
+    {
+      constexpr int CB = JAMD_XBEAM_CB;
+      for (int s0 = tid; s0 < n_keep; s0 += CB * NT) {
+        bool ok[CB]; int node[CB]; int4 nr[CB]; u32x4 rec[CB];
+        int l_tre[CB], l_cword[CB], l_wid[CB], lmreq[CB], l_to[CB];       // l_to: forward-DFA state (TOKEN2.to_state), 0 without one
+        float l_ls[CB];
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const int jn = s0 + k * NT;
+          ok[k] = jn < n_keep;
+          rec[k] = ok[k] ? REC(welist[jn]) : u32x4{0u, 0u, 0u, 0u};
+          node[k] = (int)rec[k].x;
+        }
+#pragma unroll
+        for (int k = 0; k < CB; k++) nr[k] = lx.node_b(node[k]);
+        // the winner's payload from its visiting index (the sources are the OLD survivors: the new ones go through CUR())
+#pragma unroll
+        for (int k = 0; k < CB; k++) {
+          const unsigned vis = rec[k].y;
           lmreq[k] = 0; l_tre[k] = -1; l_cword[k] = -1; l_wid[k] = -1; l_ls[k] = 0.0f; l_to[k] = 0;
           if (!ok[k]) continue;
           int j = (int)(vis >> s1);
@@ -1610,7 +1748,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
             const Tok tk = sv.load(j);
             const int sword = tk.pad0;
             const int last_word = lx.is_transparent(sword) ? tk.last_cword : sword;
-            l_tre[k] = sv_atom[j]; l_cword[k] = last_word; l_wid[k] = sword;
+            l_tre[k] = (int)rec[k].z; l_cword[k] = last_word; l_wid[k] = sword;
             if (dfa) {                                       // beam_inter_word() :2452-2461
               float ng = lx.penalty1;
               ng += (last_word >= 0) ? lx.cprob(last_word) : 0.0f;
@@ -1650,111 +1788,18 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
             l_ls[k] = p * lmw + pen;
           }
         }
-        {
-          int col[CB];
-#pragma unroll
-          for (int k = 0; k < CB; k++) {
-            col[k] = lx.nlc;
-            if (ok[k] && nr[k].w >= JAMD_AS_RSET && l_wid[k] >= 0) col[k] = lx.word_lc(l_wid[k]);
-          }
-#pragma unroll
-          for (int k = 0; k < CB; k++) {
-            if (nr[k].w == JAMD_AS_STATE) ent[k] = nr[k].z;
-            else if (nr[k].w == JAMD_AS_LSET) ent[k] = ~nr[k].z;
-            else ent[k] = ok[k] ? lx.lc_tab((size_t)nr[k].z * (lx.nlc + 1) + col[k]) : 0;
-          }
-        }
-        float ac[CB];
-#pragma unroll
-        for (int k = 0; k < CB; k++) ac[k] = (ok[k] && ent[k] >= 0) ? row[ent[k]] : 0.0f;
 #pragma unroll
         for (int k = 0; k < CB; k++) {
           if (!ok[k]) continue;
-          const int s = tokid[k];
-          const float score = unord((unsigned)(key[k] >> 32));
           Tok nw;
-          nw.node = node[k]; nw.pad0 = nr[k].x; nw.pad1 = l_to[k];
+          nw.node = node[k]; nw.score = __uint_as_float(rec[k].w); nw.pad0 = nr[k].x; nw.pad1 = l_to[k];
           nw.last_tre = l_tre[k]; nw.last_cword = l_cword[k]; nw.last_wid = l_wid[k]; nw.last_lscore = l_ls[k];
-          if (ent[k] >= 0) {
-            nw.score = score + ac[k];
-            const unsigned b = ordz(nw.score);
-            CURKEY(s) = b;
-            if (b > mymax) mymax = b;
-            if (b < mymin) mymin = b;
-          } else {
-            nw.score = score;
-            ARCQ(atomicAdd(&sh.n_arc, 1)) = make_int2(s, ~ent[k]);
-          }
-          CUR(s) = nw;
+          CUR(s0 + k * NT) = nw;
         }
       }
-      __syncthreads();
-      PROBE(2, 6);
-      // state-set reductions (outprob_cd(), outprob.c:287-400): four, two or one lane per (token, set), so that the
-      // frame's sets go through in one round when they can; eight member loads in flight per lane
-      const int n_set = uni(sh.n_arc);
-      const int lps = n_set <= NT / 4 ? 4 : (n_set <= NT / 2 ? 2 : 1), lsh = lps == 4 ? 2 : (lps == 2 ? 1 : 0);
-      const int sub = tid & (lps - 1), lane = tid & 63;
-      for (int q0 = 0; q0 < n_set; q0 += NT >> lsh) {
-        const int q = q0 + (tid >> lsh);
-        const bool act = q < n_set;
-        const int2 it = act ? ARCQ(q) : make_int2(0, 0);
-        const int a = act ? lx.set_off(it.y) : 0, bnd = act ? lx.set_off(it.y + 1) : 0;
-        const float sc0 = (act && sub == 0) ? CUR(it.x).score : 0.0f;      // in flight beside the member loads
-        float r;
-        if (lx.cdset_method == JAMD_IWCD_NBEST && lx.cdmax_num <= 4) {
-          r = lx.cdmax_num <= 3 ? nbest_of_set<3>(lx, row, a, bnd, sub, lps) : nbest_of_set<4>(lx, row, a, bnd, sub, lps);
-        } else if (lx.cdset_method == JAMD_IWCD_MAX) {
-          float m_ = JAMD_LOG_ZERO;
-          for (int m = a + sub; m < bnd; m += 8 * lps) {
-            int ix[8]; float pv[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) ix[jj] = (m + lps * jj < bnd) ? lx.set_states(m + lps * jj) : -1;
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) pv[jj] = (ix[jj] >= 0) ? row[ix[jj]] : JAMD_LOG_ZERO;
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) if (m_ < pv[jj]) m_ = pv[jj];
-          }
-          for (int src = 1; src < lps; src++) { const float c = __shfl(m_, (lane & ~(lps - 1)) + src, 64); if (m_ < c) m_ = c; }
-          r = m_;
-        } else {
-          r = (act && sub == 0) ? cd_reduce(row, lx.set_states_ptr(), a, bnd, lx.cdset_method, lx.cdmax_num) : 0.0f;
-        }
-        if (act && sub == 0) {
-          const float sc = sc0 + r;
-          CUR(it.x).score = sc;
-          const unsigned b = ordz(sc);
-          CURKEY(it.x) = b;
-          if (b > mymax) mymax = b;
-          if (b < mymin) mymin = b;
-        }
-      }
-      atomicMax(&sh.maxbits, mymax);
-      atomicMin(&sh.minbits, mymin);
     }
     __syncthreads();
-    row_request(t + 1);
-    PHASE(2);
-    {
-      const float mx = unord(sh.maxbits);
-      thr = (wk.width >= 0.0f) ? (mx - wk.width) : JAMD_LOG_ZERO;
-      if (t == 0) thr = JAMD_LOG_ZERO;
-    }
-    if (n_new == 0) {
-      if (tid == 0) { res->status = JAMD_PASS1_DIED; res->died_at = t; }
-      stopped = true;
-      __syncthreads();
-      break;
-    }
-    if (sh.n_atom > wk.atom_cap) {
-      if (tid == 0) res->status = JAMD_PASS1_OVERFLOW;
-      stopped = true;
-      __syncthreads();
-      break;
-    }
-    // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune<WIDE, NT>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
-    for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(welist[j]));
+    for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(j));
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
     for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
