@@ -1297,11 +1297,14 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
       if (b + ln < S) __builtin_amdgcn_global_load_lds((glb_void *)(rg + b + ln), (lds_void *)(rowc + b), 4, 0, 0);
   };
   row_request(resume ? base : (dfa ? 0 : 1));
+  int par = 0;      // wide layout: the survivors live at o_sv (0) or at the head of the CUR() area (1), in turns: step E writes the next frame's where this frame's are not
+  (void)par;
   for (int t = resume ? base : (dfa ? 0 : 1); t <= (finish ? T : T - 1); t++) {
     tid = tid_now();
 #if JAMD_XARGS_RELOAD
     XBEAM_VIEWS(xargs_now());                              // this frame's view of the launch constants (see xargs_now())
 #endif
+    if constexpr (WIDE) sv.p = reinterpret_cast<u32x4 *>(ub + (par ? wk.o_cur : wk.o_sv));   // (the survivors' two homes: step E)
     const int n_surv = uni(sh.n_surv);
     __syncthreads();
     if (tid == 0) { sh.n_new = 0; sh.n_we = 0; sh.n_arc = 0; sh.we_best = 0ull; sh.maxbits = ord(JAMD_LOG_ZERO); sh.minbits = 0xffffffffu; }
@@ -1794,12 +1797,14 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
           Tok nw;
           nw.node = node[k]; nw.score = __uint_as_float(rec[k].w); nw.pad0 = nr[k].x; nw.pad1 = l_to[k];
           nw.last_tre = l_tre[k]; nw.last_cword = l_cword[k]; nw.last_wid = l_wid[k]; nw.last_lscore = l_ls[k];
-          CUR(s0 + k * NT) = nw;
+          if constexpr (WIDE) { XSv<true> svn; svn.p = reinterpret_cast<u32x4 *>(ub + (par ? wk.o_sv : wk.o_cur)); svn.store(s0 + k * NT, nw); }
+          else CUR(s0 + k * NT) = nw;
         }
       }
     }
     __syncthreads();
-    for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(j));
+    if constexpr (WIDE) par ^= 1;
+    else { for (int j = tid; j < n_keep; j += NT) sv.store(j, CUR(j)); }   // (LDS: the sources had to be read first)
     if (tid == 0) sh.n_surv = n_keep;
     // the pruning step used the cell area: empty it again
     for (int i = tid; i < cl.nslot; i += NT) { cl.lkey[i] = 0ull; cl.lnode[i] = -1; cl.lfirst[i] = 0u; }
@@ -1813,6 +1818,12 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
       if (!stopped) {
         u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
         for (int i = tid; i < wk.sv_bytes / 16; i += NT) dst[i] = sv.p[i];
+      }
+    } else {
+      if (!stopped && par) {                                 // the next launch finds the survivors at o_sv
+        const u32x4 *src = (const u32x4 *)(ub + wk.o_cur);
+        u32x4 *dst = (u32x4 *)(ub + wk.o_sv);
+        for (int i = tid; i < 2 * sh.n_surv; i += NT) dst[i] = src[i];
       }
     }
     if (tid == 0) {
