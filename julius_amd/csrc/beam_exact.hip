@@ -29,7 +29,7 @@
 //          replayed one by one by a single wave with range queries over the top-k list (sorted by counting
 //          over score bins), and only up to the last turn that can still change the order.  The
 //          equivalence was fuzzed against the sequential code (tests/test_prune_order.py does it on the
-//          device; DESIGN.md section 3 "K6x" has the argument).
+//          device; HISTORY.md part II section 3 "K6x" has the argument).
 //        - sort_token_downward() (beam < tokens <= 2 beam) and oversize frames run the sequential
 //          extraction on one lane, in LDS.
 // Everything else -- LM factoring, outprob_style(), trellis atoms, score pruning -- is the arithmetic of
@@ -1190,7 +1190,7 @@ __device__ __forceinline__ const XKArgs &xargs_now() {
 
 // JAMD_HALF_WAVES (development, tools/build_variant.sh): waves per SIMD the HALF shape is compiled for.  4 = 128 VGPRs (two
 // workgroups fill a CU's register file); 5 = 96 VGPRs, which leaves a fifth of the file to a co-resident scoring wave
-// (with JAMD_HALF_LDS_KB=62 also the LDS for one gmm_tile workgroup): the experiment of DESIGN.md section 5, "K1 beside K6x".
+// (with JAMD_HALF_LDS_KB=62 also the LDS for one gmm_tile workgroup): the experiment of HISTORY.md part II section 5, "K1 beside K6x".
 #ifndef JAMD_HALF_WAVES
 #define JAMD_HALF_WAVES 4
 #endif
