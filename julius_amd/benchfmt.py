@@ -113,6 +113,8 @@ def _nested(r, lean=False):
         out["timing"] = {k: _num(tm[k], 4) for k in (("decode_s",) if lean else ("decode_s", "models_s", "host_read_s")) if k in tm}
         if "vs_e2e_same_task" in r:
             out["vs_e2e"] = _num(r["vs_e2e_same_task"], 3)
+    if "strong_scaling_note" in r and not lean:
+        out["note"] = "no N>1 run exists; fixed 512-utt batch: floor = longest utterance alone, ~2.2x at 8 GPUs"
     if "error" in r:
         out["error"] = _short(r["error"], 120)
     cfg = r.get("config") or {}
