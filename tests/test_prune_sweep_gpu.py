@@ -172,3 +172,23 @@ def test_whole_array_of_the_sort(engine, oracle, beam):
         worder, warr = oracle.sort_token_arrange(sc, beam)
         assert np.array_equal(order, worder) and np.array_equal(arr, warr), levels
     bm.close()
+
+
+def test_frames_the_sweep_does_not_hold(engine, oracle):
+    """The sweep's entries carry their positions as 16-bit routes (round 6): a frame of 2^16 tokens or more is not held and
+    goes to the extraction loop (the heap in global memory), as is a frame on either side of that size with many events --
+    the order stays the sequential loop's, and jamd_beam_prune_info() says which way a frame went."""
+    beam = 4000
+    bm = _beam(engine, beam)
+    rng = np.random.default_rng(65536)
+    for n, swept_wanted in ((65535, True), (65536, False), (70001, False)):
+        sc = (-rng.random(n) * 300.0 - 5000.0).astype(np.float32)
+        nd = n // 20
+        sc[rng.integers(0, n, nd)] = sc[rng.integers(0, n, nd)]
+        got = bm.prune_order(sc)
+        info = bm.prune_info()
+        want = oracle.sort_token_no_order(sc, beam)
+        assert np.array_equal(got, want), (n, info)
+        if not swept_wanted:
+            assert info <= 0, (n, info)
+    bm.close()
