@@ -1011,12 +1011,12 @@ def main():
         if wl == "all":
             # SURVEY 8d's table lists C3 at -b 800 AND -b 4000: 256 utterances, wide layout, parity vs julius -1pass -b 4000
             a4 = argparse.Namespace(**vars(args)); a4.beam = 4000; a4.no_batch = True
-            r.update(run_e2e(a4, dd, [("e2e_b4000", 256, 2, 1, "weak")], use_dnn=False))
+            r.update(run_e2e(a4, dd, [("e2e_b4000", 256, 3, 1, "weak")], use_dnn=False))
             # BASELINE configs[0] (the reference's CPU-runnable plumbing case) on the device: tied-mixture scoring + grammar first pass
             r.update(run_e2e(args, dd, [("c1", 512, 5, 1, "weak")], c1=True))
         if wl == "all" or args.multipath:
             # the same task decoded with -multipath: 512 utterances per step, two per CU (the multipath frame in its half shape, round 5)
-            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 512), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
+            r.update(run_e2e(args, dd, [("e2e_mp", pick(args.utts, 512), pick(args.steps, 5), pick(args.warmup, 1), "weak")],
                              use_dnn=False, multipath=True))
         if dd.rank == 0:
             if nested:
@@ -1035,11 +1035,11 @@ def main():
         if wl == "all" or not (args.strong or args.flat or args.multipath):
             runs.append(("e2e_dnn", pick(args.utts, 256), pick(args.steps, 5), pick(args.warmup, 1), "weak"))
         if wl == "all" or (args.strong and not args.flat and not args.multipath):
-            runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 3), pick(args.warmup, 1), "strong"))
+            runs.append(("e2e_dnn_strong", max(1, strong_total // dd.world), pick(args.steps, 4), pick(args.warmup, 1), "strong"))
         r = run_e2e(args, dd, runs, use_dnn=True) if runs else {}
         if wl == "all" or args.multipath:
             # the reference's DNN recipe as its README gives it: -b 4000 WITH -multipath (the multipath frame, wide layout)
-            r.update(run_e2e(args, dd, [("e2e_dnn_mp", pick(args.utts, 256), pick(args.steps, 2), pick(args.warmup, 1), "weak")],
+            r.update(run_e2e(args, dd, [("e2e_dnn_mp", pick(args.utts, 256), pick(args.steps, 3), pick(args.warmup, 1), "weak")],
                              use_dnn=True, multipath=True))
         if wl == "all" or (args.flat and not args.multipath):
             r.update(run_e2e(args, dd, [("e2e_dnn_flat", pick(args.utts, 256), pick(args.steps, 4), pick(args.warmup, 1), "weak")],
