@@ -84,7 +84,10 @@ struct XCells {
   lds_u64 *lkey; lds_i32 *lnode; lds_u32 *lfirst;
   int nslot;
 };
-constexpr int kXProbes = 24;
+#ifndef JAMD_XPROBES
+#define JAMD_XPROBES 24
+#endif
+constexpr int kXProbes = JAMD_XPROBES;
 // The probe loop of a cell insert: fully unrolled into 24 nested conditionals (0: the compiler's choice and the default) or
 // kept as ONE loop (1).  Unrolled, every level saves an execution mask and a condition mask, eight call sites deep -- 370
 // of the kernel's remaining scalar spill slots and a sixth of its code -- but those levels only RUN for the rare lane
