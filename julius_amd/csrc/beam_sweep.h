@@ -44,7 +44,7 @@
 #pragma once
 
 constexpr int kSwEvMax = 1024;           // events (probe entries) held
-constexpr int kSwDepth = kMaxL + 4;      // path row: one slot per depth, three 16-byte words
+constexpr int kSwDepth = 16;             // path row: one slot per depth (the sweep holds heaps of < 2^16 tokens: depths 0 .. 15), two 16-byte words
 constexpr int kSwChain = 8;              // events per element (an element can bounce from tail leaf to tail leaf: five in real frames)
 constexpr int kSwChainRec = 12;          // words of an element's new chain in the global scratch: landings, then the first position
 constexpr int kSwGroup = 48;             // entries of a tie group that holds events (ordered by one thread)
@@ -357,7 +357,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         if (T > limit) break;
         glb_u32x4 *row = (glb_u32x4 *)(m.path + (size_t)T * kSwDepth);
         const u32x4 ff = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        row[0] = ff; row[1] = ff; row[2] = ff;
+        row[0] = ff; row[1] = ff;
       }
     }
     SWTICK(1);
@@ -408,7 +408,7 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
     int L = L0;
     unsigned long long clk2 = wall_clock64(); (void)clk2;
     for (int d = 0; L > 0; d++) {
-      if (d >= kSwDepth - 1) return false;
+      if (d >= kSwDepth) return false;
       // Lane-runs: a thread takes CH consecutive entries of the list, so the entry in front of all but its first is its own,
       // its place among the left- / right-goers is a count inside the thread plus ONE prefix sum per wave (DPP), and every
       // quantity of an entry comes out of its two slots by a compare (round 6; the round-4 form gave every lane one entry of a
@@ -596,8 +596,8 @@ __device__ __noinline__ bool sweep_replay(XShared &sh, unsigned char JAMD_LDS *r
         const unsigned tw = m.tailmask[(turn - 1) >> 5], bit = 1u << ((turn - 1) & 31);
         if (!(tw & bit)) { sh.sw_fail = 1; break; }
         const glb_u32x4 *row = (const glb_u32x4 *)(m.path + (size_t)turn * kSwDepth);
-        const u32x4 r0 = row[0], r1 = row[1], r2 = row[2];
-        const unsigned rw[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        const u32x4 r0 = row[0], r1 = row[1];
+        const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         unsigned h = 1u;
         bool stop = false;
 #pragma unroll
