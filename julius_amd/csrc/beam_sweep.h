@@ -745,13 +745,12 @@ __device__ __noinline__ bool down_finish(XShared &sh, unsigned char JAMD_LDS *re
         const unsigned sv = S[s];
         int p = f, child;
         while ((child = 2 * p) <= m) {
+          // both children at once: two LDS round trips a level instead of four (the slot behind the heap's end is read and ignored)
           unsigned short c = P[child];
+          const unsigned short c2 = P[child + 1];
           unsigned cv = S[c];
-          if (child < m) {
-            const unsigned short c2 = P[child + 1];
-            const unsigned cv2 = S[c2];
-            if (MINHEAP ? (cv > cv2) : (cv < cv2)) { child++; c = c2; cv = cv2; }
-          }
+          const unsigned cv2 = S[c2];
+          if (child < m && (MINHEAP ? (cv > cv2) : (cv < cv2))) { child++; c = c2; cv = cv2; }
           if (MINHEAP ? (sv <= cv) : (sv >= cv)) break;
           P[p] = c;
           p = child;
