@@ -673,10 +673,11 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
   const int tid = tid_now();
   unsigned long long tc_ = tp ? wall_clock64() : 0ull, tc3_ = tc_;
   (void)tc3_;
-#define PTICK(i) do { if (tp && tid == 0 && ((JAMD_XBEAM_PROBE != 3 && JAMD_XBEAM_PROBE != 5) || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
+#define PTICK(i) do { if (tp && tid == 0 && ((JAMD_XBEAM_PROBE != 3 && JAMD_XBEAM_PROBE != 5 && JAMD_XBEAM_PROBE != 6) || (i) == 7)) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc_; tc_ = n_; tc3_ = n_; } } while (0)
 #ifdef JAMD_DEV
 #define PTICK5(i) do { if (JAMD_XBEAM_PROBE == 5 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
 #define PTICK3(i) do { if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
+#define PTICK6(i) do { if (JAMD_XBEAM_PROBE == 6 && tp && tid == 0) { const unsigned long long n_ = wall_clock64(); tp[i] += n_ - tc3_; tc3_ = n_; } } while (0)
 #else
 #define PTICK5(i) ((void)0)
 #define PTICK3(i) ((void)0)
@@ -965,12 +966,14 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
                 if (i > ilast) { c = ncand; break; }          // nothing behind this turn can change the order
                 if (nd) break;                                // invalidated by an earlier event: next round
                 if (rs < 0) continue;
+                PTICK6(4);
                 const unsigned long long ev = apply_event(pm.compR, pm.vposR, pm.idR, nB, n, k, i, rs);
+                PTICK6(5);
                 const unsigned hole = uni((unsigned)(ev >> 32));
                 const int newr = uni((int)((unsigned)ev & 0x7fffffffu));
                 const bool tied = (uni((unsigned)ev) & 0x80000000u) != 0u;
 #ifdef JAMD_DEV
-                if (JAMD_XBEAM_PROBE == 3 && tp && tid == 0) tp[6] += 100;   // events (1 us each)
+                if ((JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 6) && tp && tid == 0) tp[6] += 100;   // events (1 us each)
 #endif
                 const int lo = newr < rs ? newr : rs, hi = newr < rs ? rs : newr;
                 // which later candidates can this change?  (ranks outside [lo, hi] keep their numbers)  One lane each;
@@ -1713,7 +1716,7 @@ beam_exact_kernel(XKArgs ka_, const float *__restrict__ scores, int S, const int
       break;
     }
     // ---- D: rank pruning with the reference's heap; the next frame visits sv[0..n_keep) in this order
-    const int n_keep = exact_prune<WIDE, NT>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5)) ? ph : nullptr);
+    const int n_keep = exact_prune<WIDE, NT>(sh, &CURKEY(0), n_new, wk.beam, Hlds, xw.heap_cap, Hglob, pm, welist, xw.prune_mode, Gcol, (TIMED && (JAMD_XBEAM_PROBE == 0 || JAMD_XBEAM_PROBE == 3 || JAMD_XBEAM_PROBE == 5 || JAMD_XBEAM_PROBE == 6)) ? ph : nullptr);
     // ---- E: the survivors' records (create_token() / propagate_token(): TOKEN2's last_tre, last_cword, last_lscore ...).
     //         Only the <= beam tokens that are kept get one: step C left {node, visiting index, trellis word, score} for every
     //         token (16 bytes instead of 32), and the sources' records and the LM look-ups are read for the survivors only.
