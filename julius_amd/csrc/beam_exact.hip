@@ -681,6 +681,7 @@ __device__ __forceinline__ int exact_prune(XShared &sh, const unsigned *keys, in
 #else
 #define PTICK5(i) ((void)0)
 #define PTICK3(i) ((void)0)
+#define PTICK6(i) ((void)0)
 #endif
   if (n <= k) {
     for (int j = tid; j < n; j += NT) svid[j] = j;
