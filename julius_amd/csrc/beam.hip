@@ -1528,7 +1528,12 @@ int jamd_lexicon_create(jamd_engine *e, const jamd_lexicon_desc *h, jamd_lexicon
     float nf; memcpy(&nf, &node, 4);
     shared_root[i] = make_float2(nf, h->fscore[-h->scid[node]]);
   }
-  UP(node_a, na.data(), na.size()); UP(node_b, nb.data(), nb.size()); UP(scid, h->scid, h->nnode);
+  {
+    std::vector<int4> nab(2 * (size_t)h->nnode);       // one 32-byte record per node (LexDev::node_a / node_b / scid)
+    for (int i = 0; i < h->nnode; i++) { nab[2 * (size_t)i] = na[i]; nab[2 * (size_t)i + 1] = nb[i]; }
+    UP(node_a, nab.data(), nab.size());
+    d.o_node_b = d.o_node_a + 16u; d.o_scid = d.o_node_a + 20u;
+  }
   UP(ac_to, h->ac_to, nac); UP(ac_a, h->ac_a, nac);
   UP(iso_root, iso_root.data(), iso_root.size()); UP(shared_root, shared_root.data(), shared_root.size());
   UP(word_end, word_end.data(), word_end.size());

@@ -22,9 +22,6 @@ constexpr int kHistBytes = 2048 * 4;    // rank-select histogram; shares its spa
 // uniform base the loads also take the `global_load v, voffset32, s[base]` form (no 64-bit address
 // arithmetic per access).
 #define JAMD_LEX_ARRAYS(X)                                                                       \
-  X(int4, node_a)          /* [nnode] {self_a bits, next_a bits, ac_off, ac_end} (wchmm->self_a/next_a/ac) */ \
-  X(int4, node_b)          /* [nnode] {stend, scid, out_id, out_kind} (stend, state[].scid, outstyle)      */ \
-  X(int, scid)             /* [nnode] again, for the destination of a transition                           */ \
   X(int, ac_to) X(float, ac_a)                                                                               \
   X(int2, iso_root)        /* [isolatenum] {root node, successor word scword[scid[root]]}                  */ \
   X(float2, shared_root)   /* [nshared]    {root node bits, fscore[-scid[root]]}                           */ \
@@ -64,6 +61,14 @@ struct LexDev {
   __device__ __forceinline__ const T *name##_ptr() const { return reinterpret_cast<const T *>(base + o_##name); }
   JAMD_LEX_ARRAYS(X)
 #undef X
+  // A node is ONE 32-byte record (round 6): {self_a bits, next_a bits, ac_off, ac_end} (wchmm->self_a / next_a / ac) and
+  // {stend, scid, out_id, out_kind} (stend, state[].scid, outstyle) -- a survivor's transitions, the successor id of its
+  // next node (the following record) and the record of the token it creates there come out of one or two 64-byte sectors,
+  // where three arrays took three or four.
+  unsigned o_node_a, o_node_b, o_scid;      // the record's first half, its second half (+ 16), scid inside it (+ 20)
+  __device__ __forceinline__ int4 node_a(int i) const { return *reinterpret_cast<const int4 *>(base + (unsigned)(o_node_a + 32u * (unsigned)i)); }
+  __device__ __forceinline__ int4 node_b(int i) const { return *reinterpret_cast<const int4 *>(base + (unsigned)(o_node_b + 32u * (unsigned)i)); }
+  __device__ __forceinline__ int scid(int i) const { return *reinterpret_cast<const int *>(base + (unsigned)(o_scid + 32u * (unsigned)i)); }
 };
 
 struct __attribute__((aligned(16))) Tok {   // TOKEN2, libjulius/include/julius/beam.h:35-45
